@@ -1,0 +1,293 @@
+"""eradiate-kernel_amd: host-side mirror of the reference's Python surface for the path / volpath hot path.
+
+Call sequence kept from the reference (/root/reference/src/python/__init__.py:124-188,
+src/librender/python/integrator_v.cpp:124-156, src/films/hdrfilm.cpp:251-259,
+docs/src/python_interface/rendering_scene.rst:11-60):
+
+    import mitsuba_amd as mitsuba            # (root-level shim around this package)
+    mitsuba.set_variant('gpu_rgb')
+    from mitsuba.core import ScalarTransform4f
+    from mitsuba.core.xml import load_dict
+    scene = load_dict({...})
+    scene.integrator().render(scene, scene.sensors()[0])
+    img = np.array(scene.sensors()[0].film().bitmap(raw=True))      # (H, W, 5) XYZAW
+
+Everything below the Python layer is libmtsamd.so (C ABI in include/mtsamd.h, HIP kernels for gfx950).
+Only the `gpu_rgb` variant exists: there is no CPU fallback in the product path.
+"""
+import ctypes as C
+import signal
+import threading
+import types
+
+import numpy as np
+
+from . import _capi as A
+from .transform import ScalarTransform4f
+from .scene_dict import build_scene_desc
+from . import volume_io
+
+__version__ = "0.1.0"
+ERADIATE_KERNEL = True          # src/python/__init__.py:191-193
+_VARIANTS = ["gpu_rgb"]
+_tls = threading.local()
+
+
+def variants():
+    """mitsuba.variants() (src/python/__init__.py:185-188)."""
+    return list(_VARIANTS)
+
+
+def variant():
+    return getattr(_tls, "variant", None)
+
+
+def set_variant(name):
+    """mitsuba.set_variant() (src/python/__init__.py:124-177): per-thread; unknown variants raise ImportError
+    with the list of compiled variants, like the reference."""
+    if name not in _VARIANTS:
+        raise ImportError("Requested an unsupported variant \"%s\". The following variants are available: %s."
+                          % (name, ", ".join(_VARIANTS)))
+    A.lib()                      # fail loudly if the HIP backend is missing
+    _tls.variant = name
+
+
+def _require_variant():
+    if variant() is None:
+        raise ImportError("Before importing any packages, you must specify the desired variant of Mitsuba "
+                          "using \"mitsuba.set_variant(..)\".\nThe following variants are available: %s."
+                          % ", ".join(_VARIANTS))
+
+
+class PixelFormat:
+    Y, YA, RGB, RGBA, XYZ, XYZA, XYZAW, MultiChannel = range(8)
+
+
+class StructType:
+    Float32 = "float32"
+
+
+class Struct:
+    Type = StructType
+
+
+class Bitmap:
+    """Minimal Bitmap: an (H, W, C) float32 image with a pixel format (src/libcore/bitmap.cpp)."""
+    PixelFormat = PixelFormat
+
+    def __init__(self, array, pixel_format):
+        self._a = np.ascontiguousarray(array, dtype=np.float32)
+        self._fmt = pixel_format
+
+    def pixel_format(self):
+        return self._fmt
+
+    def width(self):
+        return self._a.shape[1]
+
+    def height(self):
+        return self._a.shape[0]
+
+    def channel_count(self):
+        return self._a.shape[2]
+
+    def __array__(self, dtype=None, copy=None):
+        return self._a if dtype is None else self._a.astype(dtype)
+
+    def convert(self, pixel_format, component_format=StructType.Float32, srgb_gamma=False):
+        """XYZAW -> other formats: divide by the weight channel, then XYZ -> linear sRGB with the matrix of
+        src/films/hdrfilm.cpp:277-297 / include/mitsuba/core/spectrum.h:229-239."""
+        if srgb_gamma:
+            raise RuntimeError("sRGB gamma encoding is not supported")
+        a = self._a
+        if self._fmt != PixelFormat.XYZAW:
+            raise RuntimeError("Bitmap.convert(): only XYZAW sources are supported")
+        w = a[..., 4:5]
+        inv = np.where(w != 0, 1.0 / np.where(w != 0, w, 1), 0).astype(np.float32)
+        xyz = a[..., :3] * inv
+        alpha = a[..., 3:4] * inv
+        m = np.array([[3.240479, -1.537150, -0.498535],
+                      [-0.969256, 1.875991, 0.041556],
+                      [0.055648, -0.204043, 1.057311]], dtype=np.float32)
+        rgb = xyz @ m.T
+        if pixel_format == PixelFormat.RGB:
+            return Bitmap(rgb, pixel_format)
+        if pixel_format == PixelFormat.RGBA:
+            return Bitmap(np.concatenate([rgb, alpha], -1), pixel_format)
+        if pixel_format == PixelFormat.XYZ:
+            return Bitmap(xyz, pixel_format)
+        if pixel_format == PixelFormat.XYZA:
+            return Bitmap(np.concatenate([xyz, alpha], -1), pixel_format)
+        if pixel_format == PixelFormat.Y:
+            return Bitmap(xyz[..., 1:2], pixel_format)
+        raise RuntimeError("Bitmap.convert(): unsupported target pixel format")
+
+
+class Film:
+    """hdrfilm (src/films/hdrfilm.cpp): owns the XYZAW storage the integrator writes."""
+
+    def __init__(self, sensor_rec):
+        self._rec = sensor_rec
+        self._storage = None
+
+    def size(self):
+        return (self._rec.film_width, self._rec.film_height)
+
+    def crop_size(self):
+        return tuple(self._rec.crop_size)
+
+    def crop_offset(self):
+        return tuple(self._rec.crop_offset)
+
+    def bitmap(self, raw=False):
+        if self._storage is None:
+            raise RuntimeError("Film.bitmap(): nothing has been rendered yet")
+        src = Bitmap(self._storage, PixelFormat.XYZAW)
+        if raw:
+            return src
+        return src.convert(PixelFormat.RGB)
+
+
+class Sampler:
+    def __init__(self, rec):
+        self._rec = rec
+
+    def sample_count(self):
+        return self._rec.sample_count
+
+
+class Sensor:
+    def __init__(self, rec):
+        self._rec = rec
+        self._film = Film(rec)
+        self._sampler = Sampler(rec)
+
+    def film(self):
+        return self._film
+
+    def sampler(self):
+        return self._sampler
+
+    def needs_aperture_sample(self):
+        return self._rec.type == A.SENSOR_DISTANT
+
+
+class Integrator:
+    """SamplingIntegrator (include/mitsuba/render/integrator.h:42-51,114-119)."""
+
+    def __init__(self, scene):
+        self._scene = scene
+        self.last_stats = None
+
+    def render(self, scene, sensor, shard_index=0, shard_count=1, device_film=None, stream=None,
+               collect_counters=False):
+        """Integrator.render(scene, sensor) -> bool (False iff cancelled / timed out).
+
+        The reference binding releases the GIL and turns SIGINT into cancel()
+        (integrator_v.cpp:124-156); ctypes releases the GIL for the duration of mts_render, and the
+        SIGINT handler below calls mts_cancel.  Extra keyword arguments are extensions used by the
+        multi-GPU path: `shard_*` selects the blocks this rank renders, `device_film` is a device
+        pointer (e.g. torch tensor data_ptr) receiving the XYZAW film instead of host memory.
+        """
+        if scene is not self._scene:
+            raise RuntimeError("Integrator.render(): the integrator belongs to another scene")
+        rec = scene._desc.sensor
+        h, w = rec.crop_size[1], rec.crop_size[0]
+        opts = A.RenderOpts()
+        opts.shard_index, opts.shard_count = shard_index, shard_count
+        opts.device = scene._device
+        opts.stream = stream
+        opts.collect_counters = int(bool(collect_counters))
+        stats = A.Stats()
+        old = None
+        if threading.current_thread() is threading.main_thread():
+            try:
+                old = signal.signal(signal.SIGINT, lambda *a: A.lib().mts_cancel(scene._handle))
+            except ValueError:
+                old = None
+        try:
+            if device_film is not None:
+                opts.film_on_device = 1
+                A.check(A.lib().mts_render(scene._handle, C.byref(opts), C.c_void_p(int(device_film)), C.byref(stats)))
+                sensor._film._storage = None
+            else:
+                out = np.zeros((h, w, 5), dtype=np.float32)
+                opts.film_on_device = 0
+                A.check(A.lib().mts_render(scene._handle, C.byref(opts), out.ctypes.data_as(C.c_void_p), C.byref(stats)))
+                sensor._film._storage = out
+        finally:
+            if old is not None:
+                signal.signal(signal.SIGINT, old)
+        self.last_stats = {k: getattr(stats, k) for k, _ in A.Stats._fields_}
+        return not bool(stats.cancelled)
+
+    def cancel(self):
+        A.lib().mts_cancel(self._scene._handle)
+
+    def sample(self, scene, origins, directions, seed_offset=0):
+        """SamplingIntegrator.sample for a batch of rays (integrator_v.cpp:62-78): returns (rgb (n,3), valid (n,))."""
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        cols = [np.ascontiguousarray(o[:, i]) for i in range(3)] + [np.ascontiguousarray(d[:, i]) for i in range(3)]
+        rgb = np.zeros((n, 3), dtype=np.float32)
+        valid = np.zeros(n, dtype=np.uint8)
+        A.check(A.lib().mts_sample(scene._handle, n, seed_offset, *[c.ctypes.data_as(A.fp) for c in cols],
+                                   rgb.ctypes.data_as(A.fp), valid.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return rgb, valid.astype(bool)
+
+
+class Scene:
+    """Scene (src/librender/scene.cpp:22-104): owns the device-resident flattened scene."""
+
+    def __init__(self, desc, keep, device=0):
+        self._desc, self._keep, self._device = desc, keep, device
+        h = C.c_void_p()
+        A.check(A.lib().mts_scene_create(C.byref(desc), device, C.byref(h)))
+        self._handle = h
+        self._sensor = Sensor(desc.sensor)
+        self._integrator = Integrator(self)
+
+    def sensors(self):
+        return [self._sensor]
+
+    def integrator(self):
+        return self._integrator
+
+    def ray_intersect(self, o, d, mint=None, maxt=None):
+        """Scene::ray_intersect (scene.cpp:117-125) for a batch of rays; returns a dict of arrays."""
+        o = np.ascontiguousarray(o, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, dtype=np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        mint = np.full(n, 1500 * 2.0 ** -24, dtype=np.float32) if mint is None else np.ascontiguousarray(mint, dtype=np.float32)
+        maxt = np.full(n, np.inf, dtype=np.float32) if maxt is None else np.ascontiguousarray(maxt, dtype=np.float32)
+        t = np.zeros(n, np.float32); shape = np.zeros(n, np.int32); prim = np.zeros(n, np.int32)
+        p = np.zeros((n, 3), np.float32); nn = np.zeros((n, 3), np.float32)
+        A.check(A.lib().mts_ray_intersect(self._handle, n, o.ctypes.data_as(A.fp), d.ctypes.data_as(A.fp),
+                                          mint.ctypes.data_as(A.fp), maxt.ctypes.data_as(A.fp), t.ctypes.data_as(A.fp),
+                                          shape.ctypes.data_as(C.POINTER(C.c_int32)), prim.ctypes.data_as(C.POINTER(C.c_int32)),
+                                          p.ctypes.data_as(A.fp), nn.ctypes.data_as(A.fp)))
+        return {"t": t, "shape": shape, "prim_index": prim, "p": p, "n": nn}
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None):
+                A.lib().mts_scene_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+
+def load_dict(d, device=0):
+    """mitsuba.core.xml.load_dict (src/libcore/python/xml_v.cpp:23-68,100-272)."""
+    _require_variant()
+    desc, keep = build_scene_desc(d)
+    return Scene(desc, keep, device)
+
+
+# virtual modules mitsuba.core / mitsuba.render (src/python/__init__.py:115-121)
+core = types.SimpleNamespace(
+    ScalarTransform4f=ScalarTransform4f, Bitmap=Bitmap, Struct=Struct,
+    xml=types.SimpleNamespace(load_dict=load_dict),
+)
+render = types.SimpleNamespace(Scene=Scene, Integrator=Integrator, Sensor=Sensor, Film=Film)

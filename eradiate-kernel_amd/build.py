@@ -1,0 +1,55 @@
+"""In-tree build of libmtsamd.so (HIP kernels + C ABI) for gfx950, and of the oracle (test infrastructure).
+
+    python eradiate-kernel_amd/build.py [--force]
+
+hipcc cross-compiles without a GPU.  Flags that matter for parity with the CPU restatement:
+  -ffp-contract=off                          fused multiply-adds only where the source says pm_fma
+  -fhip-fp32-correctly-rounded-divide-sqrt   IEEE fp32 division / sqrt on the device
+  -fgpu-flush-denormals-to-zero              reference worker threads run with FTZ (integrator.cpp:117)
+  -mfma                                      host-side constructors use hardware fma like the oracle
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmtsamd.so")
+SOURCES = ["kernels.hip", "scene_host.cpp", "capi.cpp"]
+HEADERS = ["pmath.h", "dmath.h", "dscene.h", "integrator_dev.h", "launch.h", "scene_host.h"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+         "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fgpu-flush-denormals-to-zero",
+         "-mfma", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_backend(force=False, verbose=True, extra=()):
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(ROOT, "include", "mtsamd.h"), __file__]
+    if not force and not _stale(LIB, deps):
+        return LIB
+    cmd = [HIPCC] + FLAGS + list(extra) + ["-x", "hip"] + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def build_oracle(force=False, verbose=True):
+    odir = os.path.join(ROOT, "oracle")
+    cmd = ["make", "-C", odir] + (["-B"] if force else [])
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    return os.path.join(odir, "liboracle.so")
+
+
+if __name__ == "__main__":
+    force = "--force" in sys.argv
+    build_backend(force)
+    build_oracle(force)

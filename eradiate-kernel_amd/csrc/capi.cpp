@@ -1,0 +1,219 @@
+// capi.cpp -- the extern "C" entry points declared in include/mtsamd.h.
+//
+// mts_render mirrors SamplingIntegrator::render (/root/reference/src/librender/integrator.cpp:51-179):
+// pass / block bookkeeping on the host, one kernel launch per pass over every spiral block this shard
+// owns.  No exception crosses the boundary: errors become a non-zero status + mts_last_error().
+#include <chrono>
+#include <cstring>
+#include <cmath>
+#include <mutex>
+#include "scene_host.h"
+#include "launch.h"
+
+using namespace mtsamd;
+
+static thread_local std::string g_error;
+
+#define API_TRY try {
+#define API_CATCH } catch (const std::exception &e) { g_error = e.what(); return 1; } catch (...) { g_error = "unknown error"; return 1; } return 0;
+#define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct mts_scene { HostScene *hs; std::mutex render_mutex; };
+
+// librender/spiral.cpp:11-72
+namespace {
+struct Spiral {
+    int size_x, size_y, off_x, off_y, block_size, blocks_x, blocks_y;
+    size_t block_count, block_counter, remaining_passes;
+    int dir, pos_x, pos_y, steps_left, steps;
+    void init(int sx, int sy, int ox, int oy, int bs, size_t passes) {
+        size_x = sx; size_y = sy; off_x = ox; off_y = oy; block_size = bs; remaining_passes = passes;
+        blocks_x = (int) std::ceil((float) sx / bs); blocks_y = (int) std::ceil((float) sy / bs);
+        block_count = (size_t) blocks_x * blocks_y;
+        reset();
+    }
+    void reset() { block_counter = 0; dir = 0; pos_x = blocks_x / 2; pos_y = blocks_y / 2; steps_left = 1; steps = 1; }
+    bool next_block(DBlock &b, size_t &block_id) {
+        if (block_count == block_counter) {
+            if (remaining_passes > 1) { --remaining_passes; reset(); }
+            else return false;
+        }
+        block_id = block_counter + (remaining_passes - 1) * block_count;
+        int offx = pos_x * block_size, offy = pos_y * block_size;
+        b.sx = std::min(block_size, size_x - offx); b.sy = std::min(block_size, size_y - offy);
+        b.ox = offx + off_x; b.oy = offy + off_y;
+        ++block_counter;
+        if (block_counter != block_count) {
+            do {
+                switch (dir) { case 0: ++pos_x; break; case 1: ++pos_y; break; case 2: --pos_x; break; case 3: --pos_y; break; }
+                if (--steps_left == 0) { dir = (dir + 1) % 4; if (dir == 2 || dir == 0) ++steps; steps_left = steps; }
+            } while (pos_x < 0 || pos_y < 0 || pos_x >= blocks_x || pos_y >= blocks_y);
+        }
+        return true;
+    }
+};
+
+template <typename T> struct DeviceBuffer {
+    T *p = nullptr;
+    explicit DeviceBuffer(size_t n) { HIP_CHECK(hipMalloc((void **) &p, std::max<size_t>(n * sizeof(T), 16))); }
+    ~DeviceBuffer() { if (p) (void) hipFree(p); }
+    DeviceBuffer(const DeviceBuffer &) = delete;
+};
+} // namespace
+
+extern "C" {
+
+int mts_abi_version(void) { return MTS_ABI_VERSION; }
+const char *mts_last_error(void) { return g_error.c_str(); }
+
+int mts_abi_sizeof(const char *name) {
+#define SZ(T) if (!strcmp(name, #T)) return (int) sizeof(T);
+    SZ(mts_transform) SZ(mts_volume) SZ(mts_phase) SZ(mts_medium) SZ(mts_bsdf) SZ(mts_shape) SZ(mts_emitter)
+    SZ(mts_sensor) SZ(mts_integrator) SZ(mts_scene_desc) SZ(mts_stats) SZ(mts_render_opts)
+#undef SZ
+    return -1;
+}
+
+int mts_device_count(int *count) {
+    API_TRY
+    HIP_CHECK(hipGetDeviceCount(count));
+    API_CATCH
+}
+
+int mts_scene_create(const mts_scene_desc *desc, int device, mts_scene **out) {
+    API_TRY
+    if (!out) throw std::runtime_error("mts_scene_create: out is NULL");
+    HostScene *hs = build_host_scene(desc);
+    try { upload_host_scene(*hs, device); } catch (...) { free_host_scene(hs); throw; }
+    mts_scene *s = new mts_scene(); s->hs = hs;
+    *out = s;
+    API_CATCH
+}
+
+int mts_scene_destroy(mts_scene *scene) {
+    if (scene) { free_host_scene(scene->hs); delete scene; }
+    return 0;
+}
+
+int mts_cancel(mts_scene *scene) {
+    if (!scene) { g_error = "mts_cancel: scene is NULL"; return 1; }
+    scene->hs->stop.store(1);
+    return 0;
+}
+
+int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_stats *stats) {
+    API_TRY
+    if (!scene || !film) throw std::runtime_error("mts_render: NULL argument");
+    std::lock_guard<std::mutex> guard(scene->render_mutex);         // one render per handle at a time
+    HostScene &hs = *scene->hs;
+    mts_render_opts opts; memset(&opts, 0, sizeof(opts)); opts.shard_count = 1;
+    if (opts_) opts = *opts_;
+    if (opts.shard_count < 1 || opts.shard_index < 0 || opts.shard_index >= opts.shard_count) throw std::runtime_error("mts_render: invalid shard specification");
+    auto t0 = std::chrono::steady_clock::now();
+    hs.stop.store(0);                                               // integrator.cpp:53
+    HIP_CHECK(hipSetDevice(hs.device));
+    hipStream_t stream = (hipStream_t) opts.stream;
+    const DSensor &se = hs.scene.sensor;
+    // integrator.cpp:58-65
+    size_t total_spp = (size_t) se.sample_count;
+    size_t samples_per_pass = hs.integrator.samples_per_pass < 0 ? total_spp : std::min((size_t) hs.integrator.samples_per_pass, total_spp);
+    if (samples_per_pass == 0 || (total_spp % samples_per_pass) != 0)
+        throw std::runtime_error("sample_count (" + std::to_string(total_spp) + ") must be a multiple of samples_per_pass (" + std::to_string(samples_per_pass) + ").");
+    size_t n_passes = (total_spp + samples_per_pass - 1) / samples_per_pass;
+    // integrator.cpp:26-32,89-97: the reference's heuristic depends on the host thread count; this
+    // backend pins MTS_BLOCK_SIZE = 32 when the scene leaves block_size at 0
+    uint32_t block_size = hs.integrator.block_size > 0 ? (uint32_t) hs.integrator.block_size : 32u;
+    { uint32_t p = 1; while (p < block_size) p <<= 1; block_size = p; }
+    if (block_size > 1024) throw std::runtime_error("block_size too large");
+    // spiral.cpp: enumerate every (pass, block) pair in the reference's order; keep this shard's blocks
+    Spiral spiral; spiral.init(se.crop_w, se.crop_h, se.crop_x, se.crop_y, (int) block_size, n_passes);
+    std::vector<std::vector<DBlock>> pass_blocks(n_passes);
+    uint64_t samples = 0;
+    for (size_t pass = 0; pass < n_passes; ++pass)
+        for (size_t k = 0; k < spiral.block_count; ++k) {
+            DBlock b; size_t id;
+            if (!spiral.next_block(b, id)) throw std::runtime_error("spiral exhausted early");
+            if ((int) (id % (size_t) opts.shard_count) != opts.shard_index) continue;
+            if (id * (uint64_t) block_size * block_size >= ((uint64_t) 1 << 63)) throw std::runtime_error("block id overflow");
+            b.id = (uint32_t) id;
+            pass_blocks[pass].push_back(b);
+            samples += (uint64_t) b.sx * b.sy * samples_per_pass;
+        }
+    const size_t film_floats = (size_t) se.crop_w * se.crop_h * 5;
+    float *d_film = film;
+    std::unique_ptr<DeviceBuffer<float>> film_buf;
+    if (!opts.film_on_device) { film_buf.reset(new DeviceBuffer<float>(film_floats)); d_film = film_buf->p; }
+    DeviceBuffer<unsigned long long> d_counters(4);
+    HIP_CHECK(hipMemsetAsync(d_film, 0, film_floats * sizeof(float), stream));               // hdrfilm.cpp:201-203 (storage cleared by prepare())
+    HIP_CHECK(hipMemsetAsync(d_counters.p, 0, 4 * sizeof(unsigned long long), stream));
+    hipEvent_t ev0, ev1;
+    HIP_CHECK(hipEventCreate(&ev0)); HIP_CHECK(hipEventCreate(&ev1));
+    double kernel_ms = 0.0; int launches = 0; bool cancelled = false;
+    const float timeout = hs.integrator.timeout;
+    try {
+        for (size_t pass = 0; pass < n_passes; ++pass) {
+            // should_stop(), integrator.h:143-146 -- checked at pass granularity
+            if (hs.stop.load() || (timeout > 0.f && std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count() > timeout)) { cancelled = true; break; }
+            const std::vector<DBlock> &blocks = pass_blocks[pass];
+            if (blocks.empty()) continue;
+            DeviceBuffer<DBlock> d_blocks(blocks.size());
+            HIP_CHECK(hipMemcpyAsync(d_blocks.p, blocks.data(), blocks.size() * sizeof(DBlock), hipMemcpyHostToDevice, stream));
+            HIP_CHECK(hipEventRecord(ev0, stream));
+            HIP_CHECK(launch_render(hs.scene, d_blocks.p, (uint32_t) blocks.size(), block_size, (uint32_t) samples_per_pass, d_film, d_counters.p,
+                                    opts.collect_counters != 0, stream));
+            HIP_CHECK(hipEventRecord(ev1, stream));
+            HIP_CHECK(hipEventSynchronize(ev1));
+            float ms = 0.f; HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
+            kernel_ms += ms; ++launches;
+        }
+        if (!opts.film_on_device) HIP_CHECK(hipMemcpyAsync(film, d_film, film_floats * sizeof(float), hipMemcpyDeviceToHost, stream));
+        unsigned long long h_counters[4] = { 0, 0, 0, 0 };
+        HIP_CHECK(hipMemcpyAsync(h_counters, d_counters.p, sizeof(h_counters), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        if (stats) {
+            memset(stats, 0, sizeof(*stats));
+            stats->samples = samples; stats->n_iter = h_counters[0]; stats->n_lookup = h_counters[1]; stats->n_nee_step = h_counters[2];
+            stats->kernel_ms = kernel_ms; stats->kernel_launches = launches; stats->cancelled = cancelled ? 1 : 0;
+            stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
+    } catch (...) { (void) hipEventDestroy(ev0); (void) hipEventDestroy(ev1); throw; }
+    (void) hipEventDestroy(ev0); (void) hipEventDestroy(ev1);
+    API_CATCH
+}
+
+int mts_sample(mts_scene *scene, int32_t n, uint64_t seed_offset, const float *ox, const float *oy, const float *oz,
+               const float *dx, const float *dy, const float *dz, float *out_rgb, uint8_t *out_valid) {
+    API_TRY
+    if (!scene || n < 0) throw std::runtime_error("mts_sample: invalid argument");
+    if (n == 0) return 0;
+    HostScene &hs = *scene->hs;
+    HIP_CHECK(hipSetDevice(hs.device));
+    DeviceBuffer<float> d_rays((size_t) 6 * n), d_rgb((size_t) 3 * n);
+    DeviceBuffer<uint8_t> d_valid((size_t) n);
+    const float *rows[6] = { ox, oy, oz, dx, dy, dz };
+    for (int r = 0; r < 6; ++r) HIP_CHECK(hipMemcpy(d_rays.p + (size_t) r * n, rows[r], (size_t) n * sizeof(float), hipMemcpyHostToDevice));
+    HIP_CHECK(launch_sample(hs.scene, n, seed_offset, d_rays.p, d_rgb.p, d_valid.p, nullptr));
+    HIP_CHECK(hipMemcpy(out_rgb, d_rgb.p, (size_t) 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(out_valid, d_valid.p, (size_t) n, hipMemcpyDeviceToHost));
+    API_CATCH
+}
+
+int mts_ray_intersect(mts_scene *scene, int32_t n, const float *o, const float *d, const float *mint, const float *maxt,
+                      float *out_t, int32_t *out_shape, int32_t *out_prim, float *out_p, float *out_n) {
+    API_TRY
+    if (!scene || n < 0) throw std::runtime_error("mts_ray_intersect: invalid argument");
+    if (n == 0) return 0;
+    HostScene &hs = *scene->hs;
+    HIP_CHECK(hipSetDevice(hs.device));
+    DeviceBuffer<float> d_o((size_t) 3 * n), d_d((size_t) 3 * n), d_mint(n), d_maxt(n), d_t(n), d_p((size_t) 3 * n), d_n((size_t) 3 * n);
+    DeviceBuffer<int32_t> d_shape(n), d_prim(n);
+    HIP_CHECK(hipMemcpy(d_o.p, o, (size_t) 3 * n * 4, hipMemcpyHostToDevice)); HIP_CHECK(hipMemcpy(d_d.p, d, (size_t) 3 * n * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_mint.p, mint, (size_t) n * 4, hipMemcpyHostToDevice)); HIP_CHECK(hipMemcpy(d_maxt.p, maxt, (size_t) n * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(launch_intersect(hs.scene, n, d_o.p, d_d.p, d_mint.p, d_maxt.p, d_t.p, d_shape.p, d_prim.p, d_p.p, d_n.p, nullptr));
+    HIP_CHECK(hipMemcpy(out_t, d_t.p, (size_t) n * 4, hipMemcpyDeviceToHost)); HIP_CHECK(hipMemcpy(out_shape, d_shape.p, (size_t) n * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(out_prim, d_prim.p, (size_t) n * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(out_p, d_p.p, (size_t) 3 * n * 4, hipMemcpyDeviceToHost)); HIP_CHECK(hipMemcpy(out_n, d_n.p, (size_t) 3 * n * 4, hipMemcpyDeviceToHost));
+    API_CATCH
+}
+
+} // extern "C"

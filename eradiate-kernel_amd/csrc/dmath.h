@@ -1,0 +1,144 @@
+// dmath.h -- small fp32 vector / transform toolkit used by the host-side plugin constructors and the
+// HIP kernels.  Every operation is an explicit IEEE add / mul / fma / div / sqrt (see pmath.h), so host
+// and device evaluate identical bits.  Conventions for operations the reference leaves to enoki
+// (absent): dot = fma chain, cross = fmsub form, rcp = 1/x, normalize = v * (1/sqrt(|v|^2)).
+// Citations are relative to /root/reference.
+#pragma once
+#include "pmath.h"
+
+#if defined(__HIPCC__)
+#  define DM_HD __host__ __device__ __forceinline__
+#else
+#  define DM_HD static inline
+#endif
+
+namespace mtsamd {
+
+struct F3 { float x, y, z; };
+struct F2 { float x, y; };
+
+DM_HD F3 f3(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
+DM_HD F3 f3(const float *p) { F3 r; r.x = p[0]; r.y = p[1]; r.z = p[2]; return r; }
+DM_HD F3 f3s(float s) { F3 r; r.x = s; r.y = s; r.z = s; return r; }
+DM_HD F3 operator+(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+DM_HD F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+DM_HD F3 operator-(F3 a) { return f3(-a.x, -a.y, -a.z); }
+DM_HD F3 operator*(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+DM_HD F3 operator*(float s, F3 a) { return f3(a.x * s, a.y * s, a.z * s); }
+DM_HD F3 operator*(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
+DM_HD F3 operator/(F3 a, float s) { return f3(a.x / s, a.y / s, a.z / s); }
+DM_HD F3 operator/(F3 a, F3 b) { return f3(a.x / b.x, a.y / b.y, a.z / b.z); }
+DM_HD float dot(F3 a, F3 b) { return pm_fma(a.z, b.z, pm_fma(a.y, b.y, a.x * b.x)); }
+DM_HD float squared_norm(F3 a) { return dot(a, a); }
+DM_HD float norm(F3 a) { return pm_sqrt(squared_norm(a)); }
+DM_HD F3 normalize(F3 a) { return a * pm_rsqrt(squared_norm(a)); }
+DM_HD F3 cross(F3 a, F3 b) {
+    return f3(pm_fma(a.y, b.z, -(a.z * b.y)), pm_fma(a.z, b.x, -(a.x * b.z)), pm_fma(a.x, b.y, -(a.y * b.x)));
+}
+DM_HD F3 fmadd(F3 a, float s, F3 c) { return f3(pm_fma(a.x, s, c.x), pm_fma(a.y, s, c.y), pm_fma(a.z, s, c.z)); }
+DM_HD F3 fnmadd(F3 a, float s, F3 c) { return f3(pm_fma(-a.x, s, c.x), pm_fma(-a.y, s, c.y), pm_fma(-a.z, s, c.z)); }
+DM_HD float hmax(F3 a) { return pm_max(pm_max(a.x, a.y), a.z); }
+DM_HD float hmin(F3 a) { return pm_min(pm_min(a.x, a.y), a.z); }
+DM_HD float hmax_abs(F3 a) { return pm_max(pm_max(pm_abs(a.x), pm_abs(a.y)), pm_abs(a.z)); }
+DM_HD F3 vrcp(F3 a) { return f3(1.0f / a.x, 1.0f / a.y, 1.0f / a.z); }
+DM_HD float pick(F3 a, uint32_t i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+DM_HD bool any_nonzero(F3 a) { return a.x != 0.f || a.y != 0.f || a.z != 0.f; }
+
+// core/math.h:13-38
+#define MTS_PI 3.14159265358979323846f
+#define MTS_INV_PI 0.31830988618379067154f
+#define MTS_INV_TWO_PI 0.15915494309189533577f
+#define MTS_INV_FOUR_PI 0.07957747154594766788f
+#define MTS_TWO_PI 6.28318530717958647692f
+#define MTS_EPSILON (1.1920929e-07f / 2)
+#define MTS_RAY_EPSILON (MTS_EPSILON * 1500)
+#define MTS_SHADOW_EPSILON (MTS_RAY_EPSILON * 10)
+
+// core/vector.h:116-136
+DM_HD void coordinate_system(F3 n, F3 &s, F3 &t) {
+    float sign = pm_sign(n.z), a = -pm_rcp(sign + n.z), b = n.x * n.y * a;
+    s = f3(pm_mulsign(n.x * n.x * a, n.z) + 1.f, pm_mulsign(b, n.z), pm_mulsign_neg(n.x, n.z));
+    t = f3(b, sign + n.y * n.y * a, -n.y);
+}
+
+// core/frame.h:17-37
+struct Frame3 { F3 s, t, n; };
+DM_HD Frame3 make_frame(F3 n) { Frame3 f; f.n = n; coordinate_system(n, f.s, f.t); return f; }
+DM_HD F3 to_local(const Frame3 &f, F3 v) { return f3(dot(v, f.s), dot(v, f.t), dot(v, f.n)); }
+DM_HD F3 to_world(const Frame3 &f, F3 v) { return f.s * v.x + f.t * v.y + f.n * v.z; }
+
+// core/transform.h:90-141; matrices are row-major float[16]
+DM_HD F3 mat_point_affine(const float *m, F3 p) {
+    return f3(pm_fma(m[2], p.z, pm_fma(m[1], p.y, pm_fma(m[0], p.x, m[3]))),
+              pm_fma(m[6], p.z, pm_fma(m[5], p.y, pm_fma(m[4], p.x, m[7]))),
+              pm_fma(m[10], p.z, pm_fma(m[9], p.y, pm_fma(m[8], p.x, m[11]))));
+}
+DM_HD F3 mat_point(const float *m, F3 p) {
+    float w = pm_fma(m[14], p.z, pm_fma(m[13], p.y, pm_fma(m[12], p.x, m[15])));
+    F3 r = mat_point_affine(m, p);
+    return f3(r.x / w, r.y / w, r.z / w);
+}
+DM_HD F3 mat_vector(const float *m, F3 v) {
+    return f3(pm_fma(m[2], v.z, pm_fma(m[1], v.y, m[0] * v.x)),
+              pm_fma(m[6], v.z, pm_fma(m[5], v.y, m[4] * v.x)),
+              pm_fma(m[10], v.z, pm_fma(m[9], v.y, m[8] * v.x)));
+}
+
+// core/warp.h:23,54-90,255-260,287-301,325-333
+DM_HD float circ(float x) { return pm_safe_sqrt(pm_fma(-x, x, 1.f)); }
+DM_HD F2 square_to_uniform_disk_concentric(F2 sample) {
+    float x = pm_fma(2.f, sample.x, -1.f), y = pm_fma(2.f, sample.y, -1.f);
+    bool is_zero = x == 0.f && y == 0.f, quadrant_1_or_3 = pm_abs(x) < pm_abs(y);
+    float r = quadrant_1_or_3 ? y : x, rp = quadrant_1_or_3 ? x : y;
+    float phi = .25f * MTS_PI * rp / r;
+    if (quadrant_1_or_3) phi = .5f * MTS_PI - phi;
+    if (is_zero) phi = 0.f;
+    float s, c; pm_sincos(phi, &s, &c);
+    F2 p; p.x = r * c; p.y = r * s;
+    return p;
+}
+DM_HD F3 square_to_uniform_sphere(F2 sample) {
+    float z = pm_fma(-2.f, sample.y, 1.f), r = circ(z);
+    float s, c; pm_sincos(2.f * MTS_PI * sample.x, &s, &c);
+    return f3(r * c, r * s, z);
+}
+DM_HD F3 square_to_uniform_hemisphere(F2 sample) {
+    F2 p = square_to_uniform_disk_concentric(sample);
+    float z = 1.f - pm_fma(p.y, p.y, p.x * p.x);
+    float k = pm_sqrt(z + 1.f);
+    return f3(p.x * k, p.y * k, z);
+}
+DM_HD F3 square_to_cosine_hemisphere(F2 sample) {
+    F2 p = square_to_uniform_disk_concentric(sample);
+    float z = pm_safe_sqrt(1.f - pm_fma(p.y, p.y, p.x * p.x));
+    return f3(p.x, p.y, z);
+}
+
+// PCG32 (public algorithm; enoki::PCG32 via core/random.h:52-54) with the default stream
+#define PCG32_DEFAULT_STATE 0x853c49e6748fea9bULL
+#define PCG32_DEFAULT_STREAM 0xda3e39cb94b95bdbULL
+#define PCG32_MULT 0x5851f42d4c957f2dULL
+struct Pcg32 {
+    uint64_t state, inc;
+    DM_HD uint32_t next_uint32() {
+        uint64_t old = state;
+        state = old * PCG32_MULT + inc;
+        uint32_t xorshifted = (uint32_t) (((old >> 18u) ^ old) >> 27u);
+        uint32_t rot = (uint32_t) (old >> 59u);
+        return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31u));
+    }
+    DM_HD void seed(uint64_t initstate, uint64_t initseq) {
+        state = 0u; inc = (initseq << 1u) | 1u;
+        next_uint32(); state += initstate; next_uint32();
+    }
+    DM_HD float next_1d() { return pm_from_bits((next_uint32() >> 9) | 0x3f800000u) - 1.0f; }
+    DM_HD F2 next_2d() { F2 p; p.x = next_1d(); p.y = next_1d(); return p; }
+};
+
+// enoki::morton_decode (librender/integrator.cpp:200)
+DM_HD uint32_t compact_bits(uint32_t x) {
+    x &= 0x55555555u; x = (x ^ (x >> 1)) & 0x33333333u; x = (x ^ (x >> 2)) & 0x0f0f0f0fu;
+    x = (x ^ (x >> 4)) & 0x00ff00ffu; x = (x ^ (x >> 8)) & 0x0000ffffu; return x;
+}
+
+} // namespace mtsamd

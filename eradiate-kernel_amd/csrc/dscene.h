@@ -1,0 +1,114 @@
+// dscene.h -- flattened, device-resident scene: what the reference's plugins hold after construction,
+// as POD records in HBM.  Built on the host by scene_host.cpp (the "plugin constructors"), read by the
+// render kernels through wave-uniform (scalar) loads: every record below is indexed by values that
+// are uniform across a wavefront except where noted, so the scene lives in SGPRs / the scalar cache
+// and costs no vector memory traffic.  Citations are relative to /root/reference.
+#pragma once
+#include <stdint.h>
+
+namespace mtsamd {
+
+struct DXf { float m[16]; float it[16]; };            // Transform4f: matrix + inverse transpose (transform.h:36-50)
+
+struct DBBox { float min[3], max[3]; };
+
+// Volume (render/texture.h:210-279, textures/grid3d.cpp, textures/constant3d.cpp)
+struct DVolume {
+    int32_t type;                 // MTS_VOLUME_*
+    float value[3];
+    float w2l[16];                // world_to_local matrix (row-major)
+    DBBox bbox;
+    const float *data;            // device pointer, nz*ny*nx*channels, x fastest
+    int32_t nx, ny, nz, channels, filter, wrap;
+    float max;
+    int32_t has_max;
+};
+
+// Phase functions (phase/*.cpp); the tabulated distribution of tabphase (core/distr_1d.h:293-345)
+struct DPhase {
+    int32_t type;
+    float g;
+    int32_t child[2];
+    int32_t weight_volume;
+    const float *pdf, *cdf;       // device pointers
+    int32_t size;
+    float range_x, range_y, integral, normalization, interval_size, inv_interval_size;
+    uint32_t valid_x, valid_y;
+};
+
+// Media (media/homogeneous.cpp, media/heterogeneous.cpp)
+struct DMedium {
+    int32_t type, sigma_t, albedo, phase;
+    float scale;
+    int32_t sample_emitters, has_spectral_extinction, is_homogeneous;
+    float max_density;
+    DBBox aabb;
+};
+
+struct DBsdf { int32_t type; float reflectance[3], rho_0[3], k[3], g[3], rho_c[3]; uint32_t flags; };
+
+// Shapes (shapes/rectangle.cpp, shapes/cube.cpp + librender/mesh.cpp, shapes/sphere.cpp)
+struct DShape {
+    int32_t type;
+    DXf to_world, to_object;
+    int32_t bsdf, interior, exterior, emitter;   // bsdf always resolved (default diffuse appended by the host)
+    float frame_s[3], frame_t[3], frame_n[3];     // rectangle.cpp:66-74
+    float inv_surface_area;
+    float center[3], radius;                      // sphere
+    int32_t flip_normals;
+    int32_t vertex_offset, face_offset;           // into the scene-wide mesh arrays
+    int32_t has_normals, has_texcoords;
+    int32_t is_medium_transition;
+};
+
+struct DPrim { int32_t shape, index; };
+
+struct DEmitter { int32_t type; DXf to_world; float radiance[3]; int32_t shape; float bsphere_center[3], bsphere_radius; };
+
+struct DRFilter { int32_t type; float radius, stddev, alpha, bias; float values[32]; float scale_factor; int32_t border_size; };
+
+struct DSensor {
+    int32_t type;
+    DXf to_world;
+    float s2c[16];                 // sample_to_camera matrix (perspective.cpp:107-111)
+    float near_clip, far_clip, ppo[2];
+    int32_t direction_type, flip_directions, target_type;
+    float target_point[3];
+    DShape target_shape;
+    float target_area;
+    float bsphere_center[3], bsphere_radius;
+    int32_t needs_aperture_sample, medium;
+    int32_t width, height, crop_x, crop_y, crop_w, crop_h;
+    DRFilter rfilter;
+    int32_t sample_count;
+    uint64_t seed;
+};
+
+struct DIntegrator { int32_t type, max_depth, rr_depth, hide_emitters; };
+
+// One spiral block (librender/spiral.cpp:27-72) assigned to this launch
+struct DBlock { int32_t ox, oy, sx, sy; uint32_t id; };
+
+struct DScene {
+    const DVolume *volumes;
+    const DPhase *phases;
+    const DMedium *media;
+    const DBsdf *bsdfs;
+    const DShape *shapes;
+    const DPrim *prims;
+    const DEmitter *emitters;
+    const float *positions, *normals, *texcoords;   // world-space mesh data of all meshes
+    const uint32_t *faces;
+    int32_t volume_count, phase_count, medium_count, bsdf_count, shape_count, prim_count, emitter_count;
+    int32_t environment;
+    DBBox bbox;
+    DSensor sensor;
+    DIntegrator integrator;
+};
+
+// bsdf.h:38-124
+enum : uint32_t { F_Null = 0x1, F_DiffuseReflection = 0x2, F_GlossyReflection = 0x8,
+                  F_FrontSide = 0x8000, F_BackSide = 0x10000,
+                  F_Smooth = 0x2 | 0x4 | 0x8 | 0x10, F_Delta = 0x1 | 0x20 | 0x40 };
+
+} // namespace mtsamd

@@ -1,0 +1,912 @@
+// integrator_dev.h -- device functions of the path / volpath hot path (gfx950).
+//
+// One lane owns one pixel and runs that pixel's samples sequentially with the reference's scalar
+// PCG32 stream (librender/integrator.cpp:198), so every random draw below happens in exactly the
+// order of the scalar_rgb variant (SURVEY.md section 8(a')).  All scene records are read through
+// wave-uniform addresses (scalar loads); the only per-lane memory traffic is the volume gathers.
+// Citations are relative to /root/reference.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dscene.h"
+#include "dmath.h"
+#include "../../include/mtsamd.h"
+
+namespace mtsamd {
+
+#define DEV __device__ __forceinline__
+#define DEV_NOINLINE __device__ __noinline__
+
+struct DRay { F3 o, d, d_rcp; float mint, maxt; };
+DEV DRay make_ray(F3 o, F3 d, float mint, float maxt) { DRay r; r.o = o; r.d = d; r.d_rcp = vrcp(d); r.mint = mint; r.maxt = maxt; return r; }
+DEV F3 ray_at(const DRay &r, float t) { return fmadd(r.d, t, r.o); }                       // core/ray.h:65
+DEV DRay spawn_ray(F3 p, F3 d) { return make_ray(p, d, (1.f + hmax_abs(p)) * MTS_RAY_EPSILON, pm_inf()); }   // render/interaction.h:58-61
+
+struct Counters { uint32_t n_iter, n_lookup, n_nee_step; };
+
+// What survives of a SurfaceInteraction between loop iterations: the hit distance, the hit point
+// (computed from the ray that found it), and the primitive; normals / frames / wi are rebuilt on
+// demand by complete_surface() with the same arithmetic.
+struct Hit { float t; F3 p; F2 uv; int32_t shape, prim; };
+struct Surf { F3 n; Frame3 sh; F3 wi; };
+DEV bool hit_valid(const Hit &h) { return h.t != pm_inf(); }
+
+// core/bbox.h:302-325
+DEV bool bbox_ray_intersect(const DBBox &b, const DRay &ray, float &mint, float &maxt) {
+    F3 bmin = f3(b.min), bmax = f3(b.max);
+    bool active = (ray.d.x != 0.f || (ray.o.x > bmin.x || ray.o.x < bmax.x)) &&
+                  (ray.d.y != 0.f || (ray.o.y > bmin.y || ray.o.y < bmax.y)) &&
+                  (ray.d.z != 0.f || (ray.o.z > bmin.z || ray.o.z < bmax.z));
+    F3 t1 = (bmin - ray.o) * ray.d_rcp, t2 = (bmax - ray.o) * ray.d_rcp;
+    F3 t1p = f3(pm_min(t1.x, t2.x), pm_min(t1.y, t2.y), pm_min(t1.z, t2.z));
+    F3 t2p = f3(pm_max(t1.x, t2.x), pm_max(t1.y, t2.y), pm_max(t1.z, t2.z));
+    mint = hmax(t1p);
+    maxt = hmin(t2p);
+    return active && maxt >= mint;
+}
+
+// ---------------------------------------------------------------- primitives
+// shapes/rectangle.cpp:139-155
+DEV float rectangle_intersect(const DShape &s, const DRay &ray, F2 &uv) {
+    F3 o = mat_point_affine(s.to_object.m, ray.o), d = mat_vector(s.to_object.m, ray.d);
+    float t = -o.z * (1.0f / d.z);
+    float lx = pm_fma(d.x, t, o.x), ly = pm_fma(d.y, t, o.y);
+    bool active = t >= ray.mint && t <= ray.maxt && pm_abs(lx) <= 1.f && pm_abs(ly) <= 1.f;
+    uv.x = lx; uv.y = ly;
+    return active ? t : pm_inf();
+}
+// render/mesh.h:195-226
+DEV float triangle_intersect(const DScene &sc, const DShape &s, int index, const DRay &ray, F2 &uv) {
+    const uint32_t *fi = sc.faces + 3 * (s.face_offset + index);
+    const float *P = sc.positions + 3 * s.vertex_offset;
+    F3 p0 = f3(P + 3 * fi[0]), p1 = f3(P + 3 * fi[1]), p2 = f3(P + 3 * fi[2]);
+    F3 e1 = p1 - p0, e2 = p2 - p0;
+    F3 pvec = cross(ray.d, e2);
+    float inv_det = pm_rcp(dot(e1, pvec));
+    F3 tvec = ray.o - p0;
+    float u = dot(tvec, pvec) * inv_det;
+    bool active = u >= 0.f && u <= 1.f;
+    F3 qvec = cross(tvec, e1);
+    float v = dot(ray.d, qvec) * inv_det;
+    active = active && v >= 0.f && u + v <= 1.f;
+    float t = dot(e2, qvec) * inv_det;
+    active = active && t >= ray.mint && t <= ray.maxt;
+    uv.x = u; uv.y = v;
+    return active ? t : pm_inf();
+}
+// shapes/sphere.cpp:272-306 in double precision (the reference's CPU path, sphere.cpp:276) + core/math.h:371-411
+DEV float sphere_intersect(const DShape &s, const DRay &ray) {
+    double mint = ray.mint, maxt = ray.maxt;
+    double ox = (double) ray.o.x - (double) s.center[0], oy = (double) ray.o.y - (double) s.center[1], oz = (double) ray.o.z - (double) s.center[2];
+    double dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
+    double A = pm_fma_d(dz, dz, pm_fma_d(dy, dy, dx * dx));
+    double B = 2.0 * pm_fma_d(oz, dz, pm_fma_d(oy, dy, ox * dx));
+    double Cc = pm_fma_d(oz, oz, pm_fma_d(oy, oy, ox * ox)) - (double) s.radius * (double) s.radius;
+    bool linear_case = A == 0.0, valid_linear = linear_case && B != 0.0;
+    double x0 = -Cc / B, x1 = x0;
+    double discrim = pm_fma_d(B, B, -(4.0 * A * Cc));
+    bool valid_quadratic = !linear_case && discrim >= 0.0;
+    if (valid_quadratic) {
+        double sqrt_discrim = __builtin_sqrt(discrim);
+        double temp = -0.5 * (B + __builtin_copysign(sqrt_discrim, B));
+        double x0p = temp / A, x1p = Cc / temp;
+        x0 = x1p < x0p ? x1p : x0p; x1 = x0p < x1p ? x1p : x0p;
+    }
+    bool found = valid_linear || valid_quadratic;
+    bool out_bounds = !(x0 <= maxt && x1 >= mint);
+    bool in_bounds = x0 < mint && x1 > maxt;
+    bool active = found && !out_bounds && !in_bounds;
+    return active ? (x0 < mint ? (float) x1 : (float) x0) : pm_inf();
+}
+
+// ---------------------------------------------------------------- scene traversal
+// Closest hit with the semantics of ShapeKDTree::ray_intersect_scalar (render/kdtree.h:2078-2171):
+// clip against the scene bounding box, accept t in [mint, maxt], shrink maxt on every accepted hit, a
+// later primitive at the same t replaces the earlier one (`t <= maxt`).  For the handful of
+// primitives of the atmosphere scenes the "acceleration structure" is the primitive list itself,
+// walked with wave-uniform (scalar) loads -- no per-lane memory traffic at all.
+template <bool ShadowRay>
+DEV Hit ray_intersect_preliminary(const DScene &sc, DRay ray) {
+    Hit h; h.t = pm_inf(); h.p = f3s(0.f); h.uv.x = h.uv.y = 0.f; h.shape = -1; h.prim = 0;
+    float bmint, bmaxt;
+    bbox_ray_intersect(sc.bbox, ray, bmint, bmaxt);
+    float mint = pm_max(ray.mint, bmint), maxt = pm_min(ray.maxt, bmaxt);
+    if (!(mint <= maxt)) return h;
+    for (int i = 0; i < sc.prim_count; ++i) {
+        const DPrim pr = sc.prims[i];
+        const DShape &s = sc.shapes[pr.shape];
+        F2 uv; uv.x = uv.y = 0.f; float t;
+        if (s.type == MTS_SHAPE_RECTANGLE) t = rectangle_intersect(s, ray, uv);
+        else if (s.type == MTS_SHAPE_SPHERE) t = sphere_intersect(s, ray);
+        else t = triangle_intersect(sc, s, pr.index, ray, uv);
+        if (t != pm_inf()) {
+            h.t = t; h.uv = uv; h.shape = pr.shape; h.prim = pr.index;
+            if (ShadowRay) return h;
+            ray.maxt = t;
+        }
+    }
+    return h;
+}
+
+// Hit point: rectangle.cpp:181-185, mesh.cpp:470-483, sphere.cpp:325-327
+DEV void hit_point(const DScene &sc, const DRay &ray, Hit &h) {
+    const DShape &s = sc.shapes[h.shape];
+    if (s.type == MTS_SHAPE_RECTANGLE) {
+        F3 p = ray_at(ray, h.t), n = f3(s.frame_n);
+        float dist = dot(f3(s.to_world.m[3], s.to_world.m[7], s.to_world.m[11]) - p, n);
+        h.p = fmadd(n, dist, p);
+    } else if (s.type == MTS_SHAPE_SPHERE) {
+        F3 n = normalize(ray_at(ray, h.t) - f3(s.center));
+        h.p = fmadd(n, s.radius, f3(s.center));
+        h.uv.x = n.x; h.uv.y = n.y; h.prim = (int32_t) pm_bits(n.z);     // keep the exact normal for complete_surface()
+    } else {
+        const uint32_t *fi = sc.faces + 3 * (s.face_offset + h.prim);
+        const float *P = sc.positions + 3 * s.vertex_offset;
+        F3 p0 = f3(P + 3 * fi[0]), p1 = f3(P + 3 * fi[1]), p2 = f3(P + 3 * fi[2]);
+        float b1 = h.uv.x, b2 = h.uv.y, b0 = 1.f - b1 - b2;
+        h.p = p0 * b0 + p1 * b1 + p2 * b2;
+    }
+}
+
+// librender/scene_native.inl:23-41
+DEV Hit ray_intersect(const DScene &sc, const DRay &ray) {
+    Hit h = ray_intersect_preliminary<false>(sc, ray);
+    if (hit_valid(h)) hit_point(sc, ray, h);
+    return h;
+}
+DEV bool ray_test(const DScene &sc, const DRay &ray) { return hit_valid(ray_intersect_preliminary<true>(sc, ray)); }
+
+// Rebuild n, shading frame and wi: rectangle.cpp:186-193, mesh.cpp:485-545, sphere.cpp:328-371,
+// interaction.h:153-156,571-596.  `d` is the direction of the ray that produced the hit.
+DEV void complete_surface(const DScene &sc, const Hit &h, F3 d, Surf &sf) {
+    const DShape &s = sc.shapes[h.shape];
+    F3 dp_du, dp_dv, shn;
+    if (s.type == MTS_SHAPE_RECTANGLE) {
+        sf.n = f3(s.frame_n); shn = sf.n; dp_du = f3(s.frame_s);
+    } else if (s.type == MTS_SHAPE_SPHERE) {
+        // hit_point() parked the unit normal normalize(ray(t) - center) in (uv.x, uv.y, bits(prim))
+        shn = f3(h.uv.x, h.uv.y, pm_from_bits((uint32_t) h.prim));
+        F3 local = mat_point_affine(s.to_object.m, h.p);
+        dp_du = mat_vector(s.to_world.m, f3(-local.y, local.x, 0.f)) * (2.f * MTS_PI);
+        if (s.flip_normals) shn = -shn;
+        sf.n = shn;
+    } else {
+        const uint32_t *fi = sc.faces + 3 * (s.face_offset + h.prim);
+        const float *P = sc.positions + 3 * s.vertex_offset;
+        F3 p0 = f3(P + 3 * fi[0]), p1 = f3(P + 3 * fi[1]), p2 = f3(P + 3 * fi[2]);
+        float b1 = h.uv.x, b2 = h.uv.y, b0 = 1.f - b1 - b2;
+        F3 dp0 = p1 - p0, dp1 = p2 - p0;
+        sf.n = normalize(cross(dp0, dp1));
+        coordinate_system(sf.n, dp_du, dp_dv);
+        if (s.has_texcoords) {
+            const float *T = sc.texcoords + 2 * s.vertex_offset;
+            float u0x = T[2 * fi[0]], u0y = T[2 * fi[0] + 1], u1x = T[2 * fi[1]], u1y = T[2 * fi[1] + 1], u2x = T[2 * fi[2]], u2y = T[2 * fi[2] + 1];
+            float d0x = u1x - u0x, d0y = u1y - u0y, d1x = u2x - u0x, d1y = u2y - u0y;
+            float det = pm_fma(d0x, d1y, -(d0y * d1x)), inv_det = pm_rcp(det);
+            if (det != 0.f)
+                dp_du = f3(pm_fma(d1y, dp0.x, -(d0y * dp1.x)), pm_fma(d1y, dp0.y, -(d0y * dp1.y)), pm_fma(d1y, dp0.z, -(d0y * dp1.z))) * inv_det;
+        }
+        if (s.has_normals) {
+            const float *N = sc.normals + 3 * s.vertex_offset;
+            F3 n0 = f3(N + 3 * fi[0]), n1 = f3(N + 3 * fi[1]), n2 = f3(N + 3 * fi[2]);
+            shn = normalize(n0 * b0 + n1 * b1 + n2 * b2);
+        } else shn = sf.n;
+    }
+    sf.sh.n = shn;
+    sf.sh.s = normalize(fnmadd(shn, dot(shn, dp_du), dp_du));
+    sf.sh.t = cross(shn, sf.sh.s);
+    sf.wi = to_local(sf.sh, -d);
+}
+
+// ---------------------------------------------------------------- volumes
+// textures/grid3d.cpp:234-250
+DEV int wrap_coord(int wrap, int value, int res) {
+    if (wrap == MTS_WRAP_CLAMP) return min(max(value, 0), res - 1);
+    int div = value / res;
+    int mod = value - div * res;
+    if (mod < 0) mod += res;
+    if (wrap == MTS_WRAP_MIRROR) mod = (((div & 1) == 0) ^ (value < 0)) ? mod : res - 1 - mod;
+    return mod;
+}
+DEV float trilerp(float d000, float d100, float d010, float d110, float d001, float d101, float d011, float d111, F3 w0, F3 w1) {
+    float v00 = pm_fma(w0.x, d000, w1.x * d100), v01 = pm_fma(w0.x, d001, w1.x * d101),
+          v10 = pm_fma(w0.x, d010, w1.x * d110), v11 = pm_fma(w0.x, d011, w1.x * d111);
+    float v0 = pm_fma(w0.y, v00, w1.y * v10), v1 = pm_fma(w0.y, v01, w1.y * v11);
+    return pm_fma(w0.z, v0, w1.z * v1);
+}
+// textures/grid3d.cpp:220-232,259-360 ; textures/constant3d.cpp
+DEV F3 volume_eval(const DVolume &v, F3 p_world) {
+    if (v.type == MTS_VOLUME_CONST) return f3(v.value);
+    F3 p = mat_point(v.w2l, p_world);
+    const float *D = v.data; const int nx = v.nx, ny = v.ny, nz = v.nz, ch = v.channels;
+    if (v.filter == MTS_FILTER_TRILINEAR) {
+        p = f3(pm_fma(p.x, (float) nx, -.5f), pm_fma(p.y, (float) ny, -.5f), pm_fma(p.z, (float) nz, -.5f));
+        int ix = (int) pm_floor(p.x), iy = (int) pm_floor(p.y), iz = (int) pm_floor(p.z);
+        F3 w1 = p - f3((float) ix, (float) iy, (float) iz), w0 = f3(1.f - w1.x, 1.f - w1.y, 1.f - w1.z);
+        int x0 = wrap_coord(v.wrap, ix, nx), x1 = wrap_coord(v.wrap, ix + 1, nx), y0 = wrap_coord(v.wrap, iy, ny), y1 = wrap_coord(v.wrap, iy + 1, ny),
+            z0 = wrap_coord(v.wrap, iz, nz), z1 = wrap_coord(v.wrap, iz + 1, nz);
+        int r00 = (z0 * ny + y0) * nx, r10 = (z0 * ny + y1) * nx, r01 = (z1 * ny + y0) * nx, r11 = (z1 * ny + y1) * nx;
+        if (ch == 1) {
+            float r = trilerp(D[r00 + x0], D[r00 + x1], D[r10 + x0], D[r10 + x1], D[r01 + x0], D[r01 + x1], D[r11 + x0], D[r11 + x1], w0, w1);
+            return f3s(r);
+        }
+        float out[3];
+        for (int c = 0; c < 3; ++c)
+            out[c] = trilerp(D[(r00 + x0) * 3 + c], D[(r00 + x1) * 3 + c], D[(r10 + x0) * 3 + c], D[(r10 + x1) * 3 + c],
+                             D[(r01 + x0) * 3 + c], D[(r01 + x1) * 3 + c], D[(r11 + x0) * 3 + c], D[(r11 + x1) * 3 + c], w0, w1);
+        return f3(out[0], out[1], out[2]);
+    }
+    p = f3(p.x * (float) nx, p.y * (float) ny, p.z * (float) nz);
+    int x = wrap_coord(v.wrap, (int) pm_floor(p.x), nx), y = wrap_coord(v.wrap, (int) pm_floor(p.y), ny), z = wrap_coord(v.wrap, (int) pm_floor(p.z), nz);
+    int index = ((z * ny + y) * nx + x) * ch;
+    if (ch == 1) return f3s(D[index]);
+    return f3(D[index], D[index + 1], D[index + 2]);
+}
+// eval_1: grid3d.cpp:187-202, constant3d.cpp
+DEV float volume_eval_1(const DVolume &v, F3 p_world) {
+    F3 r = volume_eval(v, p_world);
+    if (v.type == MTS_VOLUME_CONST) return (r.x + r.y + r.z) * (1.f / 3.f);
+    if (v.channels == 1) return r.x;
+    return r.x * 0.212671f + r.y * 0.715160f + r.z * 0.072169f;
+}
+
+// ---------------------------------------------------------------- media
+struct MediumSample { float t, mint; F3 p, sigma_s, sigma_n, sigma_t, combined; };
+DEV bool ms_valid(const MediumSample &m) { return m.t != pm_inf(); }
+
+// librender/medium.cpp:34-75 ; media/homogeneous.cpp:33-54 ; media/heterogeneous.cpp:33-54
+template <bool COUNT>
+DEV MediumSample medium_sample_interaction(const DScene &sc, int medium, const DRay &ray, float sample, uint32_t channel, Counters &cnt) {
+    const DMedium &m = sc.media[medium];
+    MediumSample mi;
+    bool active = true; float mint = 0.f, maxt = pm_inf();
+    if (!m.is_homogeneous) {
+        active = bbox_ray_intersect(m.aabb, ray, mint, maxt);
+        active = active && (pm_isfinite(mint) || pm_isfinite(maxt));
+        if (!active) { mint = 0.f; maxt = pm_inf(); }
+    }
+    mint = pm_max(ray.mint, mint);
+    maxt = pm_min(ray.maxt, maxt);
+    F3 combined = m.is_homogeneous ? volume_eval(sc.volumes[m.sigma_t], ray.o) * m.scale : f3s(m.max_density);
+    float mext = pick(combined, channel);
+    float sampled_t = mint + (-pm_log(1.f - sample) / mext);
+    bool valid_mi = active && (sampled_t <= maxt);
+    mi.t = valid_mi ? sampled_t : pm_inf();
+    mi.p = ray_at(ray, sampled_t);
+    mi.mint = mint;
+    mi.sigma_s = mi.sigma_n = mi.sigma_t = f3s(0.f);
+    if (m.is_homogeneous) {
+        F3 st = volume_eval(sc.volumes[m.sigma_t], mi.p) * m.scale;
+        mi.sigma_t = st; mi.sigma_s = st * volume_eval(sc.volumes[m.albedo], mi.p);
+    } else if (valid_mi) {
+        F3 st = m.scale * volume_eval(sc.volumes[m.sigma_t], mi.p);
+        mi.sigma_t = st; mi.sigma_s = st * volume_eval(sc.volumes[m.albedo], mi.p);
+        mi.sigma_n = f3s(m.max_density) - st;
+        if (COUNT) cnt.n_lookup++;
+    }
+    mi.combined = combined;
+    return mi;
+}
+
+// ---------------------------------------------------------------- phase functions
+DEV float eval_hg(float g, float cos_theta) {                                               // phase/hg.cpp:52-55
+    float temp = 1.0f + g * g + 2.0f * g * cos_theta;
+    return MTS_INV_FOUR_PI * (1 - g * g) / (temp * pm_sqrt(temp));
+}
+DEV float eval_rayleigh(float cos_theta) { return (3.f / 16.f) * MTS_INV_PI * (1.f + cos_theta * cos_theta); }   // phase/rayleigh.cpp:42-45
+// core/distr_1d.h:378-400
+DEV float distr_eval_pdf(const DPhase &d, float x) {
+    bool active = x >= d.range_x && x <= d.range_y;
+    x = (x - d.range_x) * d.inv_interval_size;
+    long long xi = (long long) x;
+    uint32_t index = (uint32_t) (xi < 0 ? 0 : (xi > (long long) d.size - 2 ? (long long) d.size - 2 : xi));
+    float y0 = active ? d.pdf[index] : 0.f, y1 = active ? d.pdf[index + 1] : 0.f;
+    float w1 = x - (float) index, w0 = 1.f - w1;
+    return pm_fma(w0, y0, w1 * y1);
+}
+// core/distr_1d.h:438-461
+DEV float distr_sample(const DPhase &d, float value) {
+    value *= d.integral;
+    uint32_t start = d.valid_x, end = d.valid_y, iterations = 0;
+    if (start < end) { uint32_t diff = end - start; iterations = 1; while (diff >>= 1) iterations++; }
+    for (uint32_t i = 0; i < iterations; ++i) {
+        uint32_t middle = (start + end) >> 1;
+        bool cond = d.cdf[middle] < value;
+        if (cond) start = min(middle + 1, end); else end = middle;
+    }
+    uint32_t index = start;
+    float y0 = d.pdf[index], y1 = d.pdf[index + 1], c0 = index > 0 ? d.cdf[index - 1] : 0.f;
+    value = (value - c0) * d.inv_interval_size;
+    float t_linear = (y0 - pm_safe_sqrt(y0 * y0 + 2.f * value * (y1 - y0))) / (y0 - y1), t_const = value / y0;
+    float t = (y0 == y1) ? t_const : t_linear;
+    return pm_fma((float) index + t, d.interval_size, d.range_x);
+}
+
+// Leaf phase functions (blendphase recursion is resolved by the two callers below; nesting depth 1)
+DEV float phase_eval_leaf(const DPhase &ph, F3 wi, F3 wo) {
+    switch (ph.type) {
+        case MTS_PHASE_HG: return eval_hg(ph.g, dot(wo, wi));                                // hg.cpp:81-84
+        case MTS_PHASE_RAYLEIGH: return eval_rayleigh(dot(wo, wi));                          // rayleigh.cpp:69-73
+        case MTS_PHASE_TABULATED: return distr_eval_pdf(ph, -dot(wo, wi)) * ph.normalization * MTS_INV_TWO_PI;   // tabphase.cpp:72-78
+        default: return MTS_INV_FOUR_PI;                                                      // isotropic.cpp:43-47
+    }
+}
+DEV float phase_eval(const DScene &sc, int phase, F3 wi, F3 p, F3 wo) {
+    const DPhase &ph = sc.phases[phase];
+    if (ph.type != MTS_PHASE_BLEND) return phase_eval_leaf(ph, wi, wo);
+    float w = volume_eval_1(sc.volumes[ph.weight_volume], p);                                 // blendphase.cpp:113-139
+    float weight = pm_min(pm_max(w, 0.f), 1.f);
+    return phase_eval_leaf(sc.phases[ph.child[0]], wi, wo) * (1 - weight) + phase_eval_leaf(sc.phases[ph.child[1]], wi, wo) * weight;
+}
+DEV F3 phase_sample_leaf(const DPhase &ph, const Frame3 &frame, F2 sample2) {
+    float cos_theta;
+    switch (ph.type) {
+        case MTS_PHASE_HG:                                                                    // hg.cpp:57-79
+            if (pm_abs(ph.g) < MTS_EPSILON) cos_theta = 1 - 2 * sample2.x;
+            else { float sqr_term = (1 - ph.g * ph.g) / (1 - ph.g + 2 * ph.g * sample2.x); cos_theta = (1 + ph.g * ph.g - sqr_term * sqr_term) / (2 * ph.g); }
+            break;
+        case MTS_PHASE_RAYLEIGH: {                                                            // rayleigh.cpp:47-67
+            float z = 2.f * (2.f * sample2.x - 1.f), tmp = pm_sqrt(z * z + 1.f);
+            cos_theta = pm_cbrt(z + tmp) + pm_cbrt(z - tmp);
+            break;
+        }
+        case MTS_PHASE_TABULATED: cos_theta = distr_sample(ph, sample2.x); break;             // tabphase.cpp:53-70
+        default: return square_to_uniform_sphere(sample2);                                    // isotropic.cpp:31-41
+    }
+    float sin_theta = pm_safe_sqrt(1.0f - cos_theta * cos_theta);
+    float sin_phi, cos_phi; pm_sincos(2.f * MTS_PI * sample2.y, &sin_phi, &cos_phi);
+    return to_world(frame, f3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta));
+}
+// Returns wo; the pdf is never used by the integrators (volpath.cpp:171 discards it).
+DEV F3 phase_sample(const DScene &sc, int phase, const Frame3 &frame, F3 p, float sample1, F2 sample2) {
+    const DPhase &ph = sc.phases[phase];
+    if (ph.type != MTS_PHASE_BLEND) return phase_sample_leaf(ph, frame, sample2);
+    float w = volume_eval_1(sc.volumes[ph.weight_volume], p);                                 // blendphase.cpp:68-111
+    float weight = pm_min(pm_max(w, 0.f), 1.f);
+    if (sample1 > weight) return phase_sample_leaf(sc.phases[ph.child[0]], frame, sample2);
+    return phase_sample_leaf(sc.phases[ph.child[1]], frame, sample2);
+}
+
+// ---------------------------------------------------------------- BSDFs
+struct BSDFSample { F3 wo; float pdf, eta; uint32_t sampled_type; };
+DEV float frame_tan_theta(F3 v) { float temp = pm_fma(-v.z, v.z, 1.f); return pm_safe_sqrt(temp) / v.z; }   // core/frame.h:67-70
+DEV float frame_sin_theta(F3 v) { return pm_safe_sqrt(pm_fma(v.x, v.x, v.y * v.y)); }
+DEV void frame_sincos_phi(F3 v, float &s, float &c) {                                        // core/frame.h:107-118
+    float sin_theta_2 = pm_fma(v.x, v.x, v.y * v.y), inv_sin_theta = pm_rsqrt(sin_theta_2);
+    float rx = v.x * inv_sin_theta, ry = v.y * inv_sin_theta;
+    if (pm_abs(sin_theta_2) <= 4.f * MTS_EPSILON) { rx = 1.f; ry = 0.f; }
+    else { rx = pm_min(pm_max(rx, -1.f), 1.f); ry = pm_min(pm_max(ry, -1.f), 1.f); }
+    s = ry; c = rx;
+}
+// bsdfs/rpv.cpp:85-131
+DEV_NOINLINE F3 eval_rpv(const DBsdf &b, F3 wi, F3 wo) {
+    float sin_phi1, cos_phi1, sin_phi2, cos_phi2;
+    frame_sincos_phi(wi, sin_phi1, cos_phi1); frame_sincos_phi(wo, sin_phi2, cos_phi2);
+    float cos_phi1_minus_phi2 = cos_phi1 * cos_phi2 + sin_phi1 * sin_phi2;
+    float sin_theta1 = frame_sin_theta(wi), cos_theta1 = wi.z, tan_theta1 = frame_tan_theta(wi);
+    float sin_theta2 = frame_sin_theta(wo), cos_theta2 = wo.z, tan_theta2 = frame_tan_theta(wo);
+    float G = pm_safe_sqrt(tan_theta1 * tan_theta1 + tan_theta2 * tan_theta2 - 2.f * tan_theta1 * tan_theta2 * cos_phi1_minus_phi2);
+    float cos_g = cos_theta1 * cos_theta2 + sin_theta1 * sin_theta2 * cos_phi1_minus_phi2;
+    float out[3];
+    for (int c = 0; c < 3; ++c) {
+        float g = b.g[c];
+        float F = (1.f - g * g) / pm_pow((1.f + g * g + 2.f * g * cos_g), 1.5f);
+        out[c] = b.rho_0[c] * (pm_pow(cos_theta1 * cos_theta2 * (cos_theta1 + cos_theta2), b.k[c] - 1.f) * F * (1.f + (1.f - b.rho_c[c]) / (1 + G))) * MTS_INV_PI;
+    }
+    return f3(out[0], out[1], out[2]);
+}
+DEV F3 bsdf_eval(const DBsdf &b, F3 wi, F3 wo) {
+    bool active = wi.z > 0.f && wo.z > 0.f;
+    if (b.type == MTS_BSDF_DIFFUSE) return active ? f3(b.reflectance) * MTS_INV_PI * wo.z : f3s(0.f);     // diffuse.cpp:106-120
+    if (b.type == MTS_BSDF_RPV) return active ? eval_rpv(b, wi, wo) * pm_abs(wo.z) : f3s(0.f);             // rpv.cpp:133-142
+    return f3s(0.f);                                                                                       // null.cpp:60-63
+}
+DEV float bsdf_pdf(const DBsdf &b, F3 wi, F3 wo) {
+    if (b.type == MTS_BSDF_NULL) return 0.f;                                                               // null.cpp:65-68
+    float pdf = MTS_INV_PI * wo.z;                                                                          // warp.h:343-350
+    return (wi.z > 0.f && wo.z > 0.f) ? pdf : 0.f;                                                         // diffuse.cpp:122-135, rpv.cpp:144-153
+}
+DEV F3 bsdf_sample(const DBsdf &b, F3 wi, F2 sample2, BSDFSample &bs) {
+    bs.wo = f3s(0.f); bs.pdf = 0.f; bs.eta = 0.f; bs.sampled_type = 0;
+    if (b.type == MTS_BSDF_NULL) {                                                                         // null.cpp:41-58
+        bs.wo = -wi; bs.sampled_type = F_Null; bs.eta = 1.f; bs.pdf = 1.f;
+        return f3s(1.f);
+    }
+    bool active = wi.z > 0.f;
+    if (b.type == MTS_BSDF_DIFFUSE) {                                                                      // diffuse.cpp:78-104
+        if (!active) return f3s(0.f);
+        bs.wo = square_to_cosine_hemisphere(sample2);
+        bs.pdf = MTS_INV_PI * bs.wo.z; bs.eta = 1.f; bs.sampled_type = F_DiffuseReflection;
+        return (bs.pdf > 0.f) ? f3(b.reflectance) : f3s(0.f);
+    }
+    bs.wo = square_to_cosine_hemisphere(sample2);                                                          // rpv.cpp:85-102
+    bs.pdf = MTS_INV_PI * bs.wo.z; bs.eta = 1.f; bs.sampled_type = F_GlossyReflection;
+    F3 value = eval_rpv(b, wi, bs.wo);
+    return (active && bs.pdf > 0.f) ? value : f3s(0.f);
+}
+
+// ---------------------------------------------------------------- emitters
+struct DirSample { F3 p, n, d; float pdf, dist; bool delta; int32_t emitter; };
+
+// shapes/rectangle.cpp:111-124 ; shapes/sphere.cpp (sample_position)
+DEV void shape_sample_position(const DShape &s, F2 sample, F3 &p, F3 &n, float &pdf) {
+    if (s.type == MTS_SHAPE_RECTANGLE) {
+        p = mat_point_affine(s.to_world.m, f3(sample.x * 2.f - 1.f, sample.y * 2.f - 1.f, 0.f));
+        n = f3(s.frame_n);
+    } else {
+        F3 local = square_to_uniform_sphere(sample);
+        p = fmadd(local, s.radius, f3(s.center));
+        n = s.flip_normals ? -local : local;
+    }
+    pdf = s.inv_surface_area;
+}
+// librender/shape.cpp:293-310 ; shapes/sphere.cpp (sample_direction)
+DEV_NOINLINE DirSample shape_sample_direction(const DShape &s, F3 ref_p, F2 sample) {
+    DirSample ds; ds.delta = false; ds.emitter = -1;
+    if (s.type == MTS_SHAPE_RECTANGLE) {
+        shape_sample_position(s, sample, ds.p, ds.n, ds.pdf);
+        ds.d = ds.p - ref_p;
+        float dist_squared = squared_norm(ds.d);
+        ds.dist = pm_sqrt(dist_squared);
+        ds.d = ds.d / ds.dist;
+        float dp = pm_abs(dot(ds.d, ds.n));
+        ds.pdf *= (dp != 0.f) ? dist_squared / dp : 0.f;
+        return ds;
+    }
+    F3 center = f3(s.center);
+    F3 dc_v = center - ref_p;
+    float dc_2 = squared_norm(dc_v);
+    float radius_adj = s.radius * (s.flip_normals ? (1.f + MTS_RAY_EPSILON) : (1.f - MTS_RAY_EPSILON));
+    if (dc_2 > radius_adj * radius_adj) {
+        float inv_dc = pm_rsqrt(dc_2), sin_theta_max = s.radius * inv_dc, sin_theta_max_2 = sin_theta_max * sin_theta_max,
+              inv_sin_theta_max = pm_rcp(sin_theta_max), cos_theta_max = pm_safe_sqrt(1.f - sin_theta_max_2);
+        float q = pm_fma(cos_theta_max - 1.f, sample.x, 1.f);
+        float sin_theta_2 = sin_theta_max_2 > 0.00068523f ? 1.f - q * q : sin_theta_max_2 * sample.x;
+        float cos_theta = pm_safe_sqrt(1.f - sin_theta_2);
+        float cos_alpha = sin_theta_2 * inv_sin_theta_max + cos_theta * pm_safe_sqrt(pm_fma(-sin_theta_2, inv_sin_theta_max * inv_sin_theta_max, 1.f)),
+              sin_alpha = pm_safe_sqrt(pm_fma(-cos_alpha, cos_alpha, 1.f));
+        float sin_phi, cos_phi; pm_sincos(sample.y * (2.f * MTS_PI), &sin_phi, &cos_phi);
+        F3 d = to_world(make_frame(dc_v * -inv_dc), f3(cos_phi * sin_alpha, sin_phi * sin_alpha, cos_alpha));
+        ds.p = fmadd(d, s.radius, center); ds.n = d; ds.d = ds.p - ref_p;
+        float dist2 = squared_norm(ds.d);
+        ds.dist = pm_sqrt(dist2); ds.d = ds.d / ds.dist;
+        ds.pdf = MTS_INV_TWO_PI / (1.f - cos_theta_max);
+        if (ds.dist == 0.f) ds.pdf = 0.f;
+    } else {
+        F3 d = square_to_uniform_sphere(sample);
+        ds.p = fmadd(d, s.radius, center); ds.n = d; ds.d = ds.p - ref_p;
+        float dist2 = squared_norm(ds.d);
+        ds.dist = pm_sqrt(dist2); ds.d = ds.d / ds.dist;
+        ds.pdf = s.inv_surface_area * dist2 / pm_abs(dot(ds.d, ds.n));
+    }
+    ds.delta = s.radius == 0.f;
+    if (s.flip_normals) ds.n = -ds.n;
+    return ds;
+}
+DEV float shape_pdf_direction(const DShape &s, F3 ref_p, const DirSample &ds) {
+    if (s.type == MTS_SHAPE_RECTANGLE) {                                                      // shape.cpp:312-323
+        float pdf = s.inv_surface_area, dp = pm_abs(dot(ds.d, ds.n));
+        pdf *= (dp != 0.f) ? (ds.dist * ds.dist) / dp : 0.f;
+        return pdf;
+    }
+    float sin_alpha = s.radius * pm_rcp(norm(f3(s.center) - ref_p)), cos_alpha = pm_safe_sqrt(1.f - sin_alpha * sin_alpha);
+    return sin_alpha < 0x1.fffffep-1f ? MTS_INV_TWO_PI / (1.f - cos_alpha) : s.inv_surface_area * (ds.dist * ds.dist) / pm_abs(dot(ds.d, ds.n));
+}
+// emitters/directional.cpp:109-141, emitters/area.cpp:122-165, emitters/constant.cpp:81-111
+DEV DirSample emitter_sample_direction(const DScene &sc, int ei, F3 ref_p, F2 sample, F3 &spec) {
+    const DEmitter &e = sc.emitters[ei];
+    DirSample ds;
+    if (e.type == MTS_EMITTER_DIRECTIONAL) {
+        F3 d = mat_vector(e.to_world.m, f3(0.f, 0.f, 1.f));
+        float dist = 2.f * e.bsphere_radius;
+        ds.p = ref_p - d * dist; ds.n = d; ds.pdf = 1.f; ds.delta = true; ds.d = -d; ds.dist = dist;
+        spec = f3(e.radiance);
+    } else if (e.type == MTS_EMITTER_CONSTANT) {
+        F3 d = square_to_uniform_sphere(sample);
+        float dist = 2.f * e.bsphere_radius;
+        ds.p = ref_p + d * dist; ds.n = -d; ds.pdf = MTS_INV_FOUR_PI; ds.delta = false; ds.d = d; ds.dist = dist;
+        spec = f3(e.radiance) / ds.pdf;
+    } else {
+        ds = shape_sample_direction(sc.shapes[e.shape], ref_p, sample);
+        bool active = dot(ds.d, ds.n) < 0.f && ds.pdf != 0.f;
+        spec = active ? f3(e.radiance) / ds.pdf : f3s(0.f);
+    }
+    ds.emitter = ei;
+    return ds;
+}
+// librender/scene.cpp:168-218
+DEV DirSample sample_emitter_direction(const DScene &sc, F3 ref_p, F2 sample, bool test_visibility, F3 &spec) {
+    DirSample ds; ds.pdf = 0.f; ds.dist = 0.f; ds.delta = false; ds.emitter = -1; ds.p = ds.n = ds.d = f3s(0.f);
+    if (sc.emitter_count == 0) { spec = f3s(0.f); return ds; }
+    if (sc.emitter_count == 1) ds = emitter_sample_direction(sc, 0, ref_p, sample, spec);
+    else {
+        float n = (float) sc.emitter_count, emitter_pdf = 1.f / n;
+        uint32_t index = min((uint32_t) (sample.x * n), (uint32_t) sc.emitter_count - 1);
+        sample.x = (sample.x - index * emitter_pdf) * n;
+        ds = emitter_sample_direction(sc, (int) index, ref_p, sample, spec);
+        ds.pdf *= emitter_pdf;
+        spec = spec * pm_rcp(emitter_pdf);
+    }
+    if (test_visibility && ds.pdf != 0.f) {
+        DRay ray = make_ray(ref_p, ds.d, MTS_RAY_EPSILON * (1.f + hmax_abs(ref_p)), ds.dist * (1.f - MTS_SHADOW_EPSILON));
+        if (ray_test(sc, ray)) spec = f3s(0.f);
+    }
+    return ds;
+}
+// librender/scene.cpp:220-235
+DEV float pdf_emitter_direction(const DScene &sc, F3 ref_p, const DirSample &ds) {
+    const DEmitter &e = sc.emitters[ds.emitter];
+    float value;
+    if (e.type == MTS_EMITTER_DIRECTIONAL) value = 0.f;
+    else if (e.type == MTS_EMITTER_CONSTANT) value = MTS_INV_FOUR_PI;
+    else { float dp = dot(ds.d, ds.n); value = dp < 0.f ? shape_pdf_direction(sc.shapes[e.shape], ref_p, ds) : 0.f; }
+    if (sc.emitter_count == 1) return value;
+    return value * (1.f / sc.emitter_count);
+}
+// si.emitter(scene), render/scene.h:243-253 ; emitter->eval: area.cpp:63-71, constant.cpp:41-44, directional.cpp:75-78
+DEV int hit_emitter(const DScene &sc, const Hit &h) { return hit_valid(h) ? sc.shapes[h.shape].emitter : sc.environment; }
+DEV F3 emitter_eval(const DScene &sc, int ei, float wi_z) {
+    const DEmitter &e = sc.emitters[ei];
+    if (e.type == MTS_EMITTER_AREA) return wi_z > 0.f ? f3(e.radiance) : f3s(0.f);
+    if (e.type == MTS_EMITTER_CONSTANT) return f3(e.radiance);
+    return f3s(0.f);
+}
+// render/interaction.h:178-200
+DEV int target_medium(const DShape &s, F3 n, F3 d) { return dot(d, n) > 0 ? s.exterior : s.interior; }
+DEV F3 null_transmission(const DScene &sc, const DShape &s) { return sc.bsdfs[s.bsdf].type == MTS_BSDF_NULL ? f3s(1.f) : f3s(0.f); }   // null.cpp:70-73, bsdf.cpp:11-14
+DEV float mis_weight(float pdf_a, float pdf_b) { pdf_a *= pdf_a; pdf_b *= pdf_b; return pdf_a > 0.0f ? pdf_a / (pdf_a + pdf_b) : 0.0f; }   // volpath.cpp:479-483
+
+// Geometric normal of a hit without the full shading frame (only needed for medium transitions)
+DEV F3 hit_geo_normal(const DScene &sc, const Hit &h) {
+    const DShape &s = sc.shapes[h.shape];
+    if (s.type == MTS_SHAPE_RECTANGLE) return f3(s.frame_n);
+    Surf sf; complete_surface(sc, h, f3(0.f, 0.f, 1.f), sf);
+    return sf.n;
+}
+
+DEV F3 transmittance_exp(float t, F3 combined) { return f3(pm_exp(-t * combined.x), pm_exp(-t * combined.y), pm_exp(-t * combined.z)); }
+
+// ---------------------------------------------------------------- volpath
+// integrators/volpath.cpp:261-367: NEE with ratio tracking through media and null surfaces
+template <bool COUNT>
+DEV_NOINLINE F3 volpath_sample_emitter(const DScene &sc, F3 ref_p, bool is_medium_interaction, Pcg32 &rng, int medium, uint32_t channel, DirSample &ds, Counters &cnt) {
+    F3 transmittance = f3s(1.f), emitter_val;
+    ds = sample_emitter_direction(sc, ref_p, rng.next_2d(), false, emitter_val);
+    if (ds.pdf == 0.f) return f3s(0.f);
+    bool active = true;
+    DRay ray = spawn_ray(ref_p, ds.d);
+    if (is_medium_interaction) ray.mint = 0.f;
+    float total_dist = 0.f;
+    Hit si; si.t = pm_inf(); si.shape = -1; si.prim = 0; si.p = f3s(0.f); si.uv.x = si.uv.y = 0.f;
+    bool needs_intersection = true;
+    while (active) {
+        float remaining_dist = ds.dist * (1.f - MTS_SHADOW_EPSILON) - total_dist;
+        ray.maxt = remaining_dist;
+        active = active && remaining_dist > 0.f;
+        if (!active) break;
+        if (COUNT) cnt.n_nee_step++;
+        bool escaped_medium = false, active_medium = medium >= 0, active_surface = !active_medium;
+        if (active_medium) {
+            const DMedium &m = sc.media[medium];
+            MediumSample mi = medium_sample_interaction<COUNT>(sc, medium, ray, rng.next_1d(), channel, cnt);
+            if (m.is_homogeneous && ms_valid(mi)) ray.maxt = pm_min(mi.t, remaining_dist);
+            if (needs_intersection) si = ray_intersect(sc, ray);
+            if (si.t < mi.t) mi.t = pm_inf();
+            needs_intersection = false;
+            bool is_spectral = m.has_spectral_extinction != 0, not_spectral = !is_spectral;
+            if (is_spectral) {
+                float t = pm_min(remaining_dist, pm_min(mi.t, si.t)) - mi.mint;
+                F3 tr = transmittance_exp(t, mi.combined);
+                F3 free_flight_pdf = (si.t < mi.t || mi.t > remaining_dist) ? tr : tr * mi.combined;
+                float tr_pdf = pick(free_flight_pdf, channel);
+                transmittance = transmittance * (tr_pdf > 0.f ? tr / tr_pdf : f3s(0.f));
+            }
+            if (mi.t > remaining_dist && ms_valid(mi)) total_dist = ds.dist;
+            if (mi.t > remaining_dist) mi.t = pm_inf();
+            escaped_medium = !ms_valid(mi);
+            active_medium = ms_valid(mi);
+            if (active_medium) {
+                total_dist += mi.t;
+                ray.o = mi.p; ray.mint = 0.f; si.t = si.t - mi.t;
+                if (is_spectral) transmittance = transmittance * mi.sigma_n;
+                if (not_spectral) transmittance = transmittance * (mi.sigma_n / mi.combined);
+            }
+        }
+        bool intersect = active_surface && needs_intersection;
+        if (intersect) si = ray_intersect(sc, ray);
+        needs_intersection = needs_intersection && !intersect;
+        active_surface = active_surface || escaped_medium;
+        if (active_surface) total_dist += si.t;
+        active_surface = active_surface && hit_valid(si) && active && !active_medium;
+        if (active_surface) {
+            const DShape &s = sc.shapes[si.shape];
+            transmittance = transmittance * null_transmission(sc, s);
+            ray = spawn_ray(si.p, ray.d);
+        }
+        ray.maxt = remaining_dist;
+        needs_intersection = needs_intersection || active_surface;
+        active = active && (active_medium || active_surface) && any_nonzero(transmittance);
+        if (active_surface && sc.shapes[si.shape].is_medium_transition) medium = target_medium(sc.shapes[si.shape], hit_geo_normal(sc, si), ray.d);
+    }
+    return transmittance * emitter_val;
+}
+
+// integrators/volpath.cpp:370-465
+template <bool COUNT>
+DEV_NOINLINE F3 volpath_evaluate_direct_light(const DScene &sc, F3 ref_p, Pcg32 &rng, int medium, DRay ray, Hit si, uint32_t channel, bool active, float &emitter_pdf, Counters &cnt) {
+    F3 emitter_val = f3s(0.f), transmittance = f3s(1.f);
+    bool needs_intersection = false;
+    emitter_pdf = 0.f;
+    while (active) {
+        if (COUNT) cnt.n_nee_step++;
+        bool escaped_medium = false, active_medium = medium >= 0, active_surface = !active_medium;
+        if (active_medium) {
+            const DMedium &m = sc.media[medium];
+            MediumSample mi = medium_sample_interaction<COUNT>(sc, medium, ray, rng.next_1d(), channel, cnt);
+            if (m.is_homogeneous && ms_valid(mi)) ray.maxt = mi.t;
+            if (needs_intersection) si = ray_intersect(sc, ray);
+            if (si.t < mi.t) mi.t = pm_inf();
+            bool is_spectral = m.has_spectral_extinction != 0, not_spectral = !is_spectral;
+            if (is_spectral) {
+                float t = pm_min(mi.t, si.t) - mi.mint;                                       // medium.cpp:77-89
+                F3 tr = transmittance_exp(t, mi.combined);
+                F3 free_flight_pdf = si.t < mi.t ? tr : tr * mi.combined;
+                float tr_pdf = pick(free_flight_pdf, channel);
+                transmittance = transmittance * (tr_pdf > 0.f ? tr / tr_pdf : f3s(0.f));
+            }
+            needs_intersection = false;
+            escaped_medium = !ms_valid(mi);
+            active_medium = ms_valid(mi);
+            if (active_medium) {
+                ray.o = mi.p; ray.mint = 0.f; si.t = si.t - mi.t;
+                if (is_spectral) transmittance = transmittance * mi.sigma_n;
+                if (not_spectral) transmittance = transmittance * (mi.sigma_n / mi.combined);
+            }
+        }
+        bool intersect = active_surface && needs_intersection;
+        if (intersect) si = ray_intersect(sc, ray);
+        needs_intersection = needs_intersection && !intersect;
+        active_surface = active_surface || escaped_medium;
+        int emitter = active_surface ? hit_emitter(sc, si) : -1;
+        if (emitter >= 0) {
+            Surf sf; sf.wi = -ray.d; sf.sh.n = f3s(0.f);
+            if (hit_valid(si)) complete_surface(sc, si, ray.d, sf);
+            DirSample ds;                                                                    // render/records.h:168-174
+            ds.p = si.p; ds.n = sf.sh.n; ds.d = si.p - ref_p; ds.dist = norm(ds.d); ds.d = ds.d / ds.dist;
+            if (!hit_valid(si)) ds.d = -sf.wi;
+            ds.emitter = emitter; ds.pdf = 0.f; ds.delta = false;
+            emitter_val = emitter_eval(sc, emitter, sf.wi.z);
+            emitter_pdf = pdf_emitter_direction(sc, ref_p, ds);
+            active = false; active_surface = false; active_medium = false;
+        }
+        active_surface = active_surface && hit_valid(si) && !active_medium;
+        if (active_surface) {
+            const DShape &s = sc.shapes[si.shape];
+            transmittance = transmittance * null_transmission(sc, s);
+            ray = spawn_ray(si.p, ray.d);
+        }
+        needs_intersection = needs_intersection || active_surface;
+        active = active && (active_medium || active_surface) && any_nonzero(transmittance);
+        if (active_surface && sc.shapes[si.shape].is_medium_transition) medium = target_medium(sc.shapes[si.shape], hit_geo_normal(sc, si), ray.d);
+    }
+    return transmittance * emitter_val;
+}
+
+// integrators/volpath.cpp:38-257
+template <bool COUNT>
+DEV F3 volpath_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, bool &valid_out, Counters &cnt) {
+    const uint32_t max_depth = (uint32_t) sc.integrator.max_depth, rr_depth = (uint32_t) sc.integrator.rr_depth;
+    const bool hide_emitters = sc.integrator.hide_emitters != 0;
+    bool valid_ray = !hide_emitters && sc.environment >= 0;
+    float eta = 1.f;
+    F3 throughput = f3s(1.f), result = f3s(0.f);
+    bool active = true, specular_chain = !hide_emitters;
+    uint32_t depth = 0;
+    uint32_t channel = (uint32_t) pm_min(rng.next_1d() * 3.f, 2.f);                          // volpath.cpp:63-67
+    Hit si; si.t = pm_inf(); si.shape = -1; si.prim = 0; si.p = f3s(0.f); si.uv.x = si.uv.y = 0.f;
+    bool needs_intersection = true;
+    for (;;) {
+        active = active && any_nonzero(throughput);
+        float q = pm_min(hmax(throughput) * (eta * eta), .95f);
+        bool perform_rr = depth > rr_depth;
+        active = active && (rng.next_1d() < q || !perform_rr);
+        if (perform_rr) throughput = throughput * pm_rcp(q);
+        bool exceeded_max_depth = depth >= max_depth;
+        if (!active || exceeded_max_depth) break;
+        if (COUNT) cnt.n_iter++;
+        bool active_medium = medium >= 0, active_surface = !active_medium;
+        bool act_null_scatter = false, act_medium_scatter = false, escaped_medium = false;
+        MediumSample mi; mi.t = pm_inf();
+        bool is_spectral = false, not_spectral = false;
+        if (active_medium) {
+            const DMedium &m = sc.media[medium];
+            is_spectral = m.has_spectral_extinction != 0; not_spectral = !is_spectral;
+            mi = medium_sample_interaction<COUNT>(sc, medium, ray, rng.next_1d(), channel, cnt);
+            if (m.is_homogeneous && ms_valid(mi)) ray.maxt = mi.t;
+            if (needs_intersection) si = ray_intersect(sc, ray);
+            needs_intersection = false;
+            if (si.t < mi.t) mi.t = pm_inf();
+            if (is_spectral) {
+                float t = pm_min(mi.t, si.t) - mi.mint;                                       // medium.cpp:77-89
+                F3 tr = transmittance_exp(t, mi.combined);
+                F3 free_flight_pdf = si.t < mi.t ? tr : tr * mi.combined;
+                float tr_pdf = pick(free_flight_pdf, channel);
+                throughput = throughput * (tr_pdf > 0.f ? tr / tr_pdf : f3s(0.f));
+            }
+            escaped_medium = !ms_valid(mi);
+            active_medium = ms_valid(mi);
+            bool null_scatter = rng.next_1d() >= pick(mi.sigma_t, channel) / pick(mi.combined, channel);
+            act_null_scatter = null_scatter && active_medium;
+            act_medium_scatter = !act_null_scatter && active_medium;
+            if (is_spectral && act_null_scatter)
+                throughput = throughput * (mi.sigma_n * pick(mi.combined, channel) / pick(mi.sigma_n, channel));
+            if (act_medium_scatter) depth += 1;
+        }
+        active = active && depth < max_depth;
+        act_medium_scatter = act_medium_scatter && active;
+        if (act_null_scatter) { ray.o = mi.p; ray.mint = 0.f; si.t = si.t - mi.t; }
+        if (act_medium_scatter) {
+            if (is_spectral) throughput = throughput * (mi.sigma_s * pick(mi.combined, channel) / pick(mi.sigma_t, channel));
+            if (not_spectral) throughput = throughput * (mi.sigma_s / mi.sigma_t);
+            const DMedium &m = sc.media[medium];
+            bool sample_emitters = m.sample_emitters != 0;
+            valid_ray = true;
+            specular_chain = !sample_emitters;
+            F3 wi = -ray.d;
+            if (sample_emitters) {
+                DirSample ds;
+                F3 emitted = volpath_sample_emitter<COUNT>(sc, mi.p, true, rng, medium, channel, ds, cnt);
+                float phase_val = phase_eval(sc, m.phase, wi, mi.p, ds.d);
+                result = result + throughput * phase_val * emitted;
+            }
+            float s1 = rng.next_1d(); F2 s2 = rng.next_2d();                                  // left-to-right (SURVEY.md 8(a'))
+            F3 wo = phase_sample(sc, m.phase, make_frame(ray.d), mi.p, s1, s2);              // mi.sh_frame = Frame3f(ray.d), medium.cpp:42
+            ray = spawn_ray(mi.p, wo); ray.mint = 0.0f;
+            needs_intersection = true;
+        }
+        active_surface = active_surface || escaped_medium;
+        bool intersect = active_surface && needs_intersection;
+        if (intersect) si = ray_intersect(sc, ray);
+        Surf sf; sf.wi = -ray.d;
+        if (active_surface && hit_valid(si)) complete_surface(sc, si, ray.d, sf);
+        if (active_surface) {
+            int emitter = hit_emitter(sc, si);
+            if (specular_chain && emitter >= 0) result = result + throughput * emitter_eval(sc, emitter, sf.wi.z);
+        }
+        active_surface = active_surface && hit_valid(si);
+        if (active_surface) {
+            const DShape &shape = sc.shapes[si.shape];
+            const DBsdf &bsdf = sc.bsdfs[shape.bsdf];
+            bool active_e = (bsdf.flags & F_Smooth) != 0 && (depth + 1 < max_depth);
+            if (active_e) {
+                DirSample ds;
+                F3 emitted = volpath_sample_emitter<COUNT>(sc, si.p, false, rng, medium, channel, ds, cnt);
+                F3 wo = to_local(sf.sh, ds.d);
+                F3 bsdf_val = bsdf_eval(bsdf, sf.wi, wo);
+                float bpdf = bsdf_pdf(bsdf, sf.wi, wo);
+                result = result + throughput * bsdf_val * mis_weight(ds.pdf, ds.delta ? 0.f : bpdf) * emitted;
+            }
+            float s1 = rng.next_1d(); F2 s2 = rng.next_2d(); (void) s1;
+            BSDFSample bs;
+            F3 bsdf_val = bsdf_sample(bsdf, sf.wi, s2, bs);
+            throughput = throughput * bsdf_val;
+            eta *= bs.eta;
+            ray = spawn_ray(si.p, to_world(sf.sh, bs.wo));
+            needs_intersection = true;
+            bool non_null_bsdf = !(bs.sampled_type & F_Null);
+            if (non_null_bsdf) depth += 1;
+            valid_ray = valid_ray || non_null_bsdf;
+            specular_chain = specular_chain || (non_null_bsdf && (bs.sampled_type & F_Delta));
+            specular_chain = specular_chain && !(bs.sampled_type & F_Smooth);
+            bool add_emitter = !(bs.sampled_type & F_Delta) && any_nonzero(throughput) && (depth < max_depth);
+            bool intersect2 = needs_intersection && add_emitter;
+            Hit si_new = si;
+            if (intersect2) si_new = ray_intersect(sc, ray);
+            needs_intersection = needs_intersection && !intersect2;
+            float emitter_pdf;
+            F3 emitted = volpath_evaluate_direct_light<COUNT>(sc, si.p, rng, medium, ray, si_new, channel, add_emitter, emitter_pdf, cnt);
+            if (add_emitter && emitter_pdf != 0) result = result + mis_weight(bs.pdf, emitter_pdf) * throughput * emitted;
+            if (shape.is_medium_transition) medium = target_medium(shape, sf.n, ray.d);
+            if (intersect2) si = si_new;
+        }
+        active = active && (active_surface || active_medium);
+    }
+    valid_out = valid_ray;
+    return result;
+}
+
+// ---------------------------------------------------------------- path
+// integrators/path.cpp:100-211
+template <bool COUNT>
+DEV F3 path_sample(const DScene &sc, Pcg32 &rng, DRay ray, bool &valid_out, Counters &cnt) {
+    const int max_depth = sc.integrator.max_depth, rr_depth = sc.integrator.rr_depth;
+    float eta = 1.f, emission_weight = 1.f;
+    F3 throughput = f3s(1.f), result = f3s(0.f);
+    bool active = true;
+    Hit si = ray_intersect(sc, ray);
+    bool valid_ray = hit_valid(si);
+    int emitter = hit_emitter(sc, si);
+    for (int depth = 1;; ++depth) {
+        if (COUNT) cnt.n_iter++;
+        Surf sf; sf.wi = -ray.d;
+        if (hit_valid(si)) complete_surface(sc, si, ray.d, sf);
+        if (emitter >= 0 && active) result = result + emission_weight * throughput * emitter_eval(sc, emitter, sf.wi.z);
+        active = active && hit_valid(si);
+        if (depth > rr_depth) {
+            float q = pm_min(hmax(throughput) * (eta * eta), .95f);
+            active = active && rng.next_1d() < q;
+            throughput = throughput * pm_rcp(q);
+        }
+        if ((uint32_t) depth >= (uint32_t) max_depth || !active) break;
+        const DBsdf &bsdf = sc.bsdfs[sc.shapes[si.shape].bsdf];
+        bool active_e = (bsdf.flags & F_Smooth) != 0;
+        if (active_e) {
+            F3 emitter_val;
+            DirSample ds = sample_emitter_direction(sc, si.p, rng.next_2d(), true, emitter_val);
+            active_e = active_e && ds.pdf != 0.f;
+            F3 wo = to_local(sf.sh, ds.d);
+            F3 bsdf_val = bsdf_eval(bsdf, sf.wi, wo);
+            float bpdf = bsdf_pdf(bsdf, sf.wi, wo);
+            float mis = ds.delta ? 1.f : mis_weight(ds.pdf, bpdf);
+            if (active_e) result = result + mis * throughput * bsdf_val * emitter_val;
+        }
+        float s1 = rng.next_1d(); F2 s2 = rng.next_2d(); (void) s1;
+        BSDFSample bs;
+        F3 bsdf_val = bsdf_sample(bsdf, sf.wi, s2, bs);
+        throughput = throughput * bsdf_val;
+        active = active && any_nonzero(throughput);
+        if (!active) break;
+        eta *= bs.eta;
+        F3 ref_p = si.p;
+        ray = spawn_ray(si.p, to_world(sf.sh, bs.wo));
+        Hit si_bsdf = ray_intersect(sc, ray);
+        emitter = hit_emitter(sc, si_bsdf);
+        if (emitter >= 0) {
+            Surf sb; sb.wi = -ray.d; sb.sh.n = f3s(0.f);
+            if (hit_valid(si_bsdf)) complete_surface(sc, si_bsdf, ray.d, sb);
+            DirSample ds;                                                                    // render/records.h:168-174
+            ds.p = si_bsdf.p; ds.n = sb.sh.n; ds.d = si_bsdf.p - ref_p; ds.dist = norm(ds.d); ds.d = ds.d / ds.dist;
+            if (!hit_valid(si_bsdf)) ds.d = -sb.wi;
+            ds.emitter = emitter; ds.pdf = 0.f; ds.delta = false;
+            float emitter_pdf = !(bs.sampled_type & F_Delta) ? pdf_emitter_direction(sc, ref_p, ds) : 0.f;
+            emission_weight = mis_weight(bs.pdf, emitter_pdf);
+        }
+        si = si_bsdf;
+    }
+    valid_out = valid_ray;
+    return result;
+}
+
+// ---------------------------------------------------------------- sensors
+// sensors/perspective.cpp:210-252 ; sensors/distant.cpp:299-386
+DEV DRay sensor_sample_ray(const DScene &sc, F2 position_sample, F2 aperture_sample, F3 &weight) {
+    const DSensor &se = sc.sensor;
+    if (se.type == MTS_SENSOR_PERSPECTIVE) {
+        F3 near_p = mat_point(se.s2c, f3(position_sample.x + se.ppo[0], position_sample.y + se.ppo[1], 0.f));
+        F3 d = normalize(near_p);
+        float inv_z = pm_rcp(d.z);
+        weight = f3s(1.f);
+        return make_ray(mat_point_affine(se.to_world.m, f3s(0.f)), mat_vector(se.to_world.m, d), se.near_clip * inv_z, se.far_clip * inv_z);
+    }
+    F3 v0 = f3(0.f, 0.f, 1.f);
+    if (se.direction_type == 2) v0 = square_to_uniform_hemisphere(position_sample);
+    else if (se.direction_type == 1) { float s, c; pm_sincos(MTS_PI * position_sample.x, &s, &c); v0.x = c; v0.z = s; }
+    F3 d = se.flip_directions ? mat_vector(se.to_world.m, v0) : mat_vector(se.to_world.m, -v0);
+    F3 ray_target = f3(se.target_point), o;
+    float w = 1.f;
+    if (se.target_type == MTS_DISTANT_TARGET_SHAPE) {
+        F3 n; float pdf;
+        shape_sample_position(se.target_shape, aperture_sample, ray_target, n, pdf);
+        w = 1.f / pdf / se.target_area;
+    } else if (se.target_type == MTS_DISTANT_TARGET_NONE) {
+        F2 offset = square_to_uniform_disk_concentric(aperture_sample);
+        F3 perp_offset = mat_vector(se.to_world.m, f3(offset.x, offset.y, 0.f));
+        ray_target = f3(se.bsphere_center) + perp_offset * se.bsphere_radius;
+        w = 1.f / dot(-d, f3(0.f, 0.f, 1.f));
+    }
+    if (se.target_type == MTS_DISTANT_TARGET_NONE) o = ray_target - d * se.bsphere_radius;
+    else o = ray_target - d * 2.f * se.bsphere_radius;
+    weight = f3s(w);
+    return make_ray(o, d, MTS_RAY_EPSILON, pm_inf());
+}
+
+} // namespace mtsamd

@@ -1,0 +1,166 @@
+// kernels.hip -- HIP kernels of the path / volpath render loop for gfx950 (MI355X) and their launchers.
+//
+// Execution model: one lane per pixel, one wave = an 8x8 Morton tile, one 256-thread workgroup = a
+// 16x16 tile of a 32x32 spiral block.  A lane seeds the reference's per-pixel PCG32 stream
+// (librender/integrator.cpp:198) and runs all samples of its pixel; path state never leaves
+// registers, the scene is read with scalar loads, the only vector memory traffic is the volume
+// gathers and one film update per pixel.  Citations are relative to /root/reference.
+#include <hip/hip_runtime.h>
+#include "integrator_dev.h"
+#include "launch.h"
+
+namespace mtsamd {
+
+// librender/integrator.cpp:233-288 + librender/imageblock.cpp:79-172, fused: the sample is splatted
+// straight into the film.  With the default box filter a sample lands in its own pixel and is summed
+// in registers in sample order (bit-identical to the reference's block accumulation); the rare
+// sample that falls on the left/top pixel edge (u == 0) goes to the neighbour through an atomic.
+template <bool COUNT>
+__device__ __forceinline__ void render_sample(const DScene &sc, Pcg32 &rng, const DBlock &blk, uint32_t lx, uint32_t ly,
+                                              float *__restrict__ film, float acc[5], Counters &cnt) {
+    const DSensor &se = sc.sensor;
+    float px = (float) (lx + (uint32_t) blk.ox), py = (float) (ly + (uint32_t) blk.oy);
+    F2 u = rng.next_2d();
+    F2 position_sample; position_sample.x = px + u.x; position_sample.y = py + u.y;
+    F2 aperture_sample; aperture_sample.x = .5f; aperture_sample.y = .5f;
+    if (se.needs_aperture_sample) aperture_sample = rng.next_2d();
+    (void) rng.next_1d();                                       // wavelength sample (integrator.cpp:252), unused in rgb
+    F2 adjusted;
+    adjusted.x = (position_sample.x - (float) se.crop_x) / (float) se.crop_w;
+    adjusted.y = (position_sample.y - (float) se.crop_y) / (float) se.crop_h;
+    F3 ray_weight;
+    DRay ray = sensor_sample_ray(sc, adjusted, aperture_sample, ray_weight);
+    bool valid;
+    F3 L = sc.integrator.type == MTS_INTEGRATOR_VOLPATH ? volpath_sample<COUNT>(sc, rng, ray, se.medium, valid, cnt)
+                                                         : path_sample<COUNT>(sc, rng, ray, valid, cnt);
+    L = ray_weight * L;
+    float v[5];                                                 // srgb_to_xyz, core/spectrum.h:221-227
+    v[0] = pm_fma(0.180423f, L.z, pm_fma(0.357580f, L.y, 0.412453f * L.x));
+    v[1] = pm_fma(0.072169f, L.z, pm_fma(0.715160f, L.y, 0.212671f * L.x));
+    v[2] = pm_fma(0.950227f, L.z, pm_fma(0.119193f, L.y, 0.019334f * L.x));
+    v[3] = valid ? 1.f : 0.f;
+    v[4] = 1.f;
+    bool ok = true;                                             // imageblock.cpp:85-109: invalid samples are dropped
+    for (int k = 0; k < 5; ++k) ok = ok && v[k] >= -1e-5f && pm_isfinite(v[k]);
+    if (!ok) return;
+    const DRFilter &rf = se.rfilter;
+    const int border = rf.border_size;
+    const int sx = blk.sx + 2 * border, sy = blk.sy + 2 * border;
+    float posx = position_sample.x - ((float) (blk.ox - border) + .5f), posy = position_sample.y - ((float) (blk.oy - border) + .5f);
+    if (rf.radius > 0.5f + MTS_RAY_EPSILON) {
+        int lox = max((int) pm_ceil(posx - rf.radius), 0), loy = max((int) pm_ceil(posy - rf.radius), 0);
+        int hix = min((int) pm_floor(posx + rf.radius), sx - 1), hiy = min((int) pm_floor(posy + rf.radius), sy - 1);
+        uint32_t n = (uint32_t) pm_ceil((rf.radius - 2.f * MTS_RAY_EPSILON) * 2.f);
+        float basex = (float) lox - posx, basey = (float) loy - posy;
+        for (uint32_t yr = 0; yr < n; ++yr) {
+            int y = loy + (int) yr;
+            if (y > hiy) break;
+            float wy = rf.values[min((int) pm_abs((basey + (float) yr) * rf.scale_factor), 31)];     // eval_discretized, core/rfilter.h:62-65
+            int fy = blk.oy - border + y - se.crop_y;
+            for (uint32_t xr = 0; xr < n; ++xr) {
+                int x = lox + (int) xr;
+                if (x > hix) break;
+                float wx = rf.values[min((int) pm_abs((basex + (float) xr) * rf.scale_factor), 31)];
+                float weight = wy * wx;
+                int fx = blk.ox - border + x - se.crop_x;
+                if (fx >= 0 && fy >= 0 && fx < se.crop_w && fy < se.crop_h) {                         // film clipping, imageblock.cpp:49-77
+                    float *dst = film + 5 * ((size_t) fy * se.crop_w + fx);
+                    for (int k = 0; k < 5; ++k) atomicAdd(dst + k, v[k] * weight);
+                }
+            }
+        }
+    } else {
+        int lox = (int) pm_ceil(posx - .5f), loy = (int) pm_ceil(posy - .5f);
+        if (lox == (int) lx && loy == (int) ly) {
+            for (int k = 0; k < 5; ++k) acc[k] += v[k];
+        } else if (lox >= 0 && loy >= 0 && lox < sx && loy < sy) {
+            float *dst = film + 5 * ((size_t) (blk.oy + loy - se.crop_y) * se.crop_w + (blk.ox + lox - se.crop_x));
+            for (int k = 0; k < 5; ++k) atomicAdd(dst + k, v[k]);
+        }
+    }
+}
+
+// librender/integrator.cpp:181-209 (scalar branch) for every block of this launch at once
+template <bool COUNT>
+__global__ void __launch_bounds__(256) render_kernel(DScene sc, const DBlock *__restrict__ blocks, uint32_t n_blocks, uint32_t block_size,
+                                                     uint32_t sample_count, float *__restrict__ film, unsigned long long *__restrict__ counters) {
+    const uint32_t ppb = block_size * block_size;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = gid / ppb, i = gid - b * ppb;
+    if (b >= n_blocks) return;
+    const DBlock blk = blocks[b];
+    const uint32_t lx = compact_bits(i), ly = compact_bits(i >> 1);                           // morton_decode, integrator.cpp:200
+    if (lx >= (uint32_t) blk.sx || ly >= (uint32_t) blk.sy) return;
+    Pcg32 rng;
+    rng.seed(sc.sensor.seed + (uint64_t) blk.id * ppb + i, PCG32_DEFAULT_STREAM);             // sampler.cpp:83-96, integrator.cpp:198
+    float acc[5] = { 0.f, 0.f, 0.f, 0.f, 0.f };
+    Counters cnt; cnt.n_iter = cnt.n_lookup = cnt.n_nee_step = 0;
+    for (uint32_t j = 0; j < sample_count; ++j)
+        render_sample<COUNT>(sc, rng, blk, lx, ly, film, acc, cnt);
+    float *dst = film + 5 * ((size_t) (blk.oy + (int) ly - sc.sensor.crop_y) * sc.sensor.crop_w + (blk.ox + (int) lx - sc.sensor.crop_x));
+    for (int k = 0; k < 5; ++k) atomicAdd(dst + k, acc[k]);
+    if (COUNT) {
+        atomicAdd(counters + 0, (unsigned long long) cnt.n_iter);
+        atomicAdd(counters + 1, (unsigned long long) cnt.n_lookup);
+        atomicAdd(counters + 2, (unsigned long long) cnt.n_nee_step);
+    }
+}
+
+// SamplingIntegrator::sample for caller-supplied rays (librender/python/integrator_v.cpp:62-78)
+__global__ void __launch_bounds__(256) sample_kernel(DScene sc, int32_t n, uint64_t seed_offset, const float *__restrict__ rays /* 6 SoA rows */,
+                                                     float *__restrict__ out_rgb, uint8_t *__restrict__ out_valid) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Pcg32 rng; rng.seed(sc.sensor.seed + seed_offset + (uint64_t) i, PCG32_DEFAULT_STREAM);
+    DRay ray = make_ray(f3(rays[i], rays[n + i], rays[2 * n + i]), f3(rays[3 * n + i], rays[4 * n + i], rays[5 * n + i]), MTS_RAY_EPSILON, pm_inf());
+    bool valid; Counters cnt;
+    F3 L = sc.integrator.type == MTS_INTEGRATOR_VOLPATH ? volpath_sample<false>(sc, rng, ray, sc.sensor.medium, valid, cnt)
+                                                         : path_sample<false>(sc, rng, ray, valid, cnt);
+    out_rgb[3 * i] = L.x; out_rgb[3 * i + 1] = L.y; out_rgb[3 * i + 2] = L.z; out_valid[i] = valid ? 1 : 0;
+}
+
+// Scene::ray_intersect for caller-supplied rays (librender/scene.cpp:117-125)
+__global__ void __launch_bounds__(256) intersect_kernel(DScene sc, int32_t n, const float *__restrict__ o, const float *__restrict__ d,
+                                                        const float *__restrict__ mint, const float *__restrict__ maxt,
+                                                        float *__restrict__ out_t, int32_t *__restrict__ out_shape, int32_t *__restrict__ out_prim,
+                                                        float *__restrict__ out_p, float *__restrict__ out_n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    DRay ray = make_ray(f3(o + 3 * i), f3(d + 3 * i), mint[i], maxt[i]);
+    Hit h = ray_intersect(sc, ray);
+    F3 nn = f3s(0.f);
+    int prim = -1;
+    if (hit_valid(h)) {
+        Surf sf; complete_surface(sc, h, ray.d, sf); nn = sf.n;
+        prim = sc.shapes[h.shape].type == MTS_SHAPE_SPHERE ? 0 : h.prim;
+    }
+    out_t[i] = h.t; out_shape[i] = h.shape; out_prim[i] = prim;
+    out_p[3 * i] = h.p.x; out_p[3 * i + 1] = h.p.y; out_p[3 * i + 2] = h.p.z;
+    out_n[3 * i] = nn.x; out_n[3 * i + 1] = nn.y; out_n[3 * i + 2] = nn.z;
+}
+
+// ---------------------------------------------------------------- launchers
+hipError_t launch_render(const DScene &sc, const DBlock *d_blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,
+                         float *d_film, unsigned long long *d_counters, bool count, hipStream_t stream) {
+    if (n_blocks == 0) return hipSuccess;
+    const uint64_t threads = (uint64_t) n_blocks * block_size * block_size;
+    const uint32_t grid = (uint32_t) ((threads + 255) / 256);
+    if (count) hipLaunchKernelGGL(render_kernel<true>, dim3(grid), dim3(256), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_counters);
+    else hipLaunchKernelGGL(render_kernel<false>, dim3(grid), dim3(256), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_counters);
+    return hipGetLastError();
+}
+
+hipError_t launch_sample(const DScene &sc, int32_t n, uint64_t seed_offset, const float *d_rays, float *d_rgb, uint8_t *d_valid, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sample_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, sc, n, seed_offset, d_rays, d_rgb, d_valid);
+    return hipGetLastError();
+}
+
+hipError_t launch_intersect(const DScene &sc, int32_t n, const float *o, const float *d, const float *mint, const float *maxt,
+                            float *t, int32_t *shape, int32_t *prim, float *p, float *nn, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(intersect_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, sc, n, o, d, mint, maxt, t, shape, prim, p, nn);
+    return hipGetLastError();
+}
+
+} // namespace mtsamd

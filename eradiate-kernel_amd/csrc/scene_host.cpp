@@ -1,0 +1,401 @@
+// scene_host.cpp -- host side of libmtsamd.so: the "plugin constructors" that turn the C-ABI scene
+// description into the flattened device scene (dscene.h), and its upload to HBM.
+//
+// Each block follows the constructor of the reference plugin it stands for (citations relative to
+// /root/reference) with the same float arithmetic (explicit fma where the reference uses fmadd), so the
+// constants the kernels read are the ones a scalar_rgb build would hold.
+#include <cmath>
+#include <cstring>
+#include <algorithm>
+#include "scene_host.h"
+
+namespace mtsamd {
+
+static void mat_transpose(const float *a, float *o) { for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) o[r * 4 + c] = a[c * 4 + r]; }
+// enoki matrix product: result(r, j) = fma chain over k of a(r, k) * b(k, j)
+static void mat_mul(const float *a, const float *b, float *o) {
+    for (int j = 0; j < 4; ++j)
+        for (int r = 0; r < 4; ++r) {
+            float acc = a[r * 4 + 0] * b[0 * 4 + j];
+            for (int k = 1; k < 4; ++k) acc = pm_fma(a[r * 4 + k], b[k * 4 + j], acc);
+            o[r * 4 + j] = acc;
+        }
+}
+static DXf xf_from_abi(const mts_transform &t) { DXf x; memcpy(x.m, t.matrix, 64); memcpy(x.it, t.inverse_transpose, 64); return x; }
+static DXf xf_identity() { DXf x; memset(&x, 0, sizeof(x)); for (int i = 0; i < 4; ++i) x.m[i * 5] = x.it[i * 5] = 1.f; return x; }
+static DXf xf_inverse(const DXf &x) { DXf r; mat_transpose(x.it, r.m); mat_transpose(x.m, r.it); return r; }          // transform.h:59-61
+static DXf xf_mul(const DXf &a, const DXf &b) { DXf r; mat_mul(a.m, b.m, r.m); mat_mul(a.it, b.it, r.it); return r; }  // transform.h:53-56
+static DXf xf_scale(F3 s) { DXf x = xf_identity(); x.m[0] = s.x; x.m[5] = s.y; x.m[10] = s.z; x.it[0] = 1.f / s.x; x.it[5] = 1.f / s.y; x.it[10] = 1.f / s.z; return x; }
+static DXf xf_translate(F3 t) { DXf x = xf_identity(); x.m[3] = t.x; x.m[7] = t.y; x.m[11] = t.z; x.it[12] = -t.x; x.it[13] = -t.y; x.it[14] = -t.z; return x; }
+
+static void bbox_reset(DBBox &b) { for (int i = 0; i < 3; ++i) { b.min[i] = INFINITY; b.max[i] = -INFINITY; } }
+static void bbox_expand(DBBox &b, F3 p) {
+    float v[3] = { p.x, p.y, p.z };
+    for (int i = 0; i < 3; ++i) { b.min[i] = pm_min(b.min[i], v[i]); b.max[i] = pm_max(b.max[i], v[i]); }
+}
+static void bbox_expand(DBBox &b, const DBBox &o) { bbox_expand(b, f3(o.min)); bbox_expand(b, f3(o.max)); }
+static void store3(float *d, F3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+
+static void check_index(int i, int n, const char *what, bool allow_none) {
+    if (i < 0 && allow_none) return;
+    if (i < 0 || i >= n) throw std::runtime_error(std::string("index out of range: ") + what);
+}
+
+// cube.cpp:43-67
+static const float CUBE_VERTICES[24][3] = {
+    { 1, -1, -1 }, { 1, -1, 1 }, { -1, -1, 1 }, { -1, -1, -1 }, { 1, 1, -1 }, { -1, 1, -1 }, { -1, 1, 1 }, { 1, 1, 1 },
+    { 1, -1, -1 }, { 1, 1, -1 }, { 1, 1, 1 }, { 1, -1, 1 }, { 1, -1, 1 }, { 1, 1, 1 }, { -1, 1, 1 }, { -1, -1, 1 },
+    { -1, -1, 1 }, { -1, 1, 1 }, { -1, 1, -1 }, { -1, -1, -1 }, { 1, 1, -1 }, { 1, -1, -1 }, { -1, -1, -1 }, { -1, 1, -1 } };
+static const float CUBE_NORMALS[24][3] = {
+    { 0, -1, 0 }, { 0, -1, 0 }, { 0, -1, 0 }, { 0, -1, 0 }, { 0, 1, 0 }, { 0, 1, 0 }, { 0, 1, 0 }, { 0, 1, 0 },
+    { 1, 0, 0 }, { 1, 0, 0 }, { 1, 0, 0 }, { 1, 0, 0 }, { 0, 0, 1 }, { 0, 0, 1 }, { 0, 0, 1 }, { 0, 0, 1 },
+    { -1, 0, 0 }, { -1, 0, 0 }, { -1, 0, 0 }, { -1, 0, 0 }, { 0, 0, -1 }, { 0, 0, -1 }, { 0, 0, -1 }, { 0, 0, -1 } };
+static const float CUBE_TEXCOORDS[24][2] = {
+    { 0, 1 }, { 1, 1 }, { 1, 0 }, { 0, 0 }, { 0, 1 }, { 1, 1 }, { 1, 0 }, { 0, 0 }, { 0, 1 }, { 1, 1 }, { 1, 0 }, { 0, 0 },
+    { 0, 1 }, { 1, 1 }, { 1, 0 }, { 0, 0 }, { 0, 1 }, { 1, 1 }, { 1, 0 }, { 0, 0 }, { 0, 1 }, { 1, 1 }, { 1, 0 }, { 0, 0 } };
+static const uint32_t CUBE_TRIANGLES[12][3] = {
+    { 0, 1, 2 }, { 3, 0, 2 }, { 4, 5, 6 }, { 7, 4, 6 }, { 8, 9, 10 }, { 11, 8, 10 },
+    { 12, 13, 14 }, { 15, 12, 14 }, { 16, 17, 18 }, { 19, 16, 18 }, { 20, 21, 22 }, { 23, 20, 22 } };
+
+static uint32_t bsdf_flags(int type) {
+    if (type == MTS_BSDF_DIFFUSE) return F_DiffuseReflection | F_FrontSide;                // diffuse.cpp:55
+    if (type == MTS_BSDF_NULL) return F_Null | F_FrontSide | F_BackSide;                   // null.cpp:26
+    return F_GlossyReflection | F_FrontSide;                                               // rpv.cpp:66
+}
+
+// Shape constructors: rectangle.cpp:59-74, cube.cpp:70-112 (+ mesh.cpp), sphere.cpp:80-105
+static DShape build_shape(const mts_shape &d, HostScene &hs, DBBox &shape_bbox, int &prim_count) {
+    DShape s; memset(&s, 0, sizeof(s));
+    s.type = d.type;
+    s.to_world = xf_from_abi(d.to_world);
+    s.bsdf = d.bsdf; s.interior = d.interior_medium; s.exterior = d.exterior_medium; s.emitter = d.emitter;
+    s.is_medium_transition = (d.interior_medium >= 0 || d.exterior_medium >= 0) ? 1 : 0;   // shape.h:341
+    s.flip_normals = d.flip_normals != 0;
+    bbox_reset(shape_bbox);
+    if (d.type == MTS_SHAPE_RECTANGLE) {
+        if (d.flip_normals) s.to_world = xf_mul(s.to_world, xf_scale(f3(1.f, 1.f, -1.f)));
+        s.to_object = xf_inverse(s.to_world);
+        F3 dp_du = mat_vector(s.to_world.m, f3(2.f, 0.f, 0.f)), dp_dv = mat_vector(s.to_world.m, f3(0.f, 2.f, 0.f));
+        F3 n = normalize(mat_vector(s.to_world.it, f3(0.f, 0.f, 1.f)));
+        store3(s.frame_s, dp_du); store3(s.frame_t, dp_dv); store3(s.frame_n, n);
+        s.inv_surface_area = pm_rcp(norm(cross(dp_du, dp_dv)));
+        bbox_expand(shape_bbox, mat_point_affine(s.to_world.m, f3(-1.f, -1.f, 0.f)));
+        bbox_expand(shape_bbox, mat_point_affine(s.to_world.m, f3(1.f, -1.f, 0.f)));
+        bbox_expand(shape_bbox, mat_point_affine(s.to_world.m, f3(1.f, 1.f, 0.f)));
+        bbox_expand(shape_bbox, mat_point_affine(s.to_world.m, f3(-1.f, 1.f, 0.f)));
+        prim_count = 1;
+    } else if (d.type == MTS_SHAPE_CUBE || d.type == MTS_SHAPE_MESH) {
+        s.to_object = xf_inverse(s.to_world);
+        int nv, nf; const float *pos, *nor, *uv; const uint32_t *fc;
+        if (d.type == MTS_SHAPE_CUBE) { nv = 24; nf = 12; pos = &CUBE_VERTICES[0][0]; nor = &CUBE_NORMALS[0][0]; uv = &CUBE_TEXCOORDS[0][0]; fc = &CUBE_TRIANGLES[0][0]; }
+        else { nv = d.vertex_count; nf = d.face_count; pos = d.vertex_positions; nor = d.vertex_normals; uv = d.vertex_texcoords; fc = d.faces;
+               if (!pos || !fc || nv <= 0 || nf <= 0) throw std::runtime_error("mesh: missing vertex / face data"); }
+        // all meshes share one vertex index space; normals / texcoords arrays stay aligned with positions
+        s.vertex_offset = (int32_t) (hs.positions.size() / 3);
+        s.face_offset = (int32_t) (hs.faces.size() / 3);
+        s.has_normals = nor ? 1 : 0; s.has_texcoords = uv ? 1 : 0;
+        for (int i = 0; i < nv; ++i) {
+            F3 p = mat_point_affine(s.to_world.m, f3(pos + 3 * i));
+            bbox_expand(shape_bbox, p);
+            hs.positions.push_back(p.x); hs.positions.push_back(p.y); hs.positions.push_back(p.z);
+            F3 n = f3s(0.f);
+            if (nor) n = normalize(mat_vector(s.to_world.it, f3(nor + 3 * i)));
+            hs.normals.push_back(n.x); hs.normals.push_back(n.y); hs.normals.push_back(n.z);
+            hs.texcoords.push_back(uv ? uv[2 * i] : 0.f); hs.texcoords.push_back(uv ? uv[2 * i + 1] : 0.f);
+        }
+        for (int i = 0; i < 3 * nf; ++i) {
+            if (fc[i] >= (uint32_t) nv) throw std::runtime_error("mesh: face index out of range");
+            hs.faces.push_back(fc[i]);
+        }
+        prim_count = nf;
+    } else if (d.type == MTS_SHAPE_SPHERE) {
+        // to_world * translate(center) * scale(radius); radius / rotation recovered from the columns
+        // (the reference uses enoki's polar decomposition, absent; identical for rotation * uniform scale)
+        DXf tw = xf_mul(s.to_world, xf_mul(xf_translate(f3(d.center)), xf_scale(f3s(d.radius))));
+        F3 c0 = f3(tw.m[0], tw.m[4], tw.m[8]), c1 = f3(tw.m[1], tw.m[5], tw.m[9]), c2 = f3(tw.m[2], tw.m[6], tw.m[10]);
+        float r0 = norm(c0), r1 = norm(c1), r2 = norm(c2);
+        if (pm_abs(r0 - r1) > 1e-6f * r0 || pm_abs(r0 - r2) > 1e-6f * r0 ||
+            pm_abs(dot(c0, c1)) > 1e-6f * r0 * r0 || pm_abs(dot(c0, c2)) > 1e-6f * r0 * r0 || pm_abs(dot(c1, c2)) > 1e-6f * r0 * r0)
+            throw std::runtime_error("'to_world' transform shouldn't contain any scale or shear along the sphere axes");
+        F3 center = f3(tw.m[3], tw.m[7], tw.m[11]);
+        store3(s.center, center); s.radius = r0;
+        F3 q0 = c0 / r0, q1 = c1 / r0, q2 = c2 / r0;
+        float R[9] = { q0.x, q1.x, q2.x, q0.y, q1.y, q2.y, q0.z, q1.z, q2.z };
+        DXf rec = xf_identity();
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) rec.m[r * 4 + c] = R[r * 3 + c] * s.radius;
+        rec.m[3] = center.x; rec.m[7] = center.y; rec.m[11] = center.z;
+        float invm[16]; memset(invm, 0, sizeof(invm));
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) invm[r * 4 + c] = R[c * 3 + r] / s.radius;
+        for (int r = 0; r < 3; ++r) invm[r * 4 + 3] = -(invm[r * 4] * center.x + invm[r * 4 + 1] * center.y + invm[r * 4 + 2] * center.z);
+        invm[15] = 1.f;
+        mat_transpose(invm, rec.it);
+        s.to_world = rec; s.to_object = xf_inverse(rec);
+        s.inv_surface_area = pm_rcp(4.f * MTS_PI * s.radius * s.radius);
+        store3(shape_bbox.min, center - f3s(s.radius)); store3(shape_bbox.max, center + f3s(s.radius));
+        prim_count = 1;
+    } else throw std::runtime_error("unknown shape type");
+    return s;
+}
+
+static DRFilter build_rfilter(int type, float radius, float stddev) {
+    DRFilter f; memset(&f, 0, sizeof(f));
+    f.type = type;
+    if (type == MTS_RFILTER_BOX) f.radius = radius + MTS_RAY_EPSILON;                         // box.cpp:31
+    else if (type == MTS_RFILTER_GAUSSIAN) {                                                    // gaussian.cpp:33-42
+        f.stddev = stddev; f.radius = 4 * stddev; f.alpha = -1.f / (2.f * stddev * stddev); f.bias = pm_exp(f.alpha * (f.radius * f.radius));
+    } else throw std::runtime_error("unknown reconstruction filter");
+    for (int i = 0; i < 31; ++i) {                                                              // rfilter.cpp:9-20 (MTS_FILTER_RESOLUTION = 31)
+        float x = (f.radius * i) / 31;
+        f.values[i] = type == MTS_RFILTER_BOX ? (pm_abs(x) <= f.radius ? 1.f : 0.f) : pm_max(0.f, pm_exp(f.alpha * (x * x)) - f.bias);
+    }
+    f.values[31] = 0;
+    f.scale_factor = 31 / f.radius;
+    f.border_size = (int) std::ceil(f.radius - .5f - 2.f * MTS_RAY_EPSILON);
+    return f;
+}
+
+// Transform::perspective (transform.h:203-220) and perspective_projection (sensor.h:196-231)
+static DXf xf_perspective(float fov, float near_, float far_) {
+    float recip = 1.f / (far_ - near_);
+    float tan_ = std::tan(fov * .5f * (MTS_PI / 180.f)), cot = 1.f / tan_;
+    DXf x; memset(&x, 0, sizeof(x));
+    x.m[0] = cot; x.m[5] = cot; x.m[10] = far_ * recip; x.m[11] = -near_ * far_ * recip; x.m[14] = 1.f;
+    float inv[16]; memset(inv, 0, sizeof(inv));
+    inv[0] = tan_; inv[5] = tan_; inv[15] = 1.f / near_; inv[11] = 1.f; inv[14] = (near_ - far_) / (far_ * near_);
+    mat_transpose(inv, x.it);
+    return x;
+}
+
+HostScene *build_host_scene(const mts_scene_desc *d) {
+    if (!d) throw std::runtime_error("scene description is NULL");
+    if (d->abi_version != MTS_ABI_VERSION) throw std::runtime_error("scene description: ABI version mismatch");
+    std::unique_ptr<HostScene> hsp(new HostScene());
+    HostScene &hs = *hsp;
+    DScene &sc = hs.scene; memset(&sc, 0, sizeof(sc));
+
+    // ---- volumes (texture.cpp:89-92, texture.h:262-269, grid3d.cpp:137-161, volume_data.h:24-33,86-98)
+    for (int i = 0; i < d->volume_count; ++i) {
+        const mts_volume &v = d->volumes[i];
+        DVolume dv; memset(&dv, 0, sizeof(dv));
+        dv.type = v.type; memcpy(dv.value, v.value, 12);
+        DXf w2l = xf_inverse(xf_from_abi(v.to_world));
+        if (v.type == MTS_VOLUME_GRID) {
+            if (!v.data) throw std::runtime_error("gridvolume: missing data");
+            if ((long) v.nx * v.ny * v.nz < 8) throw std::runtime_error("Invalid grid dimensions (must have at least one value at each corner)");
+            if (v.channels != 1 && v.channels != 3) throw std::runtime_error("Unsupported channel count (expected 1 or 3)");
+            if ((int64_t) v.nx * v.ny * v.nz * v.channels >= (int64_t) 1 << 31) throw std::runtime_error("gridvolume: more than 2^31 values");
+            dv.nx = v.nx; dv.ny = v.ny; dv.nz = v.nz; dv.channels = v.channels; dv.filter = v.filter_type; dv.wrap = v.wrap_mode;
+            size_t n = (size_t) v.nx * v.ny * v.nz * v.channels;
+            float mx = -INFINITY;
+            for (size_t k = 0; k < n; ++k) mx = std::max(mx, v.data[k]);
+            dv.max = mx; dv.has_max = 1;
+            hs.grid_data.emplace_back(v.data, v.data + n);
+            if (v.use_grid_bbox) {
+                F3 bmin = f3(v.file_bbox_min), bmax = f3(v.file_bbox_max);
+                w2l = xf_mul(xf_mul(xf_scale(vrcp(bmax - bmin)), xf_translate(-1.f * bmin)), w2l);
+            }
+            if (v.has_max_value) dv.max = v.max_value;
+        } else if (v.type != MTS_VOLUME_CONST) throw std::runtime_error("unknown volume type");
+        else hs.grid_data.emplace_back();
+        memcpy(dv.w2l, w2l.m, 64);
+        DXf inv = xf_inverse(w2l);
+        F3 a = mat_point(inv.m, f3s(0.f)), b = mat_point(inv.m, f3s(1.f));
+        store3(dv.bbox.min, a); store3(dv.bbox.max, a); bbox_expand(dv.bbox, b);
+        hs.volumes.push_back(dv);
+    }
+    // ---- phase functions (hg.cpp:43-49, tabphase.cpp:33-51, distr_1d.h:293-345, blendphase.cpp:33-56)
+    for (int i = 0; i < d->phase_count; ++i) {
+        const mts_phase &p = d->phases[i];
+        DPhase dp; memset(&dp, 0, sizeof(dp));
+        dp.type = p.type; dp.g = p.g; dp.child[0] = p.child[0]; dp.child[1] = p.child[1]; dp.weight_volume = p.weight_volume;
+        hs.tab_pdf.emplace_back(); hs.tab_cdf.emplace_back();
+        if (p.type == MTS_PHASE_HG && (p.g >= 1 || p.g <= -1)) throw std::runtime_error("The asymmetry parameter must lie in the interval (-1, 1)!");
+        if (p.type == MTS_PHASE_BLEND) {
+            check_index(p.child[0], d->phase_count, "blendphase child", false);
+            check_index(p.child[1], d->phase_count, "blendphase child", false);
+            check_index(p.weight_volume, d->volume_count, "blendphase weight", false);
+            if (d->phases[p.child[0]].type == MTS_PHASE_BLEND || d->phases[p.child[1]].type == MTS_PHASE_BLEND)
+                throw std::runtime_error("nested blendphase plugins are not supported by this backend");
+        } else if (p.type == MTS_PHASE_TABULATED) {
+            size_t size = (size_t) p.tab_count;
+            if (size < 2 || !p.tab_values) throw std::runtime_error("ContinuousDistribution: needs at least two entries!");
+            std::vector<float> &pdf = hs.tab_pdf.back(), &cdf = hs.tab_cdf.back();
+            pdf.assign(p.tab_values, p.tab_values + size); cdf.resize(size - 1);
+            dp.size = (int32_t) size; dp.range_x = -1.f; dp.range_y = 1.f;
+            dp.valid_x = dp.valid_y = (uint32_t) -1;
+            double range = double(dp.range_y) - double(dp.range_x), interval_size = range / (size - 1), integral = 0.;
+            for (size_t k = 0; k < size - 1; ++k) {
+                double y0 = (double) pdf[k], y1 = (double) pdf[k + 1];
+                double value = 0.5 * interval_size * (y0 + y1);
+                integral += value;
+                cdf[k] = (float) integral;
+                if (y0 < 0. || y1 < 0.) throw std::runtime_error("ContinuousDistribution: entries must be non-negative!");
+                else if (value > 0.) { if (dp.valid_x == (uint32_t) -1) dp.valid_x = (uint32_t) k; dp.valid_y = (uint32_t) k; }
+            }
+            if (dp.valid_x == (uint32_t) -1) throw std::runtime_error("ContinuousDistribution: no probability mass found!");
+            dp.integral = (float) integral; dp.normalization = (float) (1. / integral);
+            dp.interval_size = (float) interval_size; dp.inv_interval_size = (float) (1. / interval_size);
+        } else if (p.type < MTS_PHASE_ISOTROPIC || p.type > MTS_PHASE_TABULATED) throw std::runtime_error("unknown phase function type");
+        hs.phases.push_back(dp);
+    }
+    // ---- media (medium.cpp:12-29, homogeneous.cpp:21-28, heterogeneous.cpp:21-31)
+    for (int i = 0; i < d->medium_count; ++i) {
+        const mts_medium &m = d->media[i];
+        check_index(m.sigma_t_volume, d->volume_count, "medium sigma_t", false);
+        check_index(m.albedo_volume, d->volume_count, "medium albedo", false);
+        check_index(m.phase, d->phase_count, "medium phase", false);
+        DMedium dm; memset(&dm, 0, sizeof(dm));
+        dm.type = m.type; dm.sigma_t = m.sigma_t_volume; dm.albedo = m.albedo_volume; dm.phase = m.phase; dm.scale = m.scale;
+        dm.sample_emitters = m.sample_emitters != 0; dm.has_spectral_extinction = m.has_spectral_extinction != 0;
+        dm.is_homogeneous = m.type == MTS_MEDIUM_HOMOGENEOUS;
+        if (m.type == MTS_MEDIUM_HETEROGENEOUS) {
+            const DVolume &st = hs.volumes[m.sigma_t_volume];
+            if (!st.has_max) throw std::runtime_error("max() not implemented (constvolume sigma_t in heterogeneous medium)");
+            dm.max_density = dm.scale * st.max;
+            dm.aabb = st.bbox;
+        } else if (m.type != MTS_MEDIUM_HOMOGENEOUS) throw std::runtime_error("unknown medium type");
+        hs.media.push_back(dm);
+    }
+    // ---- BSDFs
+    for (int i = 0; i < d->bsdf_count; ++i) {
+        const mts_bsdf &b = d->bsdfs[i];
+        if (b.type < MTS_BSDF_DIFFUSE || b.type > MTS_BSDF_RPV) throw std::runtime_error("unknown BSDF type");
+        DBsdf db; memset(&db, 0, sizeof(db));
+        db.type = b.type; memcpy(db.reflectance, b.reflectance, 12); memcpy(db.rho_0, b.rho_0, 12); memcpy(db.k, b.k, 12);
+        memcpy(db.g, b.g, 12); memcpy(db.rho_c, b.rho_c, 12); db.flags = bsdf_flags(b.type);
+        hs.bsdfs.push_back(db);
+    }
+    // default BSDFs appended after the user's (shape.cpp:74-80): diffuse 0.5, and diffuse 0 for emitters
+    DBsdf def; memset(&def, 0, sizeof(def)); def.type = MTS_BSDF_DIFFUSE; def.flags = bsdf_flags(MTS_BSDF_DIFFUSE);
+    def.reflectance[0] = def.reflectance[1] = def.reflectance[2] = .5f;
+    const int default_bsdf = (int) hs.bsdfs.size(); hs.bsdfs.push_back(def);
+    def.reflectance[0] = def.reflectance[1] = def.reflectance[2] = 0.f;
+    const int default_emitter_bsdf = (int) hs.bsdfs.size(); hs.bsdfs.push_back(def);
+    // ---- shapes + scene bounding box (scene.cpp:31-40)
+    bbox_reset(sc.bbox);
+    for (int i = 0; i < d->shape_count; ++i) {
+        const mts_shape &s = d->shapes[i];
+        check_index(s.bsdf, d->bsdf_count, "shape bsdf", true);
+        check_index(s.interior_medium, d->medium_count, "shape interior", true);
+        check_index(s.exterior_medium, d->medium_count, "shape exterior", true);
+        check_index(s.emitter, d->emitter_count, "shape emitter", true);
+        DBBox sb; int prim_count;
+        DShape ds = build_shape(s, hs, sb, prim_count);
+        if (ds.bsdf < 0) ds.bsdf = ds.emitter >= 0 ? default_emitter_bsdf : default_bsdf;
+        hs.shapes.push_back(ds);
+        bbox_expand(sc.bbox, sb);
+        for (int k = 0; k < prim_count; ++k) { DPrim p; p.shape = i; p.index = k; hs.prims.push_back(p); }
+    }
+    // ---- emitters + set_scene (scene.cpp:41-52,95-97; directional.cpp:68-73; constant.cpp:35-39; bbox.h:329-332)
+    sc.environment = -1;
+    F3 center = (f3(sc.bbox.max) + f3(sc.bbox.min)) * .5f;
+    float bsphere_radius = pm_max(MTS_RAY_EPSILON, norm(center - f3(sc.bbox.max)) * (1.f + MTS_RAY_EPSILON));
+    for (int i = 0; i < d->emitter_count; ++i) {
+        const mts_emitter &e = d->emitters[i];
+        DEmitter de; memset(&de, 0, sizeof(de));
+        de.type = e.type; de.to_world = xf_from_abi(e.to_world); memcpy(de.radiance, e.radiance, 12); de.shape = e.shape;
+        if (e.type == MTS_EMITTER_AREA) {
+            check_index(e.shape, d->shape_count, "area emitter shape", false);
+            if (hs.shapes[e.shape].type == MTS_SHAPE_CUBE || hs.shapes[e.shape].type == MTS_SHAPE_MESH)
+                throw std::runtime_error("area emitters on meshes are not supported by this backend");
+        } else if (e.type == MTS_EMITTER_CONSTANT) {
+            if (sc.environment >= 0) throw std::runtime_error("Only one environment emitter can be specified per scene.");
+            sc.environment = i;
+        } else if (e.type != MTS_EMITTER_DIRECTIONAL) throw std::runtime_error("unknown emitter type");
+        store3(de.bsphere_center, center); de.bsphere_radius = bsphere_radius;
+        hs.emitters.push_back(de);
+    }
+    // ---- sensor, film, sampler
+    const mts_sensor &s = d->sensor;
+    DSensor &se = sc.sensor;
+    se.type = s.type; se.to_world = xf_from_abi(s.to_world);
+    se.width = s.film_width; se.height = s.film_height;
+    se.crop_x = s.crop_offset[0]; se.crop_y = s.crop_offset[1]; se.crop_w = s.crop_size[0]; se.crop_h = s.crop_size[1];
+    if (se.width <= 0 || se.height <= 0 || se.crop_w <= 0 || se.crop_h <= 0 || se.crop_x < 0 || se.crop_y < 0 ||
+        se.crop_x + se.crop_w > se.width || se.crop_y + se.crop_h > se.height) throw std::runtime_error("film: invalid size / crop window");
+    se.rfilter = build_rfilter(s.rfilter_type, s.rfilter_radius, s.rfilter_stddev);
+    if (se.rfilter.radius > 16.f) throw std::runtime_error("reconstruction filter radius too large");
+    if (s.sample_count <= 0) throw std::runtime_error("sampler: sample_count must be positive");
+    se.sample_count = s.sample_count; se.seed = s.sampler_seed; se.medium = s.medium;
+    check_index(s.medium, d->medium_count, "sensor medium", true);
+    if (s.type == MTS_SENSOR_PERSPECTIVE) {
+        se.near_clip = s.near_clip; se.far_clip = s.far_clip;
+        float fsx = (float) se.width, fsy = (float) se.height;
+        float rel_size_x = (float) se.crop_w / fsx, rel_size_y = (float) se.crop_h / fsy, rel_off_x = (float) se.crop_x / fsx, rel_off_y = (float) se.crop_y / fsy;
+        float aspect = fsx / fsy;
+        DXf c2s = xf_mul(xf_scale(f3(1.f / rel_size_x, 1.f / rel_size_y, 1.f)),
+                  xf_mul(xf_translate(f3(-rel_off_x, -rel_off_y, 0.f)),
+                  xf_mul(xf_scale(f3(-0.5f, -0.5f * aspect, 1.f)),
+                  xf_mul(xf_translate(f3(-1.f, -1.f / aspect, 0.f)), xf_perspective(s.fov_x, s.near_clip, s.far_clip)))));
+        DXf s2c = xf_inverse(c2s);                                                             // perspective.cpp:107-111
+        memcpy(se.s2c, s2c.m, 64);
+        se.ppo[0] = s.principal_point_offset[0] * ((float) se.width / (float) se.crop_w);      // perspective.cpp:101-106
+        se.ppo[1] = s.principal_point_offset[1] * ((float) se.height / (float) se.crop_h);
+        se.needs_aperture_sample = 0;                                                          // perspective.cpp:122
+    } else if (s.type == MTS_SENSOR_DISTANT) {                                                 // distant.cpp:225-297
+        se.direction_type = (se.width == 1 && se.height == 1) ? 0 : (se.height == 1 ? 1 : 2);
+        se.flip_directions = s.distant_flip_directions != 0;
+        se.target_type = s.distant_target_type;
+        memcpy(se.target_point, s.distant_target_point, 12);
+        if (se.target_type == MTS_DISTANT_TARGET_SHAPE) {
+            HostScene scratch; DBBox sb; int pc;
+            if (s.distant_target_shape.type != MTS_SHAPE_RECTANGLE && s.distant_target_shape.type != MTS_SHAPE_SPHERE)
+                throw std::runtime_error("distant ray_target shape must be a rectangle or a sphere in this backend");
+            se.target_shape = build_shape(s.distant_target_shape, scratch, sb, pc);
+            se.target_area = se.target_shape.type == MTS_SHAPE_RECTANGLE
+                ? norm(cross(f3(se.target_shape.frame_s), f3(se.target_shape.frame_t)))
+                : 4.f * MTS_PI * se.target_shape.radius * se.target_shape.radius;
+        } else if (se.target_type != MTS_DISTANT_TARGET_NONE && se.target_type != MTS_DISTANT_TARGET_POINT)
+            throw std::runtime_error("distant sensor: unknown ray_target type");
+        store3(se.bsphere_center, center); se.bsphere_radius = bsphere_radius;
+        se.needs_aperture_sample = 1;                                                          // endpoint.h:244
+    } else throw std::runtime_error("unknown sensor type");
+    // ---- integrator (integrator.cpp:23-39,302-315)
+    const mts_integrator &it = d->integrator;
+    if (it.type != MTS_INTEGRATOR_PATH && it.type != MTS_INTEGRATOR_VOLPATH) throw std::runtime_error("unknown integrator type");
+    if (it.rr_depth <= 0) throw std::runtime_error("\"rr_depth\" must be set to a value greater than zero!");
+    if (it.max_depth < 0 && it.max_depth != -1) throw std::runtime_error("\"max_depth\" must be set to -1 (infinite) or a value >= 0");
+    sc.integrator.type = it.type; sc.integrator.max_depth = it.max_depth; sc.integrator.rr_depth = it.rr_depth; sc.integrator.hide_emitters = it.hide_emitters != 0;
+    hs.integrator = it;
+    sc.volume_count = (int) hs.volumes.size(); sc.phase_count = (int) hs.phases.size(); sc.medium_count = (int) hs.media.size();
+    sc.bsdf_count = (int) hs.bsdfs.size(); sc.shape_count = (int) hs.shapes.size(); sc.prim_count = (int) hs.prims.size();
+    sc.emitter_count = (int) hs.emitters.size();
+    return hsp.release();
+}
+
+// ---------------------------------------------------------------- upload
+#define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+template <typename T> static const T *upload(HostScene &hs, const std::vector<T> &v) {
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    HIP_CHECK(hipMalloc(&p, bytes));
+    hs.device_allocs.push_back(p);
+    if (!v.empty()) HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return (const T *) p;
+}
+
+void upload_host_scene(HostScene &hs, int device) {
+    HIP_CHECK(hipSetDevice(device));
+    hs.device = device;
+    for (size_t i = 0; i < hs.volumes.size(); ++i)
+        if (hs.volumes[i].type == MTS_VOLUME_GRID) hs.volumes[i].data = upload(hs, hs.grid_data[i]);
+    for (size_t i = 0; i < hs.phases.size(); ++i)
+        if (hs.phases[i].type == MTS_PHASE_TABULATED) { hs.phases[i].pdf = upload(hs, hs.tab_pdf[i]); hs.phases[i].cdf = upload(hs, hs.tab_cdf[i]); }
+    DScene &sc = hs.scene;
+    sc.volumes = upload(hs, hs.volumes); sc.phases = upload(hs, hs.phases); sc.media = upload(hs, hs.media);
+    sc.bsdfs = upload(hs, hs.bsdfs); sc.shapes = upload(hs, hs.shapes); sc.prims = upload(hs, hs.prims);
+    sc.emitters = upload(hs, hs.emitters);
+    sc.positions = upload(hs, hs.positions); sc.normals = upload(hs, hs.normals); sc.texcoords = upload(hs, hs.texcoords);
+    sc.faces = upload(hs, hs.faces);
+    HIP_CHECK(hipDeviceSynchronize());
+    hs.uploaded = true;
+}
+
+void free_host_scene(HostScene *hs) {
+    if (!hs) return;
+    if (hs->uploaded) { (void) hipSetDevice(hs->device); for (void *p : hs->device_allocs) (void) hipFree(p); }
+    delete hs;
+}
+
+} // namespace mtsamd

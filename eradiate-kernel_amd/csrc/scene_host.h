@@ -1,0 +1,38 @@
+// scene_host.h -- host-side scene object behind the opaque mts_scene handle.
+#pragma once
+#include <vector>
+#include <string>
+#include <memory>
+#include <atomic>
+#include <stdexcept>
+#include <hip/hip_runtime_api.h>
+#include "dscene.h"
+#include "dmath.h"
+#include "../../include/mtsamd.h"
+
+namespace mtsamd {
+
+struct HostScene {
+    DScene scene;                               // kernel argument (device pointers filled by upload)
+    mts_integrator integrator;
+    std::vector<DVolume> volumes;
+    std::vector<DPhase> phases;
+    std::vector<DMedium> media;
+    std::vector<DBsdf> bsdfs;
+    std::vector<DShape> shapes;
+    std::vector<DPrim> prims;
+    std::vector<DEmitter> emitters;
+    std::vector<float> positions, normals, texcoords;
+    std::vector<uint32_t> faces;
+    std::vector<std::vector<float>> grid_data, tab_pdf, tab_cdf;
+    std::vector<void *> device_allocs;
+    int device = 0;
+    bool uploaded = false;
+    std::atomic<int> stop{0};
+};
+
+HostScene *build_host_scene(const mts_scene_desc *desc);   // throws std::runtime_error
+void upload_host_scene(HostScene &hs, int device);          // throws std::runtime_error
+void free_host_scene(HostScene *hs);
+
+} // namespace mtsamd

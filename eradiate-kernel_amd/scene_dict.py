@@ -1,0 +1,634 @@
+"""load_dict: Mitsuba-style scene dictionaries -> the flattened C-ABI scene description.
+
+Mirrors the conventions of the reference's C++ `load_dict`
+(/root/reference/src/libcore/python/xml_v.cpp:100-272): key "type" selects the plugin, "id" names an
+instance, nested dicts recurse, {"type": "rgb" | "spectrum", "value": ...} become constant colours in
+rgb variants (src/libcore/xml.cpp:1073-1111), {"type": "ref", "id": ...} references an earlier
+instance, media attach to shapes under the keys "interior" / "exterior"
+(src/librender/shape.cpp:58-68), and a property nobody queried is an error (xml_v.cpp:268-269).
+Only the plugins of the path / volpath hot path are known.
+"""
+import ctypes as C
+import math
+import numpy as np
+
+from . import _capi as A
+from .transform import ScalarTransform4f, coordinate_system
+from .volume_io import read_volume
+
+
+def _key_less(a, b):
+    """Properties' SortKey (src/libcore/properties.cpp:41-63): lexicographic with numeric suffixes compared
+    as numbers, so children named shape_2, shape_10 keep their numeric order."""
+    i = 0
+    while i < len(a) and i < len(b) and a[i] == b[i]:
+        i += 1
+    while i > 0 and a[i - 1].isdigit():
+        i -= 1
+    ta, tb = a[i:], b[i:]
+    if ta[:1].isdigit() and tb[:1].isdigit() and ta.isdigit() and tb.isdigit():
+        return int(ta) < int(tb)
+    return ta < tb
+
+
+def sorted_items(d):
+    """Children in the order Properties::objects() yields them (std::map ordered by SortKey)."""
+    import functools
+    keys = sorted(d.keys(), key=functools.cmp_to_key(lambda a, b: -1 if _key_less(a, b) else (1 if _key_less(b, a) else 0)))
+    return [(k, d[k]) for k in keys]
+
+
+class Props:
+    """Properties bag with 'queried' tracking (src/libcore/properties.cpp)."""
+
+    def __init__(self, d, where):
+        if not isinstance(d, dict) or "type" not in d:
+            raise RuntimeError("Missing key 'type' in dictionary: %s" % where)
+        self.d = d
+        self.type = d["type"]
+        self.where = where
+        self.queried = {"type", "id"}
+
+    def has(self, k):
+        return k in self.d
+
+    def get(self, k, default=None):
+        self.queried.add(k)
+        return self.d.get(k, default)
+
+    def finish(self):
+        left = [k for k in self.d if k not in self.queried]
+        if left:
+            raise RuntimeError("Error while loading \"%s\": unreferenced propert%s %s in plugin of type \"%s\""
+                               % (self.where, "ies" if len(left) > 1 else "y", left, self.type))
+
+
+def _xf(t):
+    r = A.Transform()
+    if t is None:
+        t = ScalarTransform4f()
+    if not isinstance(t, ScalarTransform4f):
+        t = ScalarTransform4f(np.asarray(t, dtype=np.float32))
+    r.matrix[:] = t.matrix.reshape(-1).tolist()
+    r.inverse_transpose[:] = t.inverse_transpose.reshape(-1).tolist()
+    return r
+
+
+def _color(v, where, default=None):
+    """float | [r,g,b] | {"type":"rgb","value":..} | {"type":"spectrum"/"uniform","value":x} -> (r,g,b)."""
+    if v is None:
+        v = default
+    if isinstance(v, dict):
+        t = v.get("type")
+        if t == "rgb":
+            if len(v) != 2:
+                raise RuntimeError("'rgb' dictionary should always contain 2 entries ('type' and 'value'), got %d." % len(v))
+            c = np.asarray(v["value"], dtype=np.float32).reshape(-1)
+            if c.size == 1:
+                c = np.repeat(c, 3)
+            return tuple(float(x) for x in c[:3])
+        if t in ("spectrum", "uniform"):
+            val = v.get("value", 1.0)
+            if isinstance(val, (list, tuple)):
+                raise RuntimeError("wavelength-dependent spectra are not supported by the rgb backend: %s" % where)
+            return (float(val),) * 3
+        if t in ("srgb", "srgb_d65"):
+            c = np.asarray(v.get("color"), dtype=np.float32).reshape(-1)
+            return tuple(float(x) for x in c[:3])
+        raise RuntimeError("Unsupported texture / spectrum plugin \"%s\" in %s (rgb constants only)" % (t, where))
+    c = np.asarray(v, dtype=np.float32).reshape(-1)
+    if c.size == 1:
+        return (float(c[0]),) * 3
+    if c.size == 3:
+        return tuple(float(x) for x in c)
+    raise RuntimeError("Cannot interpret %r as a colour in %s" % (v, where))
+
+
+def parse_fov(p, aspect):
+    """src/librender/sensor.cpp:113-167."""
+    if p.has("fov") and p.has("focal_length"):
+        raise RuntimeError("Please specify either a focal length ('focal_length') or a field of view ('fov')!")
+    if p.has("fov"):
+        fov = float(p.get("fov"))
+        axis = str(p.get("fov_axis", "x")).lower()
+        if axis == "smaller":
+            axis = "y" if aspect > 1 else "x"
+        elif axis == "larger":
+            axis = "x" if aspect > 1 else "y"
+    else:
+        f = str(p.get("focal_length", "50mm"))
+        if f.endswith("mm"):
+            f = f[:-2]
+        value = float(f)
+        fov = 2.0 * math.degrees(math.atan(math.sqrt(36 * 36 + 24 * 24) / (2.0 * value)))
+        axis = "diagonal"
+    if axis == "x":
+        result = fov
+    elif axis == "y":
+        result = math.degrees(2.0 * math.atan(math.tan(0.5 * math.radians(fov)) * aspect))
+    elif axis == "diagonal":
+        diagonal = 2.0 * math.tan(0.5 * math.radians(fov))
+        width = diagonal / math.sqrt(1.0 + 1.0 / (aspect * aspect))
+        result = math.degrees(2.0 * math.atan(width * 0.5))
+    else:
+        raise RuntimeError("The 'fov_axis' parameter must be set to one of 'smaller', 'larger', 'diagonal', 'x', or 'y'!")
+    if result <= 0.0 or result >= 180.0:
+        raise RuntimeError("The horizontal field of view must be in the range [0, 180]!")
+    return float(np.float32(result))
+
+
+class SceneBuilder:
+    """Accumulates plugin records; keeps every numpy buffer alive for the lifetime of the description."""
+
+    def __init__(self):
+        self.volumes, self.phases, self.media, self.bsdfs, self.shapes, self.emitters = [], [], [], [], [], []
+        self.sensor = None
+        self.sensor_dict = None
+        self.integrator = None
+        self.keep = []
+        self.instances = {}      # id -> (kind, index)
+        self.info = {}
+
+    # ------------------------------------------------------------ helpers
+    def _register(self, d, kind, index):
+        if isinstance(d, dict) and "id" in d:
+            self.instances[d["id"]] = (kind, index)
+
+    def _resolve_ref(self, d, kind):
+        if isinstance(d, dict) and d.get("type") == "ref":
+            for k in d:
+                if k not in ("type", "id"):
+                    raise RuntimeError("Unexpected key in ref dictionary: %s" % k)
+            rid = d.get("id")
+            if rid not in self.instances:
+                raise RuntimeError("Referenced id \"%s\" not found" % rid)
+            k, i = self.instances[rid]
+            if k != kind:
+                raise RuntimeError("Referenced id \"%s\" is a %s, expected a %s" % (rid, k, kind))
+            return i
+        return None
+
+    # ------------------------------------------------------------ volumes
+    def add_volume(self, v, where, default=None):
+        r = self._resolve_ref(v, "volume")
+        if r is not None:
+            return r
+        rec = A.Volume()
+        rec.to_world = _xf(None)
+        rec.filter_type = A.FILTER_TRILINEAR
+        rec.wrap_mode = A.WRAP_CLAMP
+        if v is None:
+            v = default
+        if isinstance(v, dict) and v.get("type") in ("gridvolume", "constvolume"):
+            p = Props(v, where)
+            rec.to_world = _xf(p.get("to_world"))
+            if p.type == "constvolume":
+                rec.type = A.VOLUME_CONST
+                # constant3d.cpp: "color" texture; load_dict users pass "value" (xml.cpp spectrum shorthand)
+                val = p.get("value", p.get("color", 1.0))
+                rec.value[:] = _color(val, where)
+            else:
+                rec.type = A.VOLUME_GRID
+                if p.has("filename"):
+                    data, meta = read_volume(p.get("filename"))
+                    rec.file_bbox_min[:] = meta["bbox_min"]
+                    rec.file_bbox_max[:] = meta["bbox_max"]
+                elif p.has("data"):
+                    # in-memory grid: array of shape (nz, ny, nx[, channels]) (extension; the reference reads a file)
+                    data = np.asarray(p.get("data"), dtype=np.float32)
+                    if data.ndim == 3:
+                        data = data[..., None]
+                    rec.file_bbox_min[:] = (0.0, 0.0, 0.0)
+                    rec.file_bbox_max[:] = (1.0, 1.0, 1.0)
+                else:
+                    raise RuntimeError("gridvolume: property \"filename\" has not been specified!")
+                data = np.ascontiguousarray(data, dtype=np.float32)
+                if data.ndim != 4:
+                    raise RuntimeError("gridvolume: data must have shape (nz, ny, nx, channels)")
+                self.keep.append(data)
+                rec.data = data.ctypes.data_as(A.fp)
+                rec.nz, rec.ny, rec.nx, rec.channels = data.shape
+                ft = str(p.get("filter_type", "trilinear"))
+                if ft not in ("nearest", "trilinear"):
+                    raise RuntimeError("Invalid filter type \"%s\", must be one of: \"nearest\" or \"trilinear\"!" % ft)
+                rec.filter_type = A.FILTER_NEAREST if ft == "nearest" else A.FILTER_TRILINEAR
+                wm = str(p.get("wrap_mode", "clamp"))
+                if wm not in ("repeat", "mirror", "clamp"):
+                    raise RuntimeError("Invalid wrap mode \"%s\", must be one of: \"repeat\", \"mirror\", or \"clamp\"!" % wm)
+                rec.wrap_mode = {"repeat": A.WRAP_REPEAT, "mirror": A.WRAP_MIRROR, "clamp": A.WRAP_CLAMP}[wm]
+                rec.use_grid_bbox = int(bool(p.get("use_grid_bbox", False)))
+                p.get("raw", False)
+                if p.has("max_value"):
+                    rec.has_max_value = 1
+                    rec.max_value = float(p.get("max_value"))
+            p.finish()
+        else:
+            # float / rgb given where a volume is expected -> constvolume (properties.h:319-366)
+            rec.type = A.VOLUME_CONST
+            rec.value[:] = _color(v, where)
+        self.volumes.append(rec)
+        self._register(v, "volume", len(self.volumes) - 1)
+        return len(self.volumes) - 1
+
+    # ------------------------------------------------------------ phase functions
+    def add_phase(self, d, where):
+        r = self._resolve_ref(d, "phase")
+        if r is not None:
+            return r
+        rec = A.Phase()
+        rec.child[:] = (-1, -1)
+        rec.weight_volume = -1
+        if d is None:
+            rec.type = A.PHASE_ISOTROPIC
+        else:
+            p = Props(d, where)
+            if p.type == "isotropic":
+                rec.type = A.PHASE_ISOTROPIC
+            elif p.type == "hg":
+                rec.type = A.PHASE_HG
+                rec.g = float(p.get("g", 0.8))
+            elif p.type == "rayleigh":
+                rec.type = A.PHASE_RAYLEIGH
+            elif p.type == "tabphase":
+                rec.type = A.PHASE_TABULATED
+                vals = p.get("values")
+                if not isinstance(vals, str):
+                    raise RuntimeError("'values' must be a string")
+                arr = np.array([float(s) for s in vals.replace(",", " ").split()], dtype=np.float32)
+                self.keep.append(arr)
+                rec.tab_values = arr.ctypes.data_as(A.fp)
+                rec.tab_count = arr.size
+            elif p.type == "blendphase":
+                rec.type = A.PHASE_BLEND
+                children = []
+                for k, v in sorted_items(d):  # nested phase functions in Properties order (blendphase.cpp:33-43)
+                    if isinstance(v, dict) and v.get("type") in ("isotropic", "hg", "rayleigh", "tabphase", "blendphase", "ref") and k != "weight":
+                        p.queried.add(k)
+                        children.append(self.add_phase(v, where + "." + k))
+                if len(children) != 2:
+                    raise RuntimeError("BlendPhase: Two child phase functions must be specified!")
+                rec.child[:] = children
+                if not p.has("weight"):
+                    raise RuntimeError("Property \"weight\" has not been specified!")
+                rec.weight_volume = self.add_volume(p.get("weight"), where + ".weight")
+            else:
+                raise RuntimeError("Unknown / unsupported phase function plugin \"%s\"" % p.type)
+            p.finish()
+        self.phases.append(rec)
+        self._register(d, "phase", len(self.phases) - 1)
+        return len(self.phases) - 1
+
+    # ------------------------------------------------------------ media
+    def add_medium(self, d, where):
+        r = self._resolve_ref(d, "medium")
+        if r is not None:
+            return r
+        p = Props(d, where)
+        rec = A.Medium()
+        if p.type == "homogeneous":
+            rec.type = A.MEDIUM_HOMOGENEOUS
+        elif p.type == "heterogeneous":
+            rec.type = A.MEDIUM_HETEROGENEOUS
+        else:
+            raise RuntimeError("Unknown / unsupported medium plugin \"%s\"" % p.type)
+        rec.albedo_volume = self.add_volume(p.get("albedo"), where + ".albedo", default=0.75)
+        rec.sigma_t_volume = self.add_volume(p.get("sigma_t"), where + ".sigma_t", default=1.0)
+        rec.scale = float(p.get("scale", 1.0))
+        rec.has_spectral_extinction = int(bool(p.get("has_spectral_extinction", True)))
+        rec.sample_emitters = int(bool(p.get("sample_emitters", True)))
+        phase = None
+        for k, v in sorted_items(d):         # any nested phase function (medium.cpp:13-22)
+            if isinstance(v, dict) and v.get("type") in ("isotropic", "hg", "rayleigh", "tabphase", "blendphase") \
+                    or (isinstance(v, dict) and v.get("type") == "ref" and self.instances.get(v.get("id"), ("",))[0] == "phase"):
+                if phase is not None:
+                    raise RuntimeError("Only a single phase function can be specified per medium")
+                p.queried.add(k)
+                phase = self.add_phase(v, where + "." + k)
+        rec.phase = phase if phase is not None else self.add_phase(None, where + ".phase")
+        p.finish()
+        self.media.append(rec)
+        self._register(d, "medium", len(self.media) - 1)
+        return len(self.media) - 1
+
+    # ------------------------------------------------------------ BSDFs
+    def add_bsdf(self, d, where):
+        r = self._resolve_ref(d, "bsdf")
+        if r is not None:
+            return r
+        p = Props(d, where)
+        rec = A.Bsdf()
+        if p.type == "diffuse":
+            rec.type = A.BSDF_DIFFUSE
+            rec.reflectance[:] = _color(p.get("reflectance"), where, default=0.5)
+        elif p.type == "null":
+            rec.type = A.BSDF_NULL
+        elif p.type == "rpv":
+            rec.type = A.BSDF_RPV
+            rec.rho_0[:] = _color(p.get("rho_0"), where, default=0.1)
+            rec.g[:] = _color(p.get("g"), where, default=0.0)
+            rec.k[:] = _color(p.get("k"), where, default=0.1)
+            rec.rho_c[:] = _color(p.get("rho_c"), where) if p.has("rho_c") else tuple(rec.rho_0)
+        else:
+            raise RuntimeError("Unknown / unsupported BSDF plugin \"%s\"" % p.type)
+        p.finish()
+        self.bsdfs.append(rec)
+        self._register(d, "bsdf", len(self.bsdfs) - 1)
+        return len(self.bsdfs) - 1
+
+    # ------------------------------------------------------------ shapes
+    def make_shape(self, d, where, in_scene=True):
+        p = Props(d, where)
+        rec = A.Shape()
+        rec.bsdf = rec.interior_medium = rec.exterior_medium = rec.emitter = -1
+        rec.radius = 1.0
+        rec.to_world = _xf(p.get("to_world"))
+        if p.type == "rectangle":
+            rec.type = A.SHAPE_RECTANGLE
+            rec.flip_normals = int(bool(p.get("flip_normals", False)))
+        elif p.type == "cube":
+            rec.type = A.SHAPE_CUBE
+        elif p.type == "sphere":
+            rec.type = A.SHAPE_SPHERE
+            rec.flip_normals = int(bool(p.get("flip_normals", False)))
+            rec.center[:] = tuple(float(x) for x in np.asarray(p.get("center", (0, 0, 0)), dtype=np.float32))
+            rec.radius = float(p.get("radius", 1.0))
+        elif p.type == "mesh":
+            # in-memory triangle mesh (extension standing in for the obj / ply loaders)
+            rec.type = A.SHAPE_MESH
+            pos = np.ascontiguousarray(p.get("vertex_positions"), dtype=np.float32).reshape(-1, 3)
+            faces = np.ascontiguousarray(p.get("faces"), dtype=np.uint32).reshape(-1, 3)
+            self.keep += [pos, faces]
+            rec.vertex_positions = pos.ctypes.data_as(A.fp)
+            rec.faces = faces.ctypes.data_as(C.POINTER(C.c_uint32))
+            rec.vertex_count, rec.face_count = pos.shape[0], faces.shape[0]
+            if p.has("vertex_normals"):
+                nor = np.ascontiguousarray(p.get("vertex_normals"), dtype=np.float32).reshape(-1, 3)
+                self.keep.append(nor)
+                rec.vertex_normals = nor.ctypes.data_as(A.fp)
+            if p.has("vertex_texcoords"):
+                uv = np.ascontiguousarray(p.get("vertex_texcoords"), dtype=np.float32).reshape(-1, 2)
+                self.keep.append(uv)
+                rec.vertex_texcoords = uv.ctypes.data_as(A.fp)
+        else:
+            raise RuntimeError("Unknown / unsupported shape plugin \"%s\"" % p.type)
+        emitter_dict = None
+        for k, v in sorted_items(d):
+            if k in p.queried or not isinstance(v, dict):
+                continue
+            t = v.get("type")
+            kind = self.instances.get(v.get("id"), ("",))[0] if t == "ref" else None
+            if t in ("diffuse", "null", "rpv") or kind == "bsdf":
+                if rec.bsdf >= 0:
+                    raise RuntimeError("Only a single BSDF child object can be specified per shape.")
+                p.queried.add(k)
+                rec.bsdf = self.add_bsdf(v, where + "." + k)
+            elif t in ("homogeneous", "heterogeneous") or kind == "medium":
+                p.queried.add(k)
+                if k == "interior":
+                    rec.interior_medium = self.add_medium(v, where + "." + k)
+                elif k == "exterior":
+                    rec.exterior_medium = self.add_medium(v, where + "." + k)
+                else:
+                    self.add_medium(v, where + "." + k)   # shape.cpp:58-68: other names are ignored
+            elif t == "area":
+                if emitter_dict is not None:
+                    raise RuntimeError("Only a single Emitter child object can be specified per shape.")
+                p.queried.add(k)
+                emitter_dict = v
+        p.finish()
+        if not in_scene:
+            return rec, None
+        return rec, emitter_dict
+
+    def add_shape(self, d, where):
+        rec, emitter_dict = self.make_shape(d, where)
+        self.shapes.append(rec)
+        idx = len(self.shapes) - 1
+        if emitter_dict is not None:
+            ep = Props(emitter_dict, where + ".emitter")
+            e = A.Emitter()
+            e.type = A.EMITTER_AREA
+            e.to_world = _xf(None)
+            e.radiance[:] = _color(ep.get("radiance"), where, default=1.0)
+            e.shape = idx
+            ep.finish()
+            self.emitters.append(e)
+            self.shapes[idx].emitter = len(self.emitters) - 1
+        self._register(d, "shape", idx)
+        return idx
+
+    # ------------------------------------------------------------ emitters
+    def add_emitter(self, d, where):
+        p = Props(d, where)
+        e = A.Emitter()
+        e.shape = -1
+        if p.type == "directional":
+            e.type = A.EMITTER_DIRECTIONAL
+            if p.has("direction"):
+                if p.has("to_world"):
+                    raise RuntimeError("Only one of the parameters 'direction' and 'to_world' can be specified at the same time!'")
+                direction = np.asarray(p.get("direction"), dtype=np.float32)
+                direction = (direction / np.sqrt(np.dot(direction, direction), dtype=np.float32)).astype(np.float32)
+                up, _ = coordinate_system(direction)                       # directional.cpp:55-60
+                e.to_world = _xf(ScalarTransform4f.look_at([0, 0, 0], direction, up))
+            else:
+                e.to_world = _xf(p.get("to_world"))
+            e.radiance[:] = _color(p.get("irradiance"), where, default=1.0)
+        elif p.type == "constant":
+            e.type = A.EMITTER_CONSTANT
+            e.to_world = _xf(None)
+            e.radiance[:] = _color(p.get("radiance"), where, default=1.0)
+        elif p.type == "area":
+            raise RuntimeError("Can't sample from an area emitter without an associated Shape.")
+        else:
+            raise RuntimeError("Unknown / unsupported emitter plugin \"%s\"" % p.type)
+        p.finish()
+        self.emitters.append(e)
+        return len(self.emitters) - 1
+
+    # ------------------------------------------------------------ sensor
+    def set_sensor(self, d, where):
+        p = Props(d, where)
+        s = A.Sensor()
+        s.medium = -1
+        s.distant_target_shape.bsdf = s.distant_target_shape.interior_medium = -1
+        s.distant_target_shape.exterior_medium = s.distant_target_shape.emitter = -1
+        # film (src/librender/film.cpp:14-50, src/films/hdrfilm.cpp)
+        fd = p.get("film", {"type": "hdrfilm"})
+        fp_ = Props(fd, where + ".film")
+        if fp_.type != "hdrfilm":
+            raise RuntimeError("Unknown / unsupported film plugin \"%s\"" % fp_.type)
+        s.film_width = int(fp_.get("width", 768))
+        s.film_height = int(fp_.get("height", 576))
+        s.crop_offset[:] = (int(fp_.get("crop_offset_x", 0)), int(fp_.get("crop_offset_y", 0)))
+        s.crop_size[:] = (int(fp_.get("crop_width", s.film_width)), int(fp_.get("crop_height", s.film_height)))
+        if (s.crop_offset[0] < 0 or s.crop_offset[1] < 0 or s.crop_size[0] <= 0 or s.crop_size[1] <= 0 or
+                s.crop_offset[0] + s.crop_size[0] > s.film_width or s.crop_offset[1] + s.crop_size[1] > s.film_height):
+            raise RuntimeError("Invalid crop window specification!")
+        for k in ("pixel_format", "component_format", "file_format", "high_quality_edges"):
+            fp_.get(k)
+        rf = fp_.get("rfilter", {"type": "gaussian"})
+        rp = Props(rf, where + ".film.rfilter")
+        s.rfilter_radius, s.rfilter_stddev = 0.5, 0.5
+        if rp.type == "box":
+            s.rfilter_type = A.RFILTER_BOX
+            s.rfilter_radius = float(rp.get("radius", 0.5))
+        elif rp.type == "gaussian":
+            s.rfilter_type = A.RFILTER_GAUSSIAN
+            s.rfilter_stddev = float(rp.get("stddev", 0.5))
+        else:
+            raise RuntimeError("Unknown / unsupported reconstruction filter plugin \"%s\"" % rp.type)
+        rp.finish()
+        fp_.finish()
+        # sampler (src/librender/sensor.cpp:44-49, src/librender/sampler.cpp:11-18)
+        sd = p.get("sampler", {"type": "independent", "sample_count": 4})
+        sp = Props(sd, where + ".sampler")
+        if sp.type != "independent":
+            raise RuntimeError("Unknown / unsupported sampler plugin \"%s\" (parity target is 'independent')" % sp.type)
+        s.sample_count = int(sp.get("sample_count", 4))
+        s.sampler_seed = int(sp.get("seed", 0))
+        sp.finish()
+        if float(p.get("shutter_open", 0.0)) != float(p.get("shutter_close", 0.0)):
+            raise RuntimeError("motion blur (shutter_open != shutter_close) is not supported")
+        if p.has("medium"):
+            s.medium = self.add_medium(p.get("medium"), where + ".medium")
+        if p.type == "perspective":
+            s.type = A.SENSOR_PERSPECTIVE
+            tw = p.get("to_world")
+            tw = ScalarTransform4f() if tw is None else tw
+            m = tw.matrix[:3, :3].astype(np.float64)
+            if np.any(np.abs(m @ m.T - np.eye(3)) > 1e-3):                 # transform.h:300-312, perspective.cpp:85-86
+                raise RuntimeError("Scale factors in the camera-to-world transformation are not allowed!")
+            s.to_world = _xf(tw)
+            s.near_clip = float(p.get("near_clip", 1e-2))
+            s.far_clip = float(p.get("far_clip", 1e4))
+            p.get("focus_distance")
+            if s.near_clip <= 0:
+                raise RuntimeError("The 'near_clip' parameter must be greater than zero!")
+            if s.far_clip <= s.near_clip:
+                raise RuntimeError("The 'far_clip' parameter must be greater than 'near_clip'.")
+            s.fov_x = parse_fov(p, s.film_width / float(s.film_height))
+            s.principal_point_offset[:] = (float(p.get("principal_point_offset_x", 0.0)),
+                                           float(p.get("principal_point_offset_y", 0.0)))
+        elif p.type == "distant":
+            s.type = A.SENSOR_DISTANT
+            if p.has("direction"):                                         # distant.cpp:243-259
+                if p.has("to_world"):
+                    raise RuntimeError("Only one of the parameters 'direction' and 'to_world'can be specified at the same time!'")
+                direction = np.asarray(p.get("direction"), dtype=np.float32)
+                direction = (direction / np.sqrt(np.dot(direction, direction), dtype=np.float32)).astype(np.float32)
+                if p.has("orientation"):
+                    up = np.cross(direction, np.asarray(p.get("orientation"), dtype=np.float32)).astype(np.float32)
+                    up = (up / np.sqrt(np.dot(up, up), dtype=np.float32)).astype(np.float32)
+                else:
+                    _, up = coordinate_system(direction)
+                s.to_world = _xf(ScalarTransform4f.look_at([0, 0, 0], direction, up))
+            else:
+                s.to_world = _xf(p.get("to_world"))
+            s.distant_flip_directions = int(bool(p.get("flip_directions", False)))
+            s.distant_target_type = A.DISTANT_TARGET_NONE
+            if p.has("ray_target"):
+                rt = p.get("ray_target")
+                if isinstance(rt, dict):
+                    s.distant_target_type = A.DISTANT_TARGET_SHAPE
+                    rec, _ = self.make_shape(rt, where + ".ray_target", in_scene=False)
+                    s.distant_target_shape = rec
+                else:
+                    s.distant_target_type = A.DISTANT_TARGET_POINT
+                    s.distant_target_point[:] = tuple(float(x) for x in np.asarray(rt, dtype=np.float32))
+            if p.has("ray_origin"):
+                raise RuntimeError("distant sensor: 'ray_origin' shapes are not supported by this backend")
+        else:
+            raise RuntimeError("Unknown / unsupported sensor plugin \"%s\"" % p.type)
+        p.finish()
+        self.sensor = s
+
+    # ------------------------------------------------------------ integrator
+    def set_integrator(self, d, where):
+        p = Props(d, where)
+        it = A.Integrator()
+        if p.type == "path":
+            it.type = A.INTEGRATOR_PATH
+        elif p.type == "volpath":
+            it.type = A.INTEGRATOR_VOLPATH
+        else:
+            raise RuntimeError("Unknown / unsupported integrator plugin \"%s\"" % p.type)
+        it.max_depth = int(p.get("max_depth", -1))
+        it.rr_depth = int(p.get("rr_depth", 5))
+        it.hide_emitters = int(bool(p.get("hide_emitters", False)))
+        it.block_size = int(p.get("block_size", 0))
+        it.samples_per_pass = int(p.get("samples_per_pass", -1))
+        it.timeout = float(p.get("timeout", -1.0))
+        if it.rr_depth <= 0:
+            raise RuntimeError("\"rr_depth\" must be set to a value greater than zero!")
+        if it.max_depth < 0 and it.max_depth != -1:
+            raise RuntimeError("\"max_depth\" must be set to -1 (infinite) or a value >= 0")
+        p.finish()
+        self.integrator = it
+
+    # ------------------------------------------------------------ scene
+    def load(self, d):
+        if not isinstance(d, dict) or d.get("type") != "scene":
+            raise RuntimeError("load_dict(): the top-level dictionary must have type 'scene' in this backend")
+        SHAPES = ("rectangle", "cube", "sphere", "mesh")
+        for k, v in sorted_items(d):          # scene.cpp:23: props.objects() order
+            if k in ("type", "id"):
+                continue
+            if not isinstance(v, dict):
+                raise RuntimeError("Unexpected property \"%s\" at the scene level" % k)
+            t = v.get("type")
+            if t == "ref":
+                raise RuntimeError("Reference found at the scene level: %s" % k)
+            if t in SHAPES:
+                self.add_shape(v, k)
+            elif t in ("directional", "constant", "area"):
+                self.add_emitter(v, k)
+            elif t in ("perspective", "distant"):
+                if self.sensor is not None:
+                    raise RuntimeError("this backend supports a single sensor per scene")
+                self.set_sensor(v, k)
+            elif t in ("path", "volpath"):
+                if self.integrator is not None:
+                    raise RuntimeError("Only one integrator can be specified per scene.")
+                self.set_integrator(v, k)
+            elif t in ("diffuse", "null", "rpv"):
+                self.add_bsdf(v, k)
+            elif t in ("homogeneous", "heterogeneous"):
+                self.add_medium(v, k)
+            elif t in ("isotropic", "hg", "rayleigh", "tabphase", "blendphase"):
+                self.add_phase(v, k)
+            elif t in ("gridvolume", "constvolume"):
+                self.add_volume(v, k)
+            else:
+                raise RuntimeError("Unknown / unsupported plugin \"%s\" (key \"%s\")" % (t, k))
+        if self.sensor is None:
+            raise RuntimeError("No sensors found! (this backend does not instantiate a default camera)")
+        if self.integrator is None:
+            self.set_integrator({"type": "path"}, "integrator")          # scene.cpp:88-92
+        return self.finish()
+
+    def finish(self):
+        desc = A.SceneDesc()
+        desc.abi_version = A.MTS_ABI_VERSION
+
+        def arr(cls, items):
+            a = (cls * max(len(items), 1))(*items)
+            self.keep.append(a)
+            return a
+        desc.volumes, desc.volume_count = arr(A.Volume, self.volumes), len(self.volumes)
+        desc.phases, desc.phase_count = arr(A.Phase, self.phases), len(self.phases)
+        desc.media, desc.medium_count = arr(A.Medium, self.media), len(self.media)
+        desc.bsdfs, desc.bsdf_count = arr(A.Bsdf, self.bsdfs), len(self.bsdfs)
+        desc.shapes, desc.shape_count = arr(A.Shape, self.shapes), len(self.shapes)
+        desc.emitters, desc.emitter_count = arr(A.Emitter, self.emitters), len(self.emitters)
+        desc.sensor = self.sensor
+        desc.integrator = self.integrator
+        self.keep.append(desc)
+        return desc
+
+
+def build_scene_desc(d):
+    """Returns (SceneDesc, keepalive). The keepalive object owns every buffer the description points to."""
+    b = SceneBuilder()
+    desc = b.load(d)
+    return desc, b

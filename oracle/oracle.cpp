@@ -1,0 +1,1307 @@
+// oracle.cpp -- TEST INFRASTRUCTURE, not product code.
+//
+// CPU restatement ("oracle") of the reference's scalar_rgb path / volpath render loop.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load liboracle.so;
+// the product path (libmtsamd.so) never links, loads or calls anything in this directory.
+//
+// Pinning status: the reference can be neither compiled nor imported here
+// (enoki and every other submodule are absent), so this restatement is pinned by the reference's
+// own in-tree known answers -- TEA literals, phase-function closed forms, warp corner cases,
+// spiral order, rectangle hit counts, the directional-emitter matrix, the distant-sensor analytic
+// render -- all checked in tests/test_oracle_*.py.  The reference holds NO numeric pin for volpath
+// itself (its Z-test references live in the absent resources/data submodule), so for volpath the
+// status is "parity unpinned by in-tree data"; closed-form radiative-transfer cases
+// (tests/test_oracle_transport.py) stand in.
+//
+// Every function cites the reference file:line it follows (relative to /root/reference).
+// Semantics restated: scalar_rgb (Float = float, Spectrum = Color3f): `any_or<true>(m)` == m,
+// `none_or<false>(m)` == !m, sampler draws happen regardless of the mask argument.
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <thread>
+#include <atomic>
+#include <mutex>
+#include <chrono>
+#include <xmmintrin.h>
+#include "oracle_scene.h"
+#include "oracle.h"
+
+namespace orc {
+
+struct Counters { uint64_t n_iter = 0, n_lookup = 0, n_nee_step = 0; };
+
+// ---------------------------------------------------------------- sampler
+// src/librender/sampler.cpp:83-96 (scalar branch), src/samplers/independent.cpp:73-82
+struct Sampler {
+    PCG32 rng; uint64_t base_seed;
+    void seed(uint64_t seed_offset) { rng.seed(base_seed + seed_offset, PCG32_DEFAULT_STREAM); }
+    float next_1d() { return rng.next_float32(); }
+    P2 next_2d() { P2 p; p.x = next_1d(); p.y = next_1d(); return p; }
+};
+
+// ---------------------------------------------------------------- interactions
+// include/mitsuba/render/interaction.h
+struct SurfaceInteraction {
+    float t; V3 p, n; P2 uv; Frame sh_frame; V3 dp_du, dp_dv, wi;
+    int shape, prim_index;
+    bool is_valid() const { return t != pm_inf(); }
+    V3 to_world(V3 v) const { return sh_frame.to_world(v); }
+    V3 to_local(V3 v) const { return sh_frame.to_local(v); }
+};
+struct MediumInteraction {
+    float t; V3 p; Frame sh_frame; V3 wi;
+    V3 sigma_s, sigma_n, sigma_t, combined_extinction; float mint; int medium;
+    bool is_valid() const { return t != pm_inf(); }
+};
+// interaction.h:58-61
+static inline Ray spawn_ray(V3 p, V3 d) { return make_ray(p, d, (1.f + hmax_abs(p)) * RayEpsilon, pm_inf()); }
+
+struct PreliminaryIntersection { float t; P2 prim_uv; int prim_index, shape; };
+
+// ---------------------------------------------------------------- primitives
+// rectangle.cpp:139-155
+static inline float rectangle_intersect(const Shape &s, const Ray &ray_, P2 *uv) {
+    Ray ray = xf_ray_affine(s.to_object, ray_);
+    float t = -ray.o.z * ray.d_rcp.z;
+    V3 local = ray(t);
+    bool active = t >= ray.mint && t <= ray.maxt && pm_abs(local.x) <= 1.f && pm_abs(local.y) <= 1.f;
+    uv->x = local.x; uv->y = local.y;
+    return active ? t : pm_inf();
+}
+// mesh.h:195-226 (Moeller-Trumbore)
+static inline float triangle_intersect(const Shape &s, int index, const Ray &ray, P2 *uv) {
+    const uint32_t *fi = &s.faces[3 * index];
+    const float *P = s.positions.data();
+    V3 p0 = v3(P[3 * fi[0]], P[3 * fi[0] + 1], P[3 * fi[0] + 2]), p1 = v3(P[3 * fi[1]], P[3 * fi[1] + 1], P[3 * fi[1] + 2]),
+       p2 = v3(P[3 * fi[2]], P[3 * fi[2] + 1], P[3 * fi[2] + 2]);
+    V3 e1 = p1 - p0, e2 = p2 - p0;
+    V3 pvec = cross(ray.d, e2);
+    float inv_det = pm_rcp(dot(e1, pvec));
+    V3 tvec = ray.o - p0;
+    float u = dot(tvec, pvec) * inv_det;
+    bool active = u >= 0.f && u <= 1.f;
+    V3 qvec = cross(tvec, e1);
+    float v = dot(ray.d, qvec) * inv_det;
+    active = active && v >= 0.f && u + v <= 1.f;
+    float t = dot(e2, qvec) * inv_det;
+    active = active && t >= ray.mint && t <= ray.maxt;
+    uv->x = u; uv->y = v;
+    return active ? t : pm_inf();
+}
+// math.h:371-411 in double precision
+static inline bool solve_quadratic_d(double a, double b, double c, double *x0, double *x1) {
+    bool linear_case = a == 0.0, valid_linear = linear_case && b != 0.0;
+    *x0 = *x1 = -c / b;
+    double discrim = std::fma(b, b, -(4.0 * a * c));
+    bool valid_quadratic = !linear_case && discrim >= 0.0;
+    if (valid_quadratic) {
+        double sqrt_discrim = std::sqrt(discrim);
+        double temp = -0.5 * (b + std::copysign(sqrt_discrim, b));
+        double x0p = temp / a, x1p = c / temp;
+        double x0m = std::min(x0p, x1p), x1m = std::max(x0p, x1p);
+        *x0 = x0m; *x1 = x1m;
+    }
+    return valid_linear || valid_quadratic;
+}
+// sphere.cpp:272-306 (double precision on the CPU, sphere.cpp:276)
+static inline float sphere_intersect(const Shape &s, const Ray &ray) {
+    double mint = ray.mint, maxt = ray.maxt;
+    double ox = (double) ray.o.x - (double) s.center.x, oy = (double) ray.o.y - (double) s.center.y, oz = (double) ray.o.z - (double) s.center.z;
+    double dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
+    double A = std::fma(dz, dz, std::fma(dy, dy, dx * dx));
+    double B = 2.0 * std::fma(oz, dz, std::fma(oy, dy, ox * dx));
+    double C = std::fma(oz, oz, std::fma(oy, oy, ox * ox)) - (double) s.radius * (double) s.radius;
+    double near_t, far_t;
+    bool found = solve_quadratic_d(A, B, C, &near_t, &far_t);
+    bool out_bounds = !(near_t <= maxt && far_t >= mint);
+    bool in_bounds = near_t < mint && far_t > maxt;
+    bool active = found && !out_bounds && !in_bounds;
+    return active ? (near_t < mint ? (float) far_t : (float) near_t) : pm_inf();
+}
+
+// ---------------------------------------------------------------- scene traversal
+// Closest hit with the semantics of ShapeKDTree::ray_intersect_scalar (kdtree.h:2078-2171):
+// the ray is first clipped against the scene bounding box (:2095-2098), every primitive whose
+// t lies in [ray.mint, ray.maxt] is a candidate, ray.maxt shrinks to the accepted t (:2152-2154),
+// and a later primitive at exactly the same t replaces the earlier one (the test is `t <= maxt`).
+// The kd-tree's visiting order is replaced by shape / primitive declaration order.
+static inline PreliminaryIntersection ray_intersect_preliminary(const Scene &sc, Ray ray, bool shadow_ray) {
+    PreliminaryIntersection pi; pi.t = pm_inf(); pi.prim_uv.x = pi.prim_uv.y = 0.f; pi.prim_index = 0; pi.shape = -1;
+    float bmint, bmaxt;
+    bbox_ray_intersect(sc.bbox, ray, &bmint, &bmaxt);
+    float mint = std::max(ray.mint, bmint), maxt = std::min(ray.maxt, bmaxt);
+    if (!(mint <= maxt)) return pi;
+    for (size_t i = 0; i < sc.prims.size(); ++i) {
+        const Shape &s = sc.shapes[sc.prims[i].shape];
+        P2 uv = { 0.f, 0.f }; float t;
+        if (s.type == MTS_SHAPE_RECTANGLE) t = rectangle_intersect(s, ray, &uv);
+        else if (s.type == MTS_SHAPE_SPHERE) t = sphere_intersect(s, ray);
+        else t = triangle_intersect(s, sc.prims[i].index, ray, &uv);
+        if (t != pm_inf()) {
+            pi.t = t; pi.prim_uv = uv; pi.prim_index = sc.prims[i].index; pi.shape = sc.prims[i].shape;
+            if (shadow_ray) return pi;
+            ray.maxt = t;
+        }
+    }
+    return pi;
+}
+
+// rectangle.cpp:167-199
+static inline void rectangle_fill(const Shape &s, const Ray &ray, const PreliminaryIntersection &pi, SurfaceInteraction &si) {
+    V3 p = ray(pi.t);
+    float dist = dot(xf_translation(s.to_world) - p, s.frame.n);
+    si.p = fmadd(s.frame.n, dist, p);
+    si.n = s.frame.n; si.sh_frame.n = s.frame.n;
+    si.dp_du = s.frame.s; si.dp_dv = s.frame.t;
+    si.uv.x = pm_fma(pi.prim_uv.x, .5f, .5f); si.uv.y = pm_fma(pi.prim_uv.y, .5f, .5f);
+}
+// mesh.cpp:448-545
+static inline void mesh_fill(const Shape &s, const PreliminaryIntersection &pi, SurfaceInteraction &si) {
+    float b1 = pi.prim_uv.x, b2 = pi.prim_uv.y, b0 = 1.f - b1 - b2;
+    const uint32_t *fi = &s.faces[3 * pi.prim_index];
+    const float *P = s.positions.data();
+    V3 p0 = v3(P[3 * fi[0]], P[3 * fi[0] + 1], P[3 * fi[0] + 2]), p1 = v3(P[3 * fi[1]], P[3 * fi[1] + 1], P[3 * fi[1] + 2]),
+       p2 = v3(P[3 * fi[2]], P[3 * fi[2] + 1], P[3 * fi[2] + 2]);
+    V3 dp0 = p1 - p0, dp1 = p2 - p0;
+    si.p = p0 * b0 + p1 * b1 + p2 * b2;
+    si.n = normalize(cross(dp0, dp1));
+    si.uv.x = b1; si.uv.y = b2;
+    coordinate_system(si.n, &si.dp_du, &si.dp_dv);
+    if (!s.texcoords.empty()) {
+        const float *T = s.texcoords.data();
+        P2 uv0 = { T[2 * fi[0]], T[2 * fi[0] + 1] }, uv1 = { T[2 * fi[1]], T[2 * fi[1] + 1] }, uv2 = { T[2 * fi[2]], T[2 * fi[2] + 1] };
+        si.uv.x = uv0.x * b0 + uv1.x * b1 + uv2.x * b2;
+        si.uv.y = uv0.y * b0 + uv1.y * b1 + uv2.y * b2;
+        P2 duv0 = { uv1.x - uv0.x, uv1.y - uv0.y }, duv1 = { uv2.x - uv0.x, uv2.y - uv0.y };
+        float det = pm_fma(duv0.x, duv1.y, -(duv0.y * duv1.x)), inv_det = pm_rcp(det);
+        if (det != 0.f) {
+            // fmsub(duv1.y, dp0, duv0.y * dp1) * inv_det ; fnmadd(duv1.x, dp0, duv0.x * dp1) * inv_det
+            si.dp_du = v3(pm_fma(duv1.y, dp0.x, -(duv0.y * dp1.x)), pm_fma(duv1.y, dp0.y, -(duv0.y * dp1.y)), pm_fma(duv1.y, dp0.z, -(duv0.y * dp1.z))) * inv_det;
+            si.dp_dv = v3(pm_fma(-duv1.x, dp0.x, duv0.x * dp1.x), pm_fma(-duv1.x, dp0.y, duv0.x * dp1.y), pm_fma(-duv1.x, dp0.z, duv0.x * dp1.z)) * inv_det;
+        }
+    }
+    if (!s.normals.empty()) {
+        const float *N = s.normals.data();
+        V3 n0 = v3(N[3 * fi[0]], N[3 * fi[0] + 1], N[3 * fi[0] + 2]), n1 = v3(N[3 * fi[1]], N[3 * fi[1] + 1], N[3 * fi[1] + 2]),
+           n2 = v3(N[3 * fi[2]], N[3 * fi[2] + 1], N[3 * fi[2] + 2]);
+        si.sh_frame.n = normalize(n0 * b0 + n1 * b1 + n2 * b2);
+    } else si.sh_frame.n = si.n;
+}
+// sphere.cpp:308-380 (uv is not needed by any supported BSDF / emitter and is left at zero)
+static inline void sphere_fill(const Shape &s, const Ray &ray, const PreliminaryIntersection &pi, SurfaceInteraction &si) {
+    si.sh_frame.n = normalize(ray(pi.t) - s.center);
+    si.p = fmadd(si.sh_frame.n, s.radius, s.center);
+    V3 local = xf_point_affine(s.to_object, si.p);
+    float rd_2 = local.x * local.x + local.y * local.y;
+    si.uv.x = si.uv.y = 0.f;
+    si.dp_du = v3(-local.y, local.x, 0.f);
+    float rd = pm_sqrt(rd_2), inv_rd = pm_rcp(rd), cos_phi = local.x * inv_rd, sin_phi = local.y * inv_rd;
+    si.dp_dv = v3(local.z * cos_phi, local.z * sin_phi, -rd);
+    if (rd == 0.f) si.dp_dv = v3(1.f, 0.f, 0.f);
+    si.dp_du = xf_vector(s.to_world, si.dp_du) * (2.f * Pi);
+    si.dp_dv = xf_vector(s.to_world, si.dp_dv) * Pi;
+    if (s.flip_normals) si.sh_frame.n = -si.sh_frame.n;
+    si.n = si.sh_frame.n;
+}
+
+// scene_native.inl:23-41 + interaction.h:571-596 (HitComputeFlags::All)
+static inline SurfaceInteraction ray_intersect(const Scene &sc, const Ray &ray) {
+    PreliminaryIntersection pi = ray_intersect_preliminary(sc, ray, false);
+    SurfaceInteraction si; memset(&si, 0, sizeof(si));
+    si.shape = -1;
+    if (pi.t == pm_inf()) { si.wi = -ray.d; si.t = pm_inf(); return si; }
+    const Shape &s = sc.shapes[pi.shape];
+    si.t = pi.t;
+    if (s.type == MTS_SHAPE_RECTANGLE) rectangle_fill(s, ray, pi, si);
+    else if (s.type == MTS_SHAPE_SPHERE) sphere_fill(s, ray, pi, si);
+    else mesh_fill(s, pi, si);
+    si.prim_index = pi.prim_index; si.shape = pi.shape;
+    // initialize_sh_frame, interaction.h:153-156
+    si.sh_frame.s = normalize(fnmadd(si.sh_frame.n, dot(si.sh_frame.n, si.dp_du), si.dp_du));
+    si.sh_frame.t = cross(si.sh_frame.n, si.sh_frame.s);
+    si.wi = si.to_local(-ray.d);
+    return si;
+}
+static inline bool ray_test(const Scene &sc, const Ray &ray) { return ray_intersect_preliminary(sc, ray, true).t != pm_inf(); }   // scene_native.inl:63-67
+
+// ---------------------------------------------------------------- volumes
+// grid3d.cpp:234-250
+static inline int wrap_coord(const Volume &v, int value, int res) {
+    if (v.wrap == MTS_WRAP_CLAMP) return std::min(std::max(value, 0), res - 1);
+    int div = value / res;                  // enoki::divisor<int32_t>: truncating division, fixed up below
+    int mod = value - div * res;
+    if (mod < 0) mod += res;
+    if (v.wrap == MTS_WRAP_MIRROR) mod = (((div & 1) == 0) ^ (value < 0)) ? mod : res - 1 - mod;
+    return mod;
+}
+// grid3d.cpp:220-232,259-360 ; constant3d.cpp
+static inline V3 volume_eval(const Volume &v, V3 p_world) {
+    if (v.type == MTS_VOLUME_CONST) return v.value;
+    V3 p = xf_point(v.world_to_local, p_world);                                           // grid3d.cpp:227
+    const float *D = v.data; const int nx = v.nx, ny = v.ny, nz = v.nz, ch = v.channels;
+    if (v.filter == MTS_FILTER_TRILINEAR) {
+        p = v3(pm_fma(p.x, (float) nx, -.5f), pm_fma(p.y, (float) ny, -.5f), pm_fma(p.z, (float) nz, -.5f));
+        int ix = (int) pm_floor(p.x), iy = (int) pm_floor(p.y), iz = (int) pm_floor(p.z);
+        V3 w1 = p - v3((float) ix, (float) iy, (float) iz), w0 = v3(1.f - w1.x, 1.f - w1.y, 1.f - w1.z);
+        int x0 = wrap_coord(v, ix, nx), x1 = wrap_coord(v, ix + 1, nx), y0 = wrap_coord(v, iy, ny), y1 = wrap_coord(v, iy + 1, ny),
+            z0 = wrap_coord(v, iz, nz), z1 = wrap_coord(v, iz + 1, nz);
+        V3 r;
+        float *out[3] = { &r.x, &r.y, &r.z };
+        for (int c = 0; c < ch; ++c) {
+            #define G(X, Y, Z) D[(size_t) (((Z) * ny + (Y)) * nx + (X)) * ch + c]
+            float d000 = G(x0, y0, z0), d100 = G(x1, y0, z0), d010 = G(x0, y1, z0), d110 = G(x1, y1, z0),
+                  d001 = G(x0, y0, z1), d101 = G(x1, y0, z1), d011 = G(x0, y1, z1), d111 = G(x1, y1, z1);
+            #undef G
+            float v00 = pm_fma(w0.x, d000, w1.x * d100), v01 = pm_fma(w0.x, d001, w1.x * d101),
+                  v10 = pm_fma(w0.x, d010, w1.x * d110), v11 = pm_fma(w0.x, d011, w1.x * d111);
+            float v0 = pm_fma(w0.y, v00, w1.y * v10), v1 = pm_fma(w0.y, v01, w1.y * v11);
+            *out[c] = pm_fma(w0.z, v0, w1.z * v1);
+        }
+        if (ch == 1) { r.y = r.x; r.z = r.x; }                                             // grid3d.cpp:180-181
+        return r;
+    } else {
+        p = v3(p.x * (float) nx, p.y * (float) ny, p.z * (float) nz);
+        int x = wrap_coord(v, (int) pm_floor(p.x), nx), y = wrap_coord(v, (int) pm_floor(p.y), ny), z = wrap_coord(v, (int) pm_floor(p.z), nz);
+        size_t index = (size_t) ((z * ny + y) * nx + x) * ch;
+        if (ch == 1) return v3(D[index], D[index], D[index]);
+        return v3(D[index], D[index + 1], D[index + 2]);
+    }
+}
+// eval_1: grid3d.cpp:187-202 (1 channel: hmean of a 1-vector; 3 channels: luminance), constant3d.cpp (mean)
+static inline float volume_eval_1(const Volume &v, V3 p_world) {
+    V3 r = volume_eval(v, p_world);
+    if (v.type == MTS_VOLUME_CONST) return (r.x + r.y + r.z) * (1.f / 3.f);
+    if (v.channels == 1) return r.x;
+    return r.x * 0.212671f + r.y * 0.715160f + r.z * 0.072169f;
+}
+
+// ---------------------------------------------------------------- media
+// homogeneous.cpp:33-54, heterogeneous.cpp:33-54
+static inline V3 medium_combined_extinction(const Scene &sc, const Medium &m, V3 p) {
+    if (m.is_homogeneous) return volume_eval(sc.volumes[m.sigma_t], p) * m.scale;
+    return v3(m.max_density, m.max_density, m.max_density);
+}
+static inline void medium_scattering_coefficients(const Scene &sc, const Medium &m, V3 p, V3 *sigma_s, V3 *sigma_n, V3 *sigma_t, Counters *cnt) {
+    if (m.is_homogeneous) {
+        V3 st = volume_eval(sc.volumes[m.sigma_t], p) * m.scale;
+        *sigma_t = st; *sigma_s = st * volume_eval(sc.volumes[m.albedo], p); *sigma_n = v3(0.f, 0.f, 0.f);
+    } else {
+        V3 st = m.scale * volume_eval(sc.volumes[m.sigma_t], p);
+        *sigma_t = st; *sigma_s = st * volume_eval(sc.volumes[m.albedo], p);
+        *sigma_n = v3(m.max_density, m.max_density, m.max_density) - st;
+        if (cnt) cnt->n_lookup++;
+    }
+}
+// medium.cpp:34-75
+static inline MediumInteraction medium_sample_interaction(const Scene &sc, int medium, const Ray &ray, float sample, uint32_t channel, Counters *cnt) {
+    const Medium &m = sc.media[medium];
+    MediumInteraction mi;
+    mi.sh_frame = frame_from_normal(ray.d);
+    mi.wi = -ray.d;
+    bool active = true; float mint = 0.f, maxt = pm_inf();
+    if (!m.is_homogeneous) {
+        active = bbox_ray_intersect(m.aabb, ray, &mint, &maxt);
+        active = active && (pm_isfinite(mint) || pm_isfinite(maxt));
+        if (!active) { mint = 0.f; maxt = pm_inf(); }
+    }
+    mint = pm_max(ray.mint, mint);
+    maxt = pm_min(ray.maxt, maxt);
+    // get_combined_extinction(mi): mi.p is not initialised yet in the reference; the supported
+    // homogeneous media read a constvolume, which ignores the position.
+    V3 combined = medium_combined_extinction(sc, m, ray.o);
+    float mext = idx(combined, channel);
+    float sampled_t = mint + (-pm_log(1.f - sample) / mext);
+    bool valid_mi = active && (sampled_t <= maxt);
+    mi.t = valid_mi ? sampled_t : pm_inf();
+    mi.p = ray(sampled_t);
+    mi.medium = medium;
+    mi.mint = mint;
+    if (valid_mi) medium_scattering_coefficients(sc, m, mi.p, &mi.sigma_s, &mi.sigma_n, &mi.sigma_t, cnt);
+    else mi.sigma_s = mi.sigma_n = mi.sigma_t = v3(0.f, 0.f, 0.f);      // eval_impl: `if (none(active)) return zero` (grid3d.cpp:228-229)
+    if (!valid_mi && m.is_homogeneous) medium_scattering_coefficients(sc, m, mi.p, &mi.sigma_s, &mi.sigma_n, &mi.sigma_t, cnt);   // constvolume ignores the mask
+    mi.combined_extinction = combined;
+    return mi;
+}
+
+// ---------------------------------------------------------------- phase functions
+static inline float eval_hg(float g, float cos_theta) {                                    // hg.cpp:52-55
+    float temp = 1.0f + g * g + 2.0f * g * cos_theta;
+    return InvFourPi * (1 - g * g) / (temp * pm_sqrt(temp));
+}
+static inline float eval_rayleigh(float cos_theta) { return (3.f / 16.f) * InvPi * (1.f + cos_theta * cos_theta); }   // rayleigh.cpp:42-45
+// distr_1d.h:378-400
+static inline float distr_eval_pdf(const ContinuousDistribution &d, float x) {
+    bool active = x >= d.range_x && x <= d.range_y;
+    x = (x - d.range_x) * d.inv_interval_size;
+    uint32_t index = (uint32_t) std::min(std::max((int64_t) x, (int64_t) 0), (int64_t) d.pdf.size() - 2);
+    float y0 = active ? d.pdf[index] : 0.f, y1 = active ? d.pdf[index + 1] : 0.f;
+    float w1 = x - (float) index, w0 = 1.f - w1;
+    return pm_fma(w0, y0, w1 * y1);
+}
+// distr_1d.h:438-461 with enoki::binary_search (absent source; standard bisection on [valid.x, valid.y])
+static inline float distr_sample(const ContinuousDistribution &d, float value) {
+    value *= d.integral;
+    uint32_t start = d.valid_x, end = d.valid_y;
+    uint32_t iterations = 0;
+    if (start < end) { uint32_t diff = end - start; iterations = 1; while (diff >>= 1) iterations++; }
+    for (uint32_t i = 0; i < iterations; ++i) {
+        uint32_t middle = (start + end) >> 1;
+        bool cond = d.cdf[middle] < value;
+        if (cond) start = std::min(middle + 1, end); else end = middle;
+    }
+    uint32_t index = start;
+    float y0 = d.pdf[index], y1 = d.pdf[index + 1], c0 = index > 0 ? d.cdf[index - 1] : 0.f;
+    value = (value - c0) * d.inv_interval_size;
+    float t_linear = (y0 - pm_safe_sqrt(y0 * y0 + 2.f * value * (y1 - y0))) / (y0 - y1), t_const = value / y0;
+    float t = (y0 == y1) ? t_const : t_linear;
+    return pm_fma((float) index + t, d.interval_size, d.range_x);
+}
+
+static float phase_eval(const Scene &sc, int phase, const MediumInteraction &mi, V3 wo) {
+    const Phase &ph = sc.phases[phase];
+    switch (ph.type) {
+        case MTS_PHASE_ISOTROPIC: return InvFourPi;                                       // isotropic.cpp:43-47
+        case MTS_PHASE_HG: return eval_hg(ph.g, dot(wo, mi.wi));                          // hg.cpp:81-84
+        case MTS_PHASE_RAYLEIGH: return eval_rayleigh(dot(wo, mi.wi));                    // rayleigh.cpp:69-73
+        case MTS_PHASE_TABULATED: return distr_eval_pdf(ph.distr, -dot(wo, mi.wi)) * ph.distr.normalization * InvTwoPi;   // tabphase.cpp:72-78
+        case MTS_PHASE_BLEND: {                                                           // blendphase.cpp:113-139
+            float weight = std::min(std::max(volume_eval_1(sc.volumes[ph.weight_volume], mi.p), 0.f), 1.f);
+            return phase_eval(sc, ph.child[0], mi, wo) * (1 - weight) + phase_eval(sc, ph.child[1], mi, wo) * weight;
+        }
+    }
+    return 0.f;
+}
+static void phase_sample(const Scene &sc, int phase, const MediumInteraction &mi, float sample1, P2 sample2, V3 *wo, float *pdf) {
+    const Phase &ph = sc.phases[phase];
+    switch (ph.type) {
+        case MTS_PHASE_ISOTROPIC: *wo = square_to_uniform_sphere(sample2); *pdf = InvFourPi; return;   // isotropic.cpp:31-41
+        case MTS_PHASE_HG: {                                                              // hg.cpp:57-79
+            float cos_theta;
+            if (std::abs(ph.g) < Epsilon) cos_theta = 1 - 2 * sample2.x;
+            else { float sqr_term = (1 - ph.g * ph.g) / (1 - ph.g + 2 * ph.g * sample2.x); cos_theta = (1 + ph.g * ph.g - sqr_term * sqr_term) / (2 * ph.g); }
+            float sin_theta = pm_safe_sqrt(1.0f - cos_theta * cos_theta);
+            float sin_phi, cos_phi; pm_sincos(2 * Pi * sample2.y, &sin_phi, &cos_phi);
+            *wo = mi.sh_frame.to_world(v3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta));
+            *pdf = eval_hg(ph.g, -cos_theta);
+            return;
+        }
+        case MTS_PHASE_RAYLEIGH: {                                                        // rayleigh.cpp:47-67
+            float z = 2.f * (2.f * sample2.x - 1.f), tmp = pm_sqrt(z * z + 1.f);
+            float A = pm_cbrt(z + tmp), B = pm_cbrt(z - tmp), cos_theta = A + B;
+            float sin_theta = pm_safe_sqrt(1.0f - cos_theta * cos_theta);
+            float sin_phi, cos_phi; pm_sincos(TwoPi * sample2.y, &sin_phi, &cos_phi);
+            *wo = mi.sh_frame.to_world(v3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta));
+            *pdf = eval_rayleigh(-cos_theta);
+            return;
+        }
+        case MTS_PHASE_TABULATED: {                                                       // tabphase.cpp:53-70
+            float cos_theta = distr_sample(ph.distr, sample2.x);
+            float sin_theta = pm_safe_sqrt(1.0f - cos_theta * cos_theta);
+            float sin_phi, cos_phi; pm_sincos(2.f * Pi * sample2.y, &sin_phi, &cos_phi);
+            *wo = mi.sh_frame.to_world(v3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta));
+            *pdf = distr_eval_pdf(ph.distr, -cos_theta) * ph.distr.normalization * InvTwoPi;
+            return;
+        }
+        case MTS_PHASE_BLEND: {                                                           // blendphase.cpp:68-111
+            float weight = std::min(std::max(volume_eval_1(sc.volumes[ph.weight_volume], mi.p), 0.f), 1.f);
+            if (sample1 > weight) phase_sample(sc, ph.child[0], mi, (sample1 - weight) / (1 - weight), sample2, wo, pdf);
+            else phase_sample(sc, ph.child[1], mi, sample1 / weight, sample2, wo, pdf);
+            return;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- BSDFs
+struct BSDFSample { V3 wo; float pdf, eta; uint32_t sampled_type; };
+// frame.h:67-70,107-118
+static inline float frame_tan_theta(V3 v) { float temp = pm_fma(-v.z, v.z, 1.f); return pm_safe_sqrt(temp) / v.z; }
+static inline float frame_sin_theta(V3 v) { return pm_safe_sqrt(pm_fma(v.x, v.x, v.y * v.y)); }
+static inline void frame_sincos_phi(V3 v, float *s, float *c) {
+    float sin_theta_2 = pm_fma(v.x, v.x, v.y * v.y), inv_sin_theta = pm_rsqrt(sin_theta_2);
+    float rx = v.x * inv_sin_theta, ry = v.y * inv_sin_theta;
+    if (pm_abs(sin_theta_2) <= 4.f * Epsilon) { rx = 1.f; ry = 0.f; }
+    else { rx = std::min(std::max(rx, -1.f), 1.f); ry = std::min(std::max(ry, -1.f), 1.f); }
+    *s = ry; *c = rx;
+}
+// rpv.cpp:85-131
+static inline V3 eval_rpv(const Bsdf &b, V3 wi, V3 wo) {
+    float sin_phi1, cos_phi1, sin_phi2, cos_phi2;
+    frame_sincos_phi(wi, &sin_phi1, &cos_phi1); frame_sincos_phi(wo, &sin_phi2, &cos_phi2);
+    float cos_phi1_minus_phi2 = cos_phi1 * cos_phi2 + sin_phi1 * sin_phi2;
+    float sin_theta1 = frame_sin_theta(wi), cos_theta1 = wi.z, tan_theta1 = frame_tan_theta(wi);
+    float sin_theta2 = frame_sin_theta(wo), cos_theta2 = wo.z, tan_theta2 = frame_tan_theta(wo);
+    float G = pm_safe_sqrt(tan_theta1 * tan_theta1 + tan_theta2 * tan_theta2 - 2.f * tan_theta1 * tan_theta2 * cos_phi1_minus_phi2);
+    float cos_g = cos_theta1 * cos_theta2 + sin_theta1 * sin_theta2 * cos_phi1_minus_phi2;
+    float rho_0[3] = { b.rho_0.x, b.rho_0.y, b.rho_0.z }, rho_c[3] = { b.rho_c.x, b.rho_c.y, b.rho_c.z },
+          g[3] = { b.g.x, b.g.y, b.g.z }, k[3] = { b.k.x, b.k.y, b.k.z }, out[3];
+    for (int c = 0; c < 3; ++c) {
+        float F = (1.f - g[c] * g[c]) / pm_pow((1.f + g[c] * g[c] + 2.f * g[c] * cos_g), 1.5f);
+        out[c] = rho_0[c] * (pm_pow(cos_theta1 * cos_theta2 * (cos_theta1 + cos_theta2), k[c] - 1.f) * F * (1.f + (1.f - rho_c[c]) / (1 + G))) * InvPi;
+    }
+    return v3(out[0], out[1], out[2]);
+}
+static V3 bsdf_eval(const Bsdf &b, const SurfaceInteraction &si, V3 wo) {
+    float cos_theta_i = si.wi.z, cos_theta_o = wo.z;
+    bool active = cos_theta_i > 0.f && cos_theta_o > 0.f;
+    switch (b.type) {
+        case MTS_BSDF_DIFFUSE: return active ? b.reflectance * InvPi * cos_theta_o : v3(0, 0, 0);     // diffuse.cpp:106-120
+        case MTS_BSDF_RPV: return active ? eval_rpv(b, si.wi, wo) * pm_abs(cos_theta_o) : v3(0, 0, 0);   // rpv.cpp:133-142
+        default: return v3(0, 0, 0);                                                                  // null.cpp:60-63
+    }
+}
+static float bsdf_pdf(const Bsdf &b, const SurfaceInteraction &si, V3 wo) {
+    if (b.type == MTS_BSDF_NULL) return 0.f;                                                          // null.cpp:65-68
+    float cos_theta_i = si.wi.z, cos_theta_o = wo.z;
+    float pdf = InvPi * wo.z;                                                                          // warp.h:343-350
+    return (cos_theta_i > 0.f && cos_theta_o > 0.f) ? pdf : 0.f;                                      // diffuse.cpp:122-135, rpv.cpp:144-153
+}
+static V3 bsdf_sample(const Bsdf &b, const SurfaceInteraction &si, float /*sample1*/, P2 sample2, BSDFSample *bs) {
+    bs->wo = v3(0, 0, 0); bs->pdf = 0.f; bs->eta = 0.f; bs->sampled_type = 0;
+    if (b.type == MTS_BSDF_NULL) {                                                                    // null.cpp:41-58
+        bs->wo = -si.wi; bs->sampled_type = F_Null; bs->eta = 1.f; bs->pdf = 1.f;
+        return v3(1.f, 1.f, 1.f);
+    }
+    float cos_theta_i = si.wi.z;
+    bool active = cos_theta_i > 0.f;
+    if (b.type == MTS_BSDF_DIFFUSE) {                                                                 // diffuse.cpp:78-104
+        if (!active) return v3(0, 0, 0);
+        bs->wo = square_to_cosine_hemisphere(sample2);
+        bs->pdf = InvPi * bs->wo.z; bs->eta = 1.f; bs->sampled_type = F_DiffuseReflection;
+        return (bs->pdf > 0.f) ? b.reflectance : v3(0, 0, 0);
+    }
+    // rpv.cpp:85-102 (fields are filled even when the lane is inactive)
+    bs->wo = square_to_cosine_hemisphere(sample2);
+    bs->pdf = InvPi * bs->wo.z; bs->eta = 1.f; bs->sampled_type = F_GlossyReflection;
+    V3 value = eval_rpv(b, si.wi, bs->wo);
+    return (active && bs->pdf > 0.f) ? value : v3(0, 0, 0);
+}
+static inline V3 bsdf_eval_null_transmission(const Bsdf &b) { return b.type == MTS_BSDF_NULL ? v3(1, 1, 1) : v3(0, 0, 0); }   // null.cpp:70-73, bsdf.cpp:11-14
+
+// ---------------------------------------------------------------- emitters
+struct DirectionSample { V3 p, n, d; float pdf, dist; bool delta; int emitter; };
+
+// rectangle.cpp:111-124 / sphere.cpp sample_position
+static inline void shape_sample_position(const Shape &s, P2 sample, V3 *p, V3 *n, float *pdf) {
+    if (s.type == MTS_SHAPE_RECTANGLE) {
+        *p = xf_point_affine(s.to_world, v3(sample.x * 2.f - 1.f, sample.y * 2.f - 1.f, 0.f));
+        *n = s.frame.n; *pdf = s.inv_surface_area;
+    } else {
+        V3 local = square_to_uniform_sphere(sample);
+        *p = fmadd(local, s.radius, s.center);
+        *n = s.flip_normals ? -local : local; *pdf = s.inv_surface_area;
+    }
+}
+// shape.cpp:293-310 (generic), sphere.cpp sample_direction
+static inline DirectionSample shape_sample_direction(const Shape &s, V3 ref_p, P2 sample) {
+    DirectionSample ds; memset(&ds, 0, sizeof(ds));
+    if (s.type == MTS_SHAPE_RECTANGLE) {
+        shape_sample_position(s, sample, &ds.p, &ds.n, &ds.pdf);
+        ds.d = ds.p - ref_p;
+        float dist_squared = squared_norm(ds.d);
+        ds.dist = pm_sqrt(dist_squared);
+        ds.d = ds.d / ds.dist;
+        float dp = pm_abs(dot(ds.d, ds.n));
+        ds.pdf *= (dp != 0.f) ? dist_squared / dp : 0.f;
+        ds.delta = false;
+        return ds;
+    }
+    V3 dc_v = s.center - ref_p;
+    float dc_2 = squared_norm(dc_v);
+    float radius_adj = s.radius * (s.flip_normals ? (1.f + RayEpsilon) : (1.f - RayEpsilon));
+    if (dc_2 > radius_adj * radius_adj) {
+        float inv_dc = pm_rsqrt(dc_2), sin_theta_max = s.radius * inv_dc, sin_theta_max_2 = sin_theta_max * sin_theta_max,
+              inv_sin_theta_max = pm_rcp(sin_theta_max), cos_theta_max = pm_safe_sqrt(1.f - sin_theta_max_2);
+        float sin_theta_2 = sin_theta_max_2 > 0.00068523f ? 1.f - (pm_fma(cos_theta_max - 1.f, sample.x, 1.f)) * (pm_fma(cos_theta_max - 1.f, sample.x, 1.f))
+                                                         : sin_theta_max_2 * sample.x;
+        float cos_theta = pm_safe_sqrt(1.f - sin_theta_2);
+        float cos_alpha = sin_theta_2 * inv_sin_theta_max + cos_theta * pm_safe_sqrt(pm_fma(-sin_theta_2, inv_sin_theta_max * inv_sin_theta_max, 1.f)),
+              sin_alpha = pm_safe_sqrt(pm_fma(-cos_alpha, cos_alpha, 1.f));
+        float sin_phi, cos_phi; pm_sincos(sample.y * (2.f * Pi), &sin_phi, &cos_phi);
+        V3 d = frame_from_normal(dc_v * -inv_dc).to_world(v3(cos_phi * sin_alpha, sin_phi * sin_alpha, cos_alpha));
+        ds.p = fmadd(d, s.radius, s.center); ds.n = d; ds.d = ds.p - ref_p;
+        float dist2 = squared_norm(ds.d);
+        ds.dist = pm_sqrt(dist2); ds.d = ds.d / ds.dist;
+        ds.pdf = InvTwoPi / (1.f - cos_theta_max);                                          // warp::square_to_uniform_cone_pdf
+        if (ds.dist == 0.f) ds.pdf = 0.f;
+    } else {
+        V3 d = square_to_uniform_sphere(sample);
+        ds.p = fmadd(d, s.radius, s.center); ds.n = d; ds.d = ds.p - ref_p;
+        float dist2 = squared_norm(ds.d);
+        ds.dist = pm_sqrt(dist2); ds.d = ds.d / ds.dist;
+        ds.pdf = s.inv_surface_area * dist2 / pm_abs(dot(ds.d, ds.n));
+    }
+    ds.delta = s.radius == 0.f;
+    if (s.flip_normals) ds.n = -ds.n;
+    return ds;
+}
+static inline float shape_pdf_direction(const Shape &s, V3 ref_p, const DirectionSample &ds) {
+    if (s.type == MTS_SHAPE_RECTANGLE) {                                                   // shape.cpp:312-323
+        float pdf = s.inv_surface_area, dp = pm_abs(dot(ds.d, ds.n));
+        pdf *= (dp != 0.f) ? (ds.dist * ds.dist) / dp : 0.f;
+        return pdf;
+    }
+    float sin_alpha = s.radius * pm_rcp(norm(s.center - ref_p)), cos_alpha = pm_safe_sqrt(1.f - sin_alpha * sin_alpha);   // sphere.cpp pdf_direction
+    return sin_alpha < 0x1.fffffep-1f ? InvTwoPi / (1.f - cos_alpha) : s.inv_surface_area * (ds.dist * ds.dist) / pm_abs(dot(ds.d, ds.n));
+}
+
+// directional.cpp:109-141, area.cpp:122-165, constant.cpp:81-111
+static inline DirectionSample emitter_sample_direction(const Scene &sc, int ei, V3 ref_p, P2 sample, V3 *spec) {
+    const Emitter &e = sc.emitters[ei];
+    DirectionSample ds; memset(&ds, 0, sizeof(ds));
+    if (e.type == MTS_EMITTER_DIRECTIONAL) {
+        V3 d = xf_vector(e.to_world, v3(0.f, 0.f, 1.f));
+        float dist = 2.f * e.bsphere_radius;
+        ds.p = ref_p - d * dist; ds.n = d; ds.pdf = 1.f; ds.delta = true; ds.d = -d; ds.dist = dist;
+        *spec = e.radiance;
+    } else if (e.type == MTS_EMITTER_CONSTANT) {
+        V3 d = square_to_uniform_sphere(sample);
+        float dist = 2.f * e.bsphere_radius;
+        ds.p = ref_p + d * dist; ds.n = -d; ds.pdf = InvFourPi; ds.delta = false; ds.d = d; ds.dist = dist;
+        *spec = e.radiance / ds.pdf;
+    } else {
+        ds = shape_sample_direction(sc.shapes[e.shape], ref_p, sample);
+        bool active = dot(ds.d, ds.n) < 0.f && ds.pdf != 0.f;
+        *spec = active ? e.radiance / ds.pdf : v3(0, 0, 0);
+    }
+    ds.emitter = ei;
+    return ds;
+}
+// scene.cpp:168-218
+static inline DirectionSample sample_emitter_direction(const Scene &sc, V3 ref_p, P2 sample, bool test_visibility, V3 *spec) {
+    DirectionSample ds; memset(&ds, 0, sizeof(ds)); ds.emitter = -1;
+    if (sc.emitters.empty()) { *spec = v3(0, 0, 0); return ds; }
+    bool active = true;
+    if (sc.emitters.size() == 1) ds = emitter_sample_direction(sc, 0, ref_p, sample, spec);
+    else {
+        float n = (float) sc.emitters.size(), emitter_pdf = 1.f / n;
+        uint32_t index = std::min((uint32_t) (sample.x * n), (uint32_t) sc.emitters.size() - 1);
+        sample.x = (sample.x - index * emitter_pdf) * n;
+        ds = emitter_sample_direction(sc, (int) index, ref_p, sample, spec);
+        ds.pdf *= emitter_pdf;
+        *spec = *spec * pm_rcp(emitter_pdf);
+    }
+    active = active && ds.pdf != 0.f;
+    if (test_visibility && active) {
+        Ray ray = make_ray(ref_p, ds.d, RayEpsilon * (1.f + hmax_abs(ref_p)), ds.dist * (1.f - ShadowEpsilon));
+        if (ray_test(sc, ray)) *spec = v3(0, 0, 0);
+    }
+    return ds;
+}
+// scene.cpp:220-235
+static inline float pdf_emitter_direction(const Scene &sc, V3 ref_p, const DirectionSample &ds) {
+    const Emitter &e = sc.emitters[ds.emitter];
+    float value;
+    if (e.type == MTS_EMITTER_DIRECTIONAL) value = 0.f;                                    // directional.cpp:143-147
+    else if (e.type == MTS_EMITTER_CONSTANT) value = InvFourPi;                            // constant.cpp:113-117
+    else { float dp = dot(ds.d, ds.n); value = dp < 0.f ? shape_pdf_direction(sc.shapes[e.shape], ref_p, ds) : 0.f; }   // area.cpp:168-186
+    if (sc.emitters.size() == 1) return value;
+    return value * (1.f / sc.emitters.size());
+}
+// area.cpp:63-71, constant.cpp:41-44, directional.cpp:75-78 ; si.emitter(scene), scene.h:243-253
+static inline int si_emitter(const Scene &sc, const SurfaceInteraction &si) { return si.is_valid() ? sc.shapes[si.shape].emitter : sc.environment; }
+static inline V3 emitter_eval(const Scene &sc, int ei, const SurfaceInteraction &si) {
+    const Emitter &e = sc.emitters[ei];
+    if (e.type == MTS_EMITTER_AREA) return si.wi.z > 0.f ? e.radiance : v3(0, 0, 0);
+    if (e.type == MTS_EMITTER_CONSTANT) return e.radiance;
+    return v3(0, 0, 0);
+}
+// interaction.h:178-200
+static inline int target_medium(const Scene &sc, const SurfaceInteraction &si, V3 d) {
+    const Shape &s = sc.shapes[si.shape];
+    return dot(d, si.n) > 0 ? s.exterior : s.interior;
+}
+
+// ---------------------------------------------------------------- integrators
+static inline float mis_weight(float pdf_a, float pdf_b) { pdf_a *= pdf_a; pdf_b *= pdf_b; return pdf_a > 0.0f ? pdf_a / (pdf_a + pdf_b) : 0.0f; }   // volpath.cpp:479-483
+
+// volpath.cpp:261-367
+static V3 volpath_sample_emitter(const Scene &sc, V3 ref_p, bool is_medium_interaction, Sampler &sampler, int medium, uint32_t channel, DirectionSample *ds_out, Counters *cnt) {
+    V3 transmittance = v3(1.f, 1.f, 1.f), emitter_val;
+    DirectionSample ds = sample_emitter_direction(sc, ref_p, sampler.next_2d(), false, &emitter_val);
+    *ds_out = ds;
+    if (ds.pdf == 0.f) return v3(0.f, 0.f, 0.f);
+    bool active = true;
+    Ray ray = spawn_ray(ref_p, ds.d);
+    if (is_medium_interaction) ray.mint = 0.f;
+    float total_dist = 0.f;
+    SurfaceInteraction si; memset(&si, 0, sizeof(si)); si.t = pm_inf(); si.shape = -1;
+    bool needs_intersection = true;
+    while (active) {
+        float remaining_dist = ds.dist * (1.f - ShadowEpsilon) - total_dist;
+        ray.maxt = remaining_dist;
+        active = active && remaining_dist > 0.f;
+        if (!active) break;
+        if (cnt) cnt->n_nee_step++;
+        bool escaped_medium = false, active_medium = medium >= 0, active_surface = !active_medium;
+        if (active_medium) {
+            const Medium &m = sc.media[medium];
+            MediumInteraction mi = medium_sample_interaction(sc, medium, ray, sampler.next_1d(), channel, cnt);
+            if (m.is_homogeneous && mi.is_valid()) ray.maxt = pm_min(mi.t, remaining_dist);
+            if (needs_intersection) si = ray_intersect(sc, ray);
+            if (si.t < mi.t) mi.t = pm_inf();
+            needs_intersection = false;
+            bool is_spectral = m.has_spectral_extinction, not_spectral = !is_spectral;
+            if (is_spectral) {
+                float t = pm_min(remaining_dist, pm_min(mi.t, si.t)) - mi.mint;
+                V3 tr = v3(pm_exp(-t * mi.combined_extinction.x), pm_exp(-t * mi.combined_extinction.y), pm_exp(-t * mi.combined_extinction.z));
+                V3 free_flight_pdf = (si.t < mi.t || mi.t > remaining_dist) ? tr : tr * mi.combined_extinction;
+                float tr_pdf = idx(free_flight_pdf, channel);
+                transmittance = transmittance * (tr_pdf > 0.f ? tr / tr_pdf : v3(0.f, 0.f, 0.f));
+            }
+            if (mi.t > remaining_dist && mi.is_valid()) total_dist = ds.dist;
+            if (mi.t > remaining_dist) mi.t = pm_inf();
+            escaped_medium = !mi.is_valid();
+            active_medium = mi.is_valid();
+            is_spectral = is_spectral && active_medium; not_spectral = not_spectral && active_medium;
+            if (active_medium) {
+                total_dist += mi.t;
+                ray.o = mi.p; ray.mint = 0.f; si.t = si.t - mi.t;
+                if (is_spectral) transmittance = transmittance * mi.sigma_n;
+                if (not_spectral) transmittance = transmittance * (mi.sigma_n / mi.combined_extinction);
+            }
+        }
+        bool intersect = active_surface && needs_intersection;
+        if (intersect) si = ray_intersect(sc, ray);
+        needs_intersection = needs_intersection && !intersect;
+        active_surface = active_surface || escaped_medium;
+        if (active_surface) total_dist += si.t;
+        active_surface = active_surface && si.is_valid() && active && !active_medium;
+        if (active_surface) transmittance = transmittance * bsdf_eval_null_transmission(sc.bsdf_of(sc.shapes[si.shape]));
+        if (active_surface) ray = spawn_ray(si.p, ray.d);
+        ray.maxt = remaining_dist;
+        needs_intersection = needs_intersection || active_surface;
+        active = active && (active_medium || active_surface) && any_nonzero(transmittance);
+        if (active_surface && sc.shapes[si.shape].is_medium_transition()) medium = target_medium(sc, si, ray.d);
+    }
+    return transmittance * emitter_val;
+}
+
+// volpath.cpp:370-465
+static V3 volpath_evaluate_direct_light(const Scene &sc, V3 ref_p, Sampler &sampler, int medium, Ray ray, const SurfaceInteraction &si_ray,
+                                        uint32_t channel, bool active, float *emitter_pdf_out, Counters *cnt) {
+    V3 emitter_val = v3(0.f, 0.f, 0.f), transmittance = v3(1.f, 1.f, 1.f);
+    bool needs_intersection = false;
+    float emitter_pdf = 0.f;
+    SurfaceInteraction si = si_ray;
+    while (active) {
+        if (cnt) cnt->n_nee_step++;
+        bool escaped_medium = false, active_medium = medium >= 0, active_surface = !active_medium;
+        if (active_medium) {
+            const Medium &m = sc.media[medium];
+            MediumInteraction mi = medium_sample_interaction(sc, medium, ray, sampler.next_1d(), channel, cnt);
+            if (m.is_homogeneous && mi.is_valid()) ray.maxt = mi.t;
+            if (needs_intersection) si = ray_intersect(sc, ray);
+            if (si.t < mi.t) mi.t = pm_inf();
+            bool is_spectral = m.has_spectral_extinction, not_spectral = !is_spectral;
+            if (is_spectral) {
+                float t = pm_min(mi.t, si.t) - mi.mint;                                       // medium.cpp:77-89
+                V3 tr = v3(pm_exp(-t * mi.combined_extinction.x), pm_exp(-t * mi.combined_extinction.y), pm_exp(-t * mi.combined_extinction.z));
+                V3 free_flight_pdf = si.t < mi.t ? tr : tr * mi.combined_extinction;
+                float tr_pdf = idx(free_flight_pdf, channel);
+                transmittance = transmittance * (tr_pdf > 0.f ? tr / tr_pdf : v3(0.f, 0.f, 0.f));
+            }
+            needs_intersection = false;
+            escaped_medium = !mi.is_valid();
+            active_medium = mi.is_valid();
+            if (active_medium) {
+                ray.o = mi.p; ray.mint = 0.f; si.t = si.t - mi.t;
+                if (is_spectral) transmittance = transmittance * mi.sigma_n;
+                if (not_spectral) transmittance = transmittance * (mi.sigma_n / mi.combined_extinction);
+            }
+        }
+        bool intersect = active_surface && needs_intersection;
+        if (intersect) si = ray_intersect(sc, ray);
+        needs_intersection = needs_intersection && !intersect;
+        active_surface = active_surface || escaped_medium;
+        int emitter = active_surface ? si_emitter(sc, si) : -1;
+        bool emitter_hit = emitter >= 0 && active_surface;
+        if (emitter_hit) {
+            DirectionSample ds; memset(&ds, 0, sizeof(ds));                                  // records.h:168-174
+            ds.p = si.p; ds.n = si.sh_frame.n; ds.d = si.p - ref_p; ds.dist = norm(ds.d); ds.d = ds.d / ds.dist;
+            if (!si.is_valid()) ds.d = -si.wi;
+            ds.emitter = emitter;
+            emitter_val = emitter_eval(sc, emitter, si);
+            emitter_pdf = pdf_emitter_direction(sc, ref_p, ds);
+            active = false; active_surface = false; active_medium = false;
+        }
+        active_surface = active_surface && si.is_valid() && !active_medium;
+        if (active_surface) transmittance = transmittance * bsdf_eval_null_transmission(sc.bsdf_of(sc.shapes[si.shape]));
+        if (active_surface) ray = spawn_ray(si.p, ray.d);
+        needs_intersection = needs_intersection || active_surface;
+        active = active && (active_medium || active_surface) && any_nonzero(transmittance);
+        if (active_surface && sc.shapes[si.shape].is_medium_transition()) medium = target_medium(sc, si, ray.d);
+    }
+    *emitter_pdf_out = emitter_pdf;
+    return transmittance * emitter_val;
+}
+
+// volpath.cpp:38-257
+static V3 volpath_sample(const Scene &sc, Sampler &sampler, Ray ray, int medium, bool *valid_out, Counters *cnt) {
+    const uint32_t max_depth = (uint32_t) sc.integrator.max_depth, rr_depth = (uint32_t) sc.integrator.rr_depth;
+    const bool hide_emitters = sc.integrator.hide_emitters != 0;
+    bool valid_ray = !hide_emitters && sc.environment >= 0;
+    float eta = 1.f;
+    V3 throughput = v3(1.f, 1.f, 1.f), result = v3(0.f, 0.f, 0.f);
+    MediumInteraction mi; memset(&mi, 0, sizeof(mi)); mi.t = pm_inf();
+    bool active = true, specular_chain = !hide_emitters;
+    uint32_t depth = 0;
+    uint32_t channel = (uint32_t) pm_min(sampler.next_1d() * 3.f, 2.f);                      // volpath.cpp:63-67
+    SurfaceInteraction si; memset(&si, 0, sizeof(si)); si.t = pm_inf(); si.shape = -1;
+    bool needs_intersection = true;
+    for (;;) {
+        active = active && any_nonzero(throughput);
+        float q = pm_min(hmax(throughput) * (eta * eta), .95f);
+        bool perform_rr = depth > rr_depth;
+        active = active && (sampler.next_1d() < q || !perform_rr);
+        if (perform_rr) throughput = throughput * pm_rcp(q);
+        bool exceeded_max_depth = depth >= max_depth;
+        if (!active || exceeded_max_depth) break;
+        if (cnt) cnt->n_iter++;
+        bool active_medium = active && medium >= 0, active_surface = active && !active_medium;
+        bool act_null_scatter = false, act_medium_scatter = false, escaped_medium = false;
+        bool is_spectral = active_medium, not_spectral = false;
+        if (active_medium) { is_spectral = is_spectral && sc.media[medium].has_spectral_extinction; not_spectral = !is_spectral && active_medium; }
+        if (active_medium) {
+            const Medium &m = sc.media[medium];
+            mi = medium_sample_interaction(sc, medium, ray, sampler.next_1d(), channel, cnt);
+            if (m.is_homogeneous && mi.is_valid()) ray.maxt = mi.t;
+            if (needs_intersection) si = ray_intersect(sc, ray);
+            needs_intersection = false;
+            if (si.t < mi.t) mi.t = pm_inf();
+            if (is_spectral) {
+                float t = pm_min(mi.t, si.t) - mi.mint;                                       // medium.cpp:77-89
+                V3 tr = v3(pm_exp(-t * mi.combined_extinction.x), pm_exp(-t * mi.combined_extinction.y), pm_exp(-t * mi.combined_extinction.z));
+                V3 free_flight_pdf = si.t < mi.t ? tr : tr * mi.combined_extinction;
+                float tr_pdf = idx(free_flight_pdf, channel);
+                throughput = throughput * (tr_pdf > 0.f ? tr / tr_pdf : v3(0.f, 0.f, 0.f));
+            }
+            escaped_medium = !mi.is_valid();
+            active_medium = mi.is_valid();
+            bool null_scatter = sampler.next_1d() >= idx(mi.sigma_t, channel) / idx(mi.combined_extinction, channel);
+            act_null_scatter = null_scatter && active_medium;
+            act_medium_scatter = !act_null_scatter && active_medium;
+            if (is_spectral && act_null_scatter)
+                throughput = throughput * (mi.sigma_n * idx(mi.combined_extinction, channel) / idx(mi.sigma_n, channel));
+            if (act_medium_scatter) depth += 1;
+        }
+        active = active && depth < max_depth;
+        act_medium_scatter = act_medium_scatter && active;
+        if (act_null_scatter) { ray.o = mi.p; ray.mint = 0.f; si.t = si.t - mi.t; }
+        if (act_medium_scatter) {
+            if (is_spectral) throughput = throughput * (mi.sigma_s * idx(mi.combined_extinction, channel) / idx(mi.sigma_t, channel));
+            if (not_spectral) throughput = throughput * (mi.sigma_s / mi.sigma_t);
+            const Medium &m = sc.media[mi.medium];
+            bool sample_emitters = m.sample_emitters;
+            valid_ray = true;
+            specular_chain = !sample_emitters;
+            if (sample_emitters) {
+                DirectionSample ds;
+                V3 emitted = volpath_sample_emitter(sc, mi.p, true, sampler, medium, channel, &ds, cnt);
+                float phase_val = phase_eval(sc, m.phase, mi, ds.d);
+                result = result + throughput * phase_val * emitted;
+            }
+            float s1 = sampler.next_1d(); P2 s2 = sampler.next_2d();                          // left-to-right, SURVEY.md 8(a')
+            V3 wo; float phase_pdf;
+            phase_sample(sc, m.phase, mi, s1, s2, &wo, &phase_pdf);
+            ray = spawn_ray(mi.p, wo); ray.mint = 0.0f;
+            needs_intersection = true;
+        }
+        active_surface = active_surface || escaped_medium;
+        bool intersect = active_surface && needs_intersection;
+        if (intersect) si = ray_intersect(sc, ray);
+        if (active_surface) {
+            int emitter = si_emitter(sc, si);
+            if (specular_chain && emitter >= 0) result = result + throughput * emitter_eval(sc, emitter, si);
+        }
+        active_surface = active_surface && si.is_valid();
+        if (active_surface) {
+            const Shape &shape = sc.shapes[si.shape];
+            const Bsdf &bsdf = sc.bsdf_of(shape);
+            bool active_e = (bsdf.flags & F_Smooth) != 0 && (depth + 1 < max_depth);
+            if (active_e) {
+                DirectionSample ds;
+                V3 emitted = volpath_sample_emitter(sc, si.p, false, sampler, medium, channel, &ds, cnt);
+                V3 wo = si.to_local(ds.d);
+                V3 bsdf_val = bsdf_eval(bsdf, si, wo);
+                float bpdf = bsdf_pdf(bsdf, si, wo);
+                result = result + throughput * bsdf_val * mis_weight(ds.pdf, ds.delta ? 0.f : bpdf) * emitted;
+            }
+            float s1 = sampler.next_1d(); P2 s2 = sampler.next_2d();
+            BSDFSample bs;
+            V3 bsdf_val = bsdf_sample(bsdf, si, s1, s2, &bs);
+            throughput = throughput * bsdf_val;
+            eta *= bs.eta;
+            ray = spawn_ray(si.p, si.to_world(bs.wo));
+            needs_intersection = true;
+            bool non_null_bsdf = !(bs.sampled_type & F_Null);
+            if (non_null_bsdf) depth += 1;
+            valid_ray = valid_ray || non_null_bsdf;
+            specular_chain = specular_chain || (non_null_bsdf && (bs.sampled_type & F_Delta));
+            specular_chain = specular_chain && !(bs.sampled_type & F_Smooth);
+            bool add_emitter = !(bs.sampled_type & F_Delta) && any_nonzero(throughput) && (depth < max_depth);
+            act_null_scatter = act_null_scatter || (bs.sampled_type & F_Null);
+            bool intersect2 = needs_intersection && add_emitter;
+            SurfaceInteraction si_new = si;
+            if (intersect2) si_new = ray_intersect(sc, ray);
+            needs_intersection = needs_intersection && !intersect2;
+            float emitter_pdf;
+            V3 emitted = volpath_evaluate_direct_light(sc, si.p, sampler, medium, ray, si_new, channel, add_emitter, &emitter_pdf, cnt);
+            if (add_emitter && emitter_pdf != 0) result = result + mis_weight(bs.pdf, emitter_pdf) * throughput * emitted;
+            if (shape.is_medium_transition()) medium = target_medium(sc, si, ray.d);
+            if (intersect2) si = si_new;
+        }
+        active = active && (active_surface || active_medium);
+    }
+    *valid_out = valid_ray;
+    return result;
+}
+
+// path.cpp:100-211
+static V3 path_sample(const Scene &sc, Sampler &sampler, Ray ray, bool *valid_out, Counters *cnt) {
+    const int max_depth = sc.integrator.max_depth, rr_depth = sc.integrator.rr_depth;
+    float eta = 1.f, emission_weight = 1.f;
+    V3 throughput = v3(1.f, 1.f, 1.f), result = v3(0.f, 0.f, 0.f);
+    bool active = true;
+    SurfaceInteraction si = ray_intersect(sc, ray);
+    bool valid_ray = si.is_valid();
+    int emitter = si_emitter(sc, si);
+    for (int depth = 1;; ++depth) {
+        if (cnt) cnt->n_iter++;
+        if (emitter >= 0 && active) result = result + emission_weight * throughput * emitter_eval(sc, emitter, si);
+        active = active && si.is_valid();
+        if (depth > rr_depth) {
+            float q = pm_min(hmax(throughput) * (eta * eta), .95f);
+            active = active && sampler.next_1d() < q;
+            throughput = throughput * pm_rcp(q);
+        }
+        if ((uint32_t) depth >= (uint32_t) max_depth || !active) break;
+        const Bsdf &bsdf = sc.bsdf_of(sc.shapes[si.shape]);
+        bool active_e = active && (bsdf.flags & F_Smooth);
+        if (active_e) {
+            V3 emitter_val;
+            DirectionSample ds = sample_emitter_direction(sc, si.p, sampler.next_2d(), true, &emitter_val);
+            active_e = active_e && ds.pdf != 0.f;
+            V3 wo = si.to_local(ds.d);
+            V3 bsdf_val = bsdf_eval(bsdf, si, wo);
+            float bpdf = bsdf_pdf(bsdf, si, wo);
+            float mis = ds.delta ? 1.f : mis_weight(ds.pdf, bpdf);
+            if (active_e) result = result + mis * throughput * bsdf_val * emitter_val;
+        }
+        float s1 = sampler.next_1d(); P2 s2 = sampler.next_2d();
+        BSDFSample bs;
+        V3 bsdf_val = bsdf_sample(bsdf, si, s1, s2, &bs);
+        throughput = throughput * bsdf_val;
+        active = active && any_nonzero(throughput);
+        if (!active) break;
+        eta *= bs.eta;
+        ray = spawn_ray(si.p, si.to_world(bs.wo));
+        SurfaceInteraction si_bsdf = ray_intersect(sc, ray);
+        emitter = si_emitter(sc, si_bsdf);
+        if (emitter >= 0) {
+            DirectionSample ds; memset(&ds, 0, sizeof(ds));                                  // records.h:168-174
+            ds.p = si_bsdf.p; ds.n = si_bsdf.sh_frame.n; ds.d = si_bsdf.p - si.p; ds.dist = norm(ds.d); ds.d = ds.d / ds.dist;
+            if (!si_bsdf.is_valid()) ds.d = -si_bsdf.wi;
+            ds.emitter = emitter;
+            float emitter_pdf = !(bs.sampled_type & F_Delta) ? pdf_emitter_direction(sc, si.p, ds) : 0.f;
+            emission_weight = mis_weight(bs.pdf, emitter_pdf);
+        }
+        si = si_bsdf;
+    }
+    *valid_out = valid_ray;
+    return result;
+}
+
+// ---------------------------------------------------------------- sensors
+// perspective.cpp:210-252 (ray differentials are unused by the supported plugins)
+static Ray sensor_sample_ray(const Scene &sc, P2 position_sample, P2 aperture_sample, V3 *weight) {
+    const Sensor &se = sc.sensor;
+    if (se.type == MTS_SENSOR_PERSPECTIVE) {
+        V3 near_p = xf_point(se.sample_to_camera, v3(position_sample.x + se.principal_point_offset.x, position_sample.y + se.principal_point_offset.y, 0.f));
+        V3 d = normalize(near_p);
+        float inv_z = pm_rcp(d.z);
+        Ray ray = make_ray(xf_point_affine(se.to_world, v3(0.f, 0.f, 0.f)), xf_vector(se.to_world, d), se.near_clip * inv_z, se.far_clip * inv_z);
+        *weight = v3(1.f, 1.f, 1.f);
+        return ray;
+    }
+    // distant.cpp:299-386
+    V3 v0 = v3(0.f, 0.f, 1.f);
+    if (se.direction_type == 2) v0 = square_to_uniform_hemisphere(position_sample);
+    else if (se.direction_type == 1) { float s, c; pm_sincos(Pi * position_sample.x, &s, &c); v0.x = c; v0.z = s; }
+    V3 d = se.flip_directions ? xf_vector(se.to_world, v0) : xf_vector(se.to_world, -v0);
+    V3 ray_weight, ray_target = se.target_point, o;
+    if (se.target_type == MTS_DISTANT_TARGET_POINT) ray_weight = v3(1.f, 1.f, 1.f);
+    else if (se.target_type == MTS_DISTANT_TARGET_SHAPE) {
+        V3 n; float pdf;
+        shape_sample_position(se.target_shape, aperture_sample, &ray_target, &n, &pdf);
+        float area = se.target_shape.type == MTS_SHAPE_RECTANGLE ? norm(cross(se.target_shape.frame.s, se.target_shape.frame.t))
+                                                                 : 4.f * Pi * se.target_shape.radius * se.target_shape.radius;
+        float w = 1.f / pdf / area;
+        ray_weight = v3(w, w, w);
+    } else {
+        P2 offset = square_to_uniform_disk_concentric(aperture_sample);
+        V3 perp_offset = xf_vector(se.to_world, v3(offset.x, offset.y, 0.f));
+        ray_target = se.bsphere_center + perp_offset * se.bsphere_radius;
+        float w = 1.f / dot(-d, v3(0.f, 0.f, 1.f));
+        ray_weight = v3(w, w, w);
+    }
+    if (se.target_type == MTS_DISTANT_TARGET_NONE) o = ray_target - d * se.bsphere_radius;
+    else o = ray_target - d * 2.f * se.bsphere_radius;
+    *weight = ray_weight;
+    Ray ray; ray.o = o; ray.d = d; ray.d_rcp = vrcp(d); ray.mint = RayEpsilon; ray.maxt = pm_inf();   // ray.h:33-34 defaults
+    return ray;
+}
+
+// ---------------------------------------------------------------- image block / film
+// imageblock.cpp:10-172
+struct ImageBlock {
+    int ox, oy, w, h, border, channels;
+    const RFilter *filter;
+    std::vector<float> data;
+    void init(int w_, int h_, int channels_, const RFilter *f, bool use_border) {
+        filter = f; channels = channels_; border = (f && use_border) ? f->border_size : 0; w = w_; h = h_; ox = oy = 0;
+        data.assign((size_t) channels * (w + 2 * border) * (h + 2 * border), 0.f);
+    }
+    void set_size(int w_, int h_) { if (w_ == w && h_ == h) return; w = w_; h = h_; data.assign((size_t) channels * (w + 2 * border) * (h + 2 * border), 0.f); }
+    void clear() { std::fill(data.begin(), data.end(), 0.f); }
+    // imageblock.cpp:79-172 (scalar branch: discretised filter weights)
+    bool put(P2 pos_, const float *value) {
+        bool active = true;
+        for (int k = 0; k < channels; ++k) active = active && value[k] >= -1e-5f && pm_isfinite(value[k]);   // :85-109 (warn + drop)
+        if (!active) return false;
+        float filter_radius = filter->radius;
+        int sx = w + 2 * border, sy = h + 2 * border;
+        P2 pos = { pos_.x - ((float) (ox - border) + .5f), pos_.y - ((float) (oy - border) + .5f) };
+        if (filter_radius > 0.5f + RayEpsilon) {
+            int lox = std::max((int) pm_ceil(pos.x - filter_radius), 0), loy = std::max((int) pm_ceil(pos.y - filter_radius), 0);
+            int hix = std::min((int) pm_floor(pos.x + filter_radius), sx - 1), hiy = std::min((int) pm_floor(pos.y + filter_radius), sy - 1);
+            uint32_t n = (uint32_t) pm_ceil((filter->radius - 2.f * RayEpsilon) * 2.f);
+            float wx[64], wy[64];
+            float basex = (float) lox - pos.x, basey = (float) loy - pos.y;
+            for (uint32_t i = 0; i < n; ++i) { wx[i] = filter->eval_discretized(basex + (float) i); wy[i] = filter->eval_discretized(basey + (float) i); }
+            for (uint32_t yr = 0; yr < n; ++yr) {
+                int y = loy + (int) yr;
+                bool enabled = y <= hiy;
+                for (uint32_t xr = 0; xr < n; ++xr) {
+                    int x = lox + (int) xr;
+                    float weight = wy[yr] * wx[xr];
+                    enabled = enabled && x <= hix;
+                    if (enabled) { size_t offset = (size_t) channels * ((size_t) y * sx + x); for (int k = 0; k < channels; ++k) data[offset + k] += value[k] * weight; }
+                }
+            }
+        } else {
+            int lox = (int) pm_ceil(pos.x - .5f), loy = (int) pm_ceil(pos.y - .5f);
+            bool enabled = lox >= 0 && loy >= 0 && lox < sx && loy < sy;
+            if (enabled) { size_t offset = (size_t) channels * ((size_t) loy * sx + lox); for (int k = 0; k < channels; ++k) data[offset + k] += value[k]; }
+        }
+        return true;
+    }
+    // imageblock.cpp:49-77 (accumulate_2d with clipping)
+    void put_block(const ImageBlock &b) {
+        int ssx = b.w + 2 * b.border, ssy = b.h + 2 * b.border, tsx = w + 2 * border, tsy = h + 2 * border;
+        int offx = (b.ox - b.border) - (ox - border), offy = (b.oy - b.border) - (oy - border);
+        for (int y = 0; y < ssy; ++y) {
+            int ty = y + offy; if (ty < 0 || ty >= tsy) continue;
+            for (int x = 0; x < ssx; ++x) {
+                int tx = x + offx; if (tx < 0 || tx >= tsx) continue;
+                for (int k = 0; k < channels; ++k) data[(size_t) channels * ((size_t) ty * tsx + tx) + k] += b.data[(size_t) channels * ((size_t) y * ssx + x) + k];
+            }
+        }
+    }
+};
+
+// spiral.cpp:11-72
+struct Spiral {
+    int size_x, size_y, off_x, off_y, block_size, blocks_x, blocks_y;
+    size_t block_count, block_counter, remaining_passes;
+    int dir, pos_x, pos_y, steps_left, steps;
+    void init(int sx, int sy, int ox, int oy, int bs, size_t passes) {
+        size_x = sx; size_y = sy; off_x = ox; off_y = oy; block_size = bs; remaining_passes = passes;
+        blocks_x = (int) std::ceil((float) sx / bs); blocks_y = (int) std::ceil((float) sy / bs);
+        block_count = (size_t) blocks_x * blocks_y;
+        reset();
+    }
+    void reset() { block_counter = 0; dir = 0; pos_x = blocks_x / 2; pos_y = blocks_y / 2; steps_left = 1; steps = 1; }
+    bool next_block(int *ox, int *oy, int *sx, int *sy, size_t *block_id) {
+        if (block_count == block_counter) {
+            if (remaining_passes > 1) { --remaining_passes; reset(); }
+            else { *ox = *oy = *sx = *sy = 0; *block_id = (size_t) -1; return false; }
+        }
+        *block_id = block_counter + (remaining_passes - 1) * block_count;
+        int offx = pos_x * block_size, offy = pos_y * block_size;
+        *sx = std::min(block_size, size_x - offx); *sy = std::min(block_size, size_y - offy);
+        *ox = offx + off_x; *oy = offy + off_y;
+        ++block_counter;
+        if (block_counter != block_count) {
+            do {
+                switch (dir) { case 0: ++pos_x; break; case 1: ++pos_y; break; case 2: --pos_x; break; case 3: --pos_y; break; }
+                if (--steps_left == 0) { dir = (dir + 1) % 4; if (dir == 2 || dir == 0) ++steps; steps_left = steps; }
+            } while (pos_x < 0 || pos_y < 0 || pos_x >= blocks_x || pos_y >= blocks_y);
+        }
+        return true;
+    }
+};
+
+// ---------------------------------------------------------------- render driver
+// integrator.cpp:233-288
+static void render_sample(const Scene &sc, Sampler &sampler, ImageBlock &block, float px, float py, Counters *cnt) {
+    const Sensor &se = sc.sensor;
+    P2 u = sampler.next_2d();
+    P2 position_sample = { px + u.x, py + u.y };
+    P2 aperture_sample = { .5f, .5f };
+    if (se.needs_aperture_sample) aperture_sample = sampler.next_2d();
+    /* time: shutter_open_time == 0 for every supported sensor (no draw) */
+    float wavelength_sample = sampler.next_1d(); (void) wavelength_sample;
+    P2 adjusted = { (position_sample.x - (float) se.crop_x) / (float) se.crop_w, (position_sample.y - (float) se.crop_y) / (float) se.crop_h };
+    V3 ray_weight;
+    Ray ray = sensor_sample_ray(sc, adjusted, aperture_sample, &ray_weight);
+    bool valid;
+    V3 L = sc.integrator.type == MTS_INTEGRATOR_VOLPATH ? volpath_sample(sc, sampler, ray, se.medium, &valid, cnt)
+                                                         : path_sample(sc, sampler, ray, &valid, cnt);
+    L = ray_weight * L;
+    // srgb_to_xyz, spectrum.h:221-227 (matrix * vector = fmadd chain over columns)
+    float aovs[5];
+    aovs[0] = pm_fma(0.180423f, L.z, pm_fma(0.357580f, L.y, 0.412453f * L.x));
+    aovs[1] = pm_fma(0.072169f, L.z, pm_fma(0.715160f, L.y, 0.212671f * L.x));
+    aovs[2] = pm_fma(0.950227f, L.z, pm_fma(0.119193f, L.y, 0.019334f * L.x));
+    aovs[3] = valid ? 1.f : 0.f;
+    aovs[4] = 1.f;
+    block.put(position_sample, aovs);
+}
+
+// integrator.cpp:181-209 (scalar branch)
+static void render_block(const Scene &sc, Sampler &sampler, ImageBlock &block, uint32_t block_size, size_t sample_count, size_t block_id, Counters *cnt,
+                         const std::atomic<int> *stop) {
+    block.clear();
+    uint32_t pixel_count = block_size * block_size;
+    for (uint32_t i = 0; i < pixel_count && !(stop && stop->load(std::memory_order_relaxed)); ++i) {
+        sampler.seed(block_id * pixel_count + i);
+        uint32_t x, y; morton_decode(i, &x, &y);
+        if (x >= (uint32_t) block.w || y >= (uint32_t) block.h) continue;
+        float px = (float) (x + block.ox), py = (float) (y + block.oy);
+        for (size_t j = 0; j < sample_count; ++j) render_sample(sc, sampler, block, px, py, cnt);
+    }
+}
+
+struct OracleScene { Scene *scene; std::atomic<int> stop; };
+
+// integrator.cpp:51-179 (CPU branch; TBB replaced by std::thread workers pulling blocks)
+static int render(OracleScene *os, int n_threads, int shard_index, int shard_count, float *film_out, mts_stats *stats) {
+    const Scene &sc = *os->scene;
+    const Sensor &se = sc.sensor;
+    auto t0 = std::chrono::steady_clock::now();
+    os->stop = 0;
+    size_t total_spp = (size_t) se.sample_count;
+    size_t samples_per_pass = sc.integrator.samples_per_pass < 0 ? total_spp : std::min((size_t) sc.integrator.samples_per_pass, total_spp);
+    if (samples_per_pass == 0 || (total_spp % samples_per_pass) != 0) throw std::runtime_error("sample_count must be a multiple of samples_per_pass");
+    size_t n_passes = (total_spp + samples_per_pass - 1) / samples_per_pass;
+    // block size: pinned to MTS_BLOCK_SIZE = 32 when unspecified (SURVEY.md section 7 "hard parts": the
+    // reference's heuristic depends on the thread count, integrator.cpp:89-97)
+    uint32_t block_size = sc.integrator.block_size > 0 ? (uint32_t) sc.integrator.block_size : 32u;
+    { uint32_t p = 1; while (p < block_size) p <<= 1; block_size = p; }                       // integrator.cpp:26-32
+    ImageBlock film; film.init(se.crop_w, se.crop_h, 5, nullptr, false); film.ox = se.crop_x; film.oy = se.crop_y;   // hdrfilm.cpp:201-203
+    Spiral spiral; spiral.init(se.crop_w, se.crop_h, se.crop_x, se.crop_y, (int) block_size, n_passes);
+    size_t total_blocks = spiral.block_count * n_passes;
+    std::mutex spiral_mutex, film_mutex;
+    Counters total; uint64_t samples = 0;
+    size_t next = 0;
+    auto worker = [&]() {
+        _mm_setcsr(_mm_getcsr() | 0x8040);                                                     // scoped_flush_denormals, integrator.cpp:117
+        Sampler sampler; sampler.base_seed = se.seed;
+        ImageBlock block; block.init((int) block_size, (int) block_size, 5, &se.rfilter, true);
+        Counters cnt; uint64_t my_samples = 0;
+        for (;;) {
+            int ox, oy, sx, sy; size_t block_id;
+            {
+                std::lock_guard<std::mutex> lock(spiral_mutex);
+                if (next >= total_blocks || os->stop.load()) break;
+                ++next;
+                if (!spiral.next_block(&ox, &oy, &sx, &sy, &block_id)) break;
+            }
+            if (shard_count > 1 && (int) (block_id % (size_t) shard_count) != shard_index) continue;
+            block.set_size(sx, sy); block.ox = ox; block.oy = oy;
+            render_block(sc, sampler, block, block_size, samples_per_pass, block_id, stats ? &cnt : nullptr, &os->stop);
+            my_samples += (uint64_t) sx * sy * samples_per_pass;
+            std::lock_guard<std::mutex> lock(film_mutex);
+            film.put_block(block);
+        }
+        std::lock_guard<std::mutex> lock(film_mutex);
+        total.n_iter += cnt.n_iter; total.n_lookup += cnt.n_lookup; total.n_nee_step += cnt.n_nee_step; samples += my_samples;
+    };
+    if (n_threads <= 1) worker();
+    else { std::vector<std::thread> th; for (int i = 0; i < n_threads; ++i) th.emplace_back(worker); for (auto &t : th) t.join(); }
+    memcpy(film_out, film.data.data(), film.data.size() * sizeof(float));
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        stats->samples = samples; stats->n_iter = total.n_iter; stats->n_lookup = total.n_lookup; stats->n_nee_step = total.n_nee_step;
+        stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        stats->cancelled = os->stop.load();
+    }
+    return 0;
+}
+
+} // namespace orc
+
+// ================================================================== C interface (ctypes)
+using namespace orc;
+static thread_local std::string g_error;
+#define ORC_TRY try {
+#define ORC_CATCH } catch (const std::exception &e) { g_error = e.what(); return 1; } catch (...) { g_error = "unknown error"; return 1; } return 0;
+
+extern "C" {
+
+const char *oracle_last_error(void) { return g_error.c_str(); }
+
+int oracle_scene_create(const mts_scene_desc *desc, oracle_scene **out) {
+    ORC_TRY
+    OracleScene *os = new OracleScene(); os->scene = make_scene(desc); os->stop = 0;
+    *out = (oracle_scene *) os;
+    ORC_CATCH
+}
+int oracle_scene_destroy(oracle_scene *s) { OracleScene *os = (OracleScene *) s; if (os) { delete os->scene; delete os; } return 0; }
+int oracle_cancel(oracle_scene *s) { ((OracleScene *) s)->stop = 1; return 0; }
+
+int oracle_render(oracle_scene *s, int n_threads, int shard_index, int shard_count, float *film, mts_stats *stats) {
+    ORC_TRY
+    render((OracleScene *) s, n_threads, shard_index, shard_count < 1 ? 1 : shard_count, film, stats);
+    ORC_CATCH
+}
+
+int oracle_sample(oracle_scene *s, int32_t n, uint64_t seed_offset, const float *ox, const float *oy, const float *oz,
+                  const float *dx, const float *dy, const float *dz, float *out_rgb, uint8_t *out_valid) {
+    ORC_TRY
+    const Scene &sc = *((OracleScene *) s)->scene;
+    unsigned csr = _mm_getcsr(); _mm_setcsr(csr | 0x8040);
+    for (int i = 0; i < n; ++i) {
+        Sampler sampler; sampler.base_seed = sc.sensor.seed; sampler.seed(seed_offset + (uint64_t) i);
+        Ray ray = make_ray(v3(ox[i], oy[i], oz[i]), v3(dx[i], dy[i], dz[i]), RayEpsilon, pm_inf());
+        bool valid;
+        V3 L = sc.integrator.type == MTS_INTEGRATOR_VOLPATH ? volpath_sample(sc, sampler, ray, sc.sensor.medium, &valid, nullptr) : path_sample(sc, sampler, ray, &valid, nullptr);
+        out_rgb[3 * i] = L.x; out_rgb[3 * i + 1] = L.y; out_rgb[3 * i + 2] = L.z; out_valid[i] = valid;
+    }
+    _mm_setcsr(csr);
+    ORC_CATCH
+}
+
+int oracle_ray_intersect(oracle_scene *s, int32_t n, const float *o, const float *d, const float *mint, const float *maxt,
+                         float *out_t, int32_t *out_shape, int32_t *out_prim, float *out_p, float *out_n) {
+    ORC_TRY
+    const Scene &sc = *((OracleScene *) s)->scene;
+    for (int i = 0; i < n; ++i) {
+        Ray ray = make_ray(v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), mint[i], maxt[i]);
+        SurfaceInteraction si = ray_intersect(sc, ray);
+        out_t[i] = si.t; out_shape[i] = si.shape; out_prim[i] = si.is_valid() ? si.prim_index : -1;
+        out_p[3 * i] = si.p.x; out_p[3 * i + 1] = si.p.y; out_p[3 * i + 2] = si.p.z;
+        out_n[3 * i] = si.n.x; out_n[3 * i + 1] = si.n.y; out_n[3 * i + 2] = si.n.z;
+    }
+    ORC_CATCH
+}
+
+// ---- unit-level entry points for the known-answer tests ----
+uint32_t oracle_tea32(uint32_t v0, uint32_t v1, int rounds) { return sample_tea_32(v0, v1, rounds); }
+uint64_t oracle_tea64(uint32_t v0, uint32_t v1, int rounds) { return sample_tea_64(v0, v1, rounds); }
+float oracle_tea_float32(uint32_t v0, uint32_t v1, int rounds) { return sample_tea_float32(v0, v1, rounds); }
+void oracle_pcg32(uint64_t initstate, uint64_t initseq, int n, uint32_t *out_u32, float *out_f32) {
+    PCG32 a, b; a.seed(initstate, initseq); b = a;
+    for (int i = 0; i < n; ++i) { if (out_u32) out_u32[i] = a.next_uint32(); if (out_f32) out_f32[i] = b.next_float32(); }
+}
+void oracle_sampler_stream(uint64_t base_seed, uint64_t seed_offset, int n, float *out) {
+    Sampler s; s.base_seed = base_seed; s.seed(seed_offset); for (int i = 0; i < n; ++i) out[i] = s.next_1d();
+}
+void oracle_warp(int kind, float u, float v, float *out) {
+    P2 s = { u, v };
+    if (kind == 0) { P2 p = square_to_uniform_disk_concentric(s); out[0] = p.x; out[1] = p.y; out[2] = 0.f; }
+    else { V3 r = kind == 1 ? square_to_uniform_sphere(s) : (kind == 2 ? square_to_uniform_hemisphere(s) : square_to_cosine_hemisphere(s)); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+}
+void oracle_coordinate_system(const float *n, float *s, float *t) { V3 a, b; coordinate_system(v3(n[0], n[1], n[2]), &a, &b); s[0] = a.x; s[1] = a.y; s[2] = a.z; t[0] = b.x; t[1] = b.y; t[2] = b.z; }
+void oracle_morton_decode(uint32_t i, uint32_t *x, uint32_t *y) { morton_decode(i, x, y); }
+int oracle_spiral(int sx, int sy, int ox, int oy, int block_size, int passes, int max_blocks, int32_t *out /* 5 per block: ox, oy, sx, sy, id */) {
+    Spiral sp; sp.init(sx, sy, ox, oy, block_size, (size_t) passes);
+    int n = 0;
+    for (; n < max_blocks; ++n) { int a, b, c, d; size_t id; if (!sp.next_block(&a, &b, &c, &d, &id)) break; out[5 * n] = a; out[5 * n + 1] = b; out[5 * n + 2] = c; out[5 * n + 3] = d; out[5 * n + 4] = (int32_t) id; }
+    return n;
+}
+// ImageBlock::put for a list of samples; returns the block storage including borders
+int oracle_imageblock_put(int w, int h, int ox, int oy, int channels, int rfilter_type, float radius, float stddev, int use_border,
+                          int n, const float *pos /* 2n */, const float *values /* channels*n */, float *out, int *out_border) {
+    ORC_TRY
+    RFilter f = make_rfilter(rfilter_type, radius, stddev);
+    ImageBlock b; b.init(w, h, channels, &f, use_border != 0); b.ox = ox; b.oy = oy;
+    for (int i = 0; i < n; ++i) { P2 p = { pos[2 * i], pos[2 * i + 1] }; b.put(p, values + (size_t) channels * i); }
+    memcpy(out, b.data.data(), b.data.size() * sizeof(float));
+    *out_border = b.border;
+    ORC_CATCH
+}
+float oracle_rfilter_eval(int rfilter_type, float radius, float stddev, float x, int discretized) {
+    RFilter f = make_rfilter(rfilter_type, radius, stddev); return discretized ? f.eval_discretized(x) : f.eval(x);
+}
+// phase function unit access: wi is the incident direction stored in mi.wi (= -ray.d), p the position
+int oracle_phase_eval(oracle_scene *s, int phase, const float *wi, const float *p, const float *wo, float *out) {
+    ORC_TRY
+    const Scene &sc = *((OracleScene *) s)->scene;
+    MediumInteraction mi; memset(&mi, 0, sizeof(mi));
+    mi.wi = v3(wi[0], wi[1], wi[2]); mi.sh_frame = frame_from_normal(-mi.wi); mi.p = v3(p[0], p[1], p[2]);
+    *out = phase_eval(sc, phase, mi, v3(wo[0], wo[1], wo[2]));
+    ORC_CATCH
+}
+int oracle_phase_sample(oracle_scene *s, int phase, const float *wi, const float *p, float s1, float s2x, float s2y, float *wo, float *pdf) {
+    ORC_TRY
+    const Scene &sc = *((OracleScene *) s)->scene;
+    MediumInteraction mi; memset(&mi, 0, sizeof(mi));
+    mi.wi = v3(wi[0], wi[1], wi[2]); mi.sh_frame = frame_from_normal(-mi.wi); mi.p = v3(p[0], p[1], p[2]);
+    P2 s2 = { s2x, s2y }; V3 w;
+    phase_sample(sc, phase, mi, s1, s2, &w, pdf);
+    wo[0] = w.x; wo[1] = w.y; wo[2] = w.z;
+    ORC_CATCH
+}
+// BSDF unit access in the local shading frame
+int oracle_bsdf_eval(oracle_scene *s, int bsdf, const float *wi, const float *wo, float *value, float *pdf) {
+    ORC_TRY
+    const Scene &sc = *((OracleScene *) s)->scene;
+    SurfaceInteraction si; memset(&si, 0, sizeof(si)); si.wi = v3(wi[0], wi[1], wi[2]);
+    V3 v = bsdf_eval(sc.bsdfs[bsdf], si, v3(wo[0], wo[1], wo[2]));
+    value[0] = v.x; value[1] = v.y; value[2] = v.z; *pdf = bsdf_pdf(sc.bsdfs[bsdf], si, v3(wo[0], wo[1], wo[2]));
+    ORC_CATCH
+}
+int oracle_bsdf_sample(oracle_scene *s, int bsdf, const float *wi, float s1, float s2x, float s2y, float *wo, float *pdf, float *weight, uint32_t *sampled_type) {
+    ORC_TRY
+    const Scene &sc = *((OracleScene *) s)->scene;
+    SurfaceInteraction si; memset(&si, 0, sizeof(si)); si.wi = v3(wi[0], wi[1], wi[2]);
+    BSDFSample bs; P2 s2 = { s2x, s2y };
+    V3 w = bsdf_sample(sc.bsdfs[bsdf], si, s1, s2, &bs);
+    wo[0] = bs.wo.x; wo[1] = bs.wo.y; wo[2] = bs.wo.z; *pdf = bs.pdf; weight[0] = w.x; weight[1] = w.y; weight[2] = w.z; *sampled_type = bs.sampled_type;
+    ORC_CATCH
+}
+int oracle_volume_eval(oracle_scene *s, int volume, int n, const float *p, float *out) {
+    ORC_TRY
+    const Scene &sc = *((OracleScene *) s)->scene;
+    for (int i = 0; i < n; ++i) { V3 r = volume_eval(sc.volumes[volume], v3(p[3 * i], p[3 * i + 1], p[3 * i + 2])); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; }
+    ORC_CATCH
+}
+// sensor rays for given film positions (normalised film coordinates) and aperture samples
+int oracle_sensor_sample_ray(oracle_scene *s, int n, const float *film_sample, const float *aperture_sample, float *o, float *d, float *weight) {
+    ORC_TRY
+    const Scene &sc = *((OracleScene *) s)->scene;
+    for (int i = 0; i < n; ++i) {
+        P2 f = { film_sample[2 * i], film_sample[2 * i + 1] }, a = { aperture_sample[2 * i], aperture_sample[2 * i + 1] };
+        V3 w; Ray r = sensor_sample_ray(sc, f, a, &w);
+        o[3 * i] = r.o.x; o[3 * i + 1] = r.o.y; o[3 * i + 2] = r.o.z; d[3 * i] = r.d.x; d[3 * i + 1] = r.d.y; d[3 * i + 2] = r.d.z;
+        weight[3 * i] = w.x; weight[3 * i + 1] = w.y; weight[3 * i + 2] = w.z;
+    }
+    ORC_CATCH
+}
+int oracle_emitter_sample_direction(oracle_scene *s, const float *ref_p, float u, float v, float *d, float *dist, float *pdf, float *spec) {
+    ORC_TRY
+    const Scene &sc = *((OracleScene *) s)->scene;
+    P2 smp = { u, v }; V3 sp;
+    DirectionSample ds = sample_emitter_direction(sc, v3(ref_p[0], ref_p[1], ref_p[2]), smp, false, &sp);
+    d[0] = ds.d.x; d[1] = ds.d.y; d[2] = ds.d.z; *dist = ds.dist; *pdf = ds.pdf; spec[0] = sp.x; spec[1] = sp.y; spec[2] = sp.z;
+    ORC_CATCH
+}
+float oracle_math(int fn, float x, float y) {
+    switch (fn) { case 0: return pm_log(x); case 1: return pm_exp(x); case 2: { float s, c; pm_sincos(x, &s, &c); return s; }
+                  case 3: { float s, c; pm_sincos(x, &s, &c); return c; } case 4: return pm_cbrt(x); case 5: return pm_pow(x, y); }
+    return 0.f;
+}
+
+} // extern "C"

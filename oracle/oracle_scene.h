@@ -1,0 +1,462 @@
+// oracle_scene.h -- TEST INFRASTRUCTURE, not product code (see oracle_math.h).
+//
+// "Plugin constructors" of the CPU restatement: turns the C-ABI scene description
+// (include/mtsamd.h, one POD record per reference plugin instance) into the state the reference
+// plugins hold after construction.  Citations are relative to /root/reference.
+#pragma once
+#include <vector>
+#include <string>
+#include <stdexcept>
+#include <algorithm>
+#include "oracle_math.h"
+#include "../include/mtsamd.h"
+
+namespace orc {
+
+static inline Xf xf_from_abi(const mts_transform &t) { Xf x; memcpy(x.m, t.matrix, 64); memcpy(x.it, t.inverse_transpose, 64); return x; }
+
+// ---------------------------------------------------------------- Volume
+// include/mitsuba/render/texture.h:210-279, src/librender/texture.cpp:89-92,
+// src/textures/constant3d.cpp, src/textures/grid3d.cpp:131-161,362
+struct Volume {
+    int type;
+    V3 value;
+    Xf world_to_local;
+    BBox bbox;
+    const float *data;
+    int nx, ny, nz, channels, filter, wrap;
+    float max;
+    bool has_max;
+};
+
+static inline Volume make_volume(const mts_volume &d) {
+    Volume v = {};
+    v.type = d.type;
+    v.value = v3(d.value[0], d.value[1], d.value[2]);
+    v.world_to_local = xf_inverse(xf_from_abi(d.to_world));           // texture.cpp:90
+    v.has_max = false;
+    if (d.type == MTS_VOLUME_GRID) {
+        if (!d.data) throw std::runtime_error("gridvolume: missing data");
+        if ((long) d.nx * d.ny * d.nz < 8)                                // volume_data.h:70-73
+            throw std::runtime_error("Invalid grid dimensions (must have at least one value at each corner)");
+        if (d.channels != 1 && d.channels != 3)                           // grid3d.cpp:115-116
+            throw std::runtime_error("Unsupported channel count (expected 1 or 3)");
+        v.data = d.data; v.nx = d.nx; v.ny = d.ny; v.nz = d.nz; v.channels = d.channels;
+        v.filter = d.filter_type; v.wrap = d.wrap_mode;
+        float mx = -pm_inf();                                             // volume_data.h:86-98
+        size_t n = (size_t) d.nx * d.ny * d.nz * d.channels;
+        for (size_t i = 0; i < n; ++i) mx = std::max(mx, d.data[i]);
+        v.max = mx; v.has_max = true;
+        if (d.use_grid_bbox) {                                            // grid3d.cpp:152-155, volume_data.h:24-33
+            V3 bmin = v3(d.file_bbox_min[0], d.file_bbox_min[1], d.file_bbox_min[2]);
+            V3 bmax = v3(d.file_bbox_max[0], d.file_bbox_max[1], d.file_bbox_max[2]);
+            Xf bt = xf_mul(xf_scale(vrcp(bmax - bmin)), xf_translate(-1.f * bmin));
+            v.world_to_local = xf_mul(bt, v.world_to_local);
+        }
+        if (d.has_max_value) v.max = d.max_value;                         // grid3d.cpp:157-160
+    }
+    // update_bbox(), texture.h:262-269
+    Xf inv = xf_inverse(v.world_to_local);
+    V3 a = xf_point(inv, v3(0, 0, 0)), b = xf_point(inv, v3(1, 1, 1));
+    v.bbox.min = a; v.bbox.max = a; bbox_expand(v.bbox, b);
+    return v;
+}
+
+// ---------------------------------------------------------------- Phase functions
+// ContinuousDistribution, include/mitsuba/core/distr_1d.h:293-345
+struct ContinuousDistribution {
+    std::vector<float> pdf, cdf;
+    float range_x, range_y, integral, normalization, interval_size, inv_interval_size;
+    uint32_t valid_x, valid_y;
+};
+static inline void distr_update(ContinuousDistribution &d) {
+    size_t size = d.pdf.size();
+    if (size < 2) throw std::runtime_error("ContinuousDistribution: needs at least two entries!");
+    d.cdf.resize(size - 1);
+    d.valid_x = d.valid_y = (uint32_t) -1;
+    double range = double(d.range_y) - double(d.range_x), interval_size = range / (size - 1), integral = 0.;
+    for (size_t i = 0; i < size - 1; ++i) {
+        double y0 = (double) d.pdf[i], y1 = (double) d.pdf[i + 1];
+        double value = 0.5 * interval_size * (y0 + y1);
+        integral += value;
+        d.cdf[i] = (float) integral;
+        if (y0 < 0. || y1 < 0.) throw std::runtime_error("ContinuousDistribution: entries must be non-negative!");
+        else if (value > 0.) { if (d.valid_x == (uint32_t) -1) d.valid_x = (uint32_t) i; d.valid_y = (uint32_t) i; }
+    }
+    if (d.valid_x == (uint32_t) -1) throw std::runtime_error("ContinuousDistribution: no probability mass found!");
+    d.integral = (float) integral; d.normalization = (float) (1. / integral);
+    d.interval_size = (float) interval_size; d.inv_interval_size = (float) (1. / interval_size);
+}
+
+struct Phase {
+    int type;
+    float g;
+    int child[2];
+    int weight_volume;
+    ContinuousDistribution distr;
+};
+static inline Phase make_phase(const mts_phase &d) {
+    Phase p = {};
+    p.type = d.type; p.g = d.g; p.child[0] = d.child[0]; p.child[1] = d.child[1]; p.weight_volume = d.weight_volume;
+    if (d.type == MTS_PHASE_HG && (d.g >= 1 || d.g <= -1))              // hg.cpp:45-46
+        throw std::runtime_error("The asymmetry parameter must lie in the interval (-1, 1)!");
+    if (d.type == MTS_PHASE_TABULATED) {                                  // tabphase.cpp:33-51
+        p.distr.pdf.assign(d.tab_values, d.tab_values + d.tab_count);
+        p.distr.range_x = -1.f; p.distr.range_y = 1.f;
+        distr_update(p.distr);
+    }
+    return p;
+}
+
+// ---------------------------------------------------------------- Medium
+struct Medium {
+    int type, sigma_t, albedo, phase;
+    float scale;
+    bool sample_emitters, has_spectral_extinction, is_homogeneous;
+    float max_density;   // heterogeneous.cpp:29
+    BBox aabb;           // heterogeneous.cpp:30
+};
+
+// ---------------------------------------------------------------- BSDF
+struct Bsdf { int type; V3 reflectance, rho_0, k, g, rho_c; uint32_t flags; };
+// bsdf.h:38-124
+enum : uint32_t { F_Null = 0x1, F_DiffuseReflection = 0x2, F_DiffuseTransmission = 0x4, F_GlossyReflection = 0x8,
+                  F_GlossyTransmission = 0x10, F_DeltaReflection = 0x20, F_DeltaTransmission = 0x40,
+                  F_FrontSide = 0x8000, F_BackSide = 0x10000,
+                  F_Smooth = 0x2 | 0x4 | 0x8 | 0x10, F_Delta = 0x1 | 0x20 | 0x40 };
+
+// ---------------------------------------------------------------- Shapes
+struct Shape {
+    int type;
+    Xf to_world, to_object;
+    int bsdf, interior, exterior, emitter;
+    BBox bbox;
+    // rectangle (rectangle.cpp:66-74)
+    Frame frame;
+    float inv_surface_area;
+    // sphere (sphere.cpp:80-105)
+    V3 center; float radius; bool flip_normals;
+    // mesh (mesh.cpp, cube.cpp:54-112): world-space vertex data
+    std::vector<float> positions, normals, texcoords;
+    std::vector<uint32_t> faces;
+    int prim_count;
+    bool is_medium_transition() const { return interior >= 0 || exterior >= 0; }   // shape.h:341
+};
+
+// cube.cpp:43-67
+static const float CUBE_VERTICES[24][3] = {
+    { 1, -1, -1 }, { 1, -1, 1 }, { -1, -1, 1 }, { -1, -1, -1 }, { 1, 1, -1 }, { -1, 1, -1 }, { -1, 1, 1 }, { 1, 1, 1 },
+    { 1, -1, -1 }, { 1, 1, -1 }, { 1, 1, 1 }, { 1, -1, 1 }, { 1, -1, 1 }, { 1, 1, 1 }, { -1, 1, 1 }, { -1, -1, 1 },
+    { -1, -1, 1 }, { -1, 1, 1 }, { -1, 1, -1 }, { -1, -1, -1 }, { 1, 1, -1 }, { 1, -1, -1 }, { -1, -1, -1 }, { -1, 1, -1 } };
+static const float CUBE_NORMALS[24][3] = {
+    { 0, -1, 0 }, { 0, -1, 0 }, { 0, -1, 0 }, { 0, -1, 0 }, { 0, 1, 0 }, { 0, 1, 0 }, { 0, 1, 0 }, { 0, 1, 0 },
+    { 1, 0, 0 }, { 1, 0, 0 }, { 1, 0, 0 }, { 1, 0, 0 }, { 0, 0, 1 }, { 0, 0, 1 }, { 0, 0, 1 }, { 0, 0, 1 },
+    { -1, 0, 0 }, { -1, 0, 0 }, { -1, 0, 0 }, { -1, 0, 0 }, { 0, 0, -1 }, { 0, 0, -1 }, { 0, 0, -1 }, { 0, 0, -1 } };
+static const float CUBE_TEXCOORDS[24][2] = {
+    { 0, 1 }, { 1, 1 }, { 1, 0 }, { 0, 0 }, { 0, 1 }, { 1, 1 }, { 1, 0 }, { 0, 0 }, { 0, 1 }, { 1, 1 }, { 1, 0 }, { 0, 0 },
+    { 0, 1 }, { 1, 1 }, { 1, 0 }, { 0, 0 }, { 0, 1 }, { 1, 1 }, { 1, 0 }, { 0, 0 }, { 0, 1 }, { 1, 1 }, { 1, 0 }, { 0, 0 } };
+static const uint32_t CUBE_TRIANGLES[12][3] = {
+    { 0, 1, 2 }, { 3, 0, 2 }, { 4, 5, 6 }, { 7, 4, 6 }, { 8, 9, 10 }, { 11, 8, 10 },
+    { 12, 13, 14 }, { 15, 12, 14 }, { 16, 17, 18 }, { 19, 16, 18 }, { 20, 21, 22 }, { 23, 20, 22 } };
+
+static inline Shape make_shape(const mts_shape &d) {
+    Shape s = {};
+    s.type = d.type;
+    s.to_world = xf_from_abi(d.to_world);
+    s.bsdf = d.bsdf; s.interior = d.interior_medium; s.exterior = d.exterior_medium; s.emitter = d.emitter;
+    s.flip_normals = d.flip_normals != 0;
+    s.bbox = bbox_empty();
+    if (d.type == MTS_SHAPE_RECTANGLE) {
+        if (d.flip_normals) s.to_world = xf_mul(s.to_world, xf_scale(v3(1.f, 1.f, -1.f)));   // rectangle.cpp:61-62
+        s.to_object = xf_inverse(s.to_world);
+        V3 dp_du = xf_vector(s.to_world, v3(2.f, 0.f, 0.f)), dp_dv = xf_vector(s.to_world, v3(0.f, 2.f, 0.f));
+        V3 n = normalize(xf_normal(s.to_world, v3(0.f, 0.f, 1.f)));
+        s.frame.s = dp_du; s.frame.t = dp_dv; s.frame.n = n;                                 // rectangle.cpp:68-72
+        s.inv_surface_area = pm_rcp(norm(cross(s.frame.s, s.frame.t)));                     // rectangle.cpp:73,86
+        bbox_expand(s.bbox, xf_point_affine(s.to_world, v3(-1.f, -1.f, 0.f)));               // rectangle.cpp:77-83
+        bbox_expand(s.bbox, xf_point_affine(s.to_world, v3(1.f, -1.f, 0.f)));
+        bbox_expand(s.bbox, xf_point_affine(s.to_world, v3(1.f, 1.f, 0.f)));
+        bbox_expand(s.bbox, xf_point_affine(s.to_world, v3(-1.f, 1.f, 0.f)));
+        s.prim_count = 1;
+    } else if (d.type == MTS_SHAPE_CUBE || d.type == MTS_SHAPE_MESH) {
+        s.to_object = xf_inverse(s.to_world);
+        int nv, nf; const float *pos, *nor, *uv; const uint32_t *fc;
+        if (d.type == MTS_SHAPE_CUBE) { nv = 24; nf = 12; pos = &CUBE_VERTICES[0][0]; nor = &CUBE_NORMALS[0][0]; uv = &CUBE_TEXCOORDS[0][0]; fc = &CUBE_TRIANGLES[0][0]; }
+        else { nv = d.vertex_count; nf = d.face_count; pos = d.vertex_positions; nor = d.vertex_normals; uv = d.vertex_texcoords; fc = d.faces;
+               if (!pos || !fc || nv <= 0 || nf <= 0) throw std::runtime_error("mesh: missing vertex / face data"); }
+        s.positions.resize(3 * nv);
+        if (nor) s.normals.resize(3 * nv);
+        if (uv) s.texcoords.assign(uv, uv + 2 * nv);
+        for (int i = 0; i < nv; ++i) {                                                         // cube.cpp:88-104
+            V3 p = xf_point_affine(s.to_world, v3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]));
+            bbox_expand(s.bbox, p);
+            s.positions[3 * i] = p.x; s.positions[3 * i + 1] = p.y; s.positions[3 * i + 2] = p.z;
+            if (nor) {
+                V3 n = normalize(xf_normal(s.to_world, v3(nor[3 * i], nor[3 * i + 1], nor[3 * i + 2])));
+                s.normals[3 * i] = n.x; s.normals[3 * i + 1] = n.y; s.normals[3 * i + 2] = n.z;
+            }
+        }
+        s.faces.assign(fc, fc + 3 * nf);
+        for (int i = 0; i < 3 * nf; ++i) if (s.faces[i] >= (uint32_t) nv) throw std::runtime_error("mesh: face index out of range");
+        s.prim_count = nf;
+    } else if (d.type == MTS_SHAPE_SPHERE) {
+        // sphere.cpp:80-105: to_world * translate(center) * scale(radius); must be a uniform scale without shear.
+        Xf tw = xf_mul(s.to_world, xf_mul(xf_translate(v3(d.center[0], d.center[1], d.center[2])), xf_scale(v3(d.radius, d.radius, d.radius))));
+        V3 c0 = v3(tw.m[0], tw.m[4], tw.m[8]), c1 = v3(tw.m[1], tw.m[5], tw.m[9]), c2 = v3(tw.m[2], tw.m[6], tw.m[10]);
+        float r0 = norm(c0), r1 = norm(c1), r2 = norm(c2);
+        if (pm_abs(r0 - r1) > 1e-6f * r0 || pm_abs(r0 - r2) > 1e-6f * r0 ||
+            pm_abs(dot(c0, c1)) > 1e-6f * r0 * r0 || pm_abs(dot(c0, c2)) > 1e-6f * r0 * r0 || pm_abs(dot(c1, c2)) > 1e-6f * r0 * r0)
+            throw std::runtime_error("'to_world' transform shouldn't contain any scale or shear along the sphere axes");
+        s.center = xf_translation(tw);
+        s.radius = r0;
+        // Reconstructed transform: rotation Q = columns / radius, uniform scale, translation
+        Xf rec = xf_identity();
+        V3 q0 = c0 / r0, q1 = c1 / r0, q2 = c2 / r0;
+        float R[9] = { q0.x, q1.x, q2.x, q0.y, q1.y, q2.y, q0.z, q1.z, q2.z };
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
+            rec.m[r * 4 + c] = R[r * 3 + c] * s.radius;
+            rec.it[r * 4 + c] = R[r * 3 + c] / s.radius;
+        }
+        rec.m[3] = s.center.x; rec.m[7] = s.center.y; rec.m[11] = s.center.z;
+        // inverse transpose translation row: -(R/r)^T c
+        Xf tmp = rec;
+        float invm[16] = {};
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) invm[r * 4 + c] = R[c * 3 + r] / s.radius;
+        for (int r = 0; r < 3; ++r) invm[r * 4 + 3] = -(invm[r * 4] * s.center.x + invm[r * 4 + 1] * s.center.y + invm[r * 4 + 2] * s.center.z);
+        invm[15] = 1.f;
+        mat_transpose(invm, tmp.it);
+        s.to_world = tmp;
+        s.to_object = xf_inverse(s.to_world);
+        s.inv_surface_area = pm_rcp(4.f * Pi * s.radius * s.radius);
+        s.bbox.min = s.center - v3(s.radius, s.radius, s.radius);
+        s.bbox.max = s.center + v3(s.radius, s.radius, s.radius);
+        s.prim_count = 1;
+    } else throw std::runtime_error("unknown shape type");
+    return s;
+}
+
+// ---------------------------------------------------------------- Emitter
+struct Emitter {
+    int type; Xf to_world; V3 radiance; int shape;
+    V3 bsphere_center; float bsphere_radius;    // directional.cpp:68-73, constant.cpp:35-39
+    bool is_environment() const { return type == MTS_EMITTER_CONSTANT; }
+};
+
+// ---------------------------------------------------------------- Sensor / film / filter
+struct RFilter {
+    int type; float radius, stddev, alpha, bias;
+    float values[32]; float scale_factor; int border_size;
+    float eval(float x) const {
+        if (type == MTS_RFILTER_BOX) return pm_abs(x) <= radius ? 1.f : 0.f;              // box.cpp:35-37
+        return pm_max(0.f, pm_exp(alpha * (x * x)) - bias);                                // gaussian.cpp:45-47
+    }
+    float eval_discretized(float x) const {                                                // rfilter.h:62-65
+        int index = std::min((int) pm_abs(x * scale_factor), 31);
+        return values[index];
+    }
+};
+static inline RFilter make_rfilter(int type, float radius, float stddev) {
+    RFilter f = {};
+    f.type = type;
+    if (type == MTS_RFILTER_BOX) f.radius = radius + RayEpsilon;                           // box.cpp:31
+    else { f.stddev = stddev; f.radius = 4 * stddev; f.alpha = -1.f / (2.f * stddev * stddev); f.bias = pm_exp(f.alpha * (f.radius * f.radius)); }  // gaussian.cpp:33-42
+    for (int i = 0; i < 31; ++i) f.values[i] = f.eval((f.radius * i) / 31);               // rfilter.cpp:9-20, MTS_FILTER_RESOLUTION = 31
+    f.values[31] = 0;
+    f.scale_factor = 31 / f.radius;
+    f.border_size = (int) std::ceil(f.radius - .5f - 2.f * RayEpsilon);
+    return f;
+}
+
+struct Sensor {
+    int type; Xf to_world;
+    // perspective (perspective.cpp:101-124)
+    Xf camera_to_sample, sample_to_camera;
+    float near_clip, far_clip; P2 principal_point_offset;
+    // distant (distant.cpp:225-297)
+    int direction_type;      // 0 single, 1 sample width, 2 sample all
+    bool flip_directions;
+    int target_type; V3 target_point; Shape target_shape;
+    V3 bsphere_center; float bsphere_radius;
+    bool needs_aperture_sample;
+    int medium;
+    // film
+    int width, height, crop_x, crop_y, crop_w, crop_h;
+    RFilter rfilter;
+    int sample_count; uint64_t seed;
+};
+
+// Transform::perspective, transform.h:203-220
+static inline Xf xf_perspective(float fov, float near_, float far_) {
+    float recip = 1.f / (far_ - near_);
+    float tan_ = std::tan(fov * .5f * (Pi / 180.f)), cot = 1.f / tan_;
+    Xf x = {};
+    x.m[0] = cot; x.m[5] = cot; x.m[10] = far_ * recip; x.m[11] = -near_ * far_ * recip; x.m[14] = 1.f;
+    float inv[16] = {};
+    inv[0] = tan_; inv[5] = tan_; inv[15] = 1.f / near_; inv[11] = 1.f; inv[14] = (near_ - far_) / (far_ * near_);
+    mat_transpose(inv, x.it);
+    return x;
+}
+// sensor.h:196-231
+static inline Xf perspective_projection(int fw, int fh, int cw, int ch, int cx, int cy, float fov_x, float near_clip, float far_clip) {
+    float fsx = (float) fw, fsy = (float) fh;
+    float rel_size_x = (float) cw / fsx, rel_size_y = (float) ch / fsy, rel_off_x = (float) cx / fsx, rel_off_y = (float) cy / fsy;
+    float aspect = fsx / fsy;
+    return xf_mul(xf_scale(v3(1.f / rel_size_x, 1.f / rel_size_y, 1.f)),
+           xf_mul(xf_translate(v3(-rel_off_x, -rel_off_y, 0.f)),
+           xf_mul(xf_scale(v3(-0.5f, -0.5f * aspect, 1.f)),
+           xf_mul(xf_translate(v3(-1.f, -1.f / aspect, 0.f)),
+                  xf_perspective(fov_x, near_clip, far_clip)))));
+}
+
+// ---------------------------------------------------------------- Scene
+struct Prim { int shape; int index; };
+
+struct Scene {
+    std::vector<Volume> volumes;
+    std::vector<Phase> phases;
+    std::vector<Medium> media;
+    std::vector<Bsdf> bsdfs;
+    std::vector<Shape> shapes;
+    std::vector<Emitter> emitters;
+    int environment;
+    Sensor sensor;
+    mts_integrator integrator;
+    BBox bbox;
+    std::vector<Prim> prims;
+    Bsdf default_bsdf, default_emitter_bsdf;
+    const Bsdf &bsdf_of(const Shape &s) const {
+        if (s.bsdf >= 0) return bsdfs[s.bsdf];
+        return s.emitter >= 0 ? default_emitter_bsdf : default_bsdf;    // shape.cpp:74-80
+    }
+};
+
+static inline uint32_t bsdf_flags(int type) {
+    if (type == MTS_BSDF_DIFFUSE) return F_DiffuseReflection | F_FrontSide;              // diffuse.cpp:55
+    if (type == MTS_BSDF_NULL) return F_Null | F_FrontSide | F_BackSide;                 // null.cpp:26
+    return F_GlossyReflection | F_FrontSide;                                             // rpv.cpp:66
+}
+
+static inline void check_index(int i, size_t n, const char *what, bool allow_none) {
+    if (i < 0 && allow_none) return;
+    if (i < 0 || (size_t) i >= n) throw std::runtime_error(std::string("index out of range: ") + what);
+}
+
+static inline Scene *make_scene(const mts_scene_desc *d) {
+    if (!d || d->abi_version != MTS_ABI_VERSION) throw std::runtime_error("scene description: ABI version mismatch");
+    Scene *sc = new Scene();
+    try {
+        for (int i = 0; i < d->volume_count; ++i) sc->volumes.push_back(make_volume(d->volumes[i]));
+        for (int i = 0; i < d->phase_count; ++i) {
+            sc->phases.push_back(make_phase(d->phases[i]));
+            if (d->phases[i].type == MTS_PHASE_BLEND) {
+                check_index(d->phases[i].child[0], d->phase_count, "blendphase child", false);
+                check_index(d->phases[i].child[1], d->phase_count, "blendphase child", false);
+                check_index(d->phases[i].weight_volume, d->volume_count, "blendphase weight", false);
+            }
+        }
+        for (int i = 0; i < d->medium_count; ++i) {
+            const mts_medium &m = d->media[i];
+            check_index(m.sigma_t_volume, d->volume_count, "medium sigma_t", false);
+            check_index(m.albedo_volume, d->volume_count, "medium albedo", false);
+            check_index(m.phase, d->phase_count, "medium phase", false);
+            Medium me = {};
+            me.type = m.type; me.sigma_t = m.sigma_t_volume; me.albedo = m.albedo_volume; me.phase = m.phase;
+            me.scale = m.scale; me.sample_emitters = m.sample_emitters != 0;
+            me.has_spectral_extinction = m.has_spectral_extinction != 0;
+            me.is_homogeneous = m.type == MTS_MEDIUM_HOMOGENEOUS;
+            if (!me.is_homogeneous) {                                                      // heterogeneous.cpp:29-30
+                const Volume &st = sc->volumes[m.sigma_t_volume];
+                if (!st.has_max) throw std::runtime_error("max() not implemented (constvolume sigma_t in heterogeneous medium)");   // constant3d.cpp:37
+                me.max_density = me.scale * st.max;
+                me.aabb = st.bbox;
+            }
+            sc->media.push_back(me);
+        }
+        for (int i = 0; i < d->bsdf_count; ++i) {
+            const mts_bsdf &b = d->bsdfs[i];
+            Bsdf bs = {};
+            bs.type = b.type;
+            bs.reflectance = v3(b.reflectance[0], b.reflectance[1], b.reflectance[2]);
+            bs.rho_0 = v3(b.rho_0[0], b.rho_0[1], b.rho_0[2]); bs.k = v3(b.k[0], b.k[1], b.k[2]);
+            bs.g = v3(b.g[0], b.g[1], b.g[2]); bs.rho_c = v3(b.rho_c[0], b.rho_c[1], b.rho_c[2]);
+            bs.flags = bsdf_flags(b.type);
+            sc->bsdfs.push_back(bs);
+        }
+        sc->default_bsdf = Bsdf{ MTS_BSDF_DIFFUSE, v3(.5f, .5f, .5f), {}, {}, {}, {}, bsdf_flags(MTS_BSDF_DIFFUSE) };
+        sc->default_emitter_bsdf = Bsdf{ MTS_BSDF_DIFFUSE, v3(0.f, 0.f, 0.f), {}, {}, {}, {}, bsdf_flags(MTS_BSDF_DIFFUSE) };
+        sc->bbox = bbox_empty();
+        for (int i = 0; i < d->shape_count; ++i) {
+            const mts_shape &s = d->shapes[i];
+            check_index(s.bsdf, d->bsdf_count, "shape bsdf", true);
+            check_index(s.interior_medium, d->medium_count, "shape interior", true);
+            check_index(s.exterior_medium, d->medium_count, "shape exterior", true);
+            check_index(s.emitter, d->emitter_count, "shape emitter", true);
+            sc->shapes.push_back(make_shape(s));
+            bbox_expand(sc->bbox, sc->shapes.back().bbox);                                 // scene.cpp:38
+            for (int k = 0; k < sc->shapes.back().prim_count; ++k) sc->prims.push_back(Prim{ i, k });
+        }
+        sc->environment = -1;
+        for (int i = 0; i < d->emitter_count; ++i) {
+            const mts_emitter &e = d->emitters[i];
+            Emitter em = {};
+            em.type = e.type; em.to_world = xf_from_abi(e.to_world);
+            em.radiance = v3(e.radiance[0], e.radiance[1], e.radiance[2]); em.shape = e.shape;
+            if (e.type == MTS_EMITTER_AREA) {
+                check_index(e.shape, d->shape_count, "area emitter shape", false);
+                if (sc->shapes[e.shape].type == MTS_SHAPE_CUBE || sc->shapes[e.shape].type == MTS_SHAPE_MESH)
+                    throw std::runtime_error("area emitters on meshes are not supported by this backend");
+            }
+            if (em.is_environment()) {
+                if (sc->environment >= 0) throw std::runtime_error("Only one environment emitter can be specified per scene.");   // scene.cpp:48-50
+                sc->environment = i;
+            }
+            // set_scene: directional.cpp:68-73, constant.cpp:35-39; bbox.h:329-332
+            V3 c = (sc->bbox.max + sc->bbox.min) * .5f;
+            em.bsphere_center = c;
+            em.bsphere_radius = pm_max(RayEpsilon, norm(c - sc->bbox.max) * (1.f + RayEpsilon));
+            sc->emitters.push_back(em);
+        }
+        // Sensor
+        const mts_sensor &s = d->sensor;
+        Sensor &se = sc->sensor;
+        se = Sensor();
+        se.type = s.type; se.to_world = xf_from_abi(s.to_world);
+        se.width = s.film_width; se.height = s.film_height;
+        se.crop_x = s.crop_offset[0]; se.crop_y = s.crop_offset[1]; se.crop_w = s.crop_size[0]; se.crop_h = s.crop_size[1];
+        if (se.width <= 0 || se.height <= 0 || se.crop_w <= 0 || se.crop_h <= 0) throw std::runtime_error("film: invalid size");
+        se.rfilter = make_rfilter(s.rfilter_type, s.rfilter_radius, s.rfilter_stddev);
+        se.sample_count = s.sample_count; se.seed = s.sampler_seed; se.medium = s.medium;
+        check_index(s.medium, d->medium_count, "sensor medium", true);
+        if (s.type == MTS_SENSOR_PERSPECTIVE) {
+            se.near_clip = s.near_clip; se.far_clip = s.far_clip;
+            se.camera_to_sample = perspective_projection(se.width, se.height, se.crop_w, se.crop_h, se.crop_x, se.crop_y, s.fov_x, s.near_clip, s.far_clip);
+            se.sample_to_camera = xf_inverse(se.camera_to_sample);
+            // perspective.cpp:101-106
+            se.principal_point_offset.x = s.principal_point_offset[0] * ((float) se.width / (float) se.crop_w);
+            se.principal_point_offset.y = s.principal_point_offset[1] * ((float) se.height / (float) se.crop_h);
+            se.needs_aperture_sample = false;                                              // perspective.cpp:122
+        } else {
+            // distant.cpp:228-238
+            se.direction_type = (se.width == 1 && se.height == 1) ? 0 : (se.height == 1 ? 1 : 2);
+            se.flip_directions = s.distant_flip_directions != 0;
+            se.target_type = s.distant_target_type;
+            se.target_point = v3(s.distant_target_point[0], s.distant_target_point[1], s.distant_target_point[2]);
+            if (se.target_type == MTS_DISTANT_TARGET_SHAPE) {
+                se.target_shape = make_shape(s.distant_target_shape);
+                if (se.target_shape.type != MTS_SHAPE_RECTANGLE && se.target_shape.type != MTS_SHAPE_SPHERE)
+                    throw std::runtime_error("distant ray_target shape must be a rectangle or a sphere in this backend");
+            }
+            V3 c = (sc->bbox.max + sc->bbox.min) * .5f;                                    // distant.cpp:292-297
+            se.bsphere_center = c;
+            se.bsphere_radius = pm_max(RayEpsilon, norm(c - sc->bbox.max) * (1.f + RayEpsilon));
+            se.needs_aperture_sample = true;                                               // endpoint.h:244
+        }
+        sc->integrator = d->integrator;
+        if (sc->integrator.rr_depth <= 0) throw std::runtime_error("\"rr_depth\" must be set to a value greater than zero!");   // integrator.cpp:306-307
+        if (sc->integrator.max_depth < 0 && sc->integrator.max_depth != -1)
+            throw std::runtime_error("\"max_depth\" must be set to -1 (infinite) or a value >= 0");   // integrator.cpp:313-314
+    } catch (...) { delete sc; throw; }
+    return sc;
+}
+
+} // namespace orc
