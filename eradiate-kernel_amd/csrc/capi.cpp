@@ -127,16 +127,20 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
     if (block_size > 1024) throw std::runtime_error("block_size too large");
     // spiral.cpp: enumerate every (pass, block) pair in the reference's order; keep this shard's blocks
     Spiral spiral; spiral.init(se.crop_w, se.crop_h, se.crop_x, se.crop_y, (int) block_size, n_passes);
-    std::vector<std::vector<DBlock>> pass_blocks(n_passes);
+    // Passes are independent jobs (each block id seeds its own streams) whose results add up in the film, so
+    // all (pass, block) pairs of this shard go into ONE launch; only a timeout forces pass-sized launches,
+    // because should_stop() is honoured between launches.
+    const bool per_pass_launches = hs.integrator.timeout > 0.f;
+    std::vector<std::vector<DBlock>> pass_blocks(per_pass_launches ? n_passes : 1);
     uint64_t samples = 0;
     for (size_t pass = 0; pass < n_passes; ++pass)
         for (size_t k = 0; k < spiral.block_count; ++k) {
             DBlock b; size_t id;
             if (!spiral.next_block(b, id)) throw std::runtime_error("spiral exhausted early");
             if ((int) (id % (size_t) opts.shard_count) != opts.shard_index) continue;
-            if (id * (uint64_t) block_size * block_size >= ((uint64_t) 1 << 63)) throw std::runtime_error("block id overflow");
+            if (id >= ((uint64_t) 1 << 32)) throw std::runtime_error("block id overflow");
             b.id = (uint32_t) id;
-            pass_blocks[pass].push_back(b);
+            pass_blocks[per_pass_launches ? pass : 0].push_back(b);
             samples += (uint64_t) b.sx * b.sy * samples_per_pass;
         }
     const size_t film_floats = (size_t) se.crop_w * se.crop_h * 5;
@@ -151,8 +155,8 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
     double kernel_ms = 0.0; int launches = 0; bool cancelled = false;
     const float timeout = hs.integrator.timeout;
     try {
-        for (size_t pass = 0; pass < n_passes; ++pass) {
-            // should_stop(), integrator.h:143-146 -- checked at pass granularity
+        for (size_t pass = 0; pass < pass_blocks.size(); ++pass) {
+            // should_stop(), integrator.h:143-146 -- checked between launches
             if (hs.stop.load() || (timeout > 0.f && std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count() > timeout)) { cancelled = true; break; }
             const std::vector<DBlock> &blocks = pass_blocks[pass];
             if (blocks.empty()) continue;

@@ -1,0 +1,54 @@
+"""The C-ABI library loads, exports every symbol include/mtsamd.h declares, and the ctypes mirror has the
+compiled struct sizes.  No compute calls (works without a GPU)."""
+import ctypes as C
+import importlib
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+A = importlib.import_module("eradiate-kernel_amd._capi")
+
+
+@pytest.fixture(scope="module")
+def L():
+    importlib.import_module("eradiate-kernel_amd.build").build_backend(verbose=False)
+    return A.lib()
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "mtsamd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mts_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported(L):
+    names = declared_functions()
+    assert {"mts_scene_create", "mts_scene_destroy", "mts_render", "mts_cancel", "mts_sample", "mts_ray_intersect",
+            "mts_last_error", "mts_abi_version", "mts_device_count", "mts_abi_sizeof"} <= set(names)
+    for n in names:
+        assert hasattr(L, n), "libmtsamd.so does not export %s" % n
+    assert set(A.ABI_SYMBOLS) == set(names)
+
+
+def test_abi_version_and_struct_sizes(L):
+    assert L.mts_abi_version() == A.MTS_ABI_VERSION
+    for name, cls in A.ABI_STRUCTS.items():
+        assert L.mts_abi_sizeof(name.encode()) == C.sizeof(cls), name
+    assert L.mts_abi_sizeof(b"nonsense") == -1
+
+
+def test_errors_do_not_cross_the_boundary(L):
+    h = C.c_void_p()
+    desc = A.SceneDesc()            # abi_version = 0
+    assert L.mts_scene_create(C.byref(desc), 0, C.byref(h)) != 0
+    assert b"ABI version" in L.mts_last_error()
+    assert L.mts_cancel(None) != 0
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(A, "_lib", None)
+    monkeypatch.setattr(A, "LIB_PATH", "/nonexistent/libmtsamd.so")
+    with pytest.raises(A.BackendError):
+        A.lib()

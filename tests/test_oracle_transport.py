@@ -1,0 +1,61 @@
+"""Closed-form radiative-transfer cases for the oracle's volpath (the reference holds no in-tree numeric pin
+for volpath); the GPU path is checked against the same cases in test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+import tests.oracle_binding as ob
+import tests.transport_cases as tc
+
+
+@pytest.mark.parametrize("heterogeneous", [False, True])
+def test_absorbing_slab(heterogeneous):
+    d, expected, tol = tc.absorbing_slab(heterogeneous=heterogeneous)
+    rgb = tc.radiance_rgb(ob.OracleScene(d).render()).reshape(3)
+    assert np.allclose(rgb, expected, rtol=tol)
+
+
+def test_constant_grid_equals_homogeneous_stream():
+    """A constant-valued grid makes delta tracking consume exactly the random numbers of the homogeneous medium
+    when sigma_t equals the majorant: both renders are identical."""
+    a = ob.OracleScene(tc.absorbing_slab(2000, heterogeneous=False)[0]).render()
+    b = ob.OracleScene(tc.absorbing_slab(2000, heterogeneous=True)[0]).render()
+    assert np.allclose(a, b, rtol=1e-6)
+
+
+def test_single_scattering_slab():
+    d, expected, tol = tc.single_scattering_slab()
+    rgb = tc.radiance_rgb(ob.OracleScene(d).render()).reshape(3)
+    assert np.allclose(rgb, expected, rtol=tol)
+
+
+@pytest.mark.parametrize("kwargs", [dict(), dict(heterogeneous=True), dict(ground=False),
+                                    dict(phase={"type": "rayleigh"}), dict(phase={"type": "isotropic"}, heterogeneous=True)])
+def test_white_furnace(kwargs):
+    d, expected, tol = tc.white_furnace(**kwargs)
+    rgb = tc.radiance_rgb(ob.OracleScene(d).render())
+    assert abs(rgb.mean() - expected) < tol
+    assert np.abs(rgb - expected).max() < 0.15            # per pixel, 4000 spp
+
+
+def test_mean_transmittance_through_random_grid():
+    """Delta tracking through a random grid: E[unscattered fraction] = exp(-int sigma_t), checked with an
+    albedo-0 medium in front of a constant environment (radiance = transmittance)."""
+    import importlib
+    T = importlib.import_module("eradiate-kernel_amd.transform").ScalarTransform4f
+    rng = np.random.default_rng(21)
+    grid = (0.2 + 1.5 * rng.random((16, 16, 16))).astype(np.float32)
+    xf = T.translate([-1, -1, 0]) @ T.scale([2, 2, 1])
+    d = {"type": "scene", "integrator": {"type": "volpath", "max_depth": -1},
+         "sensor": {"type": "distant", "direction": [0, 0, 1], "ray_target": [0.13, -0.21, 1.0],
+                    "sampler": {"type": "independent", "sample_count": 60000},
+                    "film": {"type": "hdrfilm", "width": 1, "height": 1, "rfilter": {"type": "box"}}},
+         "slab": {"type": "cube", "to_world": T.translate([0, 0, 0.5]) @ T.scale([1, 1, 0.5]), "bsdf": {"type": "null"},
+                  "interior": {"type": "heterogeneous", "albedo": 0.0, "sigma_t": {"type": "gridvolume", "data": grid, "to_world": xf}}},
+         "env": {"type": "constant", "radiance": 1.0}}
+    o = ob.OracleScene(d)
+    rgb = tc.radiance_rgb(o.render()).reshape(3)
+    zs = (np.arange(4000) + 0.5) / 4000
+    pts = np.stack([np.full_like(zs, 0.13), np.full_like(zs, -0.21), zs], 1).astype(np.float32)
+    sig = o.volume_eval(0 if o.desc.volumes[0].type == 1 else 1, pts)[:, 0]
+    tau = sig.mean() * 1.0
+    assert np.allclose(rgb, np.exp(-tau), rtol=0.03)
