@@ -1106,7 +1106,8 @@ static int render(OracleScene *os, int n_threads, int shard_index, int shard_cou
     Counters total; uint64_t samples = 0;
     size_t next = 0;
     auto worker = [&]() {
-        _mm_setcsr(_mm_getcsr() | 0x8040);                                                     // scoped_flush_denormals, integrator.cpp:117
+        const unsigned saved_csr = _mm_getcsr();
+        _mm_setcsr(saved_csr | 0x8040);                                                        // scoped_flush_denormals, integrator.cpp:117
         Sampler sampler; sampler.base_seed = se.seed;
         ImageBlock block; block.init((int) block_size, (int) block_size, 5, &se.rfilter, true);
         Counters cnt; uint64_t my_samples = 0;
@@ -1125,6 +1126,7 @@ static int render(OracleScene *os, int n_threads, int shard_index, int shard_cou
             std::lock_guard<std::mutex> lock(film_mutex);
             film.put_block(block);
         }
+        _mm_setcsr(saved_csr);                                                                 // the caller's thread may run this inline
         std::lock_guard<std::mutex> lock(film_mutex);
         total.n_iter += cnt.n_iter; total.n_lookup += cnt.n_lookup; total.n_nee_step += cnt.n_nee_step; samples += my_samples;
     };
