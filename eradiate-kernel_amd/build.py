@@ -17,7 +17,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmtsamd.so")
 SOURCES = ["kernels.hip", "scene_host.cpp", "capi.cpp"]
-HEADERS = ["pmath.h", "dmath.h", "dscene.h", "integrator_dev.h", "launch.h", "scene_host.h"]
+HEADERS = ["pmath.h", "dmath.h", "dscene.h", "integrator_dev.h", "volpath_flat.h", "launch.h", "scene_host.h"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fgpu-flush-denormals-to-zero",

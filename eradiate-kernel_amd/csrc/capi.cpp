@@ -5,6 +5,7 @@
 // owns.  No exception crosses the boundary: errors become a non-zero status + mts_last_error().
 #include <chrono>
 #include <cstring>
+#include <cstdlib>
 #include <cmath>
 #include <mutex>
 #include "scene_host.h"
@@ -164,7 +165,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             HIP_CHECK(hipMemcpyAsync(d_blocks.p, blocks.data(), blocks.size() * sizeof(DBlock), hipMemcpyHostToDevice, stream));
             HIP_CHECK(hipEventRecord(ev0, stream));
             HIP_CHECK(launch_render(hs.scene, d_blocks.p, (uint32_t) blocks.size(), block_size, (uint32_t) samples_per_pass, d_film, d_counters.p,
-                                    opts.collect_counters != 0, stream));
+                                    opts.collect_counters != 0, getenv("MTSAMD_NESTED") == nullptr, stream));
             HIP_CHECK(hipEventRecord(ev1, stream));
             HIP_CHECK(hipEventSynchronize(ev1));
             float ms = 0.f; HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));

@@ -7,6 +7,7 @@
 // gathers and one film update per pixel.  Citations are relative to /root/reference.
 #include <hip/hip_runtime.h>
 #include "integrator_dev.h"
+#include "volpath_flat.h"
 #include "launch.h"
 
 namespace mtsamd {
@@ -34,54 +35,13 @@ __device__ __forceinline__ void render_sample(const DScene &sc, Pcg32 &rng, cons
     F3 L = sc.integrator.type == MTS_INTEGRATOR_VOLPATH ? volpath_sample<COUNT>(sc, rng, ray, se.medium, valid, cnt)
                                                          : path_sample<COUNT>(sc, rng, ray, valid, cnt);
     L = ray_weight * L;
-    float v[5];                                                 // srgb_to_xyz, core/spectrum.h:221-227
-    v[0] = pm_fma(0.180423f, L.z, pm_fma(0.357580f, L.y, 0.412453f * L.x));
-    v[1] = pm_fma(0.072169f, L.z, pm_fma(0.715160f, L.y, 0.212671f * L.x));
-    v[2] = pm_fma(0.950227f, L.z, pm_fma(0.119193f, L.y, 0.019334f * L.x));
-    v[3] = valid ? 1.f : 0.f;
-    v[4] = 1.f;
-    bool ok = true;                                             // imageblock.cpp:85-109: invalid samples are dropped
-    for (int k = 0; k < 5; ++k) ok = ok && v[k] >= -1e-5f && pm_isfinite(v[k]);
-    if (!ok) return;
-    const DRFilter &rf = se.rfilter;
-    const int border = rf.border_size;
-    const int sx = blk.sx + 2 * border, sy = blk.sy + 2 * border;
-    float posx = position_sample.x - ((float) (blk.ox - border) + .5f), posy = position_sample.y - ((float) (blk.oy - border) + .5f);
-    if (rf.radius > 0.5f + MTS_RAY_EPSILON) {
-        int lox = max((int) pm_ceil(posx - rf.radius), 0), loy = max((int) pm_ceil(posy - rf.radius), 0);
-        int hix = min((int) pm_floor(posx + rf.radius), sx - 1), hiy = min((int) pm_floor(posy + rf.radius), sy - 1);
-        uint32_t n = (uint32_t) pm_ceil((rf.radius - 2.f * MTS_RAY_EPSILON) * 2.f);
-        float basex = (float) lox - posx, basey = (float) loy - posy;
-        for (uint32_t yr = 0; yr < n; ++yr) {
-            int y = loy + (int) yr;
-            if (y > hiy) break;
-            float wy = rf.values[min((int) pm_abs((basey + (float) yr) * rf.scale_factor), 31)];     // eval_discretized, core/rfilter.h:62-65
-            int fy = blk.oy - border + y - se.crop_y;
-            for (uint32_t xr = 0; xr < n; ++xr) {
-                int x = lox + (int) xr;
-                if (x > hix) break;
-                float wx = rf.values[min((int) pm_abs((basex + (float) xr) * rf.scale_factor), 31)];
-                float weight = wy * wx;
-                int fx = blk.ox - border + x - se.crop_x;
-                if (fx >= 0 && fy >= 0 && fx < se.crop_w && fy < se.crop_h) {                         // film clipping, imageblock.cpp:49-77
-                    float *dst = film + 5 * ((size_t) fy * se.crop_w + fx);
-                    for (int k = 0; k < 5; ++k) atomicAdd(dst + k, v[k] * weight);
-                }
-            }
-        }
-    } else {
-        int lox = (int) pm_ceil(posx - .5f), loy = (int) pm_ceil(posy - .5f);
-        if (lox == (int) lx && loy == (int) ly) {
-            for (int k = 0; k < 5; ++k) acc[k] += v[k];
-        } else if (lox >= 0 && loy >= 0 && lox < sx && loy < sy) {
-            float *dst = film + 5 * ((size_t) (blk.oy + loy - se.crop_y) * se.crop_w + (blk.ox + lox - se.crop_x));
-            for (int k = 0; k < 5; ++k) atomicAdd(dst + k, v[k]);
-        }
-    }
+    splat_sample(sc, blk, lx, ly, position_sample, L, valid, film, acc);
 }
 
-// librender/integrator.cpp:181-209 (scalar branch) for every block of this launch at once
-template <bool COUNT>
+// librender/integrator.cpp:181-209 (scalar branch) for every block of this launch at once.
+// FLAT = true: volpath as the flat state machine of volpath_flat.h (the production kernel of the metric);
+// FLAT = false: the nested formulation of integrator_dev.h (path integrator; volpath cross-check, MTSAMD_NESTED=1).
+template <bool COUNT, bool FLAT>
 __global__ void __launch_bounds__(256) render_kernel(DScene sc, const DBlock *__restrict__ blocks, uint32_t n_blocks, uint32_t block_size,
                                                      uint32_t sample_count, float *__restrict__ film, unsigned long long *__restrict__ counters) {
     const uint32_t ppb = block_size * block_size;
@@ -95,8 +55,11 @@ __global__ void __launch_bounds__(256) render_kernel(DScene sc, const DBlock *__
     rng.seed(sc.sensor.seed + (uint64_t) blk.id * ppb + i, PCG32_DEFAULT_STREAM);             // sampler.cpp:83-96, integrator.cpp:198
     float acc[5] = { 0.f, 0.f, 0.f, 0.f, 0.f };
     Counters cnt; cnt.n_iter = cnt.n_lookup = cnt.n_nee_step = 0;
-    for (uint32_t j = 0; j < sample_count; ++j)
-        render_sample<COUNT>(sc, rng, blk, lx, ly, film, acc, cnt);
+    if (FLAT)
+        volpath_pixel_flat<COUNT>(sc, rng, blk, lx, ly, sample_count, film, acc, cnt);
+    else
+        for (uint32_t j = 0; j < sample_count; ++j)
+            render_sample<COUNT>(sc, rng, blk, lx, ly, film, acc, cnt);
     float *dst = film + 5 * ((size_t) (blk.oy + (int) ly - sc.sensor.crop_y) * sc.sensor.crop_w + (blk.ox + (int) lx - sc.sensor.crop_x));
     for (int k = 0; k < 5; ++k) atomicAdd(dst + k, acc[k]);
     if (COUNT) {
@@ -141,12 +104,15 @@ __global__ void __launch_bounds__(256) intersect_kernel(DScene sc, int32_t n, co
 
 // ---------------------------------------------------------------- launchers
 hipError_t launch_render(const DScene &sc, const DBlock *d_blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,
-                         float *d_film, unsigned long long *d_counters, bool count, hipStream_t stream) {
+                         float *d_film, unsigned long long *d_counters, bool count, bool flat, hipStream_t stream) {
     if (n_blocks == 0) return hipSuccess;
     const uint64_t threads = (uint64_t) n_blocks * block_size * block_size;
     const uint32_t grid = (uint32_t) ((threads + 255) / 256);
-    if (count) hipLaunchKernelGGL(render_kernel<true>, dim3(grid), dim3(256), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_counters);
-    else hipLaunchKernelGGL(render_kernel<false>, dim3(grid), dim3(256), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_counters);
+    const bool use_flat = flat && sc.integrator.type == MTS_INTEGRATOR_VOLPATH;
+#define LAUNCH(C, F) hipLaunchKernelGGL((render_kernel<C, F>), dim3(grid), dim3(256), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_counters)
+    if (use_flat) { if (count) LAUNCH(true, true); else LAUNCH(false, true); }
+    else { if (count) LAUNCH(true, false); else LAUNCH(false, false); }
+#undef LAUNCH
     return hipGetLastError();
 }
 
