@@ -35,6 +35,7 @@ def build_backend(force=False, verbose=True, extra=()):
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(ROOT, "include", "mtsamd.h"), __file__]
     if not force and not _stale(LIB, deps):
         return LIB
+    extra = list(extra) + os.environ.get("MTSAMD_EXTRA_FLAGS", "").split()
     cmd = [HIPCC] + FLAGS + list(extra) + ["-x", "hip"] + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -130,3 +130,12 @@ hipError_t launch_intersect(const DScene &sc, int32_t n, const float *o, const f
 }
 
 } // namespace mtsamd
+
+#if defined(MTSAMD_BLOCKSTATS)
+// diagnostic build only (python eradiate-kernel_amd/build.py with MTSAMD_EXTRA_FLAGS=-DMTSAMD_BLOCKSTATS)
+extern "C" int mts_debug_blockstats(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(mtsamd::g_blockstats), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(mtsamd::g_blockstats), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif

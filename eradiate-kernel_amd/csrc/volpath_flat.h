@@ -5,8 +5,13 @@
 // completion the other lanes of the wave idle.  Here every lane carries (mode, state) and each trip of
 // the single loop below advances every lane by at most one delta-tracking step -- whichever of the
 // three reference loops that step belongs to -- so the expensive block (free-flight sample + grid
-// gathers) is executed by all lanes together.  The blocks are ordered TOP -> INTERSECT -> MEDIUM ->
-// SURFACE -> PHASE/BSDF so a lane usually flows through several of them per trip.
+// gathers) is executed by all lanes together.
+//
+// Wave-level scheduling: the lanes of a wave sit in different states, and running every block on every
+// trip would execute each block with a handful of active lanes (measured: 17 % VALU lane utilisation).
+// So each trip first runs the cheap loop-head dispatch, then takes a census of the states with
+// __ballot / __popcll and executes only the ONE heavy block most lanes are waiting for; the others wait
+// (their state is in registers, nothing is lost) until their block wins the vote.
 //
 // The random draws happen in exactly the order of the scalar_rgb variant (SURVEY.md 8(a')); results are
 // bit-identical to the nested formulation in integrator_dev.h and to the CPU restatement.
@@ -16,7 +21,7 @@
 
 namespace mtsamd {
 
-enum : uint32_t { S_TOP = 0, S_MED = 1, S_SURF = 2, S_PHASE = 3, S_BSDF = 4, S_DIRB = 5, S_DONE = 6 };
+enum : uint32_t { S_TOP = 0, S_MED = 1, S_SURF = 2, S_PHASE = 3, S_BSDF = 4, S_DIRB = 5, S_NEW = 6, S_DONE = 7 };
 enum : uint32_t { M_MAIN = 0, M_NEE = 1, M_DIR = 2 };
 enum : uint32_t { FL_ALIVE = 1, FL_VALID_RAY = 2, FL_SPEC_CHAIN = 4, FL_NEEDS_INT = 8, FL_FROM_MEDIUM = 16 };
 
@@ -36,6 +41,10 @@ enum : uint32_t { MI_HOMOGENEOUS = 1, MI_SPECTRAL = 2, MI_SAMPLE_EMITTERS = 4, M
             wf_pending_ = false;                                            \
         }                                                                   \
     }
+
+#if defined(MTSAMD_BLOCKSTATS)
+__device__ unsigned long long g_blockstats[16];
+#endif
 
 template <bool COUNT>
 DEV MedStep medium_step(const DScene &sc, const DMedium &m, const DRay &ray, float sample, uint32_t channel, bool want_albedo, Counters &cnt) {
@@ -181,8 +190,9 @@ DEV void volpath_pixel_flat(const DScene &sc, Pcg32 &rng, const DBlock &blk, uin
 
     begin_sample();
 
-    while (st != S_DONE) {
-        // ================================================================= TOP: loop heads
+    enum { B_INT = 0, B_MED, B_SURF, B_PHASE, B_BSDF, B_NEW, B_COUNT };
+    while (__ballot(st != S_DONE)) {
+        // ================================================================= TOP: loop heads (cheap, every trip)
         if (st == S_TOP) {
             if (mode == M_MAIN) {                              // volpath.cpp:79-87
                 bool active = (flags & FL_ALIVE) && any_nonzero(thr);
@@ -190,11 +200,8 @@ DEV void volpath_pixel_flat(const DScene &sc, Pcg32 &rng, const DBlock &blk, uin
                 bool perform_rr = depth > rr_depth;
                 active = active && (rng.next_1d() < q || !perform_rr);
                 if (perform_rr) thr = thr * pm_rcp(q);
-                if (!active || depth >= max_depth) {
-                    splat_sample(sc, blk, lx, ly, position_sample, f3s(ray_weight) * res, (flags & FL_VALID_RAY) != 0, film, acc);
-                    if (++sample_idx == sample_count) st = S_DONE;
-                    else begin_sample();
-                } else {
+                if (!active || depth >= max_depth) st = S_NEW;
+                else {
                     if (COUNT) cnt.n_iter++;
                     st = medium >= 0 ? S_MED : S_SURF;
                 }
@@ -208,18 +215,41 @@ DEV void volpath_pixel_flat(const DScene &sc, Pcg32 &rng, const DBlock &blk, uin
                 st = medium >= 0 ? S_MED : S_SURF;
             }
         }
+        // ================================================================= census + vote
+        const bool want_int = (st == S_MED || st == S_SURF || st == S_DIRB) && (flags & FL_NEEDS_INT);
+        int votes[B_COUNT];
+        votes[B_INT] = __popcll(__ballot(want_int));
+        votes[B_MED] = __popcll(__ballot(st == S_MED && !want_int));
+        votes[B_SURF] = __popcll(__ballot(st == S_SURF && !want_int));
+        votes[B_PHASE] = __popcll(__ballot(st == S_PHASE));
+        votes[B_BSDF] = __popcll(__ballot(st == S_BSDF));
+        votes[B_NEW] = __popcll(__ballot(st == S_NEW));
+        int sel = B_MED, best = votes[B_MED];
+        for (int b = 0; b < B_COUNT; ++b) if (votes[b] > best) { best = votes[b]; sel = b; }
+        if (best == 0) continue;                               // only S_TOP / S_DONE lanes: next trip dispatches them
+#if defined(MTSAMD_BLOCKSTATS)                                  // diagnostic build: executions and lanes served per block
+        if (COUNT && __builtin_amdgcn_readfirstlane((int) (threadIdx.x & 63)) == (int) (threadIdx.x & 63)) {
+            atomicAdd(&g_blockstats[2 * sel], 1ull); atomicAdd(&g_blockstats[2 * sel + 1], (unsigned long long) best);
+        }
+#endif
+        // ================================================================= NEW: finish a sample, start the next (integrator.cpp:265-288)
+        if (sel == B_NEW && st == S_NEW) {
+            splat_sample(sc, blk, lx, ly, position_sample, f3s(ray_weight) * res, (flags & FL_VALID_RAY) != 0, film, acc);
+            if (++sample_idx == sample_count) st = S_DONE;
+            else begin_sample();
+        }
         // ================================================================= INTERSECT (volpath.cpp:109,182,241,298,339,395,425)
-        if ((st == S_MED || st == S_SURF || st == S_DIRB) && (flags & FL_NEEDS_INT)) {
+        if (sel == B_INT && want_int) {
             si = ray_intersect(sc, ray);
             flags &= ~FL_NEEDS_INT;
-        }
-        if (st == S_DIRB) {                                    // volpath.cpp:239-245: start the direct-light walk on a copy
-            so = ray.o; sd = ray.d; shit = si;
-            trans = f3s(1.f);
-            mode = M_DIR; st = S_TOP;
+            if (st == S_DIRB) {                                // volpath.cpp:239-245: start the direct-light walk on a copy
+                so = ray.o; sd = ray.d; shit = si;
+                trans = f3s(1.f);
+                mode = M_DIR; st = S_TOP;
+            }
         }
         // ================================================================= MEDIUM: one free-flight step
-        if (st == S_MED) {
+        if (sel == B_MED && st == S_MED && !want_int) {
             const float u = rng.next_1d();                     // volpath.cpp:105 / :294 / :391
             MedStep mi;
             WATERFALL_BEGIN(medium, mu)
@@ -308,7 +338,7 @@ DEV void volpath_pixel_flat(const DScene &sc, Pcg32 &rng, const DBlock &blk, uin
             }
         }
         // ================================================================= SURFACE
-        if (st == S_SURF) {
+        if (sel == B_SURF && st == S_SURF && !want_int) {
             const bool hit = hit_valid(si);
             if (mode == M_MAIN) {                              // volpath.cpp:184-253 (first half)
                 Surf sf; sf.wi = -ray.d; sf.n = f3s(0.f); sf.sh.s = sf.sh.t = sf.sh.n = f3s(0.f);
@@ -388,7 +418,7 @@ DEV void volpath_pixel_flat(const DScene &sc, Pcg32 &rng, const DBlock &blk, uin
             }
         }
         // ================================================================= PHASE sampling (volpath.cpp:169-175)
-        if (st == S_PHASE) {
+        if (sel == B_PHASE && st == S_PHASE) {
             const float s1 = rng.next_1d(); const F2 s2 = rng.next_2d();      // left-to-right (SURVEY.md 8(a'))
             F3 wo;
             WATERFALL_BEGIN(medium, mu)
@@ -399,7 +429,7 @@ DEV void volpath_pixel_flat(const DScene &sc, Pcg32 &rng, const DBlock &blk, uin
             st = S_TOP;
         }
         // ================================================================= BSDF sampling (volpath.cpp:214-252)
-        if (st == S_BSDF) {
+        if (sel == B_BSDF && st == S_BSDF) {
             Surf sf; int bsdf_id = 0, is_tr = 0, ext = -1, inte = -1;
             WATERFALL_BEGIN(si.shape, su)
                 const DShape &s = sc.shapes[su];
