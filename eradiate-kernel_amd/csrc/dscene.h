@@ -17,6 +17,7 @@ struct DVolume {
     int32_t type;                 // MTS_VOLUME_*
     float value[3];
     float w2l[16];                // world_to_local matrix (row-major)
+    int32_t affine;               // last row of w2l is exactly (0, 0, 0, 1): the homogeneous divide is x / 1
     DBBox bbox;
     const float *data;            // device pointer, nz*ny*nx*channels, x fastest
     int32_t nx, ny, nz, channels, filter, wrap;
@@ -39,6 +40,8 @@ struct DPhase {
 // Media (media/homogeneous.cpp, media/heterogeneous.cpp)
 struct DMedium {
     int32_t type, sigma_t, albedo, phase;
+    int32_t shared_grid;          // sigma_t and albedo are grids with identical transform / resolution / filter / wrap
+    int32_t grey;                 // every channel of sigma_t / albedo / combined extinction carries the same value
     float scale;
     int32_t sample_emitters, has_spectral_extinction, is_homogeneous;
     float max_density;
@@ -99,6 +102,7 @@ struct DScene {
     const DEmitter *emitters;
     const float *positions, *normals, *texcoords;   // world-space mesh data of all meshes
     const uint32_t *faces;
+    const float *tri;                               // per primitive (prim order): p0, e1 = p1 - p0, e2 = p2 - p0 (triangles only)
     int32_t volume_count, phase_count, medium_count, bsdf_count, shape_count, prim_count, emitter_count;
     int32_t environment;
     DBBox bbox;

@@ -16,6 +16,35 @@ namespace mtsamd {
 #define DEV __device__ __forceinline__
 #define DEV_NOINLINE __device__ __noinline__
 
+// ---- scalar-load helpers -------------------------------------------------------------------------------
+// Scene records live in global memory and are addressed with wave-uniform indices, but the compiler only
+// issues scalar loads (s_load, results in SGPRs) for memory it knows to be invariant.  cload() reads a
+// record through the constant address space -- same bytes, but invariant by definition -- so uniform
+// records cost no VGPRs and no vector-memory instructions.  The scene is never written while a kernel runs.
+#define MTS_CONST_AS __attribute__((address_space(4)))
+template <typename T> DEV T cload(const T *p) {
+    static_assert(sizeof(T) % 4 == 0, "records are dword multiples");
+    uint32_t tmp[sizeof(T) / 4];
+    const MTS_CONST_AS uint32_t *src = (const MTS_CONST_AS uint32_t *) (uintptr_t) p;
+#pragma unroll
+    for (int k = 0; k < (int) (sizeof(T) / 4); ++k) tmp[k] = src[k];
+    T r; __builtin_memcpy(&r, tmp, sizeof(T));
+    return r;
+}
+// Waterfall: `idx` may differ between lanes (a lane's current medium / shape) but rarely does.  Peel one
+// distinct value per trip so that the record can be addressed with an SGPR.  The comparison goes through
+// an opaque copy: otherwise the optimiser learns `idx == uni` inside the branch, substitutes the per-lane
+// `idx` for the uniform `uni`, and every record load degrades to a vector load again.
+#define WATERFALL_BEGIN(idx, uni)                                           \
+    for (bool wf_pending_ = true; wf_pending_;) {                           \
+        const int uni = __builtin_amdgcn_readfirstlane(idx);                \
+        int wf_cmp_ = uni; asm volatile("" : "+s"(wf_cmp_));                \
+        if ((idx) == wf_cmp_) {
+#define WATERFALL_END                                                       \
+            wf_pending_ = false;                                            \
+        }                                                                   \
+    }
+
 struct DRay { F3 o, d, d_rcp; float mint, maxt; };
 DEV DRay make_ray(F3 o, F3 d, float mint, float maxt) { DRay r; r.o = o; r.d = d; r.d_rcp = vrcp(d); r.mint = mint; r.maxt = maxt; return r; }
 DEV F3 ray_at(const DRay &r, float t) { return fmadd(r.d, t, r.o); }                       // core/ray.h:65
@@ -54,20 +83,22 @@ DEV float rectangle_intersect(const DShape &s, const DRay &ray, F2 &uv) {
     uv.x = lx; uv.y = ly;
     return active ? t : pm_inf();
 }
-// render/mesh.h:195-226
-DEV float triangle_intersect(const DScene &sc, const DShape &s, int index, const DRay &ray, F2 &uv) {
-    const uint32_t *fi = sc.faces + 3 * (s.face_offset + index);
-    const float *P = sc.positions + 3 * s.vertex_offset;
-    F3 p0 = f3(P + 3 * fi[0]), p1 = f3(P + 3 * fi[1]), p2 = f3(P + 3 * fi[2]);
-    F3 e1 = p1 - p0, e2 = p2 - p0;
+// render/mesh.h:195-226 with p0 / e1 / e2 precomputed per primitive (same subtraction, done once on the host).
+// The two `__ballot(...) == 0` exits skip the rest of the test when NO lane of the wave can still hit this
+// triangle; a lane's own result never depends on them.
+struct TriRec { float v[9]; };
+DEV float triangle_intersect(const TriRec &T, const DRay &ray, F2 &uv) {
+    F3 p0 = f3(T.v), e1 = f3(T.v + 3), e2 = f3(T.v + 6);
     F3 pvec = cross(ray.d, e2);
     float inv_det = pm_rcp(dot(e1, pvec));
     F3 tvec = ray.o - p0;
     float u = dot(tvec, pvec) * inv_det;
     bool active = u >= 0.f && u <= 1.f;
+    if (__ballot(active) == 0) return pm_inf();
     F3 qvec = cross(tvec, e1);
     float v = dot(ray.d, qvec) * inv_det;
     active = active && v >= 0.f && u + v <= 1.f;
+    if (__ballot(active) == 0) return pm_inf();
     float t = dot(e2, qvec) * inv_det;
     active = active && t >= ray.mint && t <= ray.maxt;
     uv.x = u; uv.y = v;
@@ -112,12 +143,12 @@ DEV Hit ray_intersect_preliminary(const DScene &sc, DRay ray) {
     float mint = pm_max(ray.mint, bmint), maxt = pm_min(ray.maxt, bmaxt);
     if (!(mint <= maxt)) return h;
     for (int i = 0; i < sc.prim_count; ++i) {
-        const DPrim pr = sc.prims[i];
-        const DShape &s = sc.shapes[pr.shape];
+        const DPrim pr = cload(sc.prims + i);
+        const DShape s = cload(sc.shapes + pr.shape);
         F2 uv; uv.x = uv.y = 0.f; float t;
         if (s.type == MTS_SHAPE_RECTANGLE) t = rectangle_intersect(s, ray, uv);
         else if (s.type == MTS_SHAPE_SPHERE) t = sphere_intersect(s, ray);
-        else t = triangle_intersect(sc, s, pr.index, ray, uv);
+        else t = triangle_intersect(cload((const TriRec *) (sc.tri + 9 * i)), ray, uv);
         if (t != pm_inf()) {
             h.t = t; h.uv = uv; h.shape = pr.shape; h.prim = pr.index;
             if (ShadowRay) return h;
@@ -128,8 +159,7 @@ DEV Hit ray_intersect_preliminary(const DScene &sc, DRay ray) {
 }
 
 // Hit point: rectangle.cpp:181-185, mesh.cpp:470-483, sphere.cpp:325-327
-DEV void hit_point(const DScene &sc, const DRay &ray, Hit &h) {
-    const DShape &s = sc.shapes[h.shape];
+DEV void hit_point(const DScene &sc, const DShape &s, const DRay &ray, Hit &h) {
     if (s.type == MTS_SHAPE_RECTANGLE) {
         F3 p = ray_at(ray, h.t), n = f3(s.frame_n);
         float dist = dot(f3(s.to_world.m[3], s.to_world.m[7], s.to_world.m[11]) - p, n);
@@ -150,15 +180,18 @@ DEV void hit_point(const DScene &sc, const DRay &ray, Hit &h) {
 // librender/scene_native.inl:23-41
 DEV Hit ray_intersect(const DScene &sc, const DRay &ray) {
     Hit h = ray_intersect_preliminary<false>(sc, ray);
-    if (hit_valid(h)) hit_point(sc, ray, h);
+    if (hit_valid(h)) {
+        WATERFALL_BEGIN(h.shape, su)
+            hit_point(sc, cload(sc.shapes + su), ray, h);
+        WATERFALL_END
+    }
     return h;
 }
 DEV bool ray_test(const DScene &sc, const DRay &ray) { return hit_valid(ray_intersect_preliminary<true>(sc, ray)); }
 
 // Rebuild n, shading frame and wi: rectangle.cpp:186-193, mesh.cpp:485-545, sphere.cpp:328-371,
 // interaction.h:153-156,571-596.  `d` is the direction of the ray that produced the hit.
-DEV void complete_surface(const DScene &sc, const Hit &h, F3 d, Surf &sf) {
-    const DShape &s = sc.shapes[h.shape];
+DEV void complete_surface(const DScene &sc, const DShape &s, const Hit &h, F3 d, Surf &sf) {
     F3 dp_du, dp_dv, shn;
     if (s.type == MTS_SHAPE_RECTANGLE) {
         sf.n = f3(s.frame_n); shn = sf.n; dp_du = f3(s.frame_s);
@@ -197,6 +230,12 @@ DEV void complete_surface(const DScene &sc, const Hit &h, F3 d, Surf &sf) {
     sf.wi = to_local(sf.sh, -d);
 }
 
+DEV void complete_surface(const DScene &sc, const Hit &h, F3 d, Surf &sf) {
+    WATERFALL_BEGIN(h.shape, su)
+        complete_surface(sc, cload(sc.shapes + su), h, d, sf);
+    WATERFALL_END
+}
+
 // ---------------------------------------------------------------- volumes
 // textures/grid3d.cpp:234-250
 DEV int wrap_coord(int wrap, int value, int res) {
@@ -216,7 +255,7 @@ DEV float trilerp(float d000, float d100, float d010, float d110, float d001, fl
 // textures/grid3d.cpp:220-232,259-360 ; textures/constant3d.cpp
 DEV F3 volume_eval(const DVolume &v, F3 p_world) {
     if (v.type == MTS_VOLUME_CONST) return f3(v.value);
-    F3 p = mat_point(v.w2l, p_world);
+    F3 p = v.affine ? mat_point_affine(v.w2l, p_world) : mat_point(v.w2l, p_world);    // x / 1 == x
     const float *D = v.data; const int nx = v.nx, ny = v.ny, nz = v.nz, ch = v.channels;
     if (v.filter == MTS_FILTER_TRILINEAR) {
         p = f3(pm_fma(p.x, (float) nx, -.5f), pm_fma(p.y, (float) ny, -.5f), pm_fma(p.z, (float) nz, -.5f));
@@ -556,11 +595,17 @@ DEV F3 null_transmission(const DScene &sc, const DShape &s) { return sc.bsdfs[s.
 DEV float mis_weight(float pdf_a, float pdf_b) { pdf_a *= pdf_a; pdf_b *= pdf_b; return pdf_a > 0.0f ? pdf_a / (pdf_a + pdf_b) : 0.0f; }   // volpath.cpp:479-483
 
 // Geometric normal of a hit without the full shading frame (only needed for medium transitions)
-DEV F3 hit_geo_normal(const DScene &sc, const Hit &h) {
-    const DShape &s = sc.shapes[h.shape];
+DEV F3 hit_geo_normal(const DScene &sc, const DShape &s, const Hit &h) {
     if (s.type == MTS_SHAPE_RECTANGLE) return f3(s.frame_n);
-    Surf sf; complete_surface(sc, h, f3(0.f, 0.f, 1.f), sf);
+    Surf sf; complete_surface(sc, s, h, f3(0.f, 0.f, 1.f), sf);
     return sf.n;
+}
+DEV F3 hit_geo_normal(const DScene &sc, const Hit &h) {
+    F3 n = f3s(0.f);
+    WATERFALL_BEGIN(h.shape, su)
+        n = hit_geo_normal(sc, cload(sc.shapes + su), h);
+    WATERFALL_END
+    return n;
 }
 
 DEV F3 transmittance_exp(float t, F3 combined) { return f3(pm_exp(-t * combined.x), pm_exp(-t * combined.y), pm_exp(-t * combined.z)); }

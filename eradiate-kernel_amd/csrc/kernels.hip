@@ -53,15 +53,18 @@ __global__ void __launch_bounds__(256) render_kernel(DScene sc, const DBlock *__
     if (lx >= (uint32_t) blk.sx || ly >= (uint32_t) blk.sy) return;
     Pcg32 rng;
     rng.seed(sc.sensor.seed + (uint64_t) blk.id * ppb + i, PCG32_DEFAULT_STREAM);             // sampler.cpp:83-96, integrator.cpp:198
-    float acc[5] = { 0.f, 0.f, 0.f, 0.f, 0.f };
     Counters cnt; cnt.n_iter = cnt.n_lookup = cnt.n_nee_step = 0;
-    if (FLAT)
-        volpath_pixel_flat<COUNT>(sc, rng, blk, lx, ly, sample_count, film, acc, cnt);
-    else
+    if (FLAT) {
+        __shared__ float cold_lds[C_COUNT * 256];
+        ColdState cold; cold.base = cold_lds + threadIdx.x;
+        volpath_pixel_flat<COUNT>(sc, rng, blk, lx, ly, sample_count, film, cold, cnt);
+    } else {
+        float acc[5] = { 0.f, 0.f, 0.f, 0.f, 0.f };
         for (uint32_t j = 0; j < sample_count; ++j)
             render_sample<COUNT>(sc, rng, blk, lx, ly, film, acc, cnt);
-    float *dst = film + 5 * ((size_t) (blk.oy + (int) ly - sc.sensor.crop_y) * sc.sensor.crop_w + (blk.ox + (int) lx - sc.sensor.crop_x));
-    for (int k = 0; k < 5; ++k) atomicAdd(dst + k, acc[k]);
+        float *dst = film + 5 * ((size_t) (blk.oy + (int) ly - sc.sensor.crop_y) * sc.sensor.crop_w + (blk.ox + (int) lx - sc.sensor.crop_x));
+        for (int k = 0; k < 5; ++k) atomicAdd(dst + k, acc[k]);
+    }
     if (COUNT) {
         atomicAdd(counters + 0, (unsigned long long) cnt.n_iter);
         atomicAdd(counters + 1, (unsigned long long) cnt.n_lookup);
@@ -133,9 +136,9 @@ hipError_t launch_intersect(const DScene &sc, int32_t n, const float *o, const f
 
 #if defined(MTSAMD_BLOCKSTATS)
 // diagnostic build only (python eradiate-kernel_amd/build.py with MTSAMD_EXTRA_FLAGS=-DMTSAMD_BLOCKSTATS)
-extern "C" int mts_debug_blockstats(unsigned long long *out16, int reset) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(mtsamd::g_blockstats), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(mtsamd::g_blockstats), z, sizeof(z)) != hipSuccess) return 1; }
+extern "C" int mts_debug_blockstats(unsigned long long *out32, int reset) {
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(mtsamd::g_blockstats), 32 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[32] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(mtsamd::g_blockstats), z, sizeof(z)) != hipSuccess) return 1; }
     return 0;
 }
 #endif

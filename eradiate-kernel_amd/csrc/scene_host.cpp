@@ -198,6 +198,7 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
         } else if (v.type != MTS_VOLUME_CONST) throw std::runtime_error("unknown volume type");
         else hs.grid_data.emplace_back();
         memcpy(dv.w2l, w2l.m, 64);
+        dv.affine = (w2l.m[12] == 0.f && w2l.m[13] == 0.f && w2l.m[14] == 0.f && w2l.m[15] == 1.f) ? 1 : 0;
         DXf inv = xf_inverse(w2l);
         F3 a = mat_point(inv.m, f3s(0.f)), b = mat_point(inv.m, f3s(1.f));
         store3(dv.bbox.min, a); store3(dv.bbox.max, a); bbox_expand(dv.bbox, b);
@@ -254,6 +255,13 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
             dm.max_density = dm.scale * st.max;
             dm.aabb = st.bbox;
         } else if (m.type != MTS_MEDIUM_HOMOGENEOUS) throw std::runtime_error("unknown medium type");
+        {   // kernel fast paths that do not change a single bit of the result
+            const DVolume &a = hs.volumes[m.sigma_t_volume], &b = hs.volumes[m.albedo_volume];
+            dm.shared_grid = (a.type == MTS_VOLUME_GRID && b.type == MTS_VOLUME_GRID && a.nx == b.nx && a.ny == b.ny && a.nz == b.nz &&
+                              a.filter == b.filter && a.wrap == b.wrap && memcmp(a.w2l, b.w2l, 64) == 0) ? 1 : 0;
+            auto grey = [](const DVolume &v) { return v.type == MTS_VOLUME_GRID ? v.channels == 1 : (v.value[0] == v.value[1] && v.value[1] == v.value[2]); };
+            dm.grey = (grey(a) && grey(b)) ? 1 : 0;
+        }
         hs.media.push_back(dm);
     }
     // ---- BSDFs
@@ -284,7 +292,17 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
         if (ds.bsdf < 0) ds.bsdf = ds.emitter >= 0 ? default_emitter_bsdf : default_bsdf;
         hs.shapes.push_back(ds);
         bbox_expand(sc.bbox, sb);
-        for (int k = 0; k < prim_count; ++k) { DPrim p; p.shape = i; p.index = k; hs.prims.push_back(p); }
+        for (int k = 0; k < prim_count; ++k) {
+            DPrim p; p.shape = i; p.index = k; hs.prims.push_back(p);
+            float rec[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+            if (ds.type == MTS_SHAPE_CUBE || ds.type == MTS_SHAPE_MESH) {        // mesh.h:201-207: p0, e1 = p1 - p0, e2 = p2 - p0
+                const uint32_t *fi = &hs.faces[3 * (ds.face_offset + k)];
+                const float *P = &hs.positions[3 * ds.vertex_offset];
+                F3 p0 = f3(P + 3 * fi[0]), e1 = f3(P + 3 * fi[1]) - p0, e2 = f3(P + 3 * fi[2]) - p0;
+                store3(rec, p0); store3(rec + 3, e1); store3(rec + 6, e2);
+            }
+            hs.tri.insert(hs.tri.end(), rec, rec + 9);
+        }
     }
     // ---- emitters + set_scene (scene.cpp:41-52,95-97; directional.cpp:68-73; constant.cpp:35-39; bbox.h:329-332)
     sc.environment = -1;
@@ -388,6 +406,7 @@ void upload_host_scene(HostScene &hs, int device) {
     sc.emitters = upload(hs, hs.emitters);
     sc.positions = upload(hs, hs.positions); sc.normals = upload(hs, hs.normals); sc.texcoords = upload(hs, hs.texcoords);
     sc.faces = upload(hs, hs.faces);
+    sc.tri = upload(hs, hs.tri);
     HIP_CHECK(hipDeviceSynchronize());
     hs.uploaded = true;
 }
