@@ -35,7 +35,7 @@ __device__ __forceinline__ void render_sample(const DScene &sc, Pcg32 &rng, cons
     F3 L = sc.integrator.type == MTS_INTEGRATOR_VOLPATH ? volpath_sample<COUNT>(sc, rng, ray, se.medium, valid, cnt)
                                                          : path_sample<COUNT>(sc, rng, ray, valid, cnt);
     L = ray_weight * L;
-    splat_sample(sc, blk, lx, ly, position_sample, L, valid, film, acc);
+    splat_sample_t<false>(sc, blk, lx, ly, position_sample, L, valid, film, acc);
 }
 
 // librender/integrator.cpp:181-209 (scalar branch) for every block of this launch at once.
@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(256) render_kernel(DScene sc, const DBlock *__
     Counters cnt; cnt.n_iter = cnt.n_lookup = cnt.n_nee_step = 0;
     if (FLAT) {
         __shared__ float cold_lds[C_COUNT * 256];
-        ColdState cold; cold.base = cold_lds + threadIdx.x;
+        ColdStore cold; cold.base = cold_lds + threadIdx.x; cold.stride = 256;
         volpath_pixel_flat<COUNT>(sc, rng, blk, lx, ly, sample_count, film, cold, cnt);
     } else {
         float acc[5] = { 0.f, 0.f, 0.f, 0.f, 0.f };
@@ -65,6 +65,20 @@ __global__ void __launch_bounds__(256) render_kernel(DScene sc, const DBlock *__
         float *dst = film + 5 * ((size_t) (blk.oy + (int) ly - sc.sensor.crop_y) * sc.sensor.crop_w + (blk.ox + (int) lx - sc.sensor.crop_x));
         for (int k = 0; k < 5; ++k) atomicAdd(dst + k, acc[k]);
     }
+    if (COUNT) {
+        atomicAdd(counters + 0, (unsigned long long) cnt.n_iter);
+        atomicAdd(counters + 1, (unsigned long long) cnt.n_lookup);
+        atomicAdd(counters + 2, (unsigned long long) cnt.n_nee_step);
+    }
+}
+
+// Workgroup-regrouping variant of the volpath render kernel (volpath_flat.h, driver 2)
+template <bool COUNT, int WG>
+__global__ void __launch_bounds__(WG) render_kernel_wg(DScene sc, const DBlock *__restrict__ blocks, uint32_t n_blocks, uint32_t block_size,
+                                                        uint32_t sample_count, float *__restrict__ film, float *__restrict__ cold_g, uint32_t cold_stride,
+                                                        unsigned long long *__restrict__ counters) {
+    Counters cnt; cnt.n_iter = cnt.n_lookup = cnt.n_nee_step = 0;
+    volpath_workgroup<COUNT, WG>(sc, blocks, n_blocks, block_size, sample_count, film, cold_g, cold_stride, cnt);
     if (COUNT) {
         atomicAdd(counters + 0, (unsigned long long) cnt.n_iter);
         atomicAdd(counters + 1, (unsigned long long) cnt.n_lookup);
@@ -106,10 +120,29 @@ __global__ void __launch_bounds__(256) intersect_kernel(DScene sc, int32_t n, co
 }
 
 // ---------------------------------------------------------------- launchers
+size_t render_workspace_floats(uint32_t n_blocks, uint32_t block_size, int variant) {
+    if (variant < 256) return 0;
+    const uint64_t threads = (uint64_t) n_blocks * block_size * block_size;
+    const uint64_t padded = (threads + variant - 1) / variant * variant;
+    return (size_t) padded * C_COUNT;
+}
+
 hipError_t launch_render(const DScene &sc, const DBlock *d_blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,
-                         float *d_film, unsigned long long *d_counters, bool count, bool flat, hipStream_t stream) {
+                         float *d_film, unsigned long long *d_counters, bool count, int variant, float *d_workspace, hipStream_t stream) {
     if (n_blocks == 0) return hipSuccess;
     const uint64_t threads = (uint64_t) n_blocks * block_size * block_size;
+    if (variant >= 256 && sc.integrator.type == MTS_INTEGRATOR_VOLPATH) {          // workgroup-regrouping kernel, variant = workgroup size
+        const uint32_t wg = (uint32_t) variant;
+        const uint32_t grid = (uint32_t) ((threads + wg - 1) / wg);
+        const uint32_t stride = grid * wg;
+#define LAUNCH_WG(C, W) hipLaunchKernelGGL((render_kernel_wg<C, W>), dim3(grid), dim3(W), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters)
+        if (wg == 256) { if (count) LAUNCH_WG(true, 256); else LAUNCH_WG(false, 256); }
+        else if (wg == 512) { if (count) LAUNCH_WG(true, 512); else LAUNCH_WG(false, 512); }
+        else { if (count) LAUNCH_WG(true, 1024); else LAUNCH_WG(false, 1024); }
+#undef LAUNCH_WG
+        return hipGetLastError();
+    }
+    const bool flat = variant != 0;
     const uint32_t grid = (uint32_t) ((threads + 255) / 256);
     const bool use_flat = flat && sc.integrator.type == MTS_INTEGRATOR_VOLPATH;
 #define LAUNCH(C, F) hipLaunchKernelGGL((render_kernel<C, F>), dim3(grid), dim3(256), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_counters)

@@ -108,8 +108,11 @@ DEV F3 transmittance_exp_g(float t, F3 combined, bool grey) {
 }
 
 // Film splat of one finished sample: librender/integrator.cpp:265-285 + librender/imageblock.cpp:79-172
-DEV void splat_sample(const DScene &sc, const DBlock &blk, uint32_t lx, uint32_t ly, F2 position_sample, F3 L, bool valid,
-                      float *__restrict__ film, float acc[5]) {
+// `own` receives the samples that land in the lane's own pixel: either register accumulators (nested
+// formulation) or the pixel's film entry itself, updated with float atomics in sample order.
+template <bool OWN_ATOMIC>
+DEV void splat_sample_t(const DScene &sc, const DBlock &blk, uint32_t lx, uint32_t ly, F2 position_sample, F3 L, bool valid,
+                        float *__restrict__ film, float *own) {
     const DSensor &se = sc.sensor;
     float v[5];                                                 // srgb_to_xyz, core/spectrum.h:221-227
     v[0] = pm_fma(0.180423f, L.z, pm_fma(0.357580f, L.y, 0.412453f * L.x));
@@ -149,7 +152,8 @@ DEV void splat_sample(const DScene &sc, const DBlock &blk, uint32_t lx, uint32_t
     } else {
         int lox = (int) pm_ceil(posx - .5f), loy = (int) pm_ceil(posy - .5f);
         if (lox == (int) lx && loy == (int) ly) {
-            for (int k = 0; k < 5; ++k) acc[k] += v[k];
+            if (OWN_ATOMIC) { for (int k = 0; k < 5; ++k) atomicAdd(own + k, v[k]); }
+            else { for (int k = 0; k < 5; ++k) own[k] += v[k]; }
         } else if (lox >= 0 && loy >= 0 && lox < sx && loy < sy) {
             float *dst = film + 5 * ((size_t) (blk.oy + loy - se.crop_y) * se.crop_w + (blk.ox + lox - se.crop_x));
             for (int k = 0; k < 5; ++k) atomicAdd(dst + k, v[k]);
@@ -157,21 +161,34 @@ DEV void splat_sample(const DScene &sc, const DBlock &blk, uint32_t lx, uint32_t
     }
 }
 
-// Cold per-lane state parked in LDS (struct-of-arrays over the 256 lanes of the workgroup, conflict-free):
-// values that are touched once per sample or once per NEE / direct-light walk, so they do not have to
-// occupy VGPRs during the thousands of tracking steps in between.
-enum { C_ACC = 0,            // 5: film accumulators X, Y, Z, A, W of this pixel
-       C_POS = 5,            // 2: film position of the current sample
-       C_RAYW = 7,           // 1: sensor ray weight
-       C_SO = 8, C_SD = 11,  // 3 + 3: parked main-path origin / direction
-       C_SHIT = 14,          // 8: parked main-path hit (t, p, uv, shape, prim)
-       C_SMED = 22,          // 1: parked medium id
-       C_CW = 23,            // 3: pending NEE weight
-       C_EMIT = 26,          // 3: emitter value of the NEE sample
-       C_COUNT = 29 };
-struct ColdState {
-    float *base;             // &lds[0][lane]
-    DEV float &f(int k) const { return base[k * 256]; }
+DEV void splat_sample(const DScene &sc, const DBlock &blk, uint32_t lx, uint32_t ly, F2 position_sample, F3 L, bool valid,
+                      float *__restrict__ film, float *own) { splat_sample_t<true>(sc, blk, lx, ly, position_sample, L, valid, film, own); }
+
+// ---------------------------------------------------------------------------------------------------------
+// Per-path state.  "Hot" fields are touched by every tracking step; "cold" fields (ColdStore) only once per
+// sample or per NEE / direct-light walk.
+struct PathState {
+    Pcg32 rng;
+    DRay ray;                       // the ray being tracked now (main path, or the NEE / direct-light walk)
+    Hit si;                         // cached closest hit of `ray`
+    int medium;                     // medium containing ray.o
+    F3 thr, res; float eta; uint32_t depth, channel;         // main path (volpath.cpp:54-67)
+    F3 trans; float wa, wb;         // walk: transmittance; NEE: wa = total_dist, wb = ds.dist; direct: wb = bs.pdf
+    uint32_t st, mode, flags, sample_idx;
+};
+// cold field offsets (floats)
+enum { C_POS = 0,            // 2: film position of the current sample
+       C_RAYW = 2,           // 1: sensor ray weight
+       C_SO = 3, C_SD = 6,   // 3 + 3: parked main-path origin / direction
+       C_SHIT = 9,           // 8: parked main-path hit (t, p, uv, shape, prim)
+       C_SMED = 17,          // 1: parked medium id
+       C_CW = 18,            // 3: pending NEE weight
+       C_EMIT = 21,          // 3: emitter value of the NEE sample
+       C_COUNT = 24 };
+// Struct-of-arrays store addressed as base[k * stride]: LDS (stride 256, one workgroup) or HBM (stride = paths in flight)
+struct ColdStore {
+    float *base; uint32_t stride;
+    DEV float &f(int k) const { return base[(size_t) k * stride]; }
     DEV void put3(int k, F3 v) const { f(k) = v.x; f(k + 1) = v.y; f(k + 2) = v.z; }
     DEV F3 get3(int k) const { return f3(f(k), f(k + 1), f(k + 2)); }
     DEV void put_hit(const Hit &h) const {
@@ -183,366 +200,504 @@ struct ColdState {
         h.shape = __float_as_int(f(C_SHIT + 6)); h.prim = __float_as_int(f(C_SHIT + 7)); return h;
     }
 };
+// What a path needs from its surroundings
+struct PathEnv {
+    DBlock blk; uint32_t lx, ly, sample_count; float *__restrict__ film; ColdStore cold;
+};
+// Scheduling classes: the heavy block a path is waiting for
+enum { B_INT = 0, B_MED, B_SURF, B_PHASE, B_NEW, B_DONE, B_COUNT };
 
-// All samples of one pixel (librender/integrator.cpp:197-209 + :233-288 + integrators/volpath.cpp)
 template <bool COUNT>
-DEV void volpath_pixel_flat(const DScene &sc, Pcg32 &rng, const DBlock &blk, uint32_t lx, uint32_t ly, uint32_t sample_count,
-                            float *__restrict__ film, const ColdState cold, Counters &cnt) {
-    const DSensor &se = sc.sensor;
-    const uint32_t max_depth = (uint32_t) sc.integrator.max_depth, rr_depth = (uint32_t) sc.integrator.rr_depth;
-    const bool hide_emitters = sc.integrator.hide_emitters != 0;
+struct VolpathMachine {
+    const DScene &sc;
+    Counters &cnt;
+    DEV VolpathMachine(const DScene &sc_, Counters &cnt_) : sc(sc_), cnt(cnt_) {}
 
-    // ---- hot per-lane state (registers)
-    DRay ray;                       // the ray being tracked now (main path, or the NEE / direct-light walk)
-    Hit si;                         // cached closest hit of `ray`
-    int medium;                     // medium containing ray.o
-    F3 thr, res; float eta; uint32_t depth, channel;         // main path (volpath.cpp:54-67)
-    F3 trans; float wa, wb;         // walk: transmittance; NEE: wa = total_dist, wb = ds.dist; direct: wb = bs.pdf
-    uint32_t st, mode, flags, sample_idx = 0;
-
-    // A freshly spawned ray that cannot reach the scene's bounding box is resolved on the spot (this is the
-    // first test of ShapeKDTree::ray_intersect_scalar, kdtree.h:2095-2098); everything else queues for INTERSECT.
-    auto queue_intersection = [&]() {
+    // A freshly spawned ray that cannot reach the scene's bounding box is resolved on the spot (the first
+    // test of ShapeKDTree::ray_intersect_scalar, kdtree.h:2095-2098); everything else queues for INTERSECT.
+    DEV void queue_intersection(PathState &p) const {
         float bmint, bmaxt;
-        bbox_ray_intersect(sc.bbox, ray, bmint, bmaxt);
-        si.t = pm_inf(); si.shape = -1;
-        if (pm_max(ray.mint, bmint) <= bmaxt) flags |= FL_NEEDS_INT; else flags &= ~FL_NEEDS_INT;
-    };
-    auto begin_sample = [&]() {                                // integrator.cpp:242-264, volpath.cpp:48-71
-        const float px = (float) (lx + (uint32_t) blk.ox), py = (float) (ly + (uint32_t) blk.oy);
-        F2 u = rng.next_2d();
+        bbox_ray_intersect(sc.bbox, p.ray, bmint, bmaxt);
+        p.si.t = pm_inf(); p.si.shape = -1;
+        if (pm_max(p.ray.mint, bmint) <= bmaxt) p.flags |= FL_NEEDS_INT; else p.flags &= ~FL_NEEDS_INT;
+    }
+    DEV void begin_sample(PathState &p, const PathEnv &e) const {      // integrator.cpp:242-264, volpath.cpp:48-71
+        const DSensor &se = sc.sensor;
+        const float px = (float) (e.lx + (uint32_t) e.blk.ox), py = (float) (e.ly + (uint32_t) e.blk.oy);
+        F2 u = p.rng.next_2d();
         F2 position_sample; position_sample.x = px + u.x; position_sample.y = py + u.y;
         F2 aperture_sample; aperture_sample.x = .5f; aperture_sample.y = .5f;
-        if (se.needs_aperture_sample) aperture_sample = rng.next_2d();
-        (void) rng.next_1d();                                  // wavelength sample, unused in rgb
+        if (se.needs_aperture_sample) aperture_sample = p.rng.next_2d();
+        (void) p.rng.next_1d();                                // wavelength sample, unused in rgb
         F2 adjusted;
         adjusted.x = (position_sample.x - (float) se.crop_x) / (float) se.crop_w;
         adjusted.y = (position_sample.y - (float) se.crop_y) / (float) se.crop_h;
         F3 rw;
-        ray = sensor_sample_ray(sc, adjusted, aperture_sample, rw);
-        cold.f(C_POS) = position_sample.x; cold.f(C_POS + 1) = position_sample.y; cold.f(C_RAYW) = rw.x;   // all supported sensors: grey weight
-        medium = se.medium;
-        thr = f3s(1.f); res = f3s(0.f); eta = 1.f; depth = 0;
-        channel = (uint32_t) pm_min(rng.next_1d() * 3.f, 2.f);
-        si.p = f3s(0.f); si.uv.x = si.uv.y = 0.f; si.prim = 0;
-        flags = FL_ALIVE | ((!hide_emitters && sc.environment >= 0) ? FL_VALID_RAY : 0u) | (!hide_emitters ? FL_SPEC_CHAIN : 0u);
-        queue_intersection();
-        mode = M_MAIN; st = S_TOP;
-    };
+        p.ray = sensor_sample_ray(sc, adjusted, aperture_sample, rw);
+        e.cold.f(C_POS) = position_sample.x; e.cold.f(C_POS + 1) = position_sample.y; e.cold.f(C_RAYW) = rw.x;   // grey weight
+        p.medium = se.medium;
+        p.thr = f3s(1.f); p.res = f3s(0.f); p.eta = 1.f; p.depth = 0;
+        p.channel = (uint32_t) pm_min(p.rng.next_1d() * 3.f, 2.f);
+        p.si.p = f3s(0.f); p.si.uv.x = p.si.uv.y = 0.f; p.si.prim = 0;
+        const bool hide_emitters = sc.integrator.hide_emitters != 0;
+        p.flags = FL_ALIVE | ((!hide_emitters && sc.environment >= 0) ? FL_VALID_RAY : 0u) | (!hide_emitters ? FL_SPEC_CHAIN : 0u);
+        p.trans = f3s(1.f); p.wa = p.wb = 0.f;
+        queue_intersection(p);
+        p.mode = M_MAIN; p.st = S_TOP;
+    }
     // NEE walk finished (volpath.cpp:366 + :165-166 / :211): add the contribution, resume the main path
-    auto end_nee = [&]() {
-        F3 emitted = trans * cold.get3(C_EMIT);
-        res = res + cold.get3(C_CW) * emitted;
-        mode = M_MAIN; medium = __float_as_int(cold.f(C_SMED)); ray.d = cold.get3(C_SD);
-        if (flags & FL_FROM_MEDIUM) { ray.o = cold.get3(C_SO); st = S_PHASE; }
-        else { si = cold.get_hit(); st = S_BSDF; }
-    };
+    DEV void end_nee(PathState &p, const PathEnv &e) const {
+        F3 emitted = p.trans * e.cold.get3(C_EMIT);
+        p.res = p.res + e.cold.get3(C_CW) * emitted;
+        p.mode = M_MAIN; p.medium = __float_as_int(e.cold.f(C_SMED));
+        F3 d = e.cold.get3(C_SD);
+        p.ray.d = d; p.ray.d_rcp = vrcp(d);
+        if (p.flags & FL_FROM_MEDIUM) { p.ray.o = e.cold.get3(C_SO); p.st = S_PHASE; }
+        else { p.si = e.cold.get_hit(); p.st = S_BSDF; }
+    }
     // direct-light walk finished (volpath.cpp:464 + :246-252): MIS-weighted emitter hit, resume the main path
-    auto end_direct = [&](F3 emitter_val, float emitter_pdf) {
-        F3 emitted = trans * emitter_val;
-        if (emitter_pdf != 0.f) res = res + mis_weight(wb, emitter_pdf) * thr * emitted;
-        ray = spawn_ray(cold.get3(C_SO), cold.get3(C_SD));
-        si = cold.get_hit(); medium = __float_as_int(cold.f(C_SMED));
-        flags = (flags & ~FL_NEEDS_INT) | FL_ALIVE;
-        mode = M_MAIN; st = S_TOP;
-    };
+    DEV void end_direct(PathState &p, const PathEnv &e, F3 emitter_val, float emitter_pdf) const {
+        F3 emitted = p.trans * emitter_val;
+        if (emitter_pdf != 0.f) p.res = p.res + mis_weight(p.wb, emitter_pdf) * p.thr * emitted;
+        p.ray = spawn_ray(e.cold.get3(C_SO), e.cold.get3(C_SD));
+        p.si = e.cold.get_hit(); p.medium = __float_as_int(e.cold.f(C_SMED));
+        p.flags = (p.flags & ~FL_NEEDS_INT) | FL_ALIVE;
+        p.mode = M_MAIN; p.st = S_TOP;
+    }
 
-    for (int k = 0; k < 5; ++k) cold.f(C_ACC + k) = 0.f;
-    begin_sample();
+    // Loop heads of the three reference loops (cheap): volpath.cpp:79-87, :283-287, :385-388
+    DEV void top(PathState &p, const PathEnv &e) const {
+        if (p.st != S_TOP) return;
+        const uint32_t max_depth = (uint32_t) sc.integrator.max_depth, rr_depth = (uint32_t) sc.integrator.rr_depth;
+        if (p.mode == M_MAIN) {
+            bool active = (p.flags & FL_ALIVE) && any_nonzero(p.thr);
+            float q = pm_min(hmax(p.thr) * (p.eta * p.eta), .95f);
+            bool perform_rr = p.depth > rr_depth;
+            active = active && (p.rng.next_1d() < q || !perform_rr);
+            if (perform_rr) p.thr = p.thr * pm_rcp(q);
+            if (!active || p.depth >= max_depth) p.st = S_NEW;
+            else { if (COUNT) cnt.n_iter++; p.st = p.medium >= 0 ? S_MED : S_SURF; }
+        } else if (p.mode == M_NEE) {
+            float remaining_dist = p.wb * (1.f - MTS_SHADOW_EPSILON) - p.wa;
+            p.ray.maxt = remaining_dist;
+            if (!(remaining_dist > 0.f)) end_nee(p, e);
+            else { if (COUNT) cnt.n_nee_step++; p.st = p.medium >= 0 ? S_MED : S_SURF; }
+        } else {
+            if (COUNT) cnt.n_nee_step++;
+            p.st = p.medium >= 0 ? S_MED : S_SURF;
+        }
+    }
+    DEV static bool wants_int(const PathState &p) { return (p.st == S_MED || p.st == S_SURF || p.st == S_DIRB) && (p.flags & FL_NEEDS_INT); }
+    // heavy block this path waits for (valid once top() has run)
+    DEV static int classify(const PathState &p) {
+        if (p.st == S_DONE) return B_DONE;
+        if (wants_int(p)) return B_INT;
+        if (p.st == S_MED) return B_MED;
+        if (p.st == S_SURF || p.st == S_BSDF) return B_SURF;
+        if (p.st == S_PHASE) return B_PHASE;
+        return B_NEW;
+    }
 
-    enum { B_INT = 0, B_MED, B_SURF, B_PHASE, B_NEW, B_COUNT };
-#if defined(MTSAMD_BLOCKSTATS)
-    long long bs_t0 = clock64(); int bs_prev_sel = 7;
-    unsigned long long bs_loc[24] = {};
-#endif
-    while (__ballot(st != S_DONE)) {
-#if defined(MTSAMD_BLOCKSTATS)
-        if (COUNT) { long long t = clock64(); bs_loc[16 + bs_prev_sel] += (unsigned long long) (t - bs_t0); bs_t0 = t; bs_prev_sel = 6; }
-#endif
-        // ================================================================= TOP: loop heads (cheap, every trip)
-        if (st == S_TOP) {
-            if (mode == M_MAIN) {                              // volpath.cpp:79-87
-                bool active = (flags & FL_ALIVE) && any_nonzero(thr);
-                float q = pm_min(hmax(thr) * (eta * eta), .95f);
-                bool perform_rr = depth > rr_depth;
-                active = active && (rng.next_1d() < q || !perform_rr);
-                if (perform_rr) thr = thr * pm_rcp(q);
-                if (!active || depth >= max_depth) st = S_NEW;
-                else {
-                    if (COUNT) cnt.n_iter++;
-                    st = medium >= 0 ? S_MED : S_SURF;
-                }
-            } else if (mode == M_NEE) {                        // volpath.cpp:283-287
-                float remaining_dist = wb * (1.f - MTS_SHADOW_EPSILON) - wa;
-                ray.maxt = remaining_dist;
-                if (!(remaining_dist > 0.f)) end_nee();
-                else { if (COUNT) cnt.n_nee_step++; st = medium >= 0 ? S_MED : S_SURF; }
-            } else {                                           // volpath.cpp:385-388
-                if (COUNT) cnt.n_nee_step++;
-                st = medium >= 0 ? S_MED : S_SURF;
-            }
-        }
-        // ================================================================= census + vote
-        const bool want_int = (st == S_MED || st == S_SURF || st == S_DIRB) && (flags & FL_NEEDS_INT);
-        int votes[B_COUNT];
-        votes[B_INT] = __popcll(__ballot(want_int));
-        votes[B_MED] = __popcll(__ballot(st == S_MED && !want_int));
-        votes[B_SURF] = __popcll(__ballot((st == S_SURF && !want_int) || st == S_BSDF));
-        votes[B_PHASE] = __popcll(__ballot(st == S_PHASE));
-        votes[B_NEW] = __popcll(__ballot(st == S_NEW));
-        int sel = B_MED, best = votes[B_MED];
-        for (int b = 0; b < B_COUNT; ++b) if (votes[b] > best) { best = votes[b]; sel = b; }
-        if (best == 0) continue;                               // only S_TOP / S_DONE lanes: next trip dispatches them
-#if defined(MTSAMD_BLOCKSTATS)                                  // diagnostic build: executions and lanes served per block
-        if (COUNT) {
-            bs_loc[2 * sel] += 1ull; bs_loc[2 * sel + 1] += (unsigned long long) best;
-            long long t = clock64(); bs_loc[16 + 6] += (unsigned long long) (t - bs_t0); bs_t0 = t; bs_prev_sel = sel;
-        }
-#endif
+    // Run the blocks selected by `sel` for this lane (every lane of the wave calls this with the same `sel`;
+    // a lane whose state does not match simply falls through).  Several cheap follow-up steps run in the same call.
+    DEV void run(PathState &p, const PathEnv &e, int sel) const {
+        const DSensor &se = sc.sensor;
+        const uint32_t max_depth = (uint32_t) sc.integrator.max_depth;
+        const bool want_int = wants_int(p);
         // ================================================================= NEW: finish a sample, start the next (integrator.cpp:265-288)
-        if (sel == B_NEW && st == S_NEW) {
-            float acc[5];
-            for (int k = 0; k < 5; ++k) acc[k] = cold.f(C_ACC + k);
-            F2 position_sample; position_sample.x = cold.f(C_POS); position_sample.y = cold.f(C_POS + 1);
-            splat_sample(sc, blk, lx, ly, position_sample, f3s(cold.f(C_RAYW)) * res, (flags & FL_VALID_RAY) != 0, film, acc);
-            for (int k = 0; k < 5; ++k) cold.f(C_ACC + k) = acc[k];
-            if (++sample_idx == sample_count) st = S_DONE;
-            else begin_sample();
+        if (sel == B_NEW && p.st == S_NEW) {
+            F2 position_sample; position_sample.x = e.cold.f(C_POS); position_sample.y = e.cold.f(C_POS + 1);
+            float *own = e.film + 5 * ((size_t) (e.blk.oy + (int) e.ly - se.crop_y) * se.crop_w + (e.blk.ox + (int) e.lx - se.crop_x));
+            splat_sample(sc, e.blk, e.lx, e.ly, position_sample, f3s(e.cold.f(C_RAYW)) * p.res, (p.flags & FL_VALID_RAY) != 0, e.film, own);
+            if (++p.sample_idx == e.sample_count) p.st = S_DONE;
+            else begin_sample(p, e);
         }
         // ================================================================= INTERSECT (volpath.cpp:109,182,241,298,339,395,425)
         if (sel == B_INT && want_int) {
-            si = ray_intersect(sc, ray);
-            flags &= ~FL_NEEDS_INT;
+            p.si = ray_intersect(sc, p.ray);
+            p.flags &= ~FL_NEEDS_INT;
         }
-        if (st == S_DIRB && !(flags & FL_NEEDS_INT)) {         // volpath.cpp:239-245: start the direct-light walk on a copy
-            cold.put3(C_SO, ray.o); cold.put3(C_SD, ray.d); cold.put_hit(si);
-            trans = f3s(1.f);
-            mode = M_DIR; st = S_TOP;
+        if (p.st == S_DIRB && !(p.flags & FL_NEEDS_INT)) {     // volpath.cpp:239-245: start the direct-light walk on a copy
+            e.cold.put3(C_SO, p.ray.o); e.cold.put3(C_SD, p.ray.d); e.cold.put_hit(p.si);
+            p.trans = f3s(1.f);
+            p.mode = M_DIR; p.st = S_TOP;
         }
         // ================================================================= MEDIUM: one free-flight step
-        if (sel == B_MED && st == S_MED && !want_int) {
-            const float u = rng.next_1d();                     // volpath.cpp:105 / :294 / :391
+        if (sel == B_MED && p.st == S_MED && !want_int) {
+            const float u = p.rng.next_1d();                   // volpath.cpp:105 / :294 / :391
             MedStep mi;
-#if defined(EXP_NOWF)
-            mi = medium_step<COUNT>(sc, cload(sc.media), ray, u, channel, mode == M_MAIN, cnt);
-#else
-            WATERFALL_BEGIN(medium, mu)
-                mi = medium_step<COUNT>(sc, cload(sc.media + mu), ray, u, channel, mode == M_MAIN, cnt);
+            WATERFALL_BEGIN(p.medium, mu)
+                mi = medium_step<COUNT>(sc, cload(sc.media + mu), p.ray, u, p.channel, p.mode == M_MAIN, cnt);
             WATERFALL_END
-#endif
-            if (si.t < mi.t) mi.t = pm_inf();                  // volpath.cpp:112 / :300 / :397
+            if (p.si.t < mi.t) mi.t = pm_inf();                // volpath.cpp:112 / :300 / :397
             const bool spectral = (mi.info & MI_SPECTRAL) != 0, homogeneous = (mi.info & MI_HOMOGENEOUS) != 0, grey = (mi.info & MI_GREY) != 0;
             const F3 sigma_n = homogeneous ? f3s(0.f) : mi.combined - mi.sigma_t;
             const bool valid = mi.t != pm_inf();
-            if (mode == M_MAIN) {
+            const uint32_t channel = p.channel;
+            if (p.mode == M_MAIN) {
                 if (spectral) {                                // medium.cpp:77-89, volpath.cpp:113-117
-                    float t = pm_min(mi.t, si.t) - mi.mint;
+                    float t = pm_min(mi.t, p.si.t) - mi.mint;
                     F3 tr = transmittance_exp_g(t, mi.combined, grey);
-                    F3 free_flight_pdf = si.t < mi.t ? tr : tr * mi.combined;
+                    F3 free_flight_pdf = p.si.t < mi.t ? tr : tr * mi.combined;
                     float tr_pdf = pick(free_flight_pdf, channel);
-                    thr = thr * (tr_pdf > 0.f ? tr / tr_pdf : f3s(0.f));
+                    p.thr = p.thr * (tr_pdf > 0.f ? tr / tr_pdf : f3s(0.f));
                 }
-                const float u2 = rng.next_1d();                // volpath.cpp:123 (drawn even when the medium was left)
-                if (!valid) st = S_SURF;                       // escaped_medium: surface part of this iteration
+                const float u2 = p.rng.next_1d();              // volpath.cpp:123 (drawn even when the medium was left)
+                if (!valid) p.st = S_SURF;                     // escaped_medium: surface part of this iteration
                 else {
                     bool null_scatter = u2 >= pick(mi.sigma_t, channel) / pick(mi.combined, channel);
                     if (null_scatter) {                        // volpath.cpp:128-131,140-144
-                        if (spectral) thr = thr * (sigma_n * pick(mi.combined, channel) / pick(sigma_n, channel));
-                        ray.o = mi.p; ray.mint = 0.f; si.t = si.t - mi.t;
-                        st = S_TOP;                            // stays alive
+                        if (spectral) p.thr = p.thr * (sigma_n * pick(mi.combined, channel) / pick(sigma_n, channel));
+                        p.ray.o = mi.p; p.ray.mint = 0.f; p.si.t = p.si.t - mi.t;
+                        p.st = S_TOP;                          // stays alive
                     } else {                                   // real scattering event, volpath.cpp:133-175
-                        depth += 1;
-                        if (!(depth < max_depth)) { flags &= ~FL_ALIVE; st = S_TOP; }
+                        p.depth += 1;
+                        if (!(p.depth < max_depth)) { p.flags &= ~FL_ALIVE; p.st = S_TOP; }
                         else {
-                            if (spectral) thr = thr * (mi.sigma_s * pick(mi.combined, channel) / pick(mi.sigma_t, channel));
-                            else thr = thr * (mi.sigma_s / mi.sigma_t);
+                            if (spectral) p.thr = p.thr * (mi.sigma_s * pick(mi.combined, channel) / pick(mi.sigma_t, channel));
+                            else p.thr = p.thr * (mi.sigma_s / mi.sigma_t);
                             const bool sample_emitters = (mi.info & MI_SAMPLE_EMITTERS) != 0;
-                            flags |= FL_VALID_RAY;
-                            flags = sample_emitters ? (flags & ~FL_SPEC_CHAIN) : (flags | FL_SPEC_CHAIN);
-                            ray.o = mi.p;                      // scattering position; ray.d stays the incident direction
-                            st = S_PHASE;
+                            p.flags |= FL_VALID_RAY;
+                            p.flags = sample_emitters ? (p.flags & ~FL_SPEC_CHAIN) : (p.flags | FL_SPEC_CHAIN);
+                            p.ray.o = mi.p;                    // scattering position; ray.d stays the incident direction
+                            p.st = S_PHASE;
                             if (sample_emitters) {             // volpath.cpp:162-167 -> sample_emitter :261-281
                                 F3 emitter_val;
-                                DirSample ds = sample_emitter_direction(sc, mi.p, rng.next_2d(), false, emitter_val);
+                                DirSample ds = sample_emitter_direction(sc, mi.p, p.rng.next_2d(), false, emitter_val);
                                 if (ds.pdf != 0.f) {
-                                    float phase_val = phase_eval(sc, (int) (mi.info >> MI_PHASE_SHIFT), -ray.d, mi.p, ds.d);
-                                    cold.put3(C_CW, thr * phase_val); cold.put3(C_EMIT, emitter_val);
-                                    cold.put3(C_SO, mi.p); cold.put3(C_SD, ray.d); cold.f(C_SMED) = __int_as_float(medium);
-                                    trans = f3s(1.f); wa = 0.f; wb = ds.dist;
-                                    ray = spawn_ray(mi.p, ds.d); ray.mint = 0.f;
-                                    queue_intersection();
-                                    flags |= FL_FROM_MEDIUM;
-                                    mode = M_NEE; st = S_TOP;
+                                    float phase_val = phase_eval(sc, (int) (mi.info >> MI_PHASE_SHIFT), -p.ray.d, mi.p, ds.d);
+                                    e.cold.put3(C_CW, p.thr * phase_val); e.cold.put3(C_EMIT, emitter_val);
+                                    e.cold.put3(C_SO, mi.p); e.cold.put3(C_SD, p.ray.d); e.cold.f(C_SMED) = __int_as_float(p.medium);
+                                    p.trans = f3s(1.f); p.wa = 0.f; p.wb = ds.dist;
+                                    p.ray = spawn_ray(mi.p, ds.d); p.ray.mint = 0.f;
+                                    queue_intersection(p);
+                                    p.flags |= FL_FROM_MEDIUM;
+                                    p.mode = M_NEE; p.st = S_TOP;
                                 }
                             }
                         }
                     }
                 }
-            } else if (mode == M_NEE) {                        // volpath.cpp:303-334
-                const float remaining_dist = ray.maxt;
+            } else if (p.mode == M_NEE) {                      // volpath.cpp:303-334
+                const float remaining_dist = p.ray.maxt;
                 if (spectral) {
-                    float t = pm_min(remaining_dist, pm_min(mi.t, si.t)) - mi.mint;
+                    float t = pm_min(remaining_dist, pm_min(mi.t, p.si.t)) - mi.mint;
                     F3 tr = transmittance_exp_g(t, mi.combined, grey);
-                    F3 free_flight_pdf = (si.t < mi.t || mi.t > remaining_dist) ? tr : tr * mi.combined;
+                    F3 free_flight_pdf = (p.si.t < mi.t || mi.t > remaining_dist) ? tr : tr * mi.combined;
                     float tr_pdf = pick(free_flight_pdf, channel);
-                    trans = trans * (tr_pdf > 0.f ? tr / tr_pdf : f3s(0.f));
+                    p.trans = p.trans * (tr_pdf > 0.f ? tr / tr_pdf : f3s(0.f));
                 }
-                if (mi.t > remaining_dist && mi.t != pm_inf()) wa = wb;
+                if (mi.t > remaining_dist && mi.t != pm_inf()) p.wa = p.wb;
                 if (mi.t > remaining_dist) mi.t = pm_inf();
-                if (mi.t == pm_inf()) st = S_SURF;             // escaped_medium
+                if (mi.t == pm_inf()) p.st = S_SURF;           // escaped_medium
                 else {
-                    wa += mi.t;
-                    ray.o = mi.p; ray.mint = 0.f; si.t = si.t - mi.t;
-                    if (spectral) trans = trans * sigma_n; else trans = trans * (sigma_n / mi.combined);
-                    if (any_nonzero(trans)) st = S_TOP; else end_nee();     // volpath.cpp:358
+                    p.wa += mi.t;
+                    p.ray.o = mi.p; p.ray.mint = 0.f; p.si.t = p.si.t - mi.t;
+                    if (spectral) p.trans = p.trans * sigma_n; else p.trans = p.trans * (sigma_n / mi.combined);
+                    if (any_nonzero(p.trans)) p.st = S_TOP; else end_nee(p, e);     // volpath.cpp:358
                 }
             } else {                                           // direct-light walk, volpath.cpp:399-421
                 if (spectral) {
-                    float t = pm_min(mi.t, si.t) - mi.mint;
+                    float t = pm_min(mi.t, p.si.t) - mi.mint;
                     F3 tr = transmittance_exp_g(t, mi.combined, grey);
-                    F3 free_flight_pdf = si.t < mi.t ? tr : tr * mi.combined;
+                    F3 free_flight_pdf = p.si.t < mi.t ? tr : tr * mi.combined;
                     float tr_pdf = pick(free_flight_pdf, channel);
-                    trans = trans * (tr_pdf > 0.f ? tr / tr_pdf : f3s(0.f));
+                    p.trans = p.trans * (tr_pdf > 0.f ? tr / tr_pdf : f3s(0.f));
                 }
-                if (!valid) st = S_SURF;
+                if (!valid) p.st = S_SURF;
                 else {
-                    ray.o = mi.p; ray.mint = 0.f; si.t = si.t - mi.t;
-                    if (spectral) trans = trans * sigma_n; else trans = trans * (sigma_n / mi.combined);
-                    if (any_nonzero(trans)) st = S_TOP; else end_direct(f3s(0.f), 0.f);   // volpath.cpp:456
+                    p.ray.o = mi.p; p.ray.mint = 0.f; p.si.t = p.si.t - mi.t;
+                    if (spectral) p.trans = p.trans * sigma_n; else p.trans = p.trans * (sigma_n / mi.combined);
+                    if (any_nonzero(p.trans)) p.st = S_TOP; else end_direct(p, e, f3s(0.f), 0.f);   // volpath.cpp:456
                 }
             }
         }
-        // ================================================================= SURFACE step of a walk (cheap; runs in whatever trip produced it)
-        if (st == S_SURF && mode != M_MAIN && !(flags & FL_NEEDS_INT) && (sel == B_INT || sel == B_MED || sel == B_SURF)) {
-            const bool hit = hit_valid(si);
-            if (mode == M_NEE) {                               // volpath.cpp:336-364
-                wa += si.t;
+        // ================================================================= SURFACE step of a walk (cheap; runs in whatever call produced it)
+        if (p.st == S_SURF && p.mode != M_MAIN && !(p.flags & FL_NEEDS_INT) && (sel == B_INT || sel == B_MED || sel == B_SURF)) {
+            const bool hit = hit_valid(p.si);
+            if (p.mode == M_NEE) {                             // volpath.cpp:336-364
+                p.wa += p.si.t;
                 if (hit) {
                     F3 nt = f3s(0.f), n = f3s(0.f); int is_tr = 0, ext = -1, inte = -1;
-                    WATERFALL_BEGIN(si.shape, su)
+                    WATERFALL_BEGIN(p.si.shape, su)
                         const DShape s = cload(sc.shapes + su);
                         nt = cload(sc.bsdfs + s.bsdf).type == MTS_BSDF_NULL ? f3s(1.f) : f3s(0.f);    // null.cpp:70-73, bsdf.cpp:11-14
                         is_tr = s.is_medium_transition; ext = s.exterior; inte = s.interior;
-                        if (is_tr) n = hit_geo_normal(sc, s, si);
+                        if (is_tr) n = hit_geo_normal(sc, s, p.si);
                     WATERFALL_END
-                    trans = trans * nt;
-                    ray = spawn_ray(si.p, ray.d);
-                    queue_intersection();
-                    if (is_tr) medium = dot(ray.d, n) > 0 ? ext : inte;     // interaction.h:178-200
+                    p.trans = p.trans * nt;
+                    p.ray = spawn_ray(p.si.p, p.ray.d);
+                    queue_intersection(p);
+                    if (is_tr) p.medium = dot(p.ray.d, n) > 0 ? ext : inte;     // interaction.h:178-200
                 }
-                if (hit && any_nonzero(trans)) st = S_TOP; else end_nee();
+                if (hit && any_nonzero(p.trans)) p.st = S_TOP; else end_nee(p, e);
             } else {                                           // direct-light walk, volpath.cpp:423-462
                 int emitter = sc.environment;
-                Surf sf; sf.wi = -ray.d; sf.sh.n = f3s(0.f); sf.n = f3s(0.f);
+                Surf sf; sf.wi = -p.ray.d; sf.sh.n = f3s(0.f); sf.n = f3s(0.f);
                 F3 nt = f3s(0.f); int is_tr = 0, ext = -1, inte = -1;
                 if (hit) {
-                    WATERFALL_BEGIN(si.shape, su)
+                    WATERFALL_BEGIN(p.si.shape, su)
                         const DShape s = cload(sc.shapes + su);
                         emitter = s.emitter;
                         nt = cload(sc.bsdfs + s.bsdf).type == MTS_BSDF_NULL ? f3s(1.f) : f3s(0.f);
                         is_tr = s.is_medium_transition; ext = s.exterior; inte = s.interior;
-                        if (emitter >= 0 || is_tr) complete_surface(sc, s, si, ray.d, sf);
+                        if (emitter >= 0 || is_tr) complete_surface(sc, s, p.si, p.ray.d, sf);
                     WATERFALL_END
                 }
                 if (emitter >= 0) {                            // volpath.cpp:430-440
-                    const F3 ref_p = cold.get3(C_SO);
+                    const F3 ref_p = e.cold.get3(C_SO);
                     DirSample ds;                              // render/records.h:168-174
-                    ds.p = si.p; ds.n = sf.sh.n; ds.d = si.p - ref_p; ds.dist = norm(ds.d); ds.d = ds.d / ds.dist;
+                    ds.p = p.si.p; ds.n = sf.sh.n; ds.d = p.si.p - ref_p; ds.dist = norm(ds.d); ds.d = ds.d / ds.dist;
                     if (!hit) ds.d = -sf.wi;
                     ds.emitter = emitter; ds.pdf = 0.f; ds.delta = false;
-                    end_direct(emitter_eval(sc, emitter, sf.wi.z), pdf_emitter_direction(sc, ref_p, ds));
+                    end_direct(p, e, emitter_eval(sc, emitter, sf.wi.z), pdf_emitter_direction(sc, ref_p, ds));
                 } else {
                     if (hit) {
-                        trans = trans * nt;
-                        ray = spawn_ray(si.p, ray.d);
-                        queue_intersection();
-                        if (is_tr) medium = dot(ray.d, sf.n) > 0 ? ext : inte;
+                        p.trans = p.trans * nt;
+                        p.ray = spawn_ray(p.si.p, p.ray.d);
+                        queue_intersection(p);
+                        if (is_tr) p.medium = dot(p.ray.d, sf.n) > 0 ? ext : inte;
                     }
-                    if (hit && any_nonzero(trans)) st = S_TOP; else end_direct(f3s(0.f), 0.f);
+                    if (hit && any_nonzero(p.trans)) p.st = S_TOP; else end_direct(p, e, f3s(0.f), 0.f);
                 }
             }
         }
         // ================================================================= SURFACE interaction of the main path (volpath.cpp:184-212)
-        if (sel == B_SURF && st == S_SURF && mode == M_MAIN && !want_int) {
-            const bool hit = hit_valid(si);
-            Surf sf; sf.wi = -ray.d; sf.n = f3s(0.f); sf.sh.s = sf.sh.t = sf.sh.n = f3s(0.f);
+        if (sel == B_SURF && p.st == S_SURF && p.mode == M_MAIN && !want_int) {
+            const bool hit = hit_valid(p.si);
+            Surf sf; sf.wi = -p.ray.d; sf.n = f3s(0.f); sf.sh.s = sf.sh.t = sf.sh.n = f3s(0.f);
             int emitter = sc.environment, bsdf_id = 0;
             if (hit) {
-                WATERFALL_BEGIN(si.shape, su)
+                WATERFALL_BEGIN(p.si.shape, su)
                     const DShape s = cload(sc.shapes + su);
-                    complete_surface(sc, s, si, ray.d, sf);
+                    complete_surface(sc, s, p.si, p.ray.d, sf);
                     emitter = s.emitter; bsdf_id = s.bsdf;
                 WATERFALL_END
             }
-            if ((flags & FL_SPEC_CHAIN) && emitter >= 0) res = res + thr * emitter_eval(sc, emitter, sf.wi.z);
-            if (!hit) { flags &= ~FL_ALIVE; st = S_TOP; }
+            if ((p.flags & FL_SPEC_CHAIN) && emitter >= 0) p.res = p.res + p.thr * emitter_eval(sc, emitter, sf.wi.z);
+            if (!hit) { p.flags &= ~FL_ALIVE; p.st = S_TOP; }
             else {
-                st = S_BSDF;
+                p.st = S_BSDF;
                 const DBsdf &bsdf = sc.bsdfs[bsdf_id];
-                bool active_e = (bsdf.flags & F_Smooth) != 0 && (depth + 1 < max_depth);
+                bool active_e = (bsdf.flags & F_Smooth) != 0 && (p.depth + 1 < max_depth);
                 if (active_e) {                                // volpath.cpp:200-212 -> sample_emitter :261-281
                     F3 emitter_val;
-                    DirSample ds = sample_emitter_direction(sc, si.p, rng.next_2d(), false, emitter_val);
+                    DirSample ds = sample_emitter_direction(sc, p.si.p, p.rng.next_2d(), false, emitter_val);
                     if (ds.pdf != 0.f) {
                         F3 wo = to_local(sf.sh, ds.d);
                         F3 bsdf_val = bsdf_eval(bsdf, sf.wi, wo);
                         float bpdf = bsdf_pdf(bsdf, sf.wi, wo);
-                        cold.put3(C_CW, thr * bsdf_val * mis_weight(ds.pdf, ds.delta ? 0.f : bpdf)); cold.put3(C_EMIT, emitter_val);
-                        cold.put_hit(si); cold.put3(C_SD, ray.d); cold.f(C_SMED) = __int_as_float(medium);
-                        trans = f3s(1.f); wa = 0.f; wb = ds.dist;
-                        ray = spawn_ray(si.p, ds.d);
-                        queue_intersection();
-                        flags &= ~FL_FROM_MEDIUM;
-                        mode = M_NEE; st = S_TOP;
+                        e.cold.put3(C_CW, p.thr * bsdf_val * mis_weight(ds.pdf, ds.delta ? 0.f : bpdf)); e.cold.put3(C_EMIT, emitter_val);
+                        e.cold.put_hit(p.si); e.cold.put3(C_SD, p.ray.d); e.cold.f(C_SMED) = __int_as_float(p.medium);
+                        p.trans = f3s(1.f); p.wa = 0.f; p.wb = ds.dist;
+                        p.ray = spawn_ray(p.si.p, ds.d);
+                        queue_intersection(p);
+                        p.flags &= ~FL_FROM_MEDIUM;
+                        p.mode = M_NEE; p.st = S_TOP;
                     }
                 }
             }
         }
         // ================================================================= BSDF sampling (volpath.cpp:214-252)
-        if (sel == B_SURF && st == S_BSDF) {
+        if (sel == B_SURF && p.st == S_BSDF) {
             Surf sf; int bsdf_id = 0, is_tr = 0, ext = -1, inte = -1;
-            WATERFALL_BEGIN(si.shape, su)
+            WATERFALL_BEGIN(p.si.shape, su)
                 const DShape s = cload(sc.shapes + su);
-                complete_surface(sc, s, si, ray.d, sf);
+                complete_surface(sc, s, p.si, p.ray.d, sf);
                 bsdf_id = s.bsdf; is_tr = s.is_medium_transition; ext = s.exterior; inte = s.interior;
             WATERFALL_END
-            const float s1 = rng.next_1d(); const F2 s2 = rng.next_2d(); (void) s1;
+            const float s1 = p.rng.next_1d(); const F2 s2 = p.rng.next_2d(); (void) s1;
             BSDFSample bs;
             F3 bsdf_val = bsdf_sample(sc.bsdfs[bsdf_id], sf.wi, s2, bs);
-            thr = thr * bsdf_val;
-            eta *= bs.eta;
-            ray = spawn_ray(si.p, to_world(sf.sh, bs.wo));
-            flags |= FL_ALIVE;
+            p.thr = p.thr * bsdf_val;
+            p.eta *= bs.eta;
+            p.ray = spawn_ray(p.si.p, to_world(sf.sh, bs.wo));
+            p.flags |= FL_ALIVE;
             const bool non_null_bsdf = !(bs.sampled_type & F_Null);
-            if (non_null_bsdf) { depth += 1; flags |= FL_VALID_RAY; }
-            if (non_null_bsdf && (bs.sampled_type & F_Delta)) flags |= FL_SPEC_CHAIN;
-            if (bs.sampled_type & F_Smooth) flags &= ~FL_SPEC_CHAIN;
-            const bool add_emitter = !(bs.sampled_type & F_Delta) && any_nonzero(thr) && (depth < max_depth);
-            const int new_medium = is_tr ? (dot(ray.d, sf.n) > 0 ? ext : inte) : medium;     // volpath.cpp:249-250
-            queue_intersection();
-            if (add_emitter) { cold.f(C_SMED) = __int_as_float(new_medium); wb = bs.pdf; st = S_DIRB; }   // the walk runs in the old medium
-            else { medium = new_medium; st = S_TOP; }
+            if (non_null_bsdf) { p.depth += 1; p.flags |= FL_VALID_RAY; }
+            if (non_null_bsdf && (bs.sampled_type & F_Delta)) p.flags |= FL_SPEC_CHAIN;
+            if (bs.sampled_type & F_Smooth) p.flags &= ~FL_SPEC_CHAIN;
+            const bool add_emitter = !(bs.sampled_type & F_Delta) && any_nonzero(p.thr) && (p.depth < max_depth);
+            const int new_medium = is_tr ? (dot(p.ray.d, sf.n) > 0 ? ext : inte) : p.medium;     // volpath.cpp:249-250
+            queue_intersection(p);
+            if (add_emitter) { e.cold.f(C_SMED) = __int_as_float(new_medium); p.wb = bs.pdf; p.st = S_DIRB; }   // the walk runs in the old medium
+            else { p.medium = new_medium; p.st = S_TOP; }
         }
         // ================================================================= PHASE sampling (volpath.cpp:169-175)
-        if (st == S_PHASE && (sel == B_INT || sel == B_MED || sel == B_PHASE)) {
-            const float s1 = rng.next_1d(); const F2 s2 = rng.next_2d();      // left-to-right (SURVEY.md 8(a'))
+        if (p.st == S_PHASE && (sel == B_INT || sel == B_MED || sel == B_PHASE)) {
+            const float s1 = p.rng.next_1d(); const F2 s2 = p.rng.next_2d();      // left-to-right (SURVEY.md 8(a'))
             F3 wo;
-            WATERFALL_BEGIN(medium, mu)
-                wo = phase_sample(sc, cload(sc.media + mu).phase, make_frame(ray.d), ray.o, s1, s2);   // mi.sh_frame = Frame3f(ray.d), medium.cpp:42
+            WATERFALL_BEGIN(p.medium, mu)
+                wo = phase_sample(sc, cload(sc.media + mu).phase, make_frame(p.ray.d), p.ray.o, s1, s2);   // mi.sh_frame = Frame3f(ray.d), medium.cpp:42
             WATERFALL_END
-            ray = spawn_ray(ray.o, wo); ray.mint = 0.0f;
-            queue_intersection();
-            flags |= FL_ALIVE;
-            st = S_TOP;
+            p.ray = spawn_ray(p.ray.o, wo); p.ray.mint = 0.0f;
+            queue_intersection(p);
+            p.flags |= FL_ALIVE;
+            p.st = S_TOP;
         }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// Driver 1: one lane = one pixel, state in registers, cold state in LDS, blocks chosen by a per-wave vote.
+template <bool COUNT>
+DEV void volpath_pixel_flat(const DScene &sc, Pcg32 &rng, const DBlock &blk, uint32_t lx, uint32_t ly, uint32_t sample_count,
+                            float *__restrict__ film, ColdStore cold, Counters &cnt) {
+    VolpathMachine<COUNT> vm(sc, cnt);
+    PathEnv e; e.blk = blk; e.lx = lx; e.ly = ly; e.sample_count = sample_count; e.film = film; e.cold = cold;
+    PathState p; p.rng = rng; p.sample_idx = 0;
+    vm.begin_sample(p, e);
+#if defined(MTSAMD_BLOCKSTATS)
+    long long bs_t0 = clock64(); int bs_prev_sel = 7;
+    unsigned long long bs_loc[24] = {};
+#endif
+    while (__ballot(p.st != S_DONE)) {
+#if defined(MTSAMD_BLOCKSTATS)
+        if (COUNT) { long long t = clock64(); bs_loc[16 + bs_prev_sel] += (unsigned long long) (t - bs_t0); bs_t0 = t; bs_prev_sel = 6; }
+#endif
+        vm.top(p, e);
+        // census + vote: run the ONE heavy block most lanes of this wave are waiting for
+        const int cls = vm.classify(p);
+        int sel = B_MED, best = -1;
+        for (int b = 0; b < B_DONE; ++b) { int v = __popcll(__ballot(cls == b)); if (v > best) { best = v; sel = b; } }
+        if (best == 0) continue;
+#if defined(MTSAMD_BLOCKSTATS)
+        if (COUNT) {
+            bs_loc[2 * sel] += 1ull; bs_loc[2 * sel + 1] += (unsigned long long) best;
+            long long t = clock64(); bs_loc[16 + 6] += (unsigned long long) (t - bs_t0); bs_t0 = t; bs_prev_sel = sel;
+        }
+#endif
+        vm.run(p, e, sel);
     }
 #if defined(MTSAMD_BLOCKSTATS)
     if (COUNT && __builtin_amdgcn_readfirstlane((int) (threadIdx.x & 63)) == (int) (threadIdx.x & 63))
         for (int k = 0; k < 24; ++k) atomicAdd(&g_blockstats[k], bs_loc[k]);
 #endif
-    // the pixel's own film entry (block accumulation, imageblock.cpp:163-168) -> film (hdrfilm.cpp:207-211)
-    float *dst = film + 5 * ((size_t) (blk.oy + (int) ly - se.crop_y) * se.crop_w + (blk.ox + (int) lx - se.crop_x));
-    for (int k = 0; k < 5; ++k) atomicAdd(dst + k, cold.f(C_ACC + k));
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Driver 2: workgroup-level regrouping.  A workgroup of WG threads owns WG paths (pixels) whose hot state
+// lives in LDS as struct-of-arrays "queues"; cold state lives in HBM.  Every trip the workgroup counting-sorts
+// its paths by the heavy block they wait for (__ballot / __popcll per wave + a tiny LDS histogram), thread t
+// then processes the t-th path of the sorted order.  A wave therefore sees (almost) a single class and runs
+// that block with all 64 lanes active, instead of the ~40 % a per-wave vote can reach (measured).
+enum { H_RNG = 0, H_O = 2, H_D = 5, H_MINT = 8, H_MAXT = 9, H_SI = 10, H_MEDIUM = 18, H_THR = 19, H_RES = 22, H_ETA = 25,
+       H_DEPTH = 26, H_PACKED = 27, H_SAMPLE = 28, H_TRANS = 29, H_WA = 32, H_WB = 33, H_COUNT = 34 };
+
+template <int WG>
+struct HotStore {
+    uint32_t *base;                                          // &lds[0][path]
+    DEV uint32_t &u(int k) const { return base[k * WG]; }
+    DEV float f(int k) const { return __uint_as_float(base[k * WG]); }
+    DEV void putf(int k, float v) const { base[k * WG] = __float_as_uint(v); }
+    DEV void put3(int k, F3 v) const { putf(k, v.x); putf(k + 1, v.y); putf(k + 2, v.z); }
+    DEV F3 get3(int k) const { return f3(f(k), f(k + 1), f(k + 2)); }
+    DEV static uint32_t pack(const PathState &p, int cls) {
+        return p.st | (p.mode << 3) | (p.channel << 5) | (p.flags << 7) | ((uint32_t) cls << 12);
+    }
+    DEV static int cls_of(uint32_t packed) { return (int) (packed >> 12) & 7; }
+    DEV void store(const PathState &p, int cls) const {
+        u(H_RNG) = (uint32_t) p.rng.state; u(H_RNG + 1) = (uint32_t) (p.rng.state >> 32);
+        put3(H_O, p.ray.o); put3(H_D, p.ray.d); putf(H_MINT, p.ray.mint); putf(H_MAXT, p.ray.maxt);
+        putf(H_SI, p.si.t); put3(H_SI + 1, p.si.p); putf(H_SI + 4, p.si.uv.x); putf(H_SI + 5, p.si.uv.y);
+        u(H_SI + 6) = (uint32_t) p.si.shape; u(H_SI + 7) = (uint32_t) p.si.prim;
+        u(H_MEDIUM) = (uint32_t) p.medium; put3(H_THR, p.thr); put3(H_RES, p.res); putf(H_ETA, p.eta);
+        u(H_DEPTH) = p.depth; u(H_PACKED) = pack(p, cls); u(H_SAMPLE) = p.sample_idx;
+        put3(H_TRANS, p.trans); putf(H_WA, p.wa); putf(H_WB, p.wb);
+    }
+    DEV void load(PathState &p) const {
+        p.rng.state = (uint64_t) u(H_RNG) | ((uint64_t) u(H_RNG + 1) << 32); p.rng.inc = (PCG32_DEFAULT_STREAM << 1u) | 1u;
+        p.ray.o = get3(H_O); p.ray.d = get3(H_D); p.ray.d_rcp = vrcp(p.ray.d); p.ray.mint = f(H_MINT); p.ray.maxt = f(H_MAXT);
+        p.si.t = f(H_SI); p.si.p = get3(H_SI + 1); p.si.uv.x = f(H_SI + 4); p.si.uv.y = f(H_SI + 5);
+        p.si.shape = (int) u(H_SI + 6); p.si.prim = (int) u(H_SI + 7);
+        p.medium = (int) u(H_MEDIUM); p.thr = get3(H_THR); p.res = get3(H_RES); p.eta = f(H_ETA);
+        p.depth = u(H_DEPTH); p.sample_idx = u(H_SAMPLE);
+        const uint32_t pk = u(H_PACKED);
+        p.st = pk & 7u; p.mode = (pk >> 3) & 3u; p.channel = (pk >> 5) & 3u; p.flags = (pk >> 7) & 31u;
+        p.trans = get3(H_TRANS); p.wa = f(H_WA); p.wb = f(H_WB);
+    }
+};
+
+template <bool COUNT, int WG>
+DEV void volpath_workgroup(const DScene &sc, const DBlock *__restrict__ blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,
+                           float *__restrict__ film, float *__restrict__ cold_g, uint32_t cold_stride, Counters &cnt) {
+    constexpr int NW = WG / 64;
+    __shared__ uint32_t hot_lds[H_COUNT * WG];
+    __shared__ uint32_t s_cnt[NW][8];
+    __shared__ uint16_t s_perm[WG];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t ppb = block_size * block_size;
+    const uint32_t wg_base = blockIdx.x * WG;                // first global path id of this workgroup
+    VolpathMachine<COUNT> vm(sc, cnt);
+
+    auto env_of = [&](uint32_t pid, PathEnv &e) -> bool {   // pixel owned by path `pid`; false: outside the block / film
+        const uint32_t gid = wg_base + pid;
+        const uint32_t b = gid / ppb, i = gid - b * ppb;
+        e.sample_count = sample_count; e.film = film;
+        e.cold.base = cold_g + gid; e.cold.stride = cold_stride;
+        if (b >= n_blocks) return false;
+        e.blk = blocks[b];
+        e.lx = compact_bits(i); e.ly = compact_bits(i >> 1);  // morton_decode, integrator.cpp:200
+        return e.lx < (uint32_t) e.blk.sx && e.ly < (uint32_t) e.blk.sy;
+    };
+    {   // ---- initialise the path this thread starts with (integrator.cpp:198)
+        PathEnv e; PathState p;
+        HotStore<WG> hs; hs.base = hot_lds + tid;
+        const bool ok = env_of(tid, e);
+        p.rng.state = 0; p.rng.inc = 0; p.sample_idx = 0;
+        p.ray = make_ray(f3s(0.f), f3(0.f, 0.f, 1.f), 0.f, 0.f); p.si.t = pm_inf(); p.si.p = f3s(0.f); p.si.uv.x = p.si.uv.y = 0.f; p.si.shape = -1; p.si.prim = 0;
+        p.medium = -1; p.thr = p.res = p.trans = f3s(0.f); p.eta = 1.f; p.depth = 0; p.channel = 0; p.mode = M_MAIN; p.flags = 0; p.wa = p.wb = 0.f;
+        p.st = S_DONE;
+        if (ok) {
+            const uint32_t gid = wg_base + tid, b = gid / ppb, i = gid - b * ppb;
+            p.rng.seed(sc.sensor.seed + (uint64_t) e.blk.id * ppb + i, PCG32_DEFAULT_STREAM);     // sampler.cpp:83-96
+            vm.begin_sample(p, e);
+            vm.top(p, e);
+        }
+        hs.store(p, vm.classify(p));
+    }
+    for (;;) {
+        __syncthreads();
+        // ---- counting sort of the workgroup's paths by class
+        const int home_cls = HotStore<WG>::cls_of(hot_lds[H_PACKED * WG + tid]);
+        unsigned long long my_mask = 0; int my_count = 0;
+        for (int c = 0; c < B_COUNT; ++c) {
+            unsigned long long m = __ballot(home_cls == c);
+            if (home_cls == c) my_mask = m;
+            if ((int) lane == c) my_count = __popcll(m);
+        }
+        if (lane < (uint32_t) B_COUNT) s_cnt[wave][lane] = (uint32_t) my_count;
+        __syncthreads();
+        uint32_t base = 0, done_total = 0;
+        for (int w = 0; w < NW; ++w) {
+            for (int c = 0; c < B_COUNT; ++c) {
+                const uint32_t n = s_cnt[w][c];
+                if (c < home_cls || (c == home_cls && w < (int) wave)) base += n;
+            }
+            done_total += s_cnt[w][B_DONE];
+        }
+        if (done_total == (uint32_t) WG) break;
+        const uint32_t rank = (uint32_t) __popcll(my_mask & ((1ull << lane) - 1ull));
+        s_perm[base + rank] = (uint16_t) tid;
+        __syncthreads();
+        // ---- process the path at this thread's position of the sorted order
+        const uint32_t pid = s_perm[tid];
+        HotStore<WG> hs; hs.base = hot_lds + pid;
+        int cls = HotStore<WG>::cls_of(hs.u(H_PACKED));
+        if (cls != B_DONE) {
+            PathEnv e; PathState p;
+            env_of(pid, e);
+            hs.load(p);
+#pragma unroll 1
+            for (int c = 0; c < B_DONE; ++c) {
+                if (__ballot(vm.classify(p) == c) == 0) continue;         // nobody in this wave waits for block c
+                vm.run(p, e, c);
+                vm.top(p, e);
+            }
+            hs.store(p, vm.classify(p));
+        }
+    }
 }
 
 } // namespace mtsamd
