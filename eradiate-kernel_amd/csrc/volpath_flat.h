@@ -161,9 +161,6 @@ DEV void splat_sample_t(const DScene &sc, const DBlock &blk, uint32_t lx, uint32
     }
 }
 
-DEV void splat_sample(const DScene &sc, const DBlock &blk, uint32_t lx, uint32_t ly, F2 position_sample, F3 L, bool valid,
-                      float *__restrict__ film, float *own) { splat_sample_t<true>(sc, blk, lx, ly, position_sample, L, valid, film, own); }
-
 // ---------------------------------------------------------------------------------------------------------
 // Per-path state.  "Hot" fields are touched by every tracking step; "cold" fields (ColdStore) only once per
 // sample or per NEE / direct-light walk.
@@ -184,7 +181,8 @@ enum { C_POS = 0,            // 2: film position of the current sample
        C_SMED = 17,          // 1: parked medium id
        C_CW = 18,            // 3: pending NEE weight
        C_EMIT = 21,          // 3: emitter value of the NEE sample
-       C_COUNT = 24 };
+       C_ACC = 24,           // 5: this path's film accumulators X, Y, Z, A, W (the reference's per-block ImageBlock entry)
+       C_COUNT = 29 };
 // Struct-of-arrays store addressed as base[k * stride]: LDS (stride 256, one workgroup) or HBM (stride = paths in flight)
 struct ColdStore {
     float *base; uint32_t stride;
@@ -307,10 +305,17 @@ struct VolpathMachine {
         // ================================================================= NEW: finish a sample, start the next (integrator.cpp:265-288)
         if (sel == B_NEW && p.st == S_NEW) {
             F2 position_sample; position_sample.x = e.cold.f(C_POS); position_sample.y = e.cold.f(C_POS + 1);
-            float *own = e.film + 5 * ((size_t) (e.blk.oy + (int) e.ly - se.crop_y) * se.crop_w + (e.blk.ox + (int) e.lx - se.crop_x));
-            splat_sample(sc, e.blk, e.lx, e.ly, position_sample, f3s(e.cold.f(C_RAYW)) * p.res, (p.flags & FL_VALID_RAY) != 0, e.film, own);
-            if (++p.sample_idx == e.sample_count) p.st = S_DONE;
-            else begin_sample(p, e);
+            float acc[5];                                      // summed in sample order like the block entry (imageblock.cpp:163-168)
+            for (int k = 0; k < 5; ++k) acc[k] = e.cold.f(C_ACC + k);
+            splat_sample_t<false>(sc, e.blk, e.lx, e.ly, position_sample, f3s(e.cold.f(C_RAYW)) * p.res, (p.flags & FL_VALID_RAY) != 0, e.film, acc);
+            if (++p.sample_idx == e.sample_count) {            // block -> film (hdrfilm.cpp:207-211)
+                float *own = e.film + 5 * ((size_t) (e.blk.oy + (int) e.ly - se.crop_y) * se.crop_w + (e.blk.ox + (int) e.lx - se.crop_x));
+                for (int k = 0; k < 5; ++k) atomicAdd(own + k, acc[k]);
+                p.st = S_DONE;
+            } else {
+                for (int k = 0; k < 5; ++k) e.cold.f(C_ACC + k) = acc[k];
+                begin_sample(p, e);
+            }
         }
         // ================================================================= INTERSECT (volpath.cpp:109,182,241,298,339,395,425)
         if (sel == B_INT && want_int) {
@@ -546,6 +551,7 @@ DEV void volpath_pixel_flat(const DScene &sc, Pcg32 &rng, const DBlock &blk, uin
     VolpathMachine<COUNT> vm(sc, cnt);
     PathEnv e; e.blk = blk; e.lx = lx; e.ly = ly; e.sample_count = sample_count; e.film = film; e.cold = cold;
     PathState p; p.rng = rng; p.sample_idx = 0;
+    for (int k = 0; k < 5; ++k) e.cold.f(C_ACC + k) = 0.f;
     vm.begin_sample(p, e);
 #if defined(MTSAMD_BLOCKSTATS)
     long long bs_t0 = clock64(); int bs_prev_sel = 7;
@@ -652,6 +658,7 @@ DEV void volpath_workgroup(const DScene &sc, const DBlock *__restrict__ blocks, 
         if (ok) {
             const uint32_t gid = wg_base + tid, b = gid / ppb, i = gid - b * ppb;
             p.rng.seed(sc.sensor.seed + (uint64_t) e.blk.id * ppb + i, PCG32_DEFAULT_STREAM);     // sampler.cpp:83-96
+            for (int k = 0; k < 5; ++k) e.cold.f(C_ACC + k) = 0.f;
             vm.begin_sample(p, e);
             vm.top(p, e);
         }

@@ -162,11 +162,11 @@ def test_full_size_properties(gpu_rgb):
     d = scenes.c3_heterogeneous(512, 512, spp)
     gpu, st = gpu_render(gpu_rgb, d)
     assert st["samples"] == 512 * 512 * spp
-    # A sample whose film offset is exactly 0 belongs to the previous pixel (imageblock.cpp:163-168 with the box
-    # filter): probability 2^-23 per draw, so all but a handful of pixels hold exactly spp unit weights and no
-    # weight is ever created.
+    # position_sample = pixel + u is rounded to fp32 (integrator.cpp:242): for u below half an ulp of the pixel
+    # coordinate the sum is the integer itself and the box-filter splat (imageblock.cpp:163-168) credits the previous
+    # pixel -- or drops the sample at a block edge.  ~1e-5 of the samples at 512^2; never creates weight.
     w = gpu[..., 4]
-    assert np.sum(w != spp) <= 16 and w.sum() <= 512 * 512 * spp and np.all(np.abs(w - spp) <= 1)
+    assert np.sum(w != spp) <= 2e-4 * w.size * spp and w.sum() <= 512 * 512 * spp and np.all(np.abs(w - spp) <= 2)
     assert np.all(gpu[..., 3] <= w) and np.all(gpu[..., :3] >= 0) and np.isfinite(gpu).all()
     d2 = scenes.c3_heterogeneous(512, 512, spp); d2["sensor"]["sampler"]["seed"] = 1
     gpu2, _ = gpu_render(gpu_rgb, d2)
