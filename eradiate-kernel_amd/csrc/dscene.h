@@ -68,7 +68,7 @@ struct DPrim { int32_t shape, index; };
 
 struct DEmitter { int32_t type; DXf to_world; float radiance[3]; int32_t shape; float bsphere_center[3], bsphere_radius; };
 
-struct DRFilter { int32_t type; float radius, stddev, alpha, bias; float values[32]; float scale_factor; int32_t border_size; };
+struct DRFilter { int32_t type; float radius, stddev, alpha, bias; const float *values /* device, 32 entries (rfilter.cpp:9-20) */; float scale_factor; int32_t border_size; };
 
 struct DSensor {
     int32_t type;

@@ -31,6 +31,15 @@ template <typename T> DEV T cload(const T *p) {
     T r; __builtin_memcpy(&r, tmp, sizeof(T));
     return r;
 }
+template <typename T> DEV T cload_k(const MTS_CONST_AS void *p) {      // same, from a constant-address-space pointer (kernel arguments)
+    static_assert(sizeof(T) % 4 == 0, "records are dword multiples");
+    uint32_t tmp[sizeof(T) / 4];
+    const MTS_CONST_AS uint32_t *src = (const MTS_CONST_AS uint32_t *) p;
+#pragma unroll
+    for (int k = 0; k < (int) (sizeof(T) / 4); ++k) tmp[k] = src[k];
+    T r; __builtin_memcpy(&r, tmp, sizeof(T));
+    return r;
+}
 // Waterfall: `idx` may differ between lanes (a lane's current medium / shape) but rarely does.  Peel one
 // distinct value per trip so that the record can be addressed with an SGPR.  The comparison goes through
 // an opaque copy: otherwise the optimiser learns `idx == uni` inside the branch, substitutes the per-lane

@@ -72,19 +72,21 @@ __global__ void __launch_bounds__(256) render_kernel(DScene sc, const DBlock *__
     }
 }
 
-// Workgroup-regrouping variant of the volpath render kernel (volpath_flat.h, driver 2)
+// Workgroup-regrouping variant of the volpath render kernel (volpath_flat.h, driver 2).  The parameter list
+// must stay in sync with WgArgs: the block functions re-read it from the kernarg segment with scalar loads.
 template <bool COUNT, int WG>
-__global__ void __launch_bounds__(WG) render_kernel_wg(DScene sc, const DBlock *__restrict__ blocks, uint32_t n_blocks, uint32_t block_size,
-                                                        uint32_t sample_count, float *__restrict__ film, float *__restrict__ cold_g, uint32_t cold_stride,
-                                                        unsigned long long *__restrict__ counters) {
+__global__ void __launch_bounds__(WG, WG >= 1024 ? 4 : (WG >= 512 ? 4 : 4)) render_kernel_wg(DScene sc, const DBlock *blocks, uint32_t n_blocks, uint32_t block_size,
+                                                        uint32_t sample_count, float *film, float *cold_g, uint32_t cold_stride,
+                                                        unsigned long long *counters) {
     Counters cnt; cnt.n_iter = cnt.n_lookup = cnt.n_nee_step = 0;
-    volpath_workgroup<COUNT, WG>(sc, blocks, n_blocks, block_size, sample_count, film, cold_g, cold_stride, cnt);
+    volpath_workgroup<COUNT, WG>((const MTS_CONST_AS void *) __builtin_amdgcn_kernarg_segment_ptr(), cnt);
     if (COUNT) {
         atomicAdd(counters + 0, (unsigned long long) cnt.n_iter);
         atomicAdd(counters + 1, (unsigned long long) cnt.n_lookup);
         atomicAdd(counters + 2, (unsigned long long) cnt.n_nee_step);
     }
 }
+static_assert(sizeof(WgArgs) % 4 == 0, "WgArgs mirrors the kernel parameters");
 
 // SamplingIntegrator::sample for caller-supplied rays (librender/python/integrator_v.cpp:62-78)
 __global__ void __launch_bounds__(256) sample_kernel(DScene sc, int32_t n, uint64_t seed_offset, const float *__restrict__ rays /* 6 SoA rows */,

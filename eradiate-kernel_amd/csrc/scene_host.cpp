@@ -137,18 +137,19 @@ static DShape build_shape(const mts_shape &d, HostScene &hs, DBBox &shape_bbox, 
     return s;
 }
 
-static DRFilter build_rfilter(int type, float radius, float stddev) {
+static DRFilter build_rfilter(int type, float radius, float stddev, std::vector<float> &values) {
     DRFilter f; memset(&f, 0, sizeof(f));
     f.type = type;
     if (type == MTS_RFILTER_BOX) f.radius = radius + MTS_RAY_EPSILON;                         // box.cpp:31
     else if (type == MTS_RFILTER_GAUSSIAN) {                                                    // gaussian.cpp:33-42
         f.stddev = stddev; f.radius = 4 * stddev; f.alpha = -1.f / (2.f * stddev * stddev); f.bias = pm_exp(f.alpha * (f.radius * f.radius));
     } else throw std::runtime_error("unknown reconstruction filter");
+    values.assign(32, 0.f);
     for (int i = 0; i < 31; ++i) {                                                              // rfilter.cpp:9-20 (MTS_FILTER_RESOLUTION = 31)
         float x = (f.radius * i) / 31;
-        f.values[i] = type == MTS_RFILTER_BOX ? (pm_abs(x) <= f.radius ? 1.f : 0.f) : pm_max(0.f, pm_exp(f.alpha * (x * x)) - f.bias);
+        values[i] = type == MTS_RFILTER_BOX ? (pm_abs(x) <= f.radius ? 1.f : 0.f) : pm_max(0.f, pm_exp(f.alpha * (x * x)) - f.bias);
     }
-    f.values[31] = 0;
+    values[31] = 0;
     f.scale_factor = 31 / f.radius;
     f.border_size = (int) std::ceil(f.radius - .5f - 2.f * MTS_RAY_EPSILON);
     return f;
@@ -331,7 +332,7 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
     se.crop_x = s.crop_offset[0]; se.crop_y = s.crop_offset[1]; se.crop_w = s.crop_size[0]; se.crop_h = s.crop_size[1];
     if (se.width <= 0 || se.height <= 0 || se.crop_w <= 0 || se.crop_h <= 0 || se.crop_x < 0 || se.crop_y < 0 ||
         se.crop_x + se.crop_w > se.width || se.crop_y + se.crop_h > se.height) throw std::runtime_error("film: invalid size / crop window");
-    se.rfilter = build_rfilter(s.rfilter_type, s.rfilter_radius, s.rfilter_stddev);
+    se.rfilter = build_rfilter(s.rfilter_type, s.rfilter_radius, s.rfilter_stddev, hs.rfilter_values);
     if (se.rfilter.radius > 16.f) throw std::runtime_error("reconstruction filter radius too large");
     if (s.sample_count <= 0) throw std::runtime_error("sampler: sample_count must be positive");
     se.sample_count = s.sample_count; se.seed = s.sampler_seed; se.medium = s.medium;
@@ -407,6 +408,7 @@ void upload_host_scene(HostScene &hs, int device) {
     sc.positions = upload(hs, hs.positions); sc.normals = upload(hs, hs.normals); sc.texcoords = upload(hs, hs.texcoords);
     sc.faces = upload(hs, hs.faces);
     sc.tri = upload(hs, hs.tri);
+    sc.sensor.rfilter.values = upload(hs, hs.rfilter_values);
     HIP_CHECK(hipDeviceSynchronize());
     hs.uploaded = true;
 }

@@ -25,6 +25,7 @@ struct HostScene {
     std::vector<float> positions, normals, texcoords;
     std::vector<uint32_t> faces;
     std::vector<float> tri;
+    std::vector<float> rfilter_values;
     std::vector<std::vector<float>> grid_data, tab_pdf, tab_cdf;
     std::vector<void *> device_allocs;
     int device = 0;

@@ -1,17 +1,18 @@
-// volpath_flat.h -- volpath (integrators/volpath.cpp:38-465) as ONE flat per-lane state machine.
+// volpath_flat.h -- volpath (integrators/volpath.cpp:38-465) as ONE flat state machine over explicit path state.
 //
 // Why: the reference nests three loops (main loop :72, NEE ratio tracking :282, direct-light walk :385).
 // Compiled as written, a wave serialises them: while a few lanes run an inner tracking loop to
-// completion the other lanes of the wave idle.  Here every lane carries (mode, state) and each trip of
-// the single loop below advances every lane by at most one delta-tracking step -- whichever of the
-// three reference loops that step belongs to -- so the expensive block (free-flight sample + grid
-// gathers) is executed by all lanes together.
+// completion the other lanes of the wave idle.  Here every path carries (mode, state); the work is cut
+// into small blocks (INTERSECT, MEDIUM step, SCATTER, walk SURFACE step, main SURFACE + BSDF, PHASE, NEW
+// sample) and a path advances by one block at a time -- whichever of the three reference loops that block
+// belongs to -- so the expensive block (free-flight sample + grid gathers) is shared by all of them.
 //
-// Wave-level scheduling: the lanes of a wave sit in different states, and running every block on every
-// trip would execute each block with a handful of active lanes (measured: 17 % VALU lane utilisation).
-// So each trip first runs the cheap loop-head dispatch, then takes a census of the states with
-// __ballot / __popcll and executes only the ONE heavy block most lanes are waiting for; the others wait
-// (their state is in registers, nothing is lost) until their block wins the vote.
+// Two drivers schedule the blocks:
+//   1. volpath_pixel_flat: one lane = one pixel, state in registers, per-wave census (__ballot/__popcll)
+//      and a vote for the block most lanes wait for (measured: ~40 % of the lanes served per block).
+//   2. volpath_workgroup: the hot state of the workgroup's paths lives in LDS as struct-of-arrays queues;
+//      every trip the paths are counting-sorted by the block they wait for, so a wave runs one block with
+//      (nearly) all lanes active, and each block is a separate function with its own small register budget.
 //
 // The random draws happen in exactly the order of the scalar_rgb variant (SURVEY.md 8(a')); results are
 // bit-identical to the nested formulation in integrator_dev.h and to the CPU restatement.
@@ -21,7 +22,7 @@
 
 namespace mtsamd {
 
-enum : uint32_t { S_TOP = 0, S_MED = 1, S_SURF = 2, S_PHASE = 3, S_BSDF = 4, S_DIRB = 5, S_NEW = 6, S_DONE = 7 };
+enum : uint32_t { S_TOP = 0, S_MED = 1, S_SURF = 2, S_PHASE = 3, S_BSDF = 4, S_DIRB = 5, S_NEW = 6, S_DONE = 7, S_SCATTER = 8 };
 enum : uint32_t { M_MAIN = 0, M_NEE = 1, M_DIR = 2 };
 enum : uint32_t { FL_ALIVE = 1, FL_VALID_RAY = 2, FL_SPEC_CHAIN = 4, FL_NEEDS_INT = 8, FL_FROM_MEDIUM = 16 };
 
@@ -202,8 +203,8 @@ struct ColdStore {
 struct PathEnv {
     DBlock blk; uint32_t lx, ly, sample_count; float *__restrict__ film; ColdStore cold;
 };
-// Scheduling classes: the heavy block a path is waiting for
-enum { B_INT = 0, B_MED, B_SURF, B_PHASE, B_NEW, B_DONE, B_COUNT };
+// Scheduling classes: the block a path is waiting for
+enum { B_INT = 0, B_MED, B_SCATTER, B_WSURF, B_SURF, B_PHASE, B_NEW, B_DONE, B_COUNT };
 
 template <bool COUNT>
 struct VolpathMachine {
@@ -286,259 +287,259 @@ struct VolpathMachine {
         }
     }
     DEV static bool wants_int(const PathState &p) { return (p.st == S_MED || p.st == S_SURF || p.st == S_DIRB) && (p.flags & FL_NEEDS_INT); }
-    // heavy block this path waits for (valid once top() has run)
+    // block this path waits for (valid once top() has run)
     DEV static int classify(const PathState &p) {
         if (p.st == S_DONE) return B_DONE;
         if (wants_int(p)) return B_INT;
         if (p.st == S_MED) return B_MED;
-        if (p.st == S_SURF || p.st == S_BSDF) return B_SURF;
+        if (p.st == S_SCATTER) return B_SCATTER;
+        if (p.st == S_SURF) return p.mode == M_MAIN ? B_SURF : B_WSURF;
+        if (p.st == S_BSDF) return B_SURF;
         if (p.st == S_PHASE) return B_PHASE;
         return B_NEW;
     }
 
-    // Run the blocks selected by `sel` for this lane (every lane of the wave calls this with the same `sel`;
-    // a lane whose state does not match simply falls through).  Several cheap follow-up steps run in the same call.
-    DEV void run(PathState &p, const PathEnv &e, int sel) const {
+    // ================================================================= NEW: finish a sample, start the next (integrator.cpp:265-288)
+    DEV void blk_new(PathState &p, const PathEnv &e) const {
+        if (p.st != S_NEW) return;
         const DSensor &se = sc.sensor;
+        F2 position_sample; position_sample.x = e.cold.f(C_POS); position_sample.y = e.cold.f(C_POS + 1);
+        float acc[5];                                          // summed in sample order like the block entry (imageblock.cpp:163-168)
+        for (int k = 0; k < 5; ++k) acc[k] = e.cold.f(C_ACC + k);
+        splat_sample_t<false>(sc, e.blk, e.lx, e.ly, position_sample, f3s(e.cold.f(C_RAYW)) * p.res, (p.flags & FL_VALID_RAY) != 0, e.film, acc);
+        if (++p.sample_idx == e.sample_count) {                // block -> film (hdrfilm.cpp:207-211)
+            float *own = e.film + 5 * ((size_t) (e.blk.oy + (int) e.ly - se.crop_y) * se.crop_w + (e.blk.ox + (int) e.lx - se.crop_x));
+            for (int k = 0; k < 5; ++k) atomicAdd(own + k, acc[k]);
+            p.st = S_DONE;
+        } else {
+            for (int k = 0; k < 5; ++k) e.cold.f(C_ACC + k) = acc[k];
+            begin_sample(p, e);
+        }
+    }
+    // ================================================================= INTERSECT (volpath.cpp:109,182,241,298,339,395,425)
+    DEV void blk_int(PathState &p, const PathEnv &e) const {
+        if (!wants_int(p)) return;
+        p.si = ray_intersect(sc, p.ray);
+        p.flags &= ~FL_NEEDS_INT;
+        start_direct(p, e);
+    }
+    DEV void start_direct(PathState &p, const PathEnv &e) const {      // volpath.cpp:239-245: the direct-light walk runs on a copy
+        if (p.st != S_DIRB || (p.flags & FL_NEEDS_INT)) return;
+        e.cold.put3(C_SO, p.ray.o); e.cold.put3(C_SD, p.ray.d); e.cold.put_hit(p.si);
+        p.trans = f3s(1.f);
+        p.mode = M_DIR; p.st = S_TOP;
+    }
+    // ================================================================= MEDIUM: one free-flight step of any of the three loops
+    DEV void blk_med(PathState &p, const PathEnv &e) const {
+        if (p.st != S_MED || (p.flags & FL_NEEDS_INT)) return;
         const uint32_t max_depth = (uint32_t) sc.integrator.max_depth;
-        const bool want_int = wants_int(p);
-        // ================================================================= NEW: finish a sample, start the next (integrator.cpp:265-288)
-        if (sel == B_NEW && p.st == S_NEW) {
-            F2 position_sample; position_sample.x = e.cold.f(C_POS); position_sample.y = e.cold.f(C_POS + 1);
-            float acc[5];                                      // summed in sample order like the block entry (imageblock.cpp:163-168)
-            for (int k = 0; k < 5; ++k) acc[k] = e.cold.f(C_ACC + k);
-            splat_sample_t<false>(sc, e.blk, e.lx, e.ly, position_sample, f3s(e.cold.f(C_RAYW)) * p.res, (p.flags & FL_VALID_RAY) != 0, e.film, acc);
-            if (++p.sample_idx == e.sample_count) {            // block -> film (hdrfilm.cpp:207-211)
-                float *own = e.film + 5 * ((size_t) (e.blk.oy + (int) e.ly - se.crop_y) * se.crop_w + (e.blk.ox + (int) e.lx - se.crop_x));
-                for (int k = 0; k < 5; ++k) atomicAdd(own + k, acc[k]);
-                p.st = S_DONE;
-            } else {
-                for (int k = 0; k < 5; ++k) e.cold.f(C_ACC + k) = acc[k];
-                begin_sample(p, e);
-            }
+        const float u = p.rng.next_1d();                       // volpath.cpp:105 / :294 / :391
+        MedStep mi;
+        WATERFALL_BEGIN(p.medium, mu)
+            mi = medium_step<COUNT>(sc, cload(sc.media + mu), p.ray, u, p.channel, p.mode == M_MAIN, cnt);
+        WATERFALL_END
+        if (p.si.t < mi.t) mi.t = pm_inf();                    // volpath.cpp:112 / :300 / :397
+        const bool spectral = (mi.info & MI_SPECTRAL) != 0, homogeneous = (mi.info & MI_HOMOGENEOUS) != 0, grey = (mi.info & MI_GREY) != 0;
+        const F3 sigma_n = homogeneous ? f3s(0.f) : mi.combined - mi.sigma_t;
+        const uint32_t channel = p.channel;
+        const bool is_main = p.mode == M_MAIN, is_nee = p.mode == M_NEE;
+        // transmittance / free-flight pdf of this step, one formula for the three loops:
+        // medium.cpp:77-89 (volpath.cpp:113-117, :401-405) and the NEE variant bounded by remaining_dist (:305-311)
+        const float remaining_dist = is_nee ? p.ray.maxt : pm_inf();
+        F3 weight = is_main ? p.thr : p.trans;
+        if (spectral) {
+            float t = pm_min(mi.t, p.si.t);
+            if (is_nee) t = pm_min(remaining_dist, t);
+            t = t - mi.mint;
+            F3 tr = transmittance_exp_g(t, mi.combined, grey);
+            F3 free_flight_pdf = (p.si.t < mi.t || mi.t > remaining_dist) ? tr : tr * mi.combined;
+            float tr_pdf = pick(free_flight_pdf, channel);
+            weight = weight * (tr_pdf > 0.f ? tr / tr_pdf : f3s(0.f));
         }
-        // ================================================================= INTERSECT (volpath.cpp:109,182,241,298,339,395,425)
-        if (sel == B_INT && want_int) {
-            p.si = ray_intersect(sc, p.ray);
-            p.flags &= ~FL_NEEDS_INT;
+        float u2 = 0.f;
+        if (is_main) u2 = p.rng.next_1d();                     // volpath.cpp:123 (drawn even when the medium was left)
+        if (is_nee) {                                          // volpath.cpp:313-315
+            if (mi.t > remaining_dist && mi.t != pm_inf()) p.wa = p.wb;
+            if (mi.t > remaining_dist) mi.t = pm_inf();
         }
-        if (p.st == S_DIRB && !(p.flags & FL_NEEDS_INT)) {     // volpath.cpp:239-245: start the direct-light walk on a copy
-            e.cold.put3(C_SO, p.ray.o); e.cold.put3(C_SD, p.ray.d); e.cold.put_hit(p.si);
-            p.trans = f3s(1.f);
-            p.mode = M_DIR; p.st = S_TOP;
+        const bool valid = mi.t != pm_inf();
+        if (!valid) {                                          // escaped_medium: surface part of this iteration
+            if (is_main) p.thr = weight; else p.trans = weight;
+            p.st = S_SURF;
+            return;
         }
-        // ================================================================= MEDIUM: one free-flight step
-        if (sel == B_MED && p.st == S_MED && !want_int) {
-            const float u = p.rng.next_1d();                   // volpath.cpp:105 / :294 / :391
-            MedStep mi;
-            WATERFALL_BEGIN(p.medium, mu)
-                mi = medium_step<COUNT>(sc, cload(sc.media + mu), p.ray, u, p.channel, p.mode == M_MAIN, cnt);
-            WATERFALL_END
-            if (p.si.t < mi.t) mi.t = pm_inf();                // volpath.cpp:112 / :300 / :397
-            const bool spectral = (mi.info & MI_SPECTRAL) != 0, homogeneous = (mi.info & MI_HOMOGENEOUS) != 0, grey = (mi.info & MI_GREY) != 0;
-            const F3 sigma_n = homogeneous ? f3s(0.f) : mi.combined - mi.sigma_t;
-            const bool valid = mi.t != pm_inf();
-            const uint32_t channel = p.channel;
-            if (p.mode == M_MAIN) {
-                if (spectral) {                                // medium.cpp:77-89, volpath.cpp:113-117
-                    float t = pm_min(mi.t, p.si.t) - mi.mint;
-                    F3 tr = transmittance_exp_g(t, mi.combined, grey);
-                    F3 free_flight_pdf = p.si.t < mi.t ? tr : tr * mi.combined;
-                    float tr_pdf = pick(free_flight_pdf, channel);
-                    p.thr = p.thr * (tr_pdf > 0.f ? tr / tr_pdf : f3s(0.f));
-                }
-                const float u2 = p.rng.next_1d();              // volpath.cpp:123 (drawn even when the medium was left)
-                if (!valid) p.st = S_SURF;                     // escaped_medium: surface part of this iteration
-                else {
-                    bool null_scatter = u2 >= pick(mi.sigma_t, channel) / pick(mi.combined, channel);
-                    if (null_scatter) {                        // volpath.cpp:128-131,140-144
-                        if (spectral) p.thr = p.thr * (sigma_n * pick(mi.combined, channel) / pick(sigma_n, channel));
-                        p.ray.o = mi.p; p.ray.mint = 0.f; p.si.t = p.si.t - mi.t;
-                        p.st = S_TOP;                          // stays alive
-                    } else {                                   // real scattering event, volpath.cpp:133-175
-                        p.depth += 1;
-                        if (!(p.depth < max_depth)) { p.flags &= ~FL_ALIVE; p.st = S_TOP; }
-                        else {
-                            if (spectral) p.thr = p.thr * (mi.sigma_s * pick(mi.combined, channel) / pick(mi.sigma_t, channel));
-                            else p.thr = p.thr * (mi.sigma_s / mi.sigma_t);
-                            const bool sample_emitters = (mi.info & MI_SAMPLE_EMITTERS) != 0;
-                            p.flags |= FL_VALID_RAY;
-                            p.flags = sample_emitters ? (p.flags & ~FL_SPEC_CHAIN) : (p.flags | FL_SPEC_CHAIN);
-                            p.ray.o = mi.p;                    // scattering position; ray.d stays the incident direction
-                            p.st = S_PHASE;
-                            if (sample_emitters) {             // volpath.cpp:162-167 -> sample_emitter :261-281
-                                F3 emitter_val;
-                                DirSample ds = sample_emitter_direction(sc, mi.p, p.rng.next_2d(), false, emitter_val);
-                                if (ds.pdf != 0.f) {
-                                    float phase_val = phase_eval(sc, (int) (mi.info >> MI_PHASE_SHIFT), -p.ray.d, mi.p, ds.d);
-                                    e.cold.put3(C_CW, p.thr * phase_val); e.cold.put3(C_EMIT, emitter_val);
-                                    e.cold.put3(C_SO, mi.p); e.cold.put3(C_SD, p.ray.d); e.cold.f(C_SMED) = __int_as_float(p.medium);
-                                    p.trans = f3s(1.f); p.wa = 0.f; p.wb = ds.dist;
-                                    p.ray = spawn_ray(mi.p, ds.d); p.ray.mint = 0.f;
-                                    queue_intersection(p);
-                                    p.flags |= FL_FROM_MEDIUM;
-                                    p.mode = M_NEE; p.st = S_TOP;
-                                }
-                            }
-                        }
-                    }
-                }
-            } else if (p.mode == M_NEE) {                      // volpath.cpp:303-334
-                const float remaining_dist = p.ray.maxt;
-                if (spectral) {
-                    float t = pm_min(remaining_dist, pm_min(mi.t, p.si.t)) - mi.mint;
-                    F3 tr = transmittance_exp_g(t, mi.combined, grey);
-                    F3 free_flight_pdf = (p.si.t < mi.t || mi.t > remaining_dist) ? tr : tr * mi.combined;
-                    float tr_pdf = pick(free_flight_pdf, channel);
-                    p.trans = p.trans * (tr_pdf > 0.f ? tr / tr_pdf : f3s(0.f));
-                }
-                if (mi.t > remaining_dist && mi.t != pm_inf()) p.wa = p.wb;
-                if (mi.t > remaining_dist) mi.t = pm_inf();
-                if (mi.t == pm_inf()) p.st = S_SURF;           // escaped_medium
-                else {
-                    p.wa += mi.t;
-                    p.ray.o = mi.p; p.ray.mint = 0.f; p.si.t = p.si.t - mi.t;
-                    if (spectral) p.trans = p.trans * sigma_n; else p.trans = p.trans * (sigma_n / mi.combined);
-                    if (any_nonzero(p.trans)) p.st = S_TOP; else end_nee(p, e);     // volpath.cpp:358
-                }
-            } else {                                           // direct-light walk, volpath.cpp:399-421
-                if (spectral) {
-                    float t = pm_min(mi.t, p.si.t) - mi.mint;
-                    F3 tr = transmittance_exp_g(t, mi.combined, grey);
-                    F3 free_flight_pdf = p.si.t < mi.t ? tr : tr * mi.combined;
-                    float tr_pdf = pick(free_flight_pdf, channel);
-                    p.trans = p.trans * (tr_pdf > 0.f ? tr / tr_pdf : f3s(0.f));
-                }
-                if (!valid) p.st = S_SURF;
-                else {
-                    p.ray.o = mi.p; p.ray.mint = 0.f; p.si.t = p.si.t - mi.t;
-                    if (spectral) p.trans = p.trans * sigma_n; else p.trans = p.trans * (sigma_n / mi.combined);
-                    if (any_nonzero(p.trans)) p.st = S_TOP; else end_direct(p, e, f3s(0.f), 0.f);   // volpath.cpp:456
-                }
-            }
-        }
-        // ================================================================= SURFACE step of a walk (cheap; runs in whatever call produced it)
-        if (p.st == S_SURF && p.mode != M_MAIN && !(p.flags & FL_NEEDS_INT) && (sel == B_INT || sel == B_MED || sel == B_SURF)) {
-            const bool hit = hit_valid(p.si);
-            if (p.mode == M_NEE) {                             // volpath.cpp:336-364
-                p.wa += p.si.t;
-                if (hit) {
-                    F3 nt = f3s(0.f), n = f3s(0.f); int is_tr = 0, ext = -1, inte = -1;
-                    WATERFALL_BEGIN(p.si.shape, su)
-                        const DShape s = cload(sc.shapes + su);
-                        nt = cload(sc.bsdfs + s.bsdf).type == MTS_BSDF_NULL ? f3s(1.f) : f3s(0.f);    // null.cpp:70-73, bsdf.cpp:11-14
-                        is_tr = s.is_medium_transition; ext = s.exterior; inte = s.interior;
-                        if (is_tr) n = hit_geo_normal(sc, s, p.si);
-                    WATERFALL_END
-                    p.trans = p.trans * nt;
-                    p.ray = spawn_ray(p.si.p, p.ray.d);
-                    queue_intersection(p);
-                    if (is_tr) p.medium = dot(p.ray.d, n) > 0 ? ext : inte;     // interaction.h:178-200
-                }
-                if (hit && any_nonzero(p.trans)) p.st = S_TOP; else end_nee(p, e);
-            } else {                                           // direct-light walk, volpath.cpp:423-462
-                int emitter = sc.environment;
-                Surf sf; sf.wi = -p.ray.d; sf.sh.n = f3s(0.f); sf.n = f3s(0.f);
-                F3 nt = f3s(0.f); int is_tr = 0, ext = -1, inte = -1;
-                if (hit) {
-                    WATERFALL_BEGIN(p.si.shape, su)
-                        const DShape s = cload(sc.shapes + su);
-                        emitter = s.emitter;
-                        nt = cload(sc.bsdfs + s.bsdf).type == MTS_BSDF_NULL ? f3s(1.f) : f3s(0.f);
-                        is_tr = s.is_medium_transition; ext = s.exterior; inte = s.interior;
-                        if (emitter >= 0 || is_tr) complete_surface(sc, s, p.si, p.ray.d, sf);
-                    WATERFALL_END
-                }
-                if (emitter >= 0) {                            // volpath.cpp:430-440
-                    const F3 ref_p = e.cold.get3(C_SO);
-                    DirSample ds;                              // render/records.h:168-174
-                    ds.p = p.si.p; ds.n = sf.sh.n; ds.d = p.si.p - ref_p; ds.dist = norm(ds.d); ds.d = ds.d / ds.dist;
-                    if (!hit) ds.d = -sf.wi;
-                    ds.emitter = emitter; ds.pdf = 0.f; ds.delta = false;
-                    end_direct(p, e, emitter_eval(sc, emitter, sf.wi.z), pdf_emitter_direction(sc, ref_p, ds));
-                } else {
-                    if (hit) {
-                        p.trans = p.trans * nt;
-                        p.ray = spawn_ray(p.si.p, p.ray.d);
-                        queue_intersection(p);
-                        if (is_tr) p.medium = dot(p.ray.d, sf.n) > 0 ? ext : inte;
-                    }
-                    if (hit && any_nonzero(p.trans)) p.st = S_TOP; else end_direct(p, e, f3s(0.f), 0.f);
-                }
-            }
-        }
-        // ================================================================= SURFACE interaction of the main path (volpath.cpp:184-212)
-        if (sel == B_SURF && p.st == S_SURF && p.mode == M_MAIN && !want_int) {
-            const bool hit = hit_valid(p.si);
-            Surf sf; sf.wi = -p.ray.d; sf.n = f3s(0.f); sf.sh.s = sf.sh.t = sf.sh.n = f3s(0.f);
-            int emitter = sc.environment, bsdf_id = 0;
-            if (hit) {
-                WATERFALL_BEGIN(p.si.shape, su)
-                    const DShape s = cload(sc.shapes + su);
-                    complete_surface(sc, s, p.si, p.ray.d, sf);
-                    emitter = s.emitter; bsdf_id = s.bsdf;
-                WATERFALL_END
-            }
-            if ((p.flags & FL_SPEC_CHAIN) && emitter >= 0) p.res = p.res + p.thr * emitter_eval(sc, emitter, sf.wi.z);
-            if (!hit) { p.flags &= ~FL_ALIVE; p.st = S_TOP; }
+        const bool real_scatter = is_main && !(u2 >= pick(mi.sigma_t, channel) / pick(mi.combined, channel));
+        if (!real_scatter) {
+            // null collision of the main path (volpath.cpp:128-131,140-144) or a step of a walk (:322-333, :411-420)
+            if (is_main) { if (spectral) weight = weight * (sigma_n * pick(mi.combined, channel) / pick(sigma_n, channel)); }
+            else { if (spectral) weight = weight * sigma_n; else weight = weight * (sigma_n / mi.combined); }
+            if (is_nee) p.wa += mi.t;
+            p.ray.o = mi.p; p.ray.mint = 0.f; p.si.t = p.si.t - mi.t;
+            p.st = S_TOP;
+            if (is_main) p.thr = weight;
             else {
-                p.st = S_BSDF;
-                const DBsdf &bsdf = sc.bsdfs[bsdf_id];
-                bool active_e = (bsdf.flags & F_Smooth) != 0 && (p.depth + 1 < max_depth);
-                if (active_e) {                                // volpath.cpp:200-212 -> sample_emitter :261-281
-                    F3 emitter_val;
-                    DirSample ds = sample_emitter_direction(sc, p.si.p, p.rng.next_2d(), false, emitter_val);
-                    if (ds.pdf != 0.f) {
-                        F3 wo = to_local(sf.sh, ds.d);
-                        F3 bsdf_val = bsdf_eval(bsdf, sf.wi, wo);
-                        float bpdf = bsdf_pdf(bsdf, sf.wi, wo);
-                        e.cold.put3(C_CW, p.thr * bsdf_val * mis_weight(ds.pdf, ds.delta ? 0.f : bpdf)); e.cold.put3(C_EMIT, emitter_val);
-                        e.cold.put_hit(p.si); e.cold.put3(C_SD, p.ray.d); e.cold.f(C_SMED) = __int_as_float(p.medium);
-                        p.trans = f3s(1.f); p.wa = 0.f; p.wb = ds.dist;
-                        p.ray = spawn_ray(p.si.p, ds.d);
-                        queue_intersection(p);
-                        p.flags &= ~FL_FROM_MEDIUM;
-                        p.mode = M_NEE; p.st = S_TOP;
-                    }
-                }
+                p.trans = weight;
+                if (!any_nonzero(weight)) { if (is_nee) end_nee(p, e); else end_direct(p, e, f3s(0.f), 0.f); }   // volpath.cpp:358 / :456
             }
+            return;
         }
-        // ================================================================= BSDF sampling (volpath.cpp:214-252)
-        if (sel == B_SURF && p.st == S_BSDF) {
-            Surf sf; int bsdf_id = 0, is_tr = 0, ext = -1, inte = -1;
+        // real scattering event of the main path, volpath.cpp:133-160
+        p.depth += 1;
+        if (!(p.depth < max_depth)) { p.thr = weight; p.flags &= ~FL_ALIVE; p.st = S_TOP; return; }
+        if (spectral) weight = weight * (mi.sigma_s * pick(mi.combined, channel) / pick(mi.sigma_t, channel));
+        else weight = weight * (mi.sigma_s / mi.sigma_t);
+        p.thr = weight;
+        const bool sample_emitters = (mi.info & MI_SAMPLE_EMITTERS) != 0;
+        p.flags |= FL_VALID_RAY;
+        p.flags = sample_emitters ? (p.flags & ~FL_SPEC_CHAIN) : (p.flags | FL_SPEC_CHAIN);
+        p.ray.o = mi.p;                                        // scattering position; ray.d stays the incident direction
+        p.st = sample_emitters ? S_SCATTER : S_PHASE;
+    }
+    // ================================================================= SCATTER: emitter sampling at a medium interaction
+    // (volpath.cpp:162-167 -> sample_emitter :261-281); the walk itself runs as M_NEE steps
+    DEV void blk_scatter(PathState &p, const PathEnv &e) const {
+        if (p.st != S_SCATTER) return;
+        p.st = S_PHASE;
+        F3 emitter_val;
+        DirSample ds = sample_emitter_direction(sc, p.ray.o, p.rng.next_2d(), false, emitter_val);
+        if (ds.pdf == 0.f) return;
+        int phase = 0;
+        WATERFALL_BEGIN(p.medium, mu)
+            phase = cload(sc.media + mu).phase;
+        WATERFALL_END
+        float phase_val = phase_eval(sc, phase, -p.ray.d, p.ray.o, ds.d);
+        e.cold.put3(C_CW, p.thr * phase_val); e.cold.put3(C_EMIT, emitter_val);
+        e.cold.put3(C_SO, p.ray.o); e.cold.put3(C_SD, p.ray.d); e.cold.f(C_SMED) = __int_as_float(p.medium);
+        p.trans = f3s(1.f); p.wa = 0.f; p.wb = ds.dist;
+        p.ray = spawn_ray(p.ray.o, ds.d); p.ray.mint = 0.f;
+        queue_intersection(p);
+        p.flags |= FL_FROM_MEDIUM;
+        p.mode = M_NEE; p.st = S_TOP;
+    }
+    // ================================================================= SURFACE step of a walk (volpath.cpp:336-364, :423-462)
+    DEV void blk_wsurf(PathState &p, const PathEnv &e) const {
+        if (p.st != S_SURF || p.mode == M_MAIN || (p.flags & FL_NEEDS_INT)) return;
+        const bool hit = hit_valid(p.si);
+        const bool is_nee = p.mode == M_NEE;
+        if (is_nee) p.wa += p.si.t;
+        int emitter = is_nee ? -1 : sc.environment;
+        Surf sf; sf.wi = -p.ray.d; sf.sh.n = f3s(0.f); sf.n = f3s(0.f);
+        F3 nt = f3s(0.f); int is_tr = 0, ext = -1, inte = -1;
+        if (hit) {
+            WATERFALL_BEGIN(p.si.shape, su)
+                const DShape s = cload(sc.shapes + su);
+                if (!is_nee) emitter = s.emitter;
+                nt = cload(sc.bsdfs + s.bsdf).type == MTS_BSDF_NULL ? f3s(1.f) : f3s(0.f);    // null.cpp:70-73, bsdf.cpp:11-14
+                is_tr = s.is_medium_transition; ext = s.exterior; inte = s.interior;
+                if (emitter >= 0) complete_surface(sc, s, p.si, p.ray.d, sf);
+                else if (is_tr) sf.n = hit_geo_normal(sc, s, p.si);
+            WATERFALL_END
+        }
+        if (emitter >= 0) {                                    // direct-light walk reached an emitter, volpath.cpp:430-440
+            const F3 ref_p = e.cold.get3(C_SO);
+            DirSample ds;                                      // render/records.h:168-174
+            ds.p = p.si.p; ds.n = sf.sh.n; ds.d = p.si.p - ref_p; ds.dist = norm(ds.d); ds.d = ds.d / ds.dist;
+            if (!hit) ds.d = -sf.wi;
+            ds.emitter = emitter; ds.pdf = 0.f; ds.delta = false;
+            end_direct(p, e, emitter_eval(sc, emitter, sf.wi.z), pdf_emitter_direction(sc, ref_p, ds));
+            return;
+        }
+        if (hit) {
+            p.trans = p.trans * nt;
+            p.ray = spawn_ray(p.si.p, p.ray.d);
+            queue_intersection(p);
+            if (is_tr) p.medium = dot(p.ray.d, sf.n) > 0 ? ext : inte;         // interaction.h:178-200
+        }
+        if (hit && any_nonzero(p.trans)) p.st = S_TOP;
+        else if (is_nee) end_nee(p, e);
+        else end_direct(p, e, f3s(0.f), 0.f);
+    }
+    // ================================================================= SURFACE interaction of the main path (volpath.cpp:184-212)
+    DEV void blk_surf(PathState &p, const PathEnv &e) const {
+        if (p.st != S_SURF || p.mode != M_MAIN || (p.flags & FL_NEEDS_INT)) return;
+        const uint32_t max_depth = (uint32_t) sc.integrator.max_depth;
+        const bool hit = hit_valid(p.si);
+        Surf sf; sf.wi = -p.ray.d; sf.n = f3s(0.f); sf.sh.s = sf.sh.t = sf.sh.n = f3s(0.f);
+        int emitter = sc.environment, bsdf_id = 0;
+        if (hit) {
             WATERFALL_BEGIN(p.si.shape, su)
                 const DShape s = cload(sc.shapes + su);
                 complete_surface(sc, s, p.si, p.ray.d, sf);
-                bsdf_id = s.bsdf; is_tr = s.is_medium_transition; ext = s.exterior; inte = s.interior;
+                emitter = s.emitter; bsdf_id = s.bsdf;
             WATERFALL_END
-            const float s1 = p.rng.next_1d(); const F2 s2 = p.rng.next_2d(); (void) s1;
-            BSDFSample bs;
-            F3 bsdf_val = bsdf_sample(sc.bsdfs[bsdf_id], sf.wi, s2, bs);
-            p.thr = p.thr * bsdf_val;
-            p.eta *= bs.eta;
-            p.ray = spawn_ray(p.si.p, to_world(sf.sh, bs.wo));
-            p.flags |= FL_ALIVE;
-            const bool non_null_bsdf = !(bs.sampled_type & F_Null);
-            if (non_null_bsdf) { p.depth += 1; p.flags |= FL_VALID_RAY; }
-            if (non_null_bsdf && (bs.sampled_type & F_Delta)) p.flags |= FL_SPEC_CHAIN;
-            if (bs.sampled_type & F_Smooth) p.flags &= ~FL_SPEC_CHAIN;
-            const bool add_emitter = !(bs.sampled_type & F_Delta) && any_nonzero(p.thr) && (p.depth < max_depth);
-            const int new_medium = is_tr ? (dot(p.ray.d, sf.n) > 0 ? ext : inte) : p.medium;     // volpath.cpp:249-250
-            queue_intersection(p);
-            if (add_emitter) { e.cold.f(C_SMED) = __int_as_float(new_medium); p.wb = bs.pdf; p.st = S_DIRB; }   // the walk runs in the old medium
-            else { p.medium = new_medium; p.st = S_TOP; }
         }
-        // ================================================================= PHASE sampling (volpath.cpp:169-175)
-        if (p.st == S_PHASE && (sel == B_INT || sel == B_MED || sel == B_PHASE)) {
-            const float s1 = p.rng.next_1d(); const F2 s2 = p.rng.next_2d();      // left-to-right (SURVEY.md 8(a'))
-            F3 wo;
-            WATERFALL_BEGIN(p.medium, mu)
-                wo = phase_sample(sc, cload(sc.media + mu).phase, make_frame(p.ray.d), p.ray.o, s1, s2);   // mi.sh_frame = Frame3f(ray.d), medium.cpp:42
-            WATERFALL_END
-            p.ray = spawn_ray(p.ray.o, wo); p.ray.mint = 0.0f;
-            queue_intersection(p);
-            p.flags |= FL_ALIVE;
-            p.st = S_TOP;
+        if ((p.flags & FL_SPEC_CHAIN) && emitter >= 0) p.res = p.res + p.thr * emitter_eval(sc, emitter, sf.wi.z);
+        if (!hit) { p.flags &= ~FL_ALIVE; p.st = S_TOP; return; }
+        p.st = S_BSDF;
+        const DBsdf &bsdf = sc.bsdfs[bsdf_id];
+        bool active_e = (bsdf.flags & F_Smooth) != 0 && (p.depth + 1 < max_depth);
+        if (!active_e) return;
+        F3 emitter_val;                                        // volpath.cpp:200-212 -> sample_emitter :261-281
+        DirSample ds = sample_emitter_direction(sc, p.si.p, p.rng.next_2d(), false, emitter_val);
+        if (ds.pdf == 0.f) return;
+        F3 wo = to_local(sf.sh, ds.d);
+        F3 bsdf_val = bsdf_eval(bsdf, sf.wi, wo);
+        float bpdf = bsdf_pdf(bsdf, sf.wi, wo);
+        e.cold.put3(C_CW, p.thr * bsdf_val * mis_weight(ds.pdf, ds.delta ? 0.f : bpdf)); e.cold.put3(C_EMIT, emitter_val);
+        e.cold.put_hit(p.si); e.cold.put3(C_SD, p.ray.d); e.cold.f(C_SMED) = __int_as_float(p.medium);
+        p.trans = f3s(1.f); p.wa = 0.f; p.wb = ds.dist;
+        p.ray = spawn_ray(p.si.p, ds.d);
+        queue_intersection(p);
+        p.flags &= ~FL_FROM_MEDIUM;
+        p.mode = M_NEE; p.st = S_TOP;
+    }
+    // ================================================================= BSDF sampling (volpath.cpp:214-252)
+    DEV void blk_bsdf(PathState &p, const PathEnv &e) const {
+        if (p.st != S_BSDF) return;
+        const uint32_t max_depth = (uint32_t) sc.integrator.max_depth;
+        Surf sf; int bsdf_id = 0, is_tr = 0, ext = -1, inte = -1;
+        WATERFALL_BEGIN(p.si.shape, su)
+            const DShape s = cload(sc.shapes + su);
+            complete_surface(sc, s, p.si, p.ray.d, sf);
+            bsdf_id = s.bsdf; is_tr = s.is_medium_transition; ext = s.exterior; inte = s.interior;
+        WATERFALL_END
+        const float s1 = p.rng.next_1d(); const F2 s2 = p.rng.next_2d(); (void) s1;
+        BSDFSample bs;
+        F3 bsdf_val = bsdf_sample(sc.bsdfs[bsdf_id], sf.wi, s2, bs);
+        p.thr = p.thr * bsdf_val;
+        p.eta *= bs.eta;
+        p.ray = spawn_ray(p.si.p, to_world(sf.sh, bs.wo));
+        p.flags |= FL_ALIVE;
+        const bool non_null_bsdf = !(bs.sampled_type & F_Null);
+        if (non_null_bsdf) { p.depth += 1; p.flags |= FL_VALID_RAY; }
+        if (non_null_bsdf && (bs.sampled_type & F_Delta)) p.flags |= FL_SPEC_CHAIN;
+        if (bs.sampled_type & F_Smooth) p.flags &= ~FL_SPEC_CHAIN;
+        const bool add_emitter = !(bs.sampled_type & F_Delta) && any_nonzero(p.thr) && (p.depth < max_depth);
+        const int new_medium = is_tr ? (dot(p.ray.d, sf.n) > 0 ? ext : inte) : p.medium;     // volpath.cpp:249-250
+        queue_intersection(p);
+        if (add_emitter) { e.cold.f(C_SMED) = __int_as_float(new_medium); p.wb = bs.pdf; p.st = S_DIRB; start_direct(p, e); }   // the walk runs in the old medium
+        else { p.medium = new_medium; p.st = S_TOP; }
+    }
+    // ================================================================= PHASE sampling (volpath.cpp:169-175)
+    DEV void blk_phase(PathState &p, const PathEnv &e) const {
+        if (p.st != S_PHASE) return;
+        const float s1 = p.rng.next_1d(); const F2 s2 = p.rng.next_2d();      // left-to-right (SURVEY.md 8(a'))
+        F3 wo;
+        WATERFALL_BEGIN(p.medium, mu)
+            wo = phase_sample(sc, cload(sc.media + mu).phase, make_frame(p.ray.d), p.ray.o, s1, s2);   // mi.sh_frame = Frame3f(ray.d), medium.cpp:42
+        WATERFALL_END
+        p.ray = spawn_ray(p.ray.o, wo); p.ray.mint = 0.0f;
+        queue_intersection(p);
+        p.flags |= FL_ALIVE;
+        p.st = S_TOP;
+    }
+
+    // Run the block(s) of class `sel` for this lane (a lane whose state does not match falls through)
+    DEV void run(PathState &p, const PathEnv &e, int sel) const {
+        switch (sel) {
+            case B_NEW: blk_new(p, e); break;
+            case B_INT: blk_int(p, e); break;
+            case B_MED: blk_med(p, e); break;
+            case B_SCATTER: blk_scatter(p, e); break;
+            case B_WSURF: blk_wsurf(p, e); break;
+            case B_SURF: blk_surf(p, e); blk_bsdf(p, e); break;
+            case B_PHASE: blk_phase(p, e); break;
+            default: break;
         }
     }
 };
@@ -559,10 +560,10 @@ DEV void volpath_pixel_flat(const DScene &sc, Pcg32 &rng, const DBlock &blk, uin
 #endif
     while (__ballot(p.st != S_DONE)) {
 #if defined(MTSAMD_BLOCKSTATS)
-        if (COUNT) { long long t = clock64(); bs_loc[16 + bs_prev_sel] += (unsigned long long) (t - bs_t0); bs_t0 = t; bs_prev_sel = 6; }
+        if (COUNT) { long long t = clock64(); bs_loc[16 + bs_prev_sel] += (unsigned long long) (t - bs_t0); bs_t0 = t; bs_prev_sel = 7; }
 #endif
         vm.top(p, e);
-        // census + vote: run the ONE heavy block most lanes of this wave are waiting for
+        // census + vote: run the ONE block most lanes of this wave are waiting for
         const int cls = vm.classify(p);
         int sel = B_MED, best = -1;
         for (int b = 0; b < B_DONE; ++b) { int v = __popcll(__ballot(cls == b)); if (v > best) { best = v; sel = b; } }
@@ -570,7 +571,7 @@ DEV void volpath_pixel_flat(const DScene &sc, Pcg32 &rng, const DBlock &blk, uin
 #if defined(MTSAMD_BLOCKSTATS)
         if (COUNT) {
             bs_loc[2 * sel] += 1ull; bs_loc[2 * sel + 1] += (unsigned long long) best;
-            long long t = clock64(); bs_loc[16 + 6] += (unsigned long long) (t - bs_t0); bs_t0 = t; bs_prev_sel = sel;
+            long long t = clock64(); bs_loc[16 + 7] += (unsigned long long) (t - bs_t0); bs_t0 = t; bs_prev_sel = sel;
         }
 #endif
         vm.run(p, e, sel);
@@ -581,13 +582,13 @@ DEV void volpath_pixel_flat(const DScene &sc, Pcg32 &rng, const DBlock &blk, uin
 #endif
 }
 
-
 // ---------------------------------------------------------------------------------------------------------
 // Driver 2: workgroup-level regrouping.  A workgroup of WG threads owns WG paths (pixels) whose hot state
 // lives in LDS as struct-of-arrays "queues"; cold state lives in HBM.  Every trip the workgroup counting-sorts
-// its paths by the heavy block they wait for (__ballot / __popcll per wave + a tiny LDS histogram), thread t
-// then processes the t-th path of the sorted order.  A wave therefore sees (almost) a single class and runs
-// that block with all 64 lanes active, instead of the ~40 % a per-wave vote can reach (measured).
+// its paths by the block they wait for (__ballot / __popcll per wave + a tiny LDS histogram), thread t then
+// processes the t-th path of the sorted order, so a wave sees (almost) a single class and runs that block
+// with all 64 lanes active.  Every block is its own function: load the path from LDS, run, store -- nothing
+// stays live across blocks, which keeps the register budget at 128 VGPRs (4 waves / SIMD).
 enum { H_RNG = 0, H_O = 2, H_D = 5, H_MINT = 8, H_MAXT = 9, H_SI = 10, H_MEDIUM = 18, H_THR = 19, H_RES = 22, H_ETA = 25,
        H_DEPTH = 26, H_PACKED = 27, H_SAMPLE = 28, H_TRANS = 29, H_WA = 32, H_WB = 33, H_COUNT = 34 };
 
@@ -600,9 +601,9 @@ struct HotStore {
     DEV void put3(int k, F3 v) const { putf(k, v.x); putf(k + 1, v.y); putf(k + 2, v.z); }
     DEV F3 get3(int k) const { return f3(f(k), f(k + 1), f(k + 2)); }
     DEV static uint32_t pack(const PathState &p, int cls) {
-        return p.st | (p.mode << 3) | (p.channel << 5) | (p.flags << 7) | ((uint32_t) cls << 12);
+        return p.st | (p.mode << 4) | (p.channel << 6) | (p.flags << 8) | ((uint32_t) cls << 13);
     }
-    DEV static int cls_of(uint32_t packed) { return (int) (packed >> 12) & 7; }
+    DEV static int cls_of(uint32_t packed) { return (int) (packed >> 13) & 7; }
     DEV void store(const PathState &p, int cls) const {
         u(H_RNG) = (uint32_t) p.rng.state; u(H_RNG + 1) = (uint32_t) (p.rng.state >> 32);
         put3(H_O, p.ray.o); put3(H_D, p.ray.d); putf(H_MINT, p.ray.mint); putf(H_MAXT, p.ray.maxt);
@@ -620,44 +621,79 @@ struct HotStore {
         p.medium = (int) u(H_MEDIUM); p.thr = get3(H_THR); p.res = get3(H_RES); p.eta = f(H_ETA);
         p.depth = u(H_DEPTH); p.sample_idx = u(H_SAMPLE);
         const uint32_t pk = u(H_PACKED);
-        p.st = pk & 7u; p.mode = (pk >> 3) & 3u; p.channel = (pk >> 5) & 3u; p.flags = (pk >> 7) & 31u;
+        p.st = pk & 15u; p.mode = (pk >> 4) & 3u; p.channel = (pk >> 6) & 3u; p.flags = (pk >> 8) & 31u;
         p.trans = get3(H_TRANS); p.wa = f(H_WA); p.wb = f(H_WB);
     }
 };
 
+#ifndef WG_ROUNDS
+#define WG_ROUNDS 6          // block executions of a wave between two re-sorts of the workgroup
+#endif
+#ifndef WG_MIN_LANES
+#define WG_MIN_LANES 28      // ... as long as the winning class still has this many lanes
+#endif
+
+// kernel arguments of render_kernel_wg, re-read by the block functions through the constant address space
+struct WgArgs {
+    DScene sc; const DBlock *blocks; uint32_t n_blocks, block_size, sample_count; float *film; float *cold_g; uint32_t cold_stride;
+    unsigned long long *counters;
+};
+
+template <int WG>
+DEV bool wg_env(const WgArgs &a, uint32_t wg_base, uint32_t pid, PathEnv &e) {     // pixel owned by path `pid`; false: outside the block
+    const uint32_t ppb = a.block_size * a.block_size;
+    const uint32_t gid = wg_base + pid;
+    const uint32_t b = gid / ppb, i = gid - b * ppb;
+    e.sample_count = a.sample_count; e.film = a.film;
+    e.cold.base = a.cold_g + gid; e.cold.stride = a.cold_stride;
+    e.lx = e.ly = 0;
+    if (b >= a.n_blocks) return false;
+    e.blk = cload(a.blocks + b);
+    e.lx = compact_bits(i); e.ly = compact_bits(i >> 1);      // morton_decode, integrator.cpp:200
+    return e.lx < (uint32_t) e.blk.sx && e.ly < (uint32_t) e.blk.sy;
+}
+
+// One block of class C for the path `pid`: load, run (repeat while the path stays in class C and enough lanes do), store.
+template <bool COUNT, int WG, int C>
+__device__ __noinline__ void wg_block(const MTS_CONST_AS void *kernarg_, uint32_t *hot_lds, uint32_t wg_base_, uint32_t pid, Counters *cnt) {
+    // arguments of a non-kernel function arrive in VGPRs; tell the compiler which ones are wave-uniform
+    const uint64_t ka = (uint64_t) (uintptr_t) kernarg_;
+    const MTS_CONST_AS void *kernarg = (const MTS_CONST_AS void *) (uintptr_t)
+        ((uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) ka) | ((uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (ka >> 32)) << 32));
+    const uint32_t wg_base = (uint32_t) __builtin_amdgcn_readfirstlane((int) wg_base_);
+    const WgArgs a = cload_k<WgArgs>(kernarg);
+    VolpathMachine<COUNT> vm(a.sc, *cnt);
+    PathEnv e; wg_env<WG>(a, wg_base, pid, e);
+    HotStore<WG> hs; hs.base = hot_lds + pid;
+    PathState p;
+    hs.load(p);
+    vm.run(p, e, C);
+    vm.top(p, e);
+    hs.store(p, vm.classify(p));
+}
+
 template <bool COUNT, int WG>
-DEV void volpath_workgroup(const DScene &sc, const DBlock *__restrict__ blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,
-                           float *__restrict__ film, float *__restrict__ cold_g, uint32_t cold_stride, Counters &cnt) {
+DEV void volpath_workgroup(const MTS_CONST_AS void *kernarg, Counters &cnt) {
     constexpr int NW = WG / 64;
     __shared__ uint32_t hot_lds[H_COUNT * WG];
     __shared__ uint32_t s_cnt[NW][8];
     __shared__ uint16_t s_perm[WG];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t ppb = block_size * block_size;
     const uint32_t wg_base = blockIdx.x * WG;                // first global path id of this workgroup
-    VolpathMachine<COUNT> vm(sc, cnt);
-
-    auto env_of = [&](uint32_t pid, PathEnv &e) -> bool {   // pixel owned by path `pid`; false: outside the block / film
-        const uint32_t gid = wg_base + pid;
-        const uint32_t b = gid / ppb, i = gid - b * ppb;
-        e.sample_count = sample_count; e.film = film;
-        e.cold.base = cold_g + gid; e.cold.stride = cold_stride;
-        if (b >= n_blocks) return false;
-        e.blk = blocks[b];
-        e.lx = compact_bits(i); e.ly = compact_bits(i >> 1);  // morton_decode, integrator.cpp:200
-        return e.lx < (uint32_t) e.blk.sx && e.ly < (uint32_t) e.blk.sy;
-    };
     {   // ---- initialise the path this thread starts with (integrator.cpp:198)
+        const WgArgs a = cload_k<WgArgs>(kernarg);
+        VolpathMachine<COUNT> vm(a.sc, cnt);
         PathEnv e; PathState p;
         HotStore<WG> hs; hs.base = hot_lds + tid;
-        const bool ok = env_of(tid, e);
+        const bool ok = wg_env<WG>(a, wg_base, tid, e);
         p.rng.state = 0; p.rng.inc = 0; p.sample_idx = 0;
         p.ray = make_ray(f3s(0.f), f3(0.f, 0.f, 1.f), 0.f, 0.f); p.si.t = pm_inf(); p.si.p = f3s(0.f); p.si.uv.x = p.si.uv.y = 0.f; p.si.shape = -1; p.si.prim = 0;
         p.medium = -1; p.thr = p.res = p.trans = f3s(0.f); p.eta = 1.f; p.depth = 0; p.channel = 0; p.mode = M_MAIN; p.flags = 0; p.wa = p.wb = 0.f;
         p.st = S_DONE;
         if (ok) {
+            const uint32_t ppb = a.block_size * a.block_size;
             const uint32_t gid = wg_base + tid, b = gid / ppb, i = gid - b * ppb;
-            p.rng.seed(sc.sensor.seed + (uint64_t) e.blk.id * ppb + i, PCG32_DEFAULT_STREAM);     // sampler.cpp:83-96
+            p.rng.seed(a.sc.sensor.seed + (uint64_t) e.blk.id * ppb + i, PCG32_DEFAULT_STREAM);     // sampler.cpp:83-96
             for (int k = 0; k < 5; ++k) e.cold.f(C_ACC + k) = 0.f;
             vm.begin_sample(p, e);
             vm.top(p, e);
@@ -688,21 +724,27 @@ DEV void volpath_workgroup(const DScene &sc, const DBlock *__restrict__ blocks, 
         const uint32_t rank = (uint32_t) __popcll(my_mask & ((1ull << lane) - 1ull));
         s_perm[base + rank] = (uint16_t) tid;
         __syncthreads();
-        // ---- process the path at this thread's position of the sorted order
+        // ---- process the path at this thread's position of the sorted order: right after the sort a wave holds
+        // (almost) one class; it then keeps going for a few rounds on a per-wave vote before the next re-sort,
+        // which amortises the workgroup barriers
         const uint32_t pid = s_perm[tid];
-        HotStore<WG> hs; hs.base = hot_lds + pid;
-        int cls = HotStore<WG>::cls_of(hs.u(H_PACKED));
-        if (cls != B_DONE) {
-            PathEnv e; PathState p;
-            env_of(pid, e);
-            hs.load(p);
 #pragma unroll 1
-            for (int c = 0; c < B_DONE; ++c) {
-                if (__ballot(vm.classify(p) == c) == 0) continue;         // nobody in this wave waits for block c
-                vm.run(p, e, c);
-                vm.top(p, e);
+        for (int round = 0; round < WG_ROUNDS; ++round) {
+            const int cls = HotStore<WG>::cls_of(hot_lds[H_PACKED * WG + pid]);
+            int sel = -1, best = 0;
+            for (int c = 0; c < B_DONE; ++c) { int v = __popcll(__ballot(cls == c)); if (v > best) { best = v; sel = c; } }
+            if (best == 0 || (round > 0 && best < WG_MIN_LANES)) break;
+            if (cls == sel) {
+                switch (sel) {
+                    case B_INT: wg_block<COUNT, WG, B_INT>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                    case B_MED: wg_block<COUNT, WG, B_MED>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                    case B_SCATTER: wg_block<COUNT, WG, B_SCATTER>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                    case B_WSURF: wg_block<COUNT, WG, B_WSURF>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                    case B_SURF: wg_block<COUNT, WG, B_SURF>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                    case B_PHASE: wg_block<COUNT, WG, B_PHASE>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                    default: wg_block<COUNT, WG, B_NEW>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                }
             }
-            hs.store(p, vm.classify(p));
         }
     }
 }
