@@ -351,10 +351,17 @@ struct VolpathMachine {
             float t = pm_min(mi.t, p.si.t);
             if (is_nee) t = pm_min(remaining_dist, t);
             t = t - mi.mint;
-            F3 tr = transmittance_exp_g(t, mi.combined, grey);
-            F3 free_flight_pdf = (p.si.t < mi.t || mi.t > remaining_dist) ? tr : tr * mi.combined;
-            float tr_pdf = pick(free_flight_pdf, channel);
-            weight = weight * (tr_pdf > 0.f ? tr / tr_pdf : f3s(0.f));
+            const bool surface_first = p.si.t < mi.t || mi.t > remaining_dist;
+            if (grey) {                                        // every channel carries the same value: one exp, one division
+                float tr = pm_exp(-t * mi.combined.x);
+                float tr_pdf = surface_first ? tr : tr * mi.combined.x;
+                weight = weight * (tr_pdf > 0.f ? tr / tr_pdf : 0.f);
+            } else {
+                F3 tr = transmittance_exp(t, mi.combined);
+                F3 free_flight_pdf = surface_first ? tr : tr * mi.combined;
+                float tr_pdf = pick(free_flight_pdf, channel);
+                weight = weight * (tr_pdf > 0.f ? tr / tr_pdf : f3s(0.f));
+            }
         }
         float u2 = 0.f;
         if (is_main) u2 = p.rng.next_1d();                     // volpath.cpp:123 (drawn even when the medium was left)
@@ -368,11 +375,16 @@ struct VolpathMachine {
             p.st = S_SURF;
             return;
         }
-        const bool real_scatter = is_main && !(u2 >= pick(mi.sigma_t, channel) / pick(mi.combined, channel));
+        const bool real_scatter = is_main && !(u2 >= (grey ? mi.sigma_t.x / mi.combined.x : pick(mi.sigma_t, channel) / pick(mi.combined, channel)));
         if (!real_scatter) {
             // null collision of the main path (volpath.cpp:128-131,140-144) or a step of a walk (:322-333, :411-420)
-            if (is_main) { if (spectral) weight = weight * (sigma_n * pick(mi.combined, channel) / pick(sigma_n, channel)); }
-            else { if (spectral) weight = weight * sigma_n; else weight = weight * (sigma_n / mi.combined); }
+            if (grey) {
+                if (is_main) { if (spectral) weight = weight * (sigma_n.x * mi.combined.x / sigma_n.x); }
+                else { if (spectral) weight = weight * sigma_n.x; else weight = weight * (sigma_n.x / mi.combined.x); }
+            } else {
+                if (is_main) { if (spectral) weight = weight * (sigma_n * pick(mi.combined, channel) / pick(sigma_n, channel)); }
+                else { if (spectral) weight = weight * sigma_n; else weight = weight * (sigma_n / mi.combined); }
+            }
             if (is_nee) p.wa += mi.t;
             p.ray.o = mi.p; p.ray.mint = 0.f; p.si.t = p.si.t - mi.t;
             p.st = S_TOP;
@@ -386,8 +398,13 @@ struct VolpathMachine {
         // real scattering event of the main path, volpath.cpp:133-160
         p.depth += 1;
         if (!(p.depth < max_depth)) { p.thr = weight; p.flags &= ~FL_ALIVE; p.st = S_TOP; return; }
-        if (spectral) weight = weight * (mi.sigma_s * pick(mi.combined, channel) / pick(mi.sigma_t, channel));
-        else weight = weight * (mi.sigma_s / mi.sigma_t);
+        if (grey) {
+            if (spectral) weight = weight * (mi.sigma_s.x * mi.combined.x / mi.sigma_t.x);
+            else weight = weight * (mi.sigma_s.x / mi.sigma_t.x);
+        } else {
+            if (spectral) weight = weight * (mi.sigma_s * pick(mi.combined, channel) / pick(mi.sigma_t, channel));
+            else weight = weight * (mi.sigma_s / mi.sigma_t);
+        }
         p.thr = weight;
         const bool sample_emitters = (mi.info & MI_SAMPLE_EMITTERS) != 0;
         p.flags |= FL_VALID_RAY;
@@ -590,7 +607,7 @@ DEV void volpath_pixel_flat(const DScene &sc, Pcg32 &rng, const DBlock &blk, uin
 // with all 64 lanes active.  Every block is its own function: load the path from LDS, run, store -- nothing
 // stays live across blocks, which keeps the register budget at 128 VGPRs (4 waves / SIMD).
 enum { H_RNG = 0, H_O = 2, H_D = 5, H_MINT = 8, H_MAXT = 9, H_SI = 10, H_MEDIUM = 18, H_THR = 19, H_RES = 22, H_ETA = 25,
-       H_DEPTH = 26, H_PACKED = 27, H_SAMPLE = 28, H_TRANS = 29, H_WA = 32, H_WB = 33, H_COUNT = 34 };
+       H_DEPTH = 26, H_PACKED = 27, H_SAMPLE = 28, H_TRANS = 29, H_WA = 32, H_WB = 33, H_DRCP = 34, H_COUNT = 37 };
 
 template <int WG>
 struct HotStore {
@@ -606,7 +623,7 @@ struct HotStore {
     DEV static int cls_of(uint32_t packed) { return (int) (packed >> 13) & 7; }
     DEV void store(const PathState &p, int cls) const {
         u(H_RNG) = (uint32_t) p.rng.state; u(H_RNG + 1) = (uint32_t) (p.rng.state >> 32);
-        put3(H_O, p.ray.o); put3(H_D, p.ray.d); putf(H_MINT, p.ray.mint); putf(H_MAXT, p.ray.maxt);
+        put3(H_O, p.ray.o); put3(H_D, p.ray.d); put3(H_DRCP, p.ray.d_rcp); putf(H_MINT, p.ray.mint); putf(H_MAXT, p.ray.maxt);
         putf(H_SI, p.si.t); put3(H_SI + 1, p.si.p); putf(H_SI + 4, p.si.uv.x); putf(H_SI + 5, p.si.uv.y);
         u(H_SI + 6) = (uint32_t) p.si.shape; u(H_SI + 7) = (uint32_t) p.si.prim;
         u(H_MEDIUM) = (uint32_t) p.medium; put3(H_THR, p.thr); put3(H_RES, p.res); putf(H_ETA, p.eta);
@@ -615,7 +632,7 @@ struct HotStore {
     }
     DEV void load(PathState &p) const {
         p.rng.state = (uint64_t) u(H_RNG) | ((uint64_t) u(H_RNG + 1) << 32); p.rng.inc = (PCG32_DEFAULT_STREAM << 1u) | 1u;
-        p.ray.o = get3(H_O); p.ray.d = get3(H_D); p.ray.d_rcp = vrcp(p.ray.d); p.ray.mint = f(H_MINT); p.ray.maxt = f(H_MAXT);
+        p.ray.o = get3(H_O); p.ray.d = get3(H_D); p.ray.d_rcp = get3(H_DRCP); p.ray.mint = f(H_MINT); p.ray.maxt = f(H_MAXT);
         p.si.t = f(H_SI); p.si.p = get3(H_SI + 1); p.si.uv.x = f(H_SI + 4); p.si.uv.y = f(H_SI + 5);
         p.si.shape = (int) u(H_SI + 6); p.si.prim = (int) u(H_SI + 7);
         p.medium = (int) u(H_MEDIUM); p.thr = get3(H_THR); p.res = get3(H_RES); p.eta = f(H_ETA);
@@ -641,11 +658,11 @@ struct WgArgs {
 
 template <int WG>
 DEV bool wg_env(const WgArgs &a, uint32_t wg_base, uint32_t pid, PathEnv &e) {     // pixel owned by path `pid`; false: outside the block
-    const uint32_t ppb = a.block_size * a.block_size;
-    const uint32_t gid = wg_base + pid;
-    const uint32_t b = gid / ppb, i = gid - b * ppb;
+    const uint32_t ppb = a.block_size * a.block_size;       // a multiple of WG (checked by the launcher): the workgroup sits in ONE block
+    const uint32_t b = wg_base / ppb;                        // uniform
+    const uint32_t i = (wg_base - b * ppb) + pid;
     e.sample_count = a.sample_count; e.film = a.film;
-    e.cold.base = a.cold_g + gid; e.cold.stride = a.cold_stride;
+    e.cold.base = a.cold_g + wg_base + pid; e.cold.stride = a.cold_stride;
     e.lx = e.ly = 0;
     if (b >= a.n_blocks) return false;
     e.blk = cload(a.blocks + b);
@@ -692,7 +709,7 @@ DEV void volpath_workgroup(const MTS_CONST_AS void *kernarg, Counters &cnt) {
         p.st = S_DONE;
         if (ok) {
             const uint32_t ppb = a.block_size * a.block_size;
-            const uint32_t gid = wg_base + tid, b = gid / ppb, i = gid - b * ppb;
+            const uint32_t i = (wg_base % ppb) + tid;
             p.rng.seed(a.sc.sensor.seed + (uint64_t) e.blk.id * ppb + i, PCG32_DEFAULT_STREAM);     // sampler.cpp:83-96
             for (int k = 0; k < 5; ++k) e.cold.f(C_ACC + k) = 0.f;
             vm.begin_sample(p, e);
