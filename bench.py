@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--res", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=8, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU-baseline sample (0 = sized for ~15 s)")
     args = ap.parse_args()
 
     import numpy as np
@@ -110,9 +110,12 @@ def main():
     avg_launch_ms = kernel_ms / max(launches, 1)
     bytes_per_launch = bytes_per_sample * samples_rank * (args.steps / max(launches, 1))
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
+    kv = os.environ.get("MTSAMD_KERNEL", "wg256")
+    kernel_name = {"nested": "render_kernel<false, false>", "flat": "render_kernel<false, true>"}.get(
+        kv, "render_kernel_wg<false, %s>" % kv[2:])
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": "render_kernel", "avg_launch_ms": round(avg_launch_ms, 3),
+                "kernel": kernel_name, "avg_launch_ms": round(avg_launch_ms, 3),
                 "bytes_per_sample": round(bytes_per_sample, 1),
                 "n_iter_per_sample": round(cs["n_iter"] / cs["samples"], 3),
                 "n_lookup_per_sample": round(cs["n_lookup"] / cs["samples"], 3),
@@ -129,13 +132,19 @@ def main():
         # the oracle (CPU restatement of scalar_rgb) on all host cores, on a bounded sample of the same workload
         import tests.oracle_binding as ob
         cores = os.cpu_count() or 1
-        dc = scenes.c3_heterogeneous(args.width, args.height, args.cpu_spp, res=args.res)
-        osc = ob.OracleScene(dc)
-        tc0 = time.perf_counter()
-        osc.render(threads=cores)
-        tcpu = time.perf_counter() - tc0
-        cpu_baseline = {"value": round(args.width * args.height * args.cpu_spp / tcpu / 1e6, 4), "unit": "Msamples/s", "cores": cores,
-                        "kind": "port", "sample": "%dx%dx%dspp of the same scene (%.1f s)" % (args.width, args.height, args.cpu_spp, tcpu)}
+        def cpu_render(spp):
+            osc = ob.OracleScene(scenes.c3_heterogeneous(args.width, args.height, spp, res=args.res))
+            tc0 = time.perf_counter()
+            osc.render(threads=cores)
+            return time.perf_counter() - tc0
+        cpu_spp = args.cpu_spp
+        if cpu_spp <= 0:                                         # calibrate with 2 spp, then size the sample for ~15 s
+            tcal = cpu_render(2)
+            cpu_spp = int(min(1024, max(2, round(15.0 / (tcal / 2.0)))))
+        tcpu = cpu_render(cpu_spp)
+        cpu_baseline = {"value": round(args.width * args.height * cpu_spp / tcpu / 1e6, 4), "unit": "Msamples/s", "cores": cores,
+                        "kind": "port", "sample": "%dx%dx%dspp of the same scene, all pixels, seed 0 (%.1f s on %d threads)"
+                                                  % (args.width, args.height, cpu_spp, tcpu, cores)}
 
     if rank == 0:
         out = {"metric": "Msamples/s volpath 512x512x1024spp plane-parallel atmosphere", "value": round(value, 2), "unit": "Msamples/s",

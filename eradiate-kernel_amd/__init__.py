@@ -100,6 +100,8 @@ class Bitmap:
         if srgb_gamma:
             raise RuntimeError("sRGB gamma encoding is not supported")
         a = self._a
+        if self._fmt in (PixelFormat.RGB, PixelFormat.RGBA) and pixel_format in (PixelFormat.RGB, self._fmt):
+            return Bitmap(a[..., :3] if pixel_format == PixelFormat.RGB else a, pixel_format)
         if self._fmt != PixelFormat.XYZAW:
             raise RuntimeError("Bitmap.convert(): only XYZAW sources are supported")
         w = a[..., 4:5]
@@ -285,9 +287,22 @@ def load_dict(d, device=0):
     return Scene(desc, keep, device)
 
 
-# virtual modules mitsuba.core / mitsuba.render (src/python/__init__.py:115-121)
-core = types.SimpleNamespace(
-    ScalarTransform4f=ScalarTransform4f, Bitmap=Bitmap, Struct=Struct,
-    xml=types.SimpleNamespace(load_dict=load_dict),
-)
-render = types.SimpleNamespace(Scene=Scene, Integrator=Integrator, Sensor=Sensor, Film=Film)
+# virtual modules mitsuba.core / mitsuba.core.xml / mitsuba.render (src/python/__init__.py:115-121), registered so
+# that `from mitsuba_amd.core.xml import load_dict` works like the reference's import line
+def _virtual_module(name, **members):
+    import sys
+    mods = []
+    for prefix in (__name__, "mitsuba_amd"):
+        m = types.ModuleType(prefix + "." + name)
+        m.__dict__.update(members)
+        sys.modules[prefix + "." + name] = m
+        mods.append(m)
+    return mods[0]
+
+
+_xml = _virtual_module("core.xml", load_dict=load_dict)
+core = _virtual_module("core", ScalarTransform4f=ScalarTransform4f, Bitmap=Bitmap, Struct=Struct, xml=_xml)
+for _p in ("mitsuba_amd",):
+    import sys as _sys
+    _sys.modules[_p + ".core"].xml = _sys.modules[_p + ".core.xml"]
+render = _virtual_module("render", Scene=Scene, Integrator=Integrator, Sensor=Sensor, Film=Film)

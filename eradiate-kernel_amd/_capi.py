@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmtsamd.so")
+LIB_PATH = os.environ.get("MTSAMD_LIB") or os.path.join(HERE, "libmtsamd.so")
 
 MTS_ABI_VERSION = 1
 

@@ -672,11 +672,15 @@ DEV bool wg_env(const WgArgs &a, uint32_t wg_base, uint32_t pid, PathEnv &e) {  
 
 // One block of class C for the path `pid`: load, run (repeat while the path stays in class C and enough lanes do), store.
 template <bool COUNT, int WG, int C>
-__device__ __noinline__ void wg_block(const MTS_CONST_AS void *kernarg_, uint32_t *hot_lds, uint32_t wg_base_, uint32_t pid, Counters *cnt) {
+#ifndef WG_BLOCK_ATTR
+#define WG_BLOCK_ATTR __forceinline__   // a real call costs 48 callee-saved VGPR spills + reloads per block visit (measured: 5 TB of scratch writes per render)
+#endif
+static __device__ WG_BLOCK_ATTR void wg_block(const MTS_CONST_AS void *kernarg_, uint32_t *hot_lds, uint32_t wg_base_, uint32_t pid, Counters *cnt) {
     // arguments of a non-kernel function arrive in VGPRs; tell the compiler which ones are wave-uniform
     const uint64_t ka = (uint64_t) (uintptr_t) kernarg_;
-    const MTS_CONST_AS void *kernarg = (const MTS_CONST_AS void *) (uintptr_t)
-        ((uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) ka) | ((uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (ka >> 32)) << 32));
+    uint32_t ka_lo = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) ka), ka_hi = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (ka >> 32));
+    asm volatile("" : "+s"(ka_lo), "+s"(ka_hi));             // opaque: scene loads stay inside this block (no hoisting when inlined)
+    const MTS_CONST_AS void *kernarg = (const MTS_CONST_AS void *) (uintptr_t) ((uint64_t) ka_lo | ((uint64_t) ka_hi << 32));
     const uint32_t wg_base = (uint32_t) __builtin_amdgcn_readfirstlane((int) wg_base_);
     const WgArgs a = cload_k<WgArgs>(kernarg);
     VolpathMachine<COUNT> vm(a.sc, *cnt);
