@@ -15,7 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libmtsamd.so")
+LIB = os.environ.get("MTSAMD_LIB_OUT") or os.path.join(HERE, "libmtsamd.so")   # MTSAMD_LIB_OUT: A/B builds next to the product
 SOURCES = ["kernels.hip", "scene_host.cpp", "capi.cpp"]
 HEADERS = ["pmath.h", "dmath.h", "dscene.h", "integrator_dev.h", "volpath_flat.h", "launch.h", "scene_host.h"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -169,9 +169,10 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             if (const char *kv = getenv("MTSAMD_KERNEL")) {
                 if (!strcmp(kv, "nested")) variant = 0; else if (!strcmp(kv, "flat")) variant = 1;
                 else if (!strcmp(kv, "wg256")) variant = 256; else if (!strcmp(kv, "wg512")) variant = 512; else if (!strcmp(kv, "wg1024")) variant = 1024;
-                else throw std::runtime_error("MTSAMD_KERNEL must be one of nested, flat, wg256, wg512, wg1024");
+                else if (!strcmp(kv, "wga256")) variant = 10256; else if (!strcmp(kv, "wga512")) variant = 10512; else if (!strcmp(kv, "wga1024")) variant = 11024;
+                else throw std::runtime_error("MTSAMD_KERNEL must be one of nested, flat, wg256, wg512, wg1024, wga256, wga512, wga1024");
             }
-            if (variant > 1 && (block_size * block_size) % (uint32_t) variant != 0) variant = 1;     // small blocks: per-lane kernel
+            if (variant > 1 && (block_size * block_size) % (uint32_t) (variant % 10000) != 0) variant = 1;     // small blocks: per-lane kernel
             DeviceBuffer<float> d_ws(render_workspace_floats((uint32_t) blocks.size(), block_size, variant));
             HIP_CHECK(launch_render(hs.scene, d_blocks.p, (uint32_t) blocks.size(), block_size, (uint32_t) samples_per_pass, d_film, d_counters.p,
                                     opts.collect_counters != 0, variant, d_ws.p, stream));

@@ -19,6 +19,7 @@ struct F2 { float x, y; };
 
 DM_HD F3 f3(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
 DM_HD F3 f3(const float *p) { F3 r; r.x = p[0]; r.y = p[1]; r.z = p[2]; return r; }
+DM_HD F3 f3(const __attribute__((address_space(1))) float *p) { F3 r; r.x = p[0]; r.y = p[1]; r.z = p[2]; return r; }
 DM_HD F3 f3s(float s) { F3 r; r.x = s; r.y = s; r.z = s; return r; }
 DM_HD F3 operator+(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
 DM_HD F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }

@@ -22,6 +22,11 @@ namespace mtsamd {
 // record through the constant address space -- same bytes, but invariant by definition -- so uniform
 // records cost no VGPRs and no vector-memory instructions.  The scene is never written while a kernel runs.
 #define MTS_CONST_AS __attribute__((address_space(4)))
+#define MTS_GLOBAL_AS __attribute__((address_space(1)))
+// Pointers read out of scene records are generic as far as the compiler can tell, and per-lane accesses through
+// them become FLAT instructions (which also tick lgkmcnt and so serialise with LDS / scalar traffic).  Every such
+// pointer is device memory: the round trip through the global address space lets InferAddressSpaces emit GLOBAL ones.
+template <typename T> __device__ __forceinline__ MTS_GLOBAL_AS T *as_global(T *p) { return (MTS_GLOBAL_AS T *) p; }
 template <typename T> DEV T cload(const T *p) {
     static_assert(sizeof(T) % 4 == 0, "records are dword multiples");
     uint32_t tmp[sizeof(T) / 4];
@@ -178,8 +183,8 @@ DEV void hit_point(const DScene &sc, const DShape &s, const DRay &ray, Hit &h) {
         h.p = fmadd(n, s.radius, f3(s.center));
         h.uv.x = n.x; h.uv.y = n.y; h.prim = (int32_t) pm_bits(n.z);     // keep the exact normal for complete_surface()
     } else {
-        const uint32_t *fi = sc.faces + 3 * (s.face_offset + h.prim);
-        const float *P = sc.positions + 3 * s.vertex_offset;
+        const MTS_GLOBAL_AS uint32_t *fi = as_global(sc.faces) + 3 * (s.face_offset + h.prim);
+        const MTS_GLOBAL_AS float *P = as_global(sc.positions) + 3 * s.vertex_offset;
         F3 p0 = f3(P + 3 * fi[0]), p1 = f3(P + 3 * fi[1]), p2 = f3(P + 3 * fi[2]);
         float b1 = h.uv.x, b2 = h.uv.y, b0 = 1.f - b1 - b2;
         h.p = p0 * b0 + p1 * b1 + p2 * b2;
@@ -212,15 +217,15 @@ DEV void complete_surface(const DScene &sc, const DShape &s, const Hit &h, F3 d,
         if (s.flip_normals) shn = -shn;
         sf.n = shn;
     } else {
-        const uint32_t *fi = sc.faces + 3 * (s.face_offset + h.prim);
-        const float *P = sc.positions + 3 * s.vertex_offset;
+        const MTS_GLOBAL_AS uint32_t *fi = as_global(sc.faces) + 3 * (s.face_offset + h.prim);
+        const MTS_GLOBAL_AS float *P = as_global(sc.positions) + 3 * s.vertex_offset;
         F3 p0 = f3(P + 3 * fi[0]), p1 = f3(P + 3 * fi[1]), p2 = f3(P + 3 * fi[2]);
         float b1 = h.uv.x, b2 = h.uv.y, b0 = 1.f - b1 - b2;
         F3 dp0 = p1 - p0, dp1 = p2 - p0;
         sf.n = normalize(cross(dp0, dp1));
         coordinate_system(sf.n, dp_du, dp_dv);
         if (s.has_texcoords) {
-            const float *T = sc.texcoords + 2 * s.vertex_offset;
+            const MTS_GLOBAL_AS float *T = as_global(sc.texcoords) + 2 * s.vertex_offset;
             float u0x = T[2 * fi[0]], u0y = T[2 * fi[0] + 1], u1x = T[2 * fi[1]], u1y = T[2 * fi[1] + 1], u2x = T[2 * fi[2]], u2y = T[2 * fi[2] + 1];
             float d0x = u1x - u0x, d0y = u1y - u0y, d1x = u2x - u0x, d1y = u2y - u0y;
             float det = pm_fma(d0x, d1y, -(d0y * d1x)), inv_det = pm_rcp(det);
@@ -228,7 +233,7 @@ DEV void complete_surface(const DScene &sc, const DShape &s, const Hit &h, F3 d,
                 dp_du = f3(pm_fma(d1y, dp0.x, -(d0y * dp1.x)), pm_fma(d1y, dp0.y, -(d0y * dp1.y)), pm_fma(d1y, dp0.z, -(d0y * dp1.z))) * inv_det;
         }
         if (s.has_normals) {
-            const float *N = sc.normals + 3 * s.vertex_offset;
+            const MTS_GLOBAL_AS float *N = as_global(sc.normals) + 3 * s.vertex_offset;
             F3 n0 = f3(N + 3 * fi[0]), n1 = f3(N + 3 * fi[1]), n2 = f3(N + 3 * fi[2]);
             shn = normalize(n0 * b0 + n1 * b1 + n2 * b2);
         } else shn = sf.n;
@@ -265,7 +270,7 @@ DEV float trilerp(float d000, float d100, float d010, float d110, float d001, fl
 DEV F3 volume_eval(const DVolume &v, F3 p_world) {
     if (v.type == MTS_VOLUME_CONST) return f3(v.value);
     F3 p = v.affine ? mat_point_affine(v.w2l, p_world) : mat_point(v.w2l, p_world);    // x / 1 == x
-    const float *D = v.data; const int nx = v.nx, ny = v.ny, nz = v.nz, ch = v.channels;
+    const MTS_GLOBAL_AS float *D = as_global(v.data); const int nx = v.nx, ny = v.ny, nz = v.nz, ch = v.channels;
     if (v.filter == MTS_FILTER_TRILINEAR) {
         p = f3(pm_fma(p.x, (float) nx, -.5f), pm_fma(p.y, (float) ny, -.5f), pm_fma(p.z, (float) nz, -.5f));
         int ix = (int) pm_floor(p.x), iy = (int) pm_floor(p.y), iz = (int) pm_floor(p.z);
@@ -347,27 +352,35 @@ DEV float distr_eval_pdf(const DPhase &d, float x) {
     x = (x - d.range_x) * d.inv_interval_size;
     long long xi = (long long) x;
     uint32_t index = (uint32_t) (xi < 0 ? 0 : (xi > (long long) d.size - 2 ? (long long) d.size - 2 : xi));
-    float y0 = active ? d.pdf[index] : 0.f, y1 = active ? d.pdf[index + 1] : 0.f;
+    const MTS_GLOBAL_AS float *pdf = as_global(d.pdf);
+    float y0 = active ? pdf[index] : 0.f, y1 = active ? pdf[index + 1] : 0.f;
     float w1 = x - (float) index, w0 = 1.f - w1;
     return pm_fma(w0, y0, w1 * y1);
 }
 // core/distr_1d.h:438-461
 DEV float distr_sample(const DPhase &d, float value) {
     value *= d.integral;
+    const MTS_GLOBAL_AS float *pdf = as_global(d.pdf), *cdf = as_global(d.cdf);
     uint32_t start = d.valid_x, end = d.valid_y, iterations = 0;
     if (start < end) { uint32_t diff = end - start; iterations = 1; while (diff >>= 1) iterations++; }
     for (uint32_t i = 0; i < iterations; ++i) {
         uint32_t middle = (start + end) >> 1;
-        bool cond = d.cdf[middle] < value;
+        bool cond = cdf[middle] < value;
         if (cond) start = min(middle + 1, end); else end = middle;
     }
     uint32_t index = start;
-    float y0 = d.pdf[index], y1 = d.pdf[index + 1], c0 = index > 0 ? d.cdf[index - 1] : 0.f;
+    float y0 = pdf[index], y1 = pdf[index + 1], c0 = index > 0 ? cdf[index - 1] : 0.f;
     value = (value - c0) * d.inv_interval_size;
     float t_linear = (y0 - pm_safe_sqrt(y0 * y0 + 2.f * value * (y1 - y0))) / (y0 - y1), t_const = value / y0;
     float t = (y0 == y1) ? t_const : t_linear;
     return pm_fma((float) index + t, d.interval_size, d.range_x);
 }
+
+// Record load: U = the index is wave-uniform (scalar loads), otherwise an ordinary per-lane read
+#ifndef EXP_NO_U
+#define EXP_NO_U 0
+#endif
+template <bool U, typename T> DEV T rload(const T *base, int i) { if (U && !EXP_NO_U) return cload(base + i); return base[i]; }
 
 // Leaf phase functions (blendphase recursion is resolved by the two callers below; nesting depth 1)
 DEV float phase_eval_leaf(const DPhase &ph, F3 wi, F3 wo) {
@@ -378,12 +391,13 @@ DEV float phase_eval_leaf(const DPhase &ph, F3 wi, F3 wo) {
         default: return MTS_INV_FOUR_PI;                                                      // isotropic.cpp:43-47
     }
 }
+template <bool U = false>
 DEV float phase_eval(const DScene &sc, int phase, F3 wi, F3 p, F3 wo) {
-    const DPhase &ph = sc.phases[phase];
+    const DPhase ph = rload<U>(sc.phases, phase);
     if (ph.type != MTS_PHASE_BLEND) return phase_eval_leaf(ph, wi, wo);
-    float w = volume_eval_1(sc.volumes[ph.weight_volume], p);                                 // blendphase.cpp:113-139
+    float w = volume_eval_1(rload<U>(sc.volumes, ph.weight_volume), p);                       // blendphase.cpp:113-139
     float weight = pm_min(pm_max(w, 0.f), 1.f);
-    return phase_eval_leaf(sc.phases[ph.child[0]], wi, wo) * (1 - weight) + phase_eval_leaf(sc.phases[ph.child[1]], wi, wo) * weight;
+    return phase_eval_leaf(rload<U>(sc.phases, ph.child[0]), wi, wo) * (1 - weight) + phase_eval_leaf(rload<U>(sc.phases, ph.child[1]), wi, wo) * weight;
 }
 DEV F3 phase_sample_leaf(const DPhase &ph, const Frame3 &frame, F2 sample2) {
     float cos_theta;
@@ -405,13 +419,14 @@ DEV F3 phase_sample_leaf(const DPhase &ph, const Frame3 &frame, F2 sample2) {
     return to_world(frame, f3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta));
 }
 // Returns wo; the pdf is never used by the integrators (volpath.cpp:171 discards it).
+template <bool U = false>
 DEV F3 phase_sample(const DScene &sc, int phase, const Frame3 &frame, F3 p, float sample1, F2 sample2) {
-    const DPhase &ph = sc.phases[phase];
+    const DPhase ph = rload<U>(sc.phases, phase);
     if (ph.type != MTS_PHASE_BLEND) return phase_sample_leaf(ph, frame, sample2);
-    float w = volume_eval_1(sc.volumes[ph.weight_volume], p);                                 // blendphase.cpp:68-111
+    float w = volume_eval_1(rload<U>(sc.volumes, ph.weight_volume), p);                       // blendphase.cpp:68-111
     float weight = pm_min(pm_max(w, 0.f), 1.f);
-    if (sample1 > weight) return phase_sample_leaf(sc.phases[ph.child[0]], frame, sample2);
-    return phase_sample_leaf(sc.phases[ph.child[1]], frame, sample2);
+    if (sample1 > weight) return phase_sample_leaf(rload<U>(sc.phases, ph.child[0]), frame, sample2);
+    return phase_sample_leaf(rload<U>(sc.phases, ph.child[1]), frame, sample2);
 }
 
 // ---------------------------------------------------------------- BSDFs
@@ -426,7 +441,8 @@ DEV void frame_sincos_phi(F3 v, float &s, float &c) {                           
     s = ry; c = rx;
 }
 // bsdfs/rpv.cpp:85-131
-DEV_NOINLINE F3 eval_rpv(const DBsdf &b, F3 wi, F3 wo) {
+struct RpvParams { float rho_0[3], k[3], g[3], rho_c[3]; };     // passed by value: a reference would pin the caller's whole DBsdf copy in scratch
+DEV_NOINLINE F3 eval_rpv_p(const RpvParams b, F3 wi, F3 wo) {
     float sin_phi1, cos_phi1, sin_phi2, cos_phi2;
     frame_sincos_phi(wi, sin_phi1, cos_phi1); frame_sincos_phi(wo, sin_phi2, cos_phi2);
     float cos_phi1_minus_phi2 = cos_phi1 * cos_phi2 + sin_phi1 * sin_phi2;
@@ -441,6 +457,11 @@ DEV_NOINLINE F3 eval_rpv(const DBsdf &b, F3 wi, F3 wo) {
         out[c] = b.rho_0[c] * (pm_pow(cos_theta1 * cos_theta2 * (cos_theta1 + cos_theta2), b.k[c] - 1.f) * F * (1.f + (1.f - b.rho_c[c]) / (1 + G))) * MTS_INV_PI;
     }
     return f3(out[0], out[1], out[2]);
+}
+DEV F3 eval_rpv(const DBsdf &b, F3 wi, F3 wo) {
+    RpvParams q;
+    for (int c = 0; c < 3; ++c) { q.rho_0[c] = b.rho_0[c]; q.k[c] = b.k[c]; q.g[c] = b.g[c]; q.rho_c[c] = b.rho_c[c]; }
+    return eval_rpv_p(q, wi, wo);
 }
 DEV F3 bsdf_eval(const DBsdf &b, F3 wi, F3 wo) {
     bool active = wi.z > 0.f && wo.z > 0.f;
@@ -540,8 +561,9 @@ DEV float shape_pdf_direction(const DShape &s, F3 ref_p, const DirSample &ds) {
     return sin_alpha < 0x1.fffffep-1f ? MTS_INV_TWO_PI / (1.f - cos_alpha) : s.inv_surface_area * (ds.dist * ds.dist) / pm_abs(dot(ds.d, ds.n));
 }
 // emitters/directional.cpp:109-141, emitters/area.cpp:122-165, emitters/constant.cpp:81-111
+template <bool U = false>
 DEV DirSample emitter_sample_direction(const DScene &sc, int ei, F3 ref_p, F2 sample, F3 &spec) {
-    const DEmitter &e = sc.emitters[ei];
+    const DEmitter e = rload<U>(sc.emitters, ei);
     DirSample ds;
     if (e.type == MTS_EMITTER_DIRECTIONAL) {
         F3 d = mat_vector(e.to_world.m, f3(0.f, 0.f, 1.f));
@@ -565,7 +587,7 @@ DEV DirSample emitter_sample_direction(const DScene &sc, int ei, F3 ref_p, F2 sa
 DEV DirSample sample_emitter_direction(const DScene &sc, F3 ref_p, F2 sample, bool test_visibility, F3 &spec) {
     DirSample ds; ds.pdf = 0.f; ds.dist = 0.f; ds.delta = false; ds.emitter = -1; ds.p = ds.n = ds.d = f3s(0.f);
     if (sc.emitter_count == 0) { spec = f3s(0.f); return ds; }
-    if (sc.emitter_count == 1) ds = emitter_sample_direction(sc, 0, ref_p, sample, spec);
+    if (sc.emitter_count == 1) ds = emitter_sample_direction<true>(sc, 0, ref_p, sample, spec);
     else {
         float n = (float) sc.emitter_count, emitter_pdf = 1.f / n;
         uint32_t index = min((uint32_t) (sample.x * n), (uint32_t) sc.emitter_count - 1);

@@ -35,7 +35,7 @@ __device__ __forceinline__ void render_sample(const DScene &sc, Pcg32 &rng, cons
     F3 L = sc.integrator.type == MTS_INTEGRATOR_VOLPATH ? volpath_sample<COUNT>(sc, rng, ray, se.medium, valid, cnt)
                                                          : path_sample<COUNT>(sc, rng, ray, valid, cnt);
     L = ray_weight * L;
-    splat_sample_t<false>(sc, blk, lx, ly, position_sample, L, valid, film, acc);
+    splat_sample_t<false>(sc, blk, lx, ly, position_sample, L, valid, as_global(film), acc);
 }
 
 // librender/integrator.cpp:181-209 (scalar branch) for every block of this launch at once.
@@ -86,6 +86,19 @@ __global__ void __launch_bounds__(WG, WG >= 1024 ? 4 : (WG >= 512 ? 4 : 4)) rend
         atomicAdd(counters + 2, (unsigned long long) cnt.n_nee_step);
     }
 }
+// Asynchronous-regrouping variant (volpath_flat.h, driver 3); same parameter list / WgArgs.
+template <bool COUNT, int WG>
+__global__ void __launch_bounds__(WG, 4) render_kernel_wga(DScene sc, const DBlock *blocks, uint32_t n_blocks, uint32_t block_size,
+                                                         uint32_t sample_count, float *film, float *cold_g, uint32_t cold_stride,
+                                                         unsigned long long *counters) {
+    Counters cnt; cnt.n_iter = cnt.n_lookup = cnt.n_nee_step = 0;
+    volpath_workgroup_async<COUNT, WG>((const MTS_CONST_AS void *) __builtin_amdgcn_kernarg_segment_ptr(), cnt);
+    if (COUNT) {
+        atomicAdd(counters + 0, (unsigned long long) cnt.n_iter);
+        atomicAdd(counters + 1, (unsigned long long) cnt.n_lookup);
+        atomicAdd(counters + 2, (unsigned long long) cnt.n_nee_step);
+    }
+}
 static_assert(sizeof(WgArgs) % 4 == 0, "WgArgs mirrors the kernel parameters");
 
 // SamplingIntegrator::sample for caller-supplied rays (librender/python/integrator_v.cpp:62-78)
@@ -124,6 +137,7 @@ __global__ void __launch_bounds__(256) intersect_kernel(DScene sc, int32_t n, co
 // ---------------------------------------------------------------- launchers
 size_t render_workspace_floats(uint32_t n_blocks, uint32_t block_size, int variant) {
     if (variant < 256) return 0;
+    if (variant >= 10000) variant -= 10000;
     const uint64_t threads = (uint64_t) n_blocks * block_size * block_size;
     const uint64_t padded = (threads + variant - 1) / variant * variant;
     return (size_t) padded * C_COUNT;
@@ -133,6 +147,17 @@ hipError_t launch_render(const DScene &sc, const DBlock *d_blocks, uint32_t n_bl
                          float *d_film, unsigned long long *d_counters, bool count, int variant, float *d_workspace, hipStream_t stream) {
     if (n_blocks == 0) return hipSuccess;
     const uint64_t threads = (uint64_t) n_blocks * block_size * block_size;
+    if (variant >= 10000 && sc.integrator.type == MTS_INTEGRATOR_VOLPATH) {        // asynchronous regrouping, variant = 10000 + workgroup size
+        const uint32_t wg = (uint32_t) (variant - 10000);
+        const uint32_t grid = (uint32_t) ((threads + wg - 1) / wg);
+        const uint32_t stride = grid * wg;
+#define LAUNCH_WGA(C, W) hipLaunchKernelGGL((render_kernel_wga<C, W>), dim3(grid), dim3(W), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters)
+        if (wg == 256) { if (count) LAUNCH_WGA(true, 256); else LAUNCH_WGA(false, 256); }
+        else if (wg == 512) { if (count) LAUNCH_WGA(true, 512); else LAUNCH_WGA(false, 512); }
+        else { if (count) LAUNCH_WGA(true, 1024); else LAUNCH_WGA(false, 1024); }
+#undef LAUNCH_WGA
+        return hipGetLastError();
+    }
     if (variant >= 256 && sc.integrator.type == MTS_INTEGRATOR_VOLPATH) {          // workgroup-regrouping kernel, variant = workgroup size
         const uint32_t wg = (uint32_t) variant;
         const uint32_t grid = (uint32_t) ((threads + wg - 1) / wg);

@@ -50,7 +50,7 @@ DEV GridCell grid_cell(const DVolume &v, F3 p_world) {
     c.r00 = (z0 * ny + y0) * nx; c.r10 = (z0 * ny + y1) * nx; c.r01 = (z1 * ny + y0) * nx; c.r11 = (z1 * ny + y1) * nx;
     return c;
 }
-DEV float grid_fetch1(const float *__restrict__ D, const GridCell &c) {
+DEV float grid_fetch1(const MTS_GLOBAL_AS float *__restrict__ D, const GridCell &c) {
 #if defined(EXP_NOGATHER)
     return trilerp(0.5f, 0.6f, 0.7f, 0.8f, 0.9f, 1.0f, 1.1f, 1.2f, c.w0, c.w1) + 1e-9f * (float) (c.r00 + c.x0 + c.r11 + c.x1 + c.r01 + c.r10);
 #endif
@@ -86,9 +86,9 @@ DEV MedStep medium_step(const DScene &sc, const DMedium m, const DRay &ray, floa
         if (m.shared_grid && m.grey && vs.filter == MTS_FILTER_TRILINEAR) {
             // both grids share one cell / one set of weights; single channel: one value serves the three channels
             GridCell c = grid_cell(vs, mi.p);
-            float st = m.scale * grid_fetch1(vs.data, c);
+            float st = m.scale * grid_fetch1(as_global(vs.data), c);
             mi.sigma_t = f3s(st);
-            if (want_albedo) mi.sigma_s = f3s(st * grid_fetch1(va.data, c));       // the tracking walks never read sigma_s
+            if (want_albedo) mi.sigma_s = f3s(st * grid_fetch1(as_global(va.data), c));       // the tracking walks never read sigma_s
         } else {
             F3 st = m.scale * volume_eval(vs, mi.p);
             mi.sigma_t = st;
@@ -113,7 +113,7 @@ DEV F3 transmittance_exp_g(float t, F3 combined, bool grey) {
 // formulation) or the pixel's film entry itself, updated with float atomics in sample order.
 template <bool OWN_ATOMIC>
 DEV void splat_sample_t(const DScene &sc, const DBlock &blk, uint32_t lx, uint32_t ly, F2 position_sample, F3 L, bool valid,
-                        float *__restrict__ film, float *own) {
+                        MTS_GLOBAL_AS float *film, float *own) {
     const DSensor &se = sc.sensor;
     float v[5];                                                 // srgb_to_xyz, core/spectrum.h:221-227
     v[0] = pm_fma(0.180423f, L.z, pm_fma(0.357580f, L.y, 0.412453f * L.x));
@@ -136,16 +136,16 @@ DEV void splat_sample_t(const DScene &sc, const DBlock &blk, uint32_t lx, uint32
         for (uint32_t yr = 0; yr < n; ++yr) {
             int y = loy + (int) yr;
             if (y > hiy) break;
-            float wy = rf.values[min((int) pm_abs((basey + (float) yr) * rf.scale_factor), 31)];     // eval_discretized, core/rfilter.h:62-65
+            float wy = as_global(rf.values)[min((int) pm_abs((basey + (float) yr) * rf.scale_factor), 31)];     // eval_discretized, core/rfilter.h:62-65
             int fy = blk.oy - border + y - se.crop_y;
             for (uint32_t xr = 0; xr < n; ++xr) {
                 int x = lox + (int) xr;
                 if (x > hix) break;
-                float wx = rf.values[min((int) pm_abs((basex + (float) xr) * rf.scale_factor), 31)];
+                float wx = as_global(rf.values)[min((int) pm_abs((basex + (float) xr) * rf.scale_factor), 31)];
                 float weight = wy * wx;
                 int fx = blk.ox - border + x - se.crop_x;
                 if (fx >= 0 && fy >= 0 && fx < se.crop_w && fy < se.crop_h) {                         // film clipping, imageblock.cpp:49-77
-                    float *dst = film + 5 * ((size_t) fy * se.crop_w + fx);
+                    float *dst = (float *) (film + 5 * ((size_t) fy * se.crop_w + fx));
                     for (int k = 0; k < 5; ++k) atomicAdd(dst + k, v[k] * weight);
                 }
             }
@@ -156,7 +156,7 @@ DEV void splat_sample_t(const DScene &sc, const DBlock &blk, uint32_t lx, uint32
             if (OWN_ATOMIC) { for (int k = 0; k < 5; ++k) atomicAdd(own + k, v[k]); }
             else { for (int k = 0; k < 5; ++k) own[k] += v[k]; }
         } else if (lox >= 0 && loy >= 0 && lox < sx && loy < sy) {
-            float *dst = film + 5 * ((size_t) (blk.oy + loy - se.crop_y) * se.crop_w + (blk.ox + lox - se.crop_x));
+            float *dst = (float *) (film + 5 * ((size_t) (blk.oy + loy - se.crop_y) * se.crop_w + (blk.ox + lox - se.crop_x)));
             for (int k = 0; k < 5; ++k) atomicAdd(dst + k, v[k]);
         }
     }
@@ -172,7 +172,7 @@ struct PathState {
     int medium;                     // medium containing ray.o
     F3 thr, res; float eta; uint32_t depth, channel;         // main path (volpath.cpp:54-67)
     F3 trans; float wa, wb;         // walk: transmittance; NEE: wa = total_dist, wb = ds.dist; direct: wb = bs.pdf
-    uint32_t st, mode, flags, sample_idx;
+    uint32_t st, mode, flags;
 };
 // cold field offsets (floats)
 enum { C_POS = 0,            // 2: film position of the current sample
@@ -183,11 +183,13 @@ enum { C_POS = 0,            // 2: film position of the current sample
        C_CW = 18,            // 3: pending NEE weight
        C_EMIT = 21,          // 3: emitter value of the NEE sample
        C_ACC = 24,           // 5: this path's film accumulators X, Y, Z, A, W (the reference's per-block ImageBlock entry)
-       C_COUNT = 29 };
+       C_SAMPLE = 29,        // 1: index of the sample in flight (bits of a uint32)
+       C_COUNT = 30 };
 // Struct-of-arrays store addressed as base[k * stride]: LDS (stride 256, one workgroup) or HBM (stride = paths in flight)
-struct ColdStore {
-    float *base; uint32_t stride;
-    DEV float &f(int k) const { return base[(size_t) k * stride]; }
+template <class Ptr /* float* into LDS, or MTS_GLOBAL_AS float* into HBM */>
+struct ColdStoreT {
+    Ptr base; uint32_t stride;
+    DEV auto &f(int k) const { return base[(size_t) k * stride]; }
     DEV void put3(int k, F3 v) const { f(k) = v.x; f(k + 1) = v.y; f(k + 2) = v.z; }
     DEV F3 get3(int k) const { return f3(f(k), f(k + 1), f(k + 2)); }
     DEV void put_hit(const Hit &h) const {
@@ -200,8 +202,11 @@ struct ColdStore {
     }
 };
 // What a path needs from its surroundings
-struct PathEnv {
-    DBlock blk; uint32_t lx, ly, sample_count; float *__restrict__ film; ColdStore cold;
+typedef ColdStoreT<float *> ColdStore;                       // generic pointer (the per-lane driver parks cold state in LDS)
+typedef ColdStoreT<MTS_GLOBAL_AS float *> ColdStoreHbm;      // workgroup driver: cold state in HBM, addressed with GLOBAL instructions
+template <class Cold>
+struct PathEnvT {
+    DBlock blk; uint32_t lx, ly, sample_count; MTS_GLOBAL_AS float *film; Cold cold;
 };
 // Scheduling classes: the block a path is waiting for
 enum { B_INT = 0, B_MED, B_SCATTER, B_WSURF, B_SURF, B_PHASE, B_NEW, B_DONE, B_COUNT };
@@ -220,7 +225,7 @@ struct VolpathMachine {
         p.si.t = pm_inf(); p.si.shape = -1;
         if (pm_max(p.ray.mint, bmint) <= bmaxt) p.flags |= FL_NEEDS_INT; else p.flags &= ~FL_NEEDS_INT;
     }
-    DEV void begin_sample(PathState &p, const PathEnv &e) const {      // integrator.cpp:242-264, volpath.cpp:48-71
+    template <class E> DEV void begin_sample(PathState &p, const E &e) const {      // integrator.cpp:242-264, volpath.cpp:48-71
         const DSensor &se = sc.sensor;
         const float px = (float) (e.lx + (uint32_t) e.blk.ox), py = (float) (e.ly + (uint32_t) e.blk.oy);
         F2 u = p.rng.next_2d();
@@ -245,7 +250,7 @@ struct VolpathMachine {
         p.mode = M_MAIN; p.st = S_TOP;
     }
     // NEE walk finished (volpath.cpp:366 + :165-166 / :211): add the contribution, resume the main path
-    DEV void end_nee(PathState &p, const PathEnv &e) const {
+    template <class E> DEV void end_nee(PathState &p, const E &e) const {
         F3 emitted = p.trans * e.cold.get3(C_EMIT);
         p.res = p.res + e.cold.get3(C_CW) * emitted;
         p.mode = M_MAIN; p.medium = __float_as_int(e.cold.f(C_SMED));
@@ -255,7 +260,7 @@ struct VolpathMachine {
         else { p.si = e.cold.get_hit(); p.st = S_BSDF; }
     }
     // direct-light walk finished (volpath.cpp:464 + :246-252): MIS-weighted emitter hit, resume the main path
-    DEV void end_direct(PathState &p, const PathEnv &e, F3 emitter_val, float emitter_pdf) const {
+    template <class E> DEV void end_direct(PathState &p, const E &e, F3 emitter_val, float emitter_pdf) const {
         F3 emitted = p.trans * emitter_val;
         if (emitter_pdf != 0.f) p.res = p.res + mis_weight(p.wb, emitter_pdf) * p.thr * emitted;
         p.ray = spawn_ray(e.cold.get3(C_SO), e.cold.get3(C_SD));
@@ -265,7 +270,7 @@ struct VolpathMachine {
     }
 
     // Loop heads of the three reference loops (cheap): volpath.cpp:79-87, :283-287, :385-388
-    DEV void top(PathState &p, const PathEnv &e) const {
+    template <class E> DEV void top(PathState &p, const E &e) const {
         if (p.st != S_TOP) return;
         const uint32_t max_depth = (uint32_t) sc.integrator.max_depth, rr_depth = (uint32_t) sc.integrator.rr_depth;
         if (p.mode == M_MAIN) {
@@ -300,37 +305,39 @@ struct VolpathMachine {
     }
 
     // ================================================================= NEW: finish a sample, start the next (integrator.cpp:265-288)
-    DEV void blk_new(PathState &p, const PathEnv &e) const {
+    template <class E> DEV void blk_new(PathState &p, const E &e) const {
         if (p.st != S_NEW) return;
         const DSensor &se = sc.sensor;
         F2 position_sample; position_sample.x = e.cold.f(C_POS); position_sample.y = e.cold.f(C_POS + 1);
         float acc[5];                                          // summed in sample order like the block entry (imageblock.cpp:163-168)
         for (int k = 0; k < 5; ++k) acc[k] = e.cold.f(C_ACC + k);
         splat_sample_t<false>(sc, e.blk, e.lx, e.ly, position_sample, f3s(e.cold.f(C_RAYW)) * p.res, (p.flags & FL_VALID_RAY) != 0, e.film, acc);
-        if (++p.sample_idx == e.sample_count) {                // block -> film (hdrfilm.cpp:207-211)
-            float *own = e.film + 5 * ((size_t) (e.blk.oy + (int) e.ly - se.crop_y) * se.crop_w + (e.blk.ox + (int) e.lx - se.crop_x));
+        const uint32_t sample_idx = __float_as_uint(e.cold.f(C_SAMPLE)) + 1u;
+        if (sample_idx == e.sample_count) {                    // block -> film (hdrfilm.cpp:207-211)
+            float *own = (float *) (e.film + 5 * ((size_t) (e.blk.oy + (int) e.ly - se.crop_y) * se.crop_w + (e.blk.ox + (int) e.lx - se.crop_x)));
             for (int k = 0; k < 5; ++k) atomicAdd(own + k, acc[k]);
             p.st = S_DONE;
         } else {
             for (int k = 0; k < 5; ++k) e.cold.f(C_ACC + k) = acc[k];
+            e.cold.f(C_SAMPLE) = __uint_as_float(sample_idx);
             begin_sample(p, e);
         }
     }
     // ================================================================= INTERSECT (volpath.cpp:109,182,241,298,339,395,425)
-    DEV void blk_int(PathState &p, const PathEnv &e) const {
+    template <class E> DEV void blk_int(PathState &p, const E &e) const {
         if (!wants_int(p)) return;
         p.si = ray_intersect(sc, p.ray);
         p.flags &= ~FL_NEEDS_INT;
         start_direct(p, e);
     }
-    DEV void start_direct(PathState &p, const PathEnv &e) const {      // volpath.cpp:239-245: the direct-light walk runs on a copy
+    template <class E> DEV void start_direct(PathState &p, const E &e) const {      // volpath.cpp:239-245: the direct-light walk runs on a copy
         if (p.st != S_DIRB || (p.flags & FL_NEEDS_INT)) return;
         e.cold.put3(C_SO, p.ray.o); e.cold.put3(C_SD, p.ray.d); e.cold.put_hit(p.si);
         p.trans = f3s(1.f);
         p.mode = M_DIR; p.st = S_TOP;
     }
     // ================================================================= MEDIUM: one free-flight step of any of the three loops
-    DEV void blk_med(PathState &p, const PathEnv &e) const {
+    template <class E> DEV void blk_med(PathState &p, const E &e) const {
         if (p.st != S_MED || (p.flags & FL_NEEDS_INT)) return;
         const uint32_t max_depth = (uint32_t) sc.integrator.max_depth;
         const float u = p.rng.next_1d();                       // volpath.cpp:105 / :294 / :391
@@ -414,17 +421,16 @@ struct VolpathMachine {
     }
     // ================================================================= SCATTER: emitter sampling at a medium interaction
     // (volpath.cpp:162-167 -> sample_emitter :261-281); the walk itself runs as M_NEE steps
-    DEV void blk_scatter(PathState &p, const PathEnv &e) const {
+    template <class E> DEV void blk_scatter(PathState &p, const E &e) const {
         if (p.st != S_SCATTER) return;
         p.st = S_PHASE;
         F3 emitter_val;
         DirSample ds = sample_emitter_direction(sc, p.ray.o, p.rng.next_2d(), false, emitter_val);
         if (ds.pdf == 0.f) return;
-        int phase = 0;
+        float phase_val = 0.f;
         WATERFALL_BEGIN(p.medium, mu)
-            phase = cload(sc.media + mu).phase;
+            phase_val = phase_eval<true>(sc, cload(sc.media + mu).phase, -p.ray.d, p.ray.o, ds.d);
         WATERFALL_END
-        float phase_val = phase_eval(sc, phase, -p.ray.d, p.ray.o, ds.d);
         e.cold.put3(C_CW, p.thr * phase_val); e.cold.put3(C_EMIT, emitter_val);
         e.cold.put3(C_SO, p.ray.o); e.cold.put3(C_SD, p.ray.d); e.cold.f(C_SMED) = __int_as_float(p.medium);
         p.trans = f3s(1.f); p.wa = 0.f; p.wb = ds.dist;
@@ -434,7 +440,7 @@ struct VolpathMachine {
         p.mode = M_NEE; p.st = S_TOP;
     }
     // ================================================================= SURFACE step of a walk (volpath.cpp:336-364, :423-462)
-    DEV void blk_wsurf(PathState &p, const PathEnv &e) const {
+    template <class E> DEV void blk_wsurf(PathState &p, const E &e) const {
         if (p.st != S_SURF || p.mode == M_MAIN || (p.flags & FL_NEEDS_INT)) return;
         const bool hit = hit_valid(p.si);
         const bool is_nee = p.mode == M_NEE;
@@ -472,7 +478,7 @@ struct VolpathMachine {
         else end_direct(p, e, f3s(0.f), 0.f);
     }
     // ================================================================= SURFACE interaction of the main path (volpath.cpp:184-212)
-    DEV void blk_surf(PathState &p, const PathEnv &e) const {
+    template <class E> DEV void blk_surf(PathState &p, const E &e) const {
         if (p.st != S_SURF || p.mode != M_MAIN || (p.flags & FL_NEEDS_INT)) return;
         const uint32_t max_depth = (uint32_t) sc.integrator.max_depth;
         const bool hit = hit_valid(p.si);
@@ -488,15 +494,21 @@ struct VolpathMachine {
         if ((p.flags & FL_SPEC_CHAIN) && emitter >= 0) p.res = p.res + p.thr * emitter_eval(sc, emitter, sf.wi.z);
         if (!hit) { p.flags &= ~FL_ALIVE; p.st = S_TOP; return; }
         p.st = S_BSDF;
-        const DBsdf &bsdf = sc.bsdfs[bsdf_id];
-        bool active_e = (bsdf.flags & F_Smooth) != 0 && (p.depth + 1 < max_depth);
+        bool active_e = false;
+        WATERFALL_BEGIN(bsdf_id, bu)
+            active_e = (cload(sc.bsdfs + bu).flags & F_Smooth) != 0 && (p.depth + 1 < max_depth);
+        WATERFALL_END
         if (!active_e) return;
         F3 emitter_val;                                        // volpath.cpp:200-212 -> sample_emitter :261-281
         DirSample ds = sample_emitter_direction(sc, p.si.p, p.rng.next_2d(), false, emitter_val);
         if (ds.pdf == 0.f) return;
         F3 wo = to_local(sf.sh, ds.d);
-        F3 bsdf_val = bsdf_eval(bsdf, sf.wi, wo);
-        float bpdf = bsdf_pdf(bsdf, sf.wi, wo);
+        F3 bsdf_val; float bpdf;
+        WATERFALL_BEGIN(bsdf_id, bu)
+            const DBsdf bsdf = cload(sc.bsdfs + bu);
+            bsdf_val = bsdf_eval(bsdf, sf.wi, wo);
+            bpdf = bsdf_pdf(bsdf, sf.wi, wo);
+        WATERFALL_END
         e.cold.put3(C_CW, p.thr * bsdf_val * mis_weight(ds.pdf, ds.delta ? 0.f : bpdf)); e.cold.put3(C_EMIT, emitter_val);
         e.cold.put_hit(p.si); e.cold.put3(C_SD, p.ray.d); e.cold.f(C_SMED) = __int_as_float(p.medium);
         p.trans = f3s(1.f); p.wa = 0.f; p.wb = ds.dist;
@@ -506,7 +518,7 @@ struct VolpathMachine {
         p.mode = M_NEE; p.st = S_TOP;
     }
     // ================================================================= BSDF sampling (volpath.cpp:214-252)
-    DEV void blk_bsdf(PathState &p, const PathEnv &e) const {
+    template <class E> DEV void blk_bsdf(PathState &p, const E &e) const {
         if (p.st != S_BSDF) return;
         const uint32_t max_depth = (uint32_t) sc.integrator.max_depth;
         Surf sf; int bsdf_id = 0, is_tr = 0, ext = -1, inte = -1;
@@ -516,8 +528,11 @@ struct VolpathMachine {
             bsdf_id = s.bsdf; is_tr = s.is_medium_transition; ext = s.exterior; inte = s.interior;
         WATERFALL_END
         const float s1 = p.rng.next_1d(); const F2 s2 = p.rng.next_2d(); (void) s1;
-        BSDFSample bs;
-        F3 bsdf_val = bsdf_sample(sc.bsdfs[bsdf_id], sf.wi, s2, bs);
+        BSDFSample bs; F3 bsdf_val;
+        WATERFALL_BEGIN(bsdf_id, bu)
+            const DBsdf bsdf = cload(sc.bsdfs + bu);
+            bsdf_val = bsdf_sample(bsdf, sf.wi, s2, bs);
+        WATERFALL_END
         p.thr = p.thr * bsdf_val;
         p.eta *= bs.eta;
         p.ray = spawn_ray(p.si.p, to_world(sf.sh, bs.wo));
@@ -533,12 +548,12 @@ struct VolpathMachine {
         else { p.medium = new_medium; p.st = S_TOP; }
     }
     // ================================================================= PHASE sampling (volpath.cpp:169-175)
-    DEV void blk_phase(PathState &p, const PathEnv &e) const {
+    template <class E> DEV void blk_phase(PathState &p, const E &e) const {
         if (p.st != S_PHASE) return;
         const float s1 = p.rng.next_1d(); const F2 s2 = p.rng.next_2d();      // left-to-right (SURVEY.md 8(a'))
         F3 wo;
         WATERFALL_BEGIN(p.medium, mu)
-            wo = phase_sample(sc, cload(sc.media + mu).phase, make_frame(p.ray.d), p.ray.o, s1, s2);   // mi.sh_frame = Frame3f(ray.d), medium.cpp:42
+            wo = phase_sample<true>(sc, cload(sc.media + mu).phase, make_frame(p.ray.d), p.ray.o, s1, s2);   // mi.sh_frame = Frame3f(ray.d), medium.cpp:42
         WATERFALL_END
         p.ray = spawn_ray(p.ray.o, wo); p.ray.mint = 0.0f;
         queue_intersection(p);
@@ -547,7 +562,7 @@ struct VolpathMachine {
     }
 
     // Run the block(s) of class `sel` for this lane (a lane whose state does not match falls through)
-    DEV void run(PathState &p, const PathEnv &e, int sel) const {
+    template <class E> DEV void run(PathState &p, const E &e, int sel) const {
         switch (sel) {
             case B_NEW: blk_new(p, e); break;
             case B_INT: blk_int(p, e); break;
@@ -567,9 +582,10 @@ template <bool COUNT>
 DEV void volpath_pixel_flat(const DScene &sc, Pcg32 &rng, const DBlock &blk, uint32_t lx, uint32_t ly, uint32_t sample_count,
                             float *__restrict__ film, ColdStore cold, Counters &cnt) {
     VolpathMachine<COUNT> vm(sc, cnt);
-    PathEnv e; e.blk = blk; e.lx = lx; e.ly = ly; e.sample_count = sample_count; e.film = film; e.cold = cold;
-    PathState p; p.rng = rng; p.sample_idx = 0;
+    PathEnvT<ColdStore> e; e.blk = blk; e.lx = lx; e.ly = ly; e.sample_count = sample_count; e.film = as_global(film); e.cold = cold;
+    PathState p; p.rng = rng;
     for (int k = 0; k < 5; ++k) e.cold.f(C_ACC + k) = 0.f;
+    e.cold.f(C_SAMPLE) = __uint_as_float(0u);
     vm.begin_sample(p, e);
 #if defined(MTSAMD_BLOCKSTATS)
     long long bs_t0 = clock64(); int bs_prev_sel = 7;
@@ -607,7 +623,7 @@ DEV void volpath_pixel_flat(const DScene &sc, Pcg32 &rng, const DBlock &blk, uin
 // with all 64 lanes active.  Every block is its own function: load the path from LDS, run, store -- nothing
 // stays live across blocks, which keeps the register budget at 128 VGPRs (4 waves / SIMD).
 enum { H_RNG = 0, H_O = 2, H_D = 5, H_MINT = 8, H_MAXT = 9, H_SI = 10, H_MEDIUM = 18, H_THR = 19, H_RES = 22, H_ETA = 25,
-       H_DEPTH = 26, H_PACKED = 27, H_SAMPLE = 28, H_TRANS = 29, H_WA = 32, H_WB = 33, H_DRCP = 34, H_COUNT = 37 };
+       H_DEPTH = 26, H_PACKED = 27, H_TRANS = 28, H_WA = 31, H_WB = 32, H_DRCP = 33, H_COUNT = 36 };
 
 template <int WG>
 struct HotStore {
@@ -627,7 +643,7 @@ struct HotStore {
         putf(H_SI, p.si.t); put3(H_SI + 1, p.si.p); putf(H_SI + 4, p.si.uv.x); putf(H_SI + 5, p.si.uv.y);
         u(H_SI + 6) = (uint32_t) p.si.shape; u(H_SI + 7) = (uint32_t) p.si.prim;
         u(H_MEDIUM) = (uint32_t) p.medium; put3(H_THR, p.thr); put3(H_RES, p.res); putf(H_ETA, p.eta);
-        u(H_DEPTH) = p.depth; u(H_PACKED) = pack(p, cls); u(H_SAMPLE) = p.sample_idx;
+        u(H_DEPTH) = p.depth; u(H_PACKED) = pack(p, cls);
         put3(H_TRANS, p.trans); putf(H_WA, p.wa); putf(H_WB, p.wb);
     }
     DEV void load(PathState &p) const {
@@ -636,7 +652,7 @@ struct HotStore {
         p.si.t = f(H_SI); p.si.p = get3(H_SI + 1); p.si.uv.x = f(H_SI + 4); p.si.uv.y = f(H_SI + 5);
         p.si.shape = (int) u(H_SI + 6); p.si.prim = (int) u(H_SI + 7);
         p.medium = (int) u(H_MEDIUM); p.thr = get3(H_THR); p.res = get3(H_RES); p.eta = f(H_ETA);
-        p.depth = u(H_DEPTH); p.sample_idx = u(H_SAMPLE);
+        p.depth = u(H_DEPTH);
         const uint32_t pk = u(H_PACKED);
         p.st = pk & 15u; p.mode = (pk >> 4) & 3u; p.channel = (pk >> 6) & 3u; p.flags = (pk >> 8) & 31u;
         p.trans = get3(H_TRANS); p.wa = f(H_WA); p.wb = f(H_WB);
@@ -657,12 +673,12 @@ struct WgArgs {
 };
 
 template <int WG>
-DEV bool wg_env(const WgArgs &a, uint32_t wg_base, uint32_t pid, PathEnv &e) {     // pixel owned by path `pid`; false: outside the block
+DEV bool wg_env(const WgArgs &a, uint32_t wg_base, uint32_t pid, PathEnvT<ColdStoreHbm> &e) {     // pixel owned by path `pid`; false: outside the block
     const uint32_t ppb = a.block_size * a.block_size;       // a multiple of WG (checked by the launcher): the workgroup sits in ONE block
     const uint32_t b = wg_base / ppb;                        // uniform
     const uint32_t i = (wg_base - b * ppb) + pid;
-    e.sample_count = a.sample_count; e.film = a.film;
-    e.cold.base = a.cold_g + wg_base + pid; e.cold.stride = a.cold_stride;
+    e.sample_count = a.sample_count; e.film = as_global(a.film);
+    e.cold.base = as_global(a.cold_g) + wg_base + pid; e.cold.stride = a.cold_stride;
     e.lx = e.ly = 0;
     if (b >= a.n_blocks) return false;
     e.blk = cload(a.blocks + b);
@@ -675,7 +691,7 @@ template <bool COUNT, int WG, int C>
 #ifndef WG_BLOCK_ATTR
 #define WG_BLOCK_ATTR __forceinline__   // a real call costs 48 callee-saved VGPR spills + reloads per block visit (measured: 5 TB of scratch writes per render)
 #endif
-static __device__ WG_BLOCK_ATTR void wg_block(const MTS_CONST_AS void *kernarg_, uint32_t *hot_lds, uint32_t wg_base_, uint32_t pid, Counters *cnt) {
+static __device__ WG_BLOCK_ATTR int wg_block(const MTS_CONST_AS void *kernarg_, uint32_t *hot_lds, uint32_t wg_base_, uint32_t pid, Counters *cnt) {
     // arguments of a non-kernel function arrive in VGPRs; tell the compiler which ones are wave-uniform
     const uint64_t ka = (uint64_t) (uintptr_t) kernarg_;
     uint32_t ka_lo = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) ka), ka_hi = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (ka >> 32));
@@ -684,13 +700,15 @@ static __device__ WG_BLOCK_ATTR void wg_block(const MTS_CONST_AS void *kernarg_,
     const uint32_t wg_base = (uint32_t) __builtin_amdgcn_readfirstlane((int) wg_base_);
     const WgArgs a = cload_k<WgArgs>(kernarg);
     VolpathMachine<COUNT> vm(a.sc, *cnt);
-    PathEnv e; wg_env<WG>(a, wg_base, pid, e);
+    PathEnvT<ColdStoreHbm> e; wg_env<WG>(a, wg_base, pid, e);
     HotStore<WG> hs; hs.base = hot_lds + pid;
     PathState p;
     hs.load(p);
     vm.run(p, e, C);
     vm.top(p, e);
-    hs.store(p, vm.classify(p));
+    const int cls = vm.classify(p);
+    hs.store(p, cls);
+    return cls;
 }
 
 template <bool COUNT, int WG>
@@ -704,10 +722,10 @@ DEV void volpath_workgroup(const MTS_CONST_AS void *kernarg, Counters &cnt) {
     {   // ---- initialise the path this thread starts with (integrator.cpp:198)
         const WgArgs a = cload_k<WgArgs>(kernarg);
         VolpathMachine<COUNT> vm(a.sc, cnt);
-        PathEnv e; PathState p;
+        PathEnvT<ColdStoreHbm> e; PathState p;
         HotStore<WG> hs; hs.base = hot_lds + tid;
         const bool ok = wg_env<WG>(a, wg_base, tid, e);
-        p.rng.state = 0; p.rng.inc = 0; p.sample_idx = 0;
+        p.rng.state = 0; p.rng.inc = 0;
         p.ray = make_ray(f3s(0.f), f3(0.f, 0.f, 1.f), 0.f, 0.f); p.si.t = pm_inf(); p.si.p = f3s(0.f); p.si.uv.x = p.si.uv.y = 0.f; p.si.shape = -1; p.si.prim = 0;
         p.medium = -1; p.thr = p.res = p.trans = f3s(0.f); p.eta = 1.f; p.depth = 0; p.channel = 0; p.mode = M_MAIN; p.flags = 0; p.wa = p.wb = 0.f;
         p.st = S_DONE;
@@ -716,11 +734,15 @@ DEV void volpath_workgroup(const MTS_CONST_AS void *kernarg, Counters &cnt) {
             const uint32_t i = (wg_base % ppb) + tid;
             p.rng.seed(a.sc.sensor.seed + (uint64_t) e.blk.id * ppb + i, PCG32_DEFAULT_STREAM);     // sampler.cpp:83-96
             for (int k = 0; k < 5; ++k) e.cold.f(C_ACC + k) = 0.f;
+            e.cold.f(C_SAMPLE) = __uint_as_float(0u);
             vm.begin_sample(p, e);
             vm.top(p, e);
         }
         hs.store(p, vm.classify(p));
     }
+#if defined(MTSAMD_BLOCKSTATS)
+    long long bs_t0 = clock64(); unsigned long long bs_loc[24] = {};     // [2c]: executions, [2c+1]: lanes, [16+c]: cycles, [16+7]: sort / barriers / vote
+#endif
     for (;;) {
         __syncthreads();
         // ---- counting sort of the workgroup's paths by class
@@ -755,6 +777,10 @@ DEV void volpath_workgroup(const MTS_CONST_AS void *kernarg, Counters &cnt) {
             int sel = -1, best = 0;
             for (int c = 0; c < B_DONE; ++c) { int v = __popcll(__ballot(cls == c)); if (v > best) { best = v; sel = c; } }
             if (best == 0 || (round > 0 && best < WG_MIN_LANES)) break;
+#if defined(MTSAMD_BLOCKSTATS)
+            if (COUNT) { bs_loc[2 * sel] += 1ull; bs_loc[2 * sel + 1] += (unsigned long long) best;
+                         long long t = clock64(); bs_loc[16 + 7] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
+#endif
             if (cls == sel) {
                 switch (sel) {
                     case B_INT: wg_block<COUNT, WG, B_INT>(kernarg, hot_lds, wg_base, pid, &cnt); break;
@@ -766,8 +792,149 @@ DEV void volpath_workgroup(const MTS_CONST_AS void *kernarg, Counters &cnt) {
                     default: wg_block<COUNT, WG, B_NEW>(kernarg, hot_lds, wg_base, pid, &cnt); break;
                 }
             }
+#if defined(MTSAMD_BLOCKSTATS)
+            if (COUNT) { long long t = clock64(); bs_loc[16 + sel] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
+#endif
         }
     }
+#if defined(MTSAMD_BLOCKSTATS)
+    if (COUNT) {
+        long long t = clock64(); bs_loc[16 + 7] += (unsigned long long) (t - bs_t0);
+        if (lane == 0) for (int k = 0; k < 24; ++k) atomicAdd(&g_blockstats[k], bs_loc[k]);
+    }
+#endif
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Driver 3: asynchronous regrouping.  Same LDS-resident path state as driver 2, but no workgroup barriers and
+// no sort: one LDS ring of path ids per block class.  A wave claims up to 64 ids from the fullest ring
+// (compare-and-swap on its head), runs that block with every claimed lane active, and appends each path to
+// the ring of the class it waits for next (wave-aggregated atomic add on the tail).  Waves never wait for
+// each other; a wave that finds only a short ring while others are still producing naps instead of running a
+// thin batch.  A ring slot holds 0xFFFF until its producer has written the id, so a consumer that claimed
+// the slot early spins for the few cycles the write takes.  There are WG paths and WG slots per ring, and a
+// path sits in at most one ring, so a slot is never overwritten before it has been consumed.
+#ifndef WGA_MIN_BATCH
+#define WGA_MIN_BATCH 48     // run a batch thinner than this only when no other wave of the workgroup is busy
+#endif
+template <int WG>
+DEV void wga_push(int cls, uint32_t pid, bool valid, uint16_t (*q_ids)[WG], uint32_t *q_tail, uint32_t *n_done, uint32_t lane) {
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll 1
+    for (int c = 0; c < B_DONE; ++c) {
+        const unsigned long long m = __ballot(valid && cls == c);
+        if (m == 0) continue;
+        const int leader = __ffsll((long long) m) - 1;
+        uint32_t base = 0;
+        if ((int) lane == leader) base = atomicAdd(&q_tail[c], (uint32_t) __popcll(m));
+        base = (uint32_t) __builtin_amdgcn_readlane((int) base, leader);
+        if (valid && cls == c) q_ids[c][(base + (uint32_t) __popcll(m & lt)) & (uint32_t) (WG - 1)] = (uint16_t) pid;
+    }
+    const unsigned long long md = __ballot(valid && cls == B_DONE);
+    if (md != 0 && (int) lane == __ffsll((long long) md) - 1) atomicAdd(n_done, (uint32_t) __popcll(md));
+}
+
+template <bool COUNT, int WG>
+DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt) {
+    constexpr int NQ = B_DONE;
+    static_assert((WG & (WG - 1)) == 0 && WG <= 32768, "ring indices wrap with a mask and ids are 16 bit");
+    __shared__ uint32_t hot_lds[H_COUNT * WG];
+    __shared__ uint16_t q_ids[NQ][WG];
+    __shared__ uint32_t q_head[8], q_tail[8], q_misc[2];     // q_misc[0]: finished paths, q_misc[1]: waves running a block
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wg_base = blockIdx.x * WG;
+    for (int c = 0; c < NQ; ++c) q_ids[c][tid] = 0xFFFFu;
+    if (tid < 8) { q_head[tid] = 0; q_tail[tid] = 0; }
+    if (tid < 2) q_misc[tid] = 0;
+    __syncthreads();
+    {   // ---- initialise the path this thread starts with (integrator.cpp:198) and queue it
+        const WgArgs a = cload_k<WgArgs>(kernarg);
+        VolpathMachine<COUNT> vm(a.sc, cnt);
+        PathEnvT<ColdStoreHbm> e; PathState p;
+        HotStore<WG> hs; hs.base = hot_lds + tid;
+        const bool ok = wg_env<WG>(a, wg_base, tid, e);
+        p.rng.state = 0; p.rng.inc = 0;
+        p.ray = make_ray(f3s(0.f), f3(0.f, 0.f, 1.f), 0.f, 0.f); p.si.t = pm_inf(); p.si.p = f3s(0.f); p.si.uv.x = p.si.uv.y = 0.f; p.si.shape = -1; p.si.prim = 0;
+        p.medium = -1; p.thr = p.res = p.trans = f3s(0.f); p.eta = 1.f; p.depth = 0; p.channel = 0; p.mode = M_MAIN; p.flags = 0; p.wa = p.wb = 0.f;
+        p.st = S_DONE;
+        if (ok) {
+            const uint32_t ppb = a.block_size * a.block_size;
+            const uint32_t i = (wg_base % ppb) + tid;
+            p.rng.seed(a.sc.sensor.seed + (uint64_t) e.blk.id * ppb + i, PCG32_DEFAULT_STREAM);     // sampler.cpp:83-96
+            for (int k = 0; k < 5; ++k) e.cold.f(C_ACC + k) = 0.f;
+            e.cold.f(C_SAMPLE) = __uint_as_float(0u);
+            vm.begin_sample(p, e);
+            vm.top(p, e);
+        }
+        const int cls = vm.classify(p);
+        hs.store(p, cls);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        wga_push<WG>(cls, tid, true, q_ids, q_tail, &q_misc[0], lane);
+    }
+#if defined(MTSAMD_BLOCKSTATS)
+    long long bs_t0 = clock64(); unsigned long long bs_loc[24] = {};     // [2c]: executions, [2c+1]: lanes, [16+c]: cycles, [16+7]: claim / push / naps
+#endif
+    for (;;) {
+        // ---- pick the fullest ring
+        uint32_t hd = 0, avail = 0;
+        if (lane < (uint32_t) NQ) {
+            hd = __atomic_load_n(&q_head[lane], __ATOMIC_RELAXED);
+            avail = __atomic_load_n(&q_tail[lane], __ATOMIC_RELAXED) - hd;
+        }
+        int sel = -1; uint32_t best = 0;
+        for (int c = 0; c < NQ; ++c) { const uint32_t v = (uint32_t) __builtin_amdgcn_readlane((int) avail, c); if (v > best) { best = v; sel = c; } }
+        if (best == 0) {
+            if (__atomic_load_n(&q_misc[0], __ATOMIC_RELAXED) == (uint32_t) WG) break;       // every path of the workgroup has finished
+            __builtin_amdgcn_s_sleep(4);
+            continue;
+        }
+        if (best < (uint32_t) WGA_MIN_BATCH && __atomic_load_n(&q_misc[1], __ATOMIC_RELAXED) != 0u) { __builtin_amdgcn_s_sleep(4); continue; }
+        // ---- claim up to 64 ids
+        const uint32_t n = best < 64u ? best : 64u;
+        const uint32_t h = (uint32_t) __builtin_amdgcn_readlane((int) hd, sel);
+        uint32_t won = 0;
+        if (lane == 0) { won = atomicCAS(&q_head[sel], h, h + n) == h ? 1u : 0u; if (won) atomicAdd(&q_misc[1], 1u); }
+        if (!__builtin_amdgcn_readfirstlane((int) won)) continue;
+        uint32_t pid = 0;
+        const bool mine = lane < n;
+        if (mine) {
+            volatile uint16_t *slot = &q_ids[sel][(h + lane) & (uint32_t) (WG - 1)];
+            uint32_t v;
+            do { v = *slot; } while (v == 0xFFFFu);
+            *slot = 0xFFFFu;
+            pid = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#if defined(MTSAMD_BLOCKSTATS)
+        if (COUNT) { bs_loc[2 * sel] += 1ull; bs_loc[2 * sel + 1] += (unsigned long long) n;
+                     long long t = clock64(); bs_loc[16 + 7] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
+#endif
+        int cls = B_DONE;
+        if (mine) {
+            switch (sel) {
+                case B_INT: cls = wg_block<COUNT, WG, B_INT>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                case B_MED: cls = wg_block<COUNT, WG, B_MED>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                case B_SCATTER: cls = wg_block<COUNT, WG, B_SCATTER>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                case B_WSURF: cls = wg_block<COUNT, WG, B_WSURF>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                case B_SURF: cls = wg_block<COUNT, WG, B_SURF>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                case B_PHASE: cls = wg_block<COUNT, WG, B_PHASE>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                default: cls = wg_block<COUNT, WG, B_NEW>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+            }
+        }
+#if defined(MTSAMD_BLOCKSTATS)
+        if (COUNT) { long long t = clock64(); bs_loc[16 + sel] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
+#endif
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        wga_push<WG>(cls, pid, mine, q_ids, q_tail, &q_misc[0], lane);
+        if (lane == 0) atomicSub(&q_misc[1], 1u);
+    }
+#if defined(MTSAMD_BLOCKSTATS)
+    if (COUNT) {
+        long long t = clock64(); bs_loc[16 + 7] += (unsigned long long) (t - bs_t0);
+        if (lane == 0) for (int k = 0; k < 24; ++k) atomicAdd(&g_blockstats[k], bs_loc[k]);
+    }
+#endif
+}
+
 
 } // namespace mtsamd

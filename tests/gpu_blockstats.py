@@ -12,11 +12,11 @@ A.lib().mts_debug_blockstats(out, 1)
 scene.integrator().render(scene, sensor, collect_counters=True)
 st = scene.integrator().last_stats
 A.lib().mts_debug_blockstats(out, 0)
-names = ["INT", "MED", "SURF", "PHASE", "NEW"]
+names = ["INT", "MED", "SCATTER", "WSURF", "SURF", "PHASE", "NEW"]
 waves = w * h / 64
 print("samples/wave-lane", spp, "kernel ms", st["kernel_ms"])
 for i, n in enumerate(names):
     ex, lanes = out[2 * i], out[2 * i + 1]
     print("%-6s executions/wave/sample %8.2f  lanes/execution %6.2f  lane-visits/sample %7.2f  cycles/execution %8.1f  cycles/wave/sample %9.0f" % (
         n, ex / waves / spp, lanes / max(ex, 1), lanes / (w * h * spp), out[16 + i] / max(ex, 1), out[16 + i] / waves / spp))
-print("TOP+vote cycles/wave/sample %9.0f   total %9.0f" % (out[16 + 6] / waves / spp, sum(out[16:23]) / waves / spp))
+print("sort/vote/barrier cycles/wave/sample %9.0f   total %9.0f" % (out[16 + 7] / waves / spp, sum(out[16:24]) / waves / spp))
