@@ -110,9 +110,11 @@ def main():
     avg_launch_ms = kernel_ms / max(launches, 1)
     bytes_per_launch = bytes_per_sample * samples_rank * (args.steps / max(launches, 1))
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
-    kv = os.environ.get("MTSAMD_KERNEL", "wg256")
-    kernel_name = {"nested": "render_kernel<false, false>", "flat": "render_kernel<false, true>"}.get(
-        kv, "render_kernel_wg<false, %s>" % kv[2:])
+    kv = os.environ.get("MTSAMD_KERNEL", "wga512")
+    if kv in ("nested", "flat"):
+        kernel_name = "render_kernel<false, %s>" % ("true" if kv == "flat" else "false")
+    else:
+        kernel_name = "render_kernel_%s<false, %s>" % (kv.rstrip("0123456789"), kv.lstrip("wga"))
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "kernel": kernel_name, "avg_launch_ms": round(avg_launch_ms, 3),

@@ -165,7 +165,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             HIP_CHECK(hipMemcpyAsync(d_blocks.p, blocks.data(), blocks.size() * sizeof(DBlock), hipMemcpyHostToDevice, stream));
             HIP_CHECK(hipEventRecord(ev0, stream));
             // kernel variant: MTSAMD_KERNEL = nested | flat | wg256 | wg512 | wg1024 (default: see DESIGN.md)
-            int variant = 256;
+            int variant = 10512;
             if (const char *kv = getenv("MTSAMD_KERNEL")) {
                 if (!strcmp(kv, "nested")) variant = 0; else if (!strcmp(kv, "flat")) variant = 1;
                 else if (!strcmp(kv, "wg256")) variant = 256; else if (!strcmp(kv, "wg512")) variant = 512; else if (!strcmp(kv, "wg1024")) variant = 1024;

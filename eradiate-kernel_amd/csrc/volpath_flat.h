@@ -815,7 +815,7 @@ DEV void volpath_workgroup(const MTS_CONST_AS void *kernarg, Counters &cnt) {
 // the slot early spins for the few cycles the write takes.  There are WG paths and WG slots per ring, and a
 // path sits in at most one ring, so a slot is never overwritten before it has been consumed.
 #ifndef WGA_MIN_BATCH
-#define WGA_MIN_BATCH 48     // run a batch thinner than this only when no other wave of the workgroup is busy
+#define WGA_MIN_BATCH 1      // a batch thinner than this runs only when no other wave of the workgroup is busy (measured: napping never pays)
 #endif
 template <int WG>
 DEV void wga_push(int cls, uint32_t pid, bool valid, uint16_t (*q_ids)[WG], uint32_t *q_tail, uint32_t *n_done, uint32_t lane) {

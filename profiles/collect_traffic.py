@@ -11,20 +11,24 @@ value is recorded next to it."""
 import csv, glob, json, os, sys
 
 
+kernel_name = None
+
+
 def kernel_sum(d, counter):
     f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    global kernel_name
     tot, n = 0.0, set()
     for path in f:
         for r in csv.DictReader(open(path)):
             k = r["Kernel_Name"]
             if "render_kernel" in k and "<false" in k and r["Counter_Name"] == counter:   # the timed (non-counting) kernel
-                tot += float(r["Counter_Value"]); n.add(r["Dispatch_Id"])
+                tot += float(r["Counter_Value"]); n.add(r["Dispatch_Id"]); kernel_name = k.split("(")[0].replace("void mtsamd::", "")
     return tot, max(len(n), 1)
 
 
 fetch_kib, nf = kernel_sum(sys.argv[1], "FETCH_SIZE")
 write_kib, nw = kernel_sum(sys.argv[2], "WRITE_SIZE")
-out = {"kernel": "render_kernel_wg<false, 256>", "launches": [nf, nw],
+out = {"kernel": kernel_name, "launches": [nf, nw],
        "fetch_bytes_raw": fetch_kib / nf * 1024.0, "fetch_bytes_corrected": 2.0 * fetch_kib / nf * 1024.0,
        "write_bytes": write_kib / nw * 1024.0}
 out["bytes_per_launch"] = out["fetch_bytes_corrected"] + out["write_bytes"]
