@@ -22,7 +22,8 @@
 
 namespace mtsamd {
 
-enum : uint32_t { S_TOP = 0, S_MED = 1, S_SURF = 2, S_PHASE = 3, S_BSDF = 4, S_DIRB = 5, S_NEW = 6, S_DONE = 7, S_SCATTER = 8 };
+enum : uint32_t { S_TOP = 0, S_MED = 1, S_SURF = 2, S_PHASE = 3, S_BSDF = 4, S_DIRB = 5, S_NEW = 6, S_DONE = 7, S_SCATTER = 8,
+                  S_ENDNEE = 9, S_ENDDIR0 = 10 };   // transient (workgroup drivers): end_nee / end_direct(0, 0) still to run on the full state
 enum : uint32_t { M_MAIN = 0, M_NEE = 1, M_DIR = 2 };
 enum : uint32_t { FL_ALIVE = 1, FL_VALID_RAY = 2, FL_SPEC_CHAIN = 4, FL_NEEDS_INT = 8, FL_FROM_MEDIUM = 16 };
 
@@ -222,7 +223,7 @@ struct VolpathMachine {
     DEV void queue_intersection(PathState &p) const {
         float bmint, bmaxt;
         bbox_ray_intersect(sc.bbox, p.ray, bmint, bmaxt);
-        p.si.t = pm_inf(); p.si.shape = -1;
+        p.si.t = pm_inf();                                     // si.shape etc. are only read behind hit_valid()
         if (pm_max(p.ray.mint, bmint) <= bmaxt) p.flags |= FL_NEEDS_INT; else p.flags &= ~FL_NEEDS_INT;
     }
     template <class E> DEV void begin_sample(PathState &p, const E &e) const {      // integrator.cpp:242-264, volpath.cpp:48-71
@@ -270,7 +271,7 @@ struct VolpathMachine {
     }
 
     // Loop heads of the three reference loops (cheap): volpath.cpp:79-87, :283-287, :385-388
-    template <class E> DEV void top(PathState &p, const E &e) const {
+    template <bool DEFER = false, class E> DEV void top(PathState &p, const E &e) const {
         if (p.st != S_TOP) return;
         const uint32_t max_depth = (uint32_t) sc.integrator.max_depth, rr_depth = (uint32_t) sc.integrator.rr_depth;
         if (p.mode == M_MAIN) {
@@ -284,7 +285,7 @@ struct VolpathMachine {
         } else if (p.mode == M_NEE) {
             float remaining_dist = p.wb * (1.f - MTS_SHADOW_EPSILON) - p.wa;
             p.ray.maxt = remaining_dist;
-            if (!(remaining_dist > 0.f)) end_nee(p, e);
+            if (!(remaining_dist > 0.f)) { if (DEFER) p.st = S_ENDNEE; else end_nee(p, e); }
             else { if (COUNT) cnt.n_nee_step++; p.st = p.medium >= 0 ? S_MED : S_SURF; }
         } else {
             if (COUNT) cnt.n_nee_step++;
@@ -337,7 +338,7 @@ struct VolpathMachine {
         p.mode = M_DIR; p.st = S_TOP;
     }
     // ================================================================= MEDIUM: one free-flight step of any of the three loops
-    template <class E> DEV void blk_med(PathState &p, const E &e) const {
+    template <bool DEFER = false, class E> DEV void blk_med(PathState &p, const E &e) const {
         if (p.st != S_MED || (p.flags & FL_NEEDS_INT)) return;
         const uint32_t max_depth = (uint32_t) sc.integrator.max_depth;
         const float u = p.rng.next_1d();                       // volpath.cpp:105 / :294 / :391
@@ -398,7 +399,10 @@ struct VolpathMachine {
             if (is_main) p.thr = weight;
             else {
                 p.trans = weight;
-                if (!any_nonzero(weight)) { if (is_nee) end_nee(p, e); else end_direct(p, e, f3s(0.f), 0.f); }   // volpath.cpp:358 / :456
+                if (!any_nonzero(weight)) {                        // volpath.cpp:358 / :456
+                    if (DEFER) p.st = is_nee ? S_ENDNEE : S_ENDDIR0;
+                    else if (is_nee) end_nee(p, e); else end_direct(p, e, f3s(0.f), 0.f);
+                }
             }
             return;
         }
@@ -562,11 +566,16 @@ struct VolpathMachine {
     }
 
     // Run the block(s) of class `sel` for this lane (a lane whose state does not match falls through)
-    template <class E> DEV void run(PathState &p, const E &e, int sel) const {
+    // the deferred tail of a block that ran with DEFER (p holds the full state here)
+    template <class E> DEV void finish(PathState &p, const E &e) const {
+        if (p.st == S_ENDNEE) end_nee(p, e);
+        else if (p.st == S_ENDDIR0) end_direct(p, e, f3s(0.f), 0.f);
+    }
+    template <bool DEFER = false, class E> DEV void run(PathState &p, const E &e, int sel) const {
         switch (sel) {
             case B_NEW: blk_new(p, e); break;
             case B_INT: blk_int(p, e); break;
-            case B_MED: blk_med(p, e); break;
+            case B_MED: blk_med<DEFER>(p, e); break;
             case B_SCATTER: blk_scatter(p, e); break;
             case B_WSURF: blk_wsurf(p, e); break;
             case B_SURF: blk_surf(p, e); blk_bsdf(p, e); break;
@@ -625,6 +634,27 @@ DEV void volpath_pixel_flat(const DScene &sc, Pcg32 &rng, const DBlock &blk, uin
 enum { H_RNG = 0, H_O = 2, H_D = 5, H_MINT = 8, H_MAXT = 9, H_SI = 10, H_MEDIUM = 18, H_THR = 19, H_RES = 22, H_ETA = 25,
        H_DEPTH = 26, H_PACKED = 27, H_TRANS = 28, H_WA = 31, H_WB = 32, H_DRCP = 33, H_COUNT = 36 };
 
+enum : uint32_t { G_RNG = 1, G_O = 2, G_D = 4 /* d and 1/d */, G_MINT = 8, G_MAXT = 16, G_SIT = 32 /* si.t */, G_SIX = 64 /* rest of si */,
+                  G_MED = 128, G_THR = 256, G_RES = 512, G_ETA = 1024, G_DEPTH = 2048, G_TRANS = 4096, G_WA = 8192, G_WB = 16384, G_ALL = 32767 };
+// What block class C (followed by top()) may read (`load`, a superset of `store`) and write (`store`).  end_nee / end_direct touch
+// almost everything; the classes with partial sets run them deferred (VolpathMachine::finish on the full state).
+template <int C> struct ClassFields { static constexpr uint32_t load = G_ALL, store = G_ALL; static constexpr bool defer = false; };
+template <> struct ClassFields<B_MED> {
+    static constexpr uint32_t load = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_MED | G_THR | G_ETA | G_DEPTH | G_TRANS | G_WA | G_WB,
+                              store = G_RNG | G_O | G_MINT | G_MAXT | G_SIT | G_THR | G_DEPTH | G_TRANS | G_WA;
+    static constexpr bool defer = true; };
+template <> struct ClassFields<B_INT> {          // every lane of the class wants the intersection: si is written, never read
+    static constexpr uint32_t load = G_O | G_D | G_MINT | G_MAXT | G_MED | G_TRANS, store = G_SIT | G_SIX | G_TRANS;
+    static constexpr bool defer = true; };
+template <> struct ClassFields<B_SCATTER> {
+    static constexpr uint32_t load = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_MED | G_THR | G_TRANS | G_WA | G_WB,
+                              store = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_TRANS | G_WA | G_WB;
+    static constexpr bool defer = true; };
+template <> struct ClassFields<B_PHASE> {
+    static constexpr uint32_t load = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_MED | G_THR | G_ETA | G_DEPTH,
+                              store = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_THR;
+    static constexpr bool defer = true; };
+
 template <int WG>
 struct HotStore {
     uint32_t *base;                                          // &lds[0][path]
@@ -637,6 +667,41 @@ struct HotStore {
         return p.st | (p.mode << 4) | (p.channel << 6) | (p.flags << 8) | ((uint32_t) cls << 13);
     }
     DEV static int cls_of(uint32_t packed) { return (int) (packed >> 13) & 7; }
+    // field groups: a block loads / stores only what it can read / write (ClassFields below)
+    template <uint32_t M> DEV void store_m(const PathState &p, int cls) const {
+        if (M & G_RNG) { u(H_RNG) = (uint32_t) p.rng.state; u(H_RNG + 1) = (uint32_t) (p.rng.state >> 32); }
+        if (M & G_O) put3(H_O, p.ray.o);
+        if (M & G_D) { put3(H_D, p.ray.d); put3(H_DRCP, p.ray.d_rcp); }
+        if (M & G_MINT) putf(H_MINT, p.ray.mint);
+        if (M & G_MAXT) putf(H_MAXT, p.ray.maxt);
+        if (M & G_SIT) putf(H_SI, p.si.t);
+        if (M & G_SIX) { put3(H_SI + 1, p.si.p); putf(H_SI + 4, p.si.uv.x); putf(H_SI + 5, p.si.uv.y); u(H_SI + 6) = (uint32_t) p.si.shape; u(H_SI + 7) = (uint32_t) p.si.prim; }
+        if (M & G_MED) u(H_MEDIUM) = (uint32_t) p.medium;
+        if (M & G_THR) put3(H_THR, p.thr);
+        if (M & G_RES) put3(H_RES, p.res);
+        if (M & G_ETA) putf(H_ETA, p.eta);
+        if (M & G_DEPTH) u(H_DEPTH) = p.depth;
+        if (M & G_TRANS) put3(H_TRANS, p.trans);
+        if (M & G_WA) putf(H_WA, p.wa);
+        if (M & G_WB) putf(H_WB, p.wb);
+        u(H_PACKED) = pack(p, cls);
+    }
+    template <uint32_t M> DEV void load_m(PathState &p) const {
+        p.rng.state = 0; p.rng.inc = (PCG32_DEFAULT_STREAM << 1u) | 1u;
+        if (M & G_RNG) p.rng.state = (uint64_t) u(H_RNG) | ((uint64_t) u(H_RNG + 1) << 32);
+        p.ray.o = (M & G_O) ? get3(H_O) : f3s(0.f);
+        p.ray.d = (M & G_D) ? get3(H_D) : f3s(0.f); p.ray.d_rcp = (M & G_D) ? get3(H_DRCP) : f3s(0.f);
+        p.ray.mint = (M & G_MINT) ? f(H_MINT) : 0.f; p.ray.maxt = (M & G_MAXT) ? f(H_MAXT) : 0.f;
+        p.si.t = (M & G_SIT) ? f(H_SI) : pm_inf();
+        p.si.p = f3s(0.f); p.si.uv.x = p.si.uv.y = 0.f; p.si.shape = -1; p.si.prim = 0;
+        if (M & G_SIX) { p.si.p = get3(H_SI + 1); p.si.uv.x = f(H_SI + 4); p.si.uv.y = f(H_SI + 5); p.si.shape = (int) u(H_SI + 6); p.si.prim = (int) u(H_SI + 7); }
+        p.medium = (M & G_MED) ? (int) u(H_MEDIUM) : -1;
+        p.thr = (M & G_THR) ? get3(H_THR) : f3s(0.f); p.res = (M & G_RES) ? get3(H_RES) : f3s(0.f);
+        p.eta = (M & G_ETA) ? f(H_ETA) : 1.f; p.depth = (M & G_DEPTH) ? u(H_DEPTH) : 0u;
+        p.trans = (M & G_TRANS) ? get3(H_TRANS) : f3s(0.f); p.wa = (M & G_WA) ? f(H_WA) : 0.f; p.wb = (M & G_WB) ? f(H_WB) : 0.f;
+        const uint32_t pk = u(H_PACKED);
+        p.st = pk & 15u; p.mode = (pk >> 4) & 3u; p.channel = (pk >> 6) & 3u; p.flags = (pk >> 8) & 31u;
+    }
     DEV void store(const PathState &p, int cls) const {
         u(H_RNG) = (uint32_t) p.rng.state; u(H_RNG + 1) = (uint32_t) (p.rng.state >> 32);
         put3(H_O, p.ray.o); put3(H_D, p.ray.d); put3(H_DRCP, p.ray.d_rcp); putf(H_MINT, p.ray.mint); putf(H_MAXT, p.ray.maxt);
@@ -702,12 +767,21 @@ static __device__ WG_BLOCK_ATTR int wg_block(const MTS_CONST_AS void *kernarg_, 
     VolpathMachine<COUNT> vm(a.sc, *cnt);
     PathEnvT<ColdStoreHbm> e; wg_env<WG>(a, wg_base, pid, e);
     HotStore<WG> hs; hs.base = hot_lds + pid;
+    typedef ClassFields<C> CF;
     PathState p;
-    hs.load(p);
-    vm.run(p, e, C);
-    vm.top(p, e);
-    const int cls = vm.classify(p);
-    hs.store(p, cls);
+    hs.template load_m<CF::load>(p);
+    vm.template run<CF::defer>(p, e, C);
+    vm.template top<CF::defer>(p, e);
+    int cls = vm.classify(p);
+    hs.template store_m<CF::store>(p, cls);
+    if (CF::defer && (p.st == S_ENDNEE || p.st == S_ENDDIR0)) {     // rare tail on the full state
+        PathState q;
+        hs.template load_m<G_ALL>(q);
+        vm.finish(q, e);
+        vm.top(q, e);
+        cls = vm.classify(q);
+        hs.template store_m<G_ALL>(q, cls);
+    }
     return cls;
 }
 
