@@ -110,11 +110,14 @@ def main():
     avg_launch_ms = kernel_ms / max(launches, 1)
     bytes_per_launch = bytes_per_sample * samples_rank * (args.steps / max(launches, 1))
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
-    kv = os.environ.get("MTSAMD_KERNEL", "wga512")
+    kv = os.environ.get("MTSAMD_KERNEL", "wga1024")
     if kv in ("nested", "flat"):
         kernel_name = "render_kernel<false, %s>" % ("true" if kv == "flat" else "false")
+    elif kv.startswith("wga"):
+        paths = int(kv[3:]); nt = int(os.environ.get("MTSAMD_WG_THREADS", "768" if paths == 1024 else str(paths)))
+        kernel_name = "render_kernel_wga<false, %d, %d, %d>" % (paths, nt, {1: 4, 0.875: 4, 0.75: 3, 0.625: 3, 0.5: 2}[nt / paths])
     else:
-        kernel_name = "render_kernel_%s<false, %s>" % (kv.rstrip("0123456789"), kv.lstrip("wga"))
+        kernel_name = "render_kernel_wg<false, %s>" % kv[2:]
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "kernel": kernel_name, "avg_launch_ms": round(avg_launch_ms, 3),

@@ -46,6 +46,10 @@ struct DMedium {
     int32_t sample_emitters, has_spectral_extinction, is_homogeneous;
     float max_density;
     DBBox aabb;
+    // MI355X layout: when sigma_t and albedo are single-channel trilinear clamp-mode grids sharing one transform, the host also
+    // uploads them interleaved, voxel by voxel {sigma_t, albedo} (padded by one voxel): the two x-neighbours of both grids are
+    // 16 contiguous bytes, so a lookup is 4 wide gathers instead of 16 dword gathers.  NULL otherwise.
+    const float *pair_grid;
 };
 
 struct DBsdf { int32_t type; float reflectance[3], rho_0[3], k[3], g[3], rho_c[3]; uint32_t flags; };

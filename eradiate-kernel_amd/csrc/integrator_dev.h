@@ -64,7 +64,16 @@ DEV DRay make_ray(F3 o, F3 d, float mint, float maxt) { DRay r; r.o = o; r.d = d
 DEV F3 ray_at(const DRay &r, float t) { return fmadd(r.d, t, r.o); }                       // core/ray.h:65
 DEV DRay spawn_ray(F3 p, F3 d) { return make_ray(p, d, (1.f + hmax_abs(p)) * MTS_RAY_EPSILON, pm_inf()); }   // render/interaction.h:58-61
 
+#if defined(MTSAMD_BLOCKSTATS)
+// diagnostic build: per-segment cycle accumulators of the MEDIUM block (clock64 = s_memtime, shader cycles)
+struct Counters { uint32_t n_iter, n_lookup, n_nee_step; unsigned long long seg[8]; long long tmark; };
+#define MTS_SEG_BEGIN(c) do { (c).tmark = clock64(); } while (0)
+#define MTS_SEG(c, k) do { long long t_ = clock64(); (c).seg[k] += (unsigned long long) (t_ - (c).tmark); (c).tmark = t_; } while (0)
+#else
 struct Counters { uint32_t n_iter, n_lookup, n_nee_step; };
+#define MTS_SEG_BEGIN(c) do { } while (0)
+#define MTS_SEG(c, k) do { } while (0)
+#endif
 
 // What survives of a SurfaceInteraction between loop iterations: the hit distance, the hit point
 // (computed from the ray that found it), and the primitive; normals / frames / wi are rebuilt on

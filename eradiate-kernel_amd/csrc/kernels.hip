@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(256) render_kernel(DScene sc, const DBlock *__
     if (lx >= (uint32_t) blk.sx || ly >= (uint32_t) blk.sy) return;
     Pcg32 rng;
     rng.seed(sc.sensor.seed + (uint64_t) blk.id * ppb + i, PCG32_DEFAULT_STREAM);             // sampler.cpp:83-96, integrator.cpp:198
-    Counters cnt; cnt.n_iter = cnt.n_lookup = cnt.n_nee_step = 0;
+    Counters cnt = {};
     if (FLAT) {
         __shared__ float cold_lds[C_COUNT * 256];
         ColdStore cold; cold.base = cold_lds + threadIdx.x; cold.stride = 256;
@@ -78,7 +78,7 @@ template <bool COUNT, int WG>
 __global__ void __launch_bounds__(WG, WG >= 1024 ? 4 : (WG >= 512 ? 4 : 4)) render_kernel_wg(DScene sc, const DBlock *blocks, uint32_t n_blocks, uint32_t block_size,
                                                         uint32_t sample_count, float *film, float *cold_g, uint32_t cold_stride,
                                                         unsigned long long *counters) {
-    Counters cnt; cnt.n_iter = cnt.n_lookup = cnt.n_nee_step = 0;
+    Counters cnt = {};
     volpath_workgroup<COUNT, WG>((const MTS_CONST_AS void *) __builtin_amdgcn_kernarg_segment_ptr(), cnt);
     if (COUNT) {
         atomicAdd(counters + 0, (unsigned long long) cnt.n_iter);
@@ -86,13 +86,14 @@ __global__ void __launch_bounds__(WG, WG >= 1024 ? 4 : (WG >= 512 ? 4 : 4)) rend
         atomicAdd(counters + 2, (unsigned long long) cnt.n_nee_step);
     }
 }
-// Asynchronous-regrouping variant (volpath_flat.h, driver 3); same parameter list / WgArgs.
-template <bool COUNT, int WG>
-__global__ void __launch_bounds__(WG, 4) render_kernel_wga(DScene sc, const DBlock *blocks, uint32_t n_blocks, uint32_t block_size,
-                                                         uint32_t sample_count, float *film, float *cold_g, uint32_t cold_stride,
-                                                         unsigned long long *counters) {
-    Counters cnt; cnt.n_iter = cnt.n_lookup = cnt.n_nee_step = 0;
-    volpath_workgroup_async<COUNT, WG>((const MTS_CONST_AS void *) __builtin_amdgcn_kernarg_segment_ptr(), cnt);
+// Asynchronous-regrouping variant (volpath_flat.h, driver 3); same parameter list / WgArgs.  WG paths are served by NT threads;
+// WPE = waves per SIMD the register budget is sized for (512 / WPE VGPRs).
+template <bool COUNT, int WG, int NT, int WPE>
+__global__ void __launch_bounds__(NT, WPE) render_kernel_wga(DScene sc, const DBlock *blocks, uint32_t n_blocks, uint32_t block_size,
+                                                           uint32_t sample_count, float *film, float *cold_g, uint32_t cold_stride,
+                                                           unsigned long long *counters) {
+    Counters cnt = {};
+    volpath_workgroup_async<COUNT, WG, NT>((const MTS_CONST_AS void *) __builtin_amdgcn_kernarg_segment_ptr(), cnt);
     if (COUNT) {
         atomicAdd(counters + 0, (unsigned long long) cnt.n_iter);
         atomicAdd(counters + 1, (unsigned long long) cnt.n_lookup);
@@ -144,17 +145,26 @@ size_t render_workspace_floats(uint32_t n_blocks, uint32_t block_size, int varia
 }
 
 hipError_t launch_render(const DScene &sc, const DBlock *d_blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,
-                         float *d_film, unsigned long long *d_counters, bool count, int variant, float *d_workspace, hipStream_t stream) {
+                         float *d_film, unsigned long long *d_counters, bool count, int variant, int wg_threads, float *d_workspace, hipStream_t stream) {
     if (n_blocks == 0) return hipSuccess;
     const uint64_t threads = (uint64_t) n_blocks * block_size * block_size;
-    if (variant >= 10000 && sc.integrator.type == MTS_INTEGRATOR_VOLPATH) {        // asynchronous regrouping, variant = 10000 + workgroup size
+    if (variant >= 10000 && sc.integrator.type == MTS_INTEGRATOR_VOLPATH) {        // asynchronous regrouping, variant = 10000 + paths per workgroup
         const uint32_t wg = (uint32_t) (variant - 10000);
         const uint32_t grid = (uint32_t) ((threads + wg - 1) / wg);
         const uint32_t stride = grid * wg;
-#define LAUNCH_WGA(C, W) hipLaunchKernelGGL((render_kernel_wga<C, W>), dim3(grid), dim3(W), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters)
-        if (wg == 256) { if (count) LAUNCH_WGA(true, 256); else LAUNCH_WGA(false, 256); }
-        else if (wg == 512) { if (count) LAUNCH_WGA(true, 512); else LAUNCH_WGA(false, 512); }
-        else { if (count) LAUNCH_WGA(true, 1024); else LAUNCH_WGA(false, 1024); }
+        const int nt = wg_threads > 0 ? wg_threads : (int) wg;
+#define LAUNCH_WGA(W, T, E) do { if (count) hipLaunchKernelGGL((render_kernel_wga<true, W, T, E>), dim3(grid), dim3(T), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters); \
+                                 else hipLaunchKernelGGL((render_kernel_wga<false, W, T, E>), dim3(grid), dim3(T), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters); } while (0)
+        if (wg == 256 && nt == 256) LAUNCH_WGA(256, 256, 4);
+        else if (wg == 512 && nt == 512) LAUNCH_WGA(512, 512, 4);
+        else if (wg == 512 && nt == 384) LAUNCH_WGA(512, 384, 3);
+        else if (wg == 512 && nt == 256) LAUNCH_WGA(512, 256, 2);
+        else if (wg == 1024 && nt == 1024) LAUNCH_WGA(1024, 1024, 4);
+        else if (wg == 1024 && nt == 896) LAUNCH_WGA(1024, 896, 4);
+        else if (wg == 1024 && nt == 768) LAUNCH_WGA(1024, 768, 3);
+        else if (wg == 1024 && nt == 640) LAUNCH_WGA(1024, 640, 3);
+        else if (wg == 1024 && nt == 512) LAUNCH_WGA(1024, 512, 2);
+        else return hipErrorInvalidConfiguration;
 #undef LAUNCH_WGA
         return hipGetLastError();
     }

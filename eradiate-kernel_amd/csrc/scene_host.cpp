@@ -262,6 +262,14 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
                               a.filter == b.filter && a.wrap == b.wrap && memcmp(a.w2l, b.w2l, 64) == 0) ? 1 : 0;
             auto grey = [](const DVolume &v) { return v.type == MTS_VOLUME_GRID ? v.channels == 1 : (v.value[0] == v.value[1] && v.value[1] == v.value[2]); };
             dm.grey = (grey(a) && grey(b)) ? 1 : 0;
+            std::vector<float> pair;
+            if (dm.shared_grid && a.channels == 1 && b.channels == 1 && a.filter == MTS_FILTER_TRILINEAR && a.wrap == MTS_WRAP_CLAMP && a.nx >= 2) {
+                const std::vector<float> &ga = hs.grid_data[m.sigma_t_volume], &gb = hs.grid_data[m.albedo_volume];
+                const size_t n = (size_t) a.nx * a.ny * a.nz;
+                pair.assign(2 * (n + 1), 0.f);
+                for (size_t k = 0; k < n; ++k) { pair[2 * k] = ga[k]; pair[2 * k + 1] = gb[k]; }
+            }
+            hs.pair_data.push_back(std::move(pair));
         }
         hs.media.push_back(dm);
     }
@@ -401,6 +409,8 @@ void upload_host_scene(HostScene &hs, int device) {
         if (hs.volumes[i].type == MTS_VOLUME_GRID) hs.volumes[i].data = upload(hs, hs.grid_data[i]);
     for (size_t i = 0; i < hs.phases.size(); ++i)
         if (hs.phases[i].type == MTS_PHASE_TABULATED) { hs.phases[i].pdf = upload(hs, hs.tab_pdf[i]); hs.phases[i].cdf = upload(hs, hs.tab_cdf[i]); }
+    for (size_t i = 0; i < hs.media.size(); ++i)
+        if (!hs.pair_data[i].empty()) hs.media[i].pair_grid = upload(hs, hs.pair_data[i]);
     DScene &sc = hs.scene;
     sc.volumes = upload(hs, hs.volumes); sc.phases = upload(hs, hs.phases); sc.media = upload(hs, hs.media);
     sc.bsdfs = upload(hs, hs.bsdfs); sc.shapes = upload(hs, hs.shapes); sc.prims = upload(hs, hs.prims);

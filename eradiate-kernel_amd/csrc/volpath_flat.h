@@ -59,6 +59,21 @@ DEV float grid_fetch1(const MTS_GLOBAL_AS float *__restrict__ D, const GridCell 
                    D[c.r01 + c.x0], D[c.r01 + c.x1], D[c.r11 + c.x0], D[c.r11 + c.x1], c.w0, c.w1);
 }
 
+// Both grids of a medium from the interleaved copy (DMedium::pair_grid): one 16-byte gather per (z, y) row covers the two
+// x-neighbours of sigma_t and albedo.  Clamp mode only: x1 is x0 + 1 except on the last column, where both are nx - 1.
+typedef float mts_float4 __attribute__((ext_vector_type(4)));
+typedef mts_float4 __attribute__((aligned(8))) mts_float4_a8;
+DEV void grid_fetch_pair(const MTS_GLOBAL_AS float *__restrict__ P, const GridCell &c, int nx, float &sigma_t, float &albedo) {
+    const int xb = min(c.x0, nx - 2);
+    const bool hi0 = c.x0 != xb, hi1 = c.x1 != xb;           // take the second voxel of the pair
+    const mts_float4 q00 = *(const MTS_GLOBAL_AS mts_float4_a8 *) (P + 2 * (c.r00 + xb)), q10 = *(const MTS_GLOBAL_AS mts_float4_a8 *) (P + 2 * (c.r10 + xb)),
+                     q01 = *(const MTS_GLOBAL_AS mts_float4_a8 *) (P + 2 * (c.r01 + xb)), q11 = *(const MTS_GLOBAL_AS mts_float4_a8 *) (P + 2 * (c.r11 + xb));
+    sigma_t = trilerp(hi0 ? q00.z : q00.x, hi1 ? q00.z : q00.x, hi0 ? q10.z : q10.x, hi1 ? q10.z : q10.x,
+                      hi0 ? q01.z : q01.x, hi1 ? q01.z : q01.x, hi0 ? q11.z : q11.x, hi1 ? q11.z : q11.x, c.w0, c.w1);
+    albedo = trilerp(hi0 ? q00.w : q00.y, hi1 ? q00.w : q00.y, hi0 ? q10.w : q10.y, hi1 ? q10.w : q10.y,
+                     hi0 ? q01.w : q01.y, hi1 ? q01.w : q01.y, hi0 ? q11.w : q11.y, hi1 ? q11.w : q11.y, c.w0, c.w1);
+}
+
 template <bool COUNT>
 DEV MedStep medium_step(const DScene &sc, const DMedium m, const DRay &ray, float sample, uint32_t channel, bool want_albedo, Counters &cnt) {
     MedStep mi;
@@ -83,8 +98,16 @@ DEV MedStep medium_step(const DScene &sc, const DMedium m, const DRay &ray, floa
         mi.sigma_t = st;
         if (want_albedo) mi.sigma_s = st * volume_eval(cload(sc.volumes + m.albedo), mi.p);
     } else if (valid_mi) {
+        if (COUNT) MTS_SEG(cnt, 1);
         const DVolume vs = cload(sc.volumes + m.sigma_t), va = cload(sc.volumes + m.albedo);
-        if (m.shared_grid && m.grey && vs.filter == MTS_FILTER_TRILINEAR) {
+        if (m.pair_grid != nullptr) {
+            GridCell c = grid_cell(vs, mi.p);
+            float st_raw, al_raw;
+            grid_fetch_pair(as_global(m.pair_grid), c, vs.nx, st_raw, al_raw);
+            float st = m.scale * st_raw;
+            mi.sigma_t = f3s(st);
+            if (want_albedo) mi.sigma_s = f3s(st * al_raw);
+        } else if (m.shared_grid && m.grey && vs.filter == MTS_FILTER_TRILINEAR) {
             // both grids share one cell / one set of weights; single channel: one value serves the three channels
             GridCell c = grid_cell(vs, mi.p);
             float st = m.scale * grid_fetch1(as_global(vs.data), c);
@@ -96,6 +119,7 @@ DEV MedStep medium_step(const DScene &sc, const DMedium m, const DRay &ray, floa
             if (want_albedo) mi.sigma_s = st * volume_eval(va, mi.p);
         }
         if (COUNT) cnt.n_lookup++;
+        if (COUNT) MTS_SEG(cnt, 2);
     }
     mi.combined = combined;
     mi.info = (m.is_homogeneous ? MI_HOMOGENEOUS : 0u) | (m.has_spectral_extinction ? MI_SPECTRAL : 0u) |
@@ -769,11 +793,16 @@ static __device__ WG_BLOCK_ATTR int wg_block(const MTS_CONST_AS void *kernarg_, 
     HotStore<WG> hs; hs.base = hot_lds + pid;
     typedef ClassFields<C> CF;
     PathState p;
+    if (COUNT && C == B_MED) MTS_SEG_BEGIN(*cnt);
     hs.template load_m<CF::load>(p);
+    if (COUNT && C == B_MED) MTS_SEG(*cnt, 0);
     vm.template run<CF::defer>(p, e, C);
+    if (COUNT && C == B_MED) MTS_SEG(*cnt, 3);
     vm.template top<CF::defer>(p, e);
+    if (COUNT && C == B_MED) MTS_SEG(*cnt, 4);
     int cls = vm.classify(p);
     hs.template store_m<CF::store>(p, cls);
+    if (COUNT && C == B_MED) MTS_SEG(*cnt, 5);
     if (CF::defer && (p.st == S_ENDNEE || p.st == S_ENDDIR0)) {     // rare tail on the full state
         PathState q;
         hs.template load_m<G_ALL>(q);
@@ -908,32 +937,34 @@ DEV void wga_push(int cls, uint32_t pid, bool valid, uint16_t (*q_ids)[WG], uint
     if (md != 0 && (int) lane == __ffsll((long long) md) - 1) atomicAdd(n_done, (uint32_t) __popcll(md));
 }
 
-template <bool COUNT, int WG>
+template <bool COUNT, int WG /* paths */, int NT /* threads: fewer threads than paths keeps the rings fuller */>
 DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt) {
     constexpr int NQ = B_DONE;
     static_assert((WG & (WG - 1)) == 0 && WG <= 32768, "ring indices wrap with a mask and ids are 16 bit");
+    static_assert(NT % 64 == 0 && WG % 64 == 0 && NT <= WG, "whole waves");
     __shared__ uint32_t hot_lds[H_COUNT * WG];
     __shared__ uint16_t q_ids[NQ][WG];
     __shared__ uint32_t q_head[8], q_tail[8], q_misc[2];     // q_misc[0]: finished paths, q_misc[1]: waves running a block
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wg_base = blockIdx.x * WG;
-    for (int c = 0; c < NQ; ++c) q_ids[c][tid] = 0xFFFFu;
+    for (int c = 0; c < NQ; ++c) for (uint32_t i = tid; i < (uint32_t) WG; i += NT) q_ids[c][i] = 0xFFFFu;
     if (tid < 8) { q_head[tid] = 0; q_tail[tid] = 0; }
     if (tid < 2) q_misc[tid] = 0;
     __syncthreads();
-    {   // ---- initialise the path this thread starts with (integrator.cpp:198) and queue it
+#pragma unroll 1
+    for (uint32_t pid0 = tid; pid0 < (uint32_t) WG; pid0 += NT) {   // ---- initialise the paths (integrator.cpp:198) and queue them
         const WgArgs a = cload_k<WgArgs>(kernarg);
         VolpathMachine<COUNT> vm(a.sc, cnt);
         PathEnvT<ColdStoreHbm> e; PathState p;
-        HotStore<WG> hs; hs.base = hot_lds + tid;
-        const bool ok = wg_env<WG>(a, wg_base, tid, e);
+        HotStore<WG> hs; hs.base = hot_lds + pid0;
+        const bool ok = wg_env<WG>(a, wg_base, pid0, e);
         p.rng.state = 0; p.rng.inc = 0;
         p.ray = make_ray(f3s(0.f), f3(0.f, 0.f, 1.f), 0.f, 0.f); p.si.t = pm_inf(); p.si.p = f3s(0.f); p.si.uv.x = p.si.uv.y = 0.f; p.si.shape = -1; p.si.prim = 0;
         p.medium = -1; p.thr = p.res = p.trans = f3s(0.f); p.eta = 1.f; p.depth = 0; p.channel = 0; p.mode = M_MAIN; p.flags = 0; p.wa = p.wb = 0.f;
         p.st = S_DONE;
         if (ok) {
             const uint32_t ppb = a.block_size * a.block_size;
-            const uint32_t i = (wg_base % ppb) + tid;
+            const uint32_t i = (wg_base % ppb) + pid0;
             p.rng.seed(a.sc.sensor.seed + (uint64_t) e.blk.id * ppb + i, PCG32_DEFAULT_STREAM);     // sampler.cpp:83-96
             for (int k = 0; k < 5; ++k) e.cold.f(C_ACC + k) = 0.f;
             e.cold.f(C_SAMPLE) = __uint_as_float(0u);
@@ -943,7 +974,7 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         const int cls = vm.classify(p);
         hs.store(p, cls);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        wga_push<WG>(cls, tid, true, q_ids, q_tail, &q_misc[0], lane);
+        wga_push<WG>(cls, pid0, true, q_ids, q_tail, &q_misc[0], lane);
     }
 #if defined(MTSAMD_BLOCKSTATS)
     long long bs_t0 = clock64(); unsigned long long bs_loc[24] = {};     // [2c]: executions, [2c+1]: lanes, [16+c]: cycles, [16+7]: claim / push / naps
@@ -1006,6 +1037,7 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
     if (COUNT) {
         long long t = clock64(); bs_loc[16 + 7] += (unsigned long long) (t - bs_t0);
         if (lane == 0) for (int k = 0; k < 24; ++k) atomicAdd(&g_blockstats[k], bs_loc[k]);
+        if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_blockstats[24 + k], cnt.seg[k]);
     }
 #endif
 }

@@ -20,3 +20,6 @@ for i, n in enumerate(names):
     print("%-6s executions/wave/sample %8.2f  lanes/execution %6.2f  lane-visits/sample %7.2f  cycles/execution %8.1f  cycles/wave/sample %9.0f" % (
         n, ex / waves / spp, lanes / max(ex, 1), lanes / (w * h * spp), out[16 + i] / max(ex, 1), out[16 + i] / waves / spp))
 print("sort/vote/barrier cycles/wave/sample %9.0f   total %9.0f" % (out[16 + 7] / waves / spp, sum(out[16:24]) / waves / spp))
+seg = ["lds load", "rng+free-flight sample", "grid lookup", "transmittance/decide", "top", "lds store", "-", "-"]
+med_exec = max(out[2], 1)
+print("MED segments (cycles / execution):", ", ".join("%s %.0f" % (n, out[24 + i] / med_exec) for i, n in enumerate(seg[:6])))
