@@ -913,28 +913,25 @@ DEV void volpath_workgroup(const MTS_CONST_AS void *kernarg, Counters &cnt) {
 // no sort: one LDS ring of path ids per block class.  A wave claims up to 64 ids from the fullest ring
 // (compare-and-swap on its head), runs that block with every claimed lane active, and appends each path to
 // the ring of the class it waits for next (wave-aggregated atomic add on the tail).  Waves never wait for
-// each other; a wave that finds only a short ring while others are still producing naps instead of running a
-// thin batch.  A ring slot holds 0xFFFF until its producer has written the id, so a consumer that claimed
+// each other; a wave that finds every ring empty naps briefly.  A ring slot holds 0xFFFF until its producer has written the id, so a consumer that claimed
 // the slot early spins for the few cycles the write takes.  There are WG paths and WG slots per ring, and a
 // path sits in at most one ring, so a slot is never overwritten before it has been consumed.
-#ifndef WGA_MIN_BATCH
-#define WGA_MIN_BATCH 1      // a batch thinner than this runs only when no other wave of the workgroup is busy (measured: napping never pays)
-#endif
+// q_ht[2c] / q_ht[2c + 1]: head / tail of ring c (monotonic counters, slot = counter mod WG); "ring" B_DONE has no slots, its
+// tail counts the finished paths.  One LDS atomic per push: lane c adds the number of paths this wave appends to ring c.
 template <int WG>
-DEV void wga_push(int cls, uint32_t pid, bool valid, uint16_t (*q_ids)[WG], uint32_t *q_tail, uint32_t *n_done, uint32_t lane) {
+DEV void wga_push(int cls, uint32_t pid, bool valid, uint16_t (*q_ids)[WG], uint32_t *q_ht, uint32_t lane) {
     const unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll 1
-    for (int c = 0; c < B_DONE; ++c) {
+    uint32_t my_count = 0, my_rank = 0;
+#pragma unroll
+    for (int c = 0; c < B_COUNT; ++c) {
         const unsigned long long m = __ballot(valid && cls == c);
-        if (m == 0) continue;
-        const int leader = __ffsll((long long) m) - 1;
-        uint32_t base = 0;
-        if ((int) lane == leader) base = atomicAdd(&q_tail[c], (uint32_t) __popcll(m));
-        base = (uint32_t) __builtin_amdgcn_readlane((int) base, leader);
-        if (valid && cls == c) q_ids[c][(base + (uint32_t) __popcll(m & lt)) & (uint32_t) (WG - 1)] = (uint16_t) pid;
+        if ((int) lane == c) my_count = (uint32_t) __popcll(m);
+        if (cls == c) my_rank = (uint32_t) __popcll(m & lt);
     }
-    const unsigned long long md = __ballot(valid && cls == B_DONE);
-    if (md != 0 && (int) lane == __ffsll((long long) md) - 1) atomicAdd(n_done, (uint32_t) __popcll(md));
+    uint32_t base = 0;
+    if (lane < (uint32_t) B_COUNT && my_count != 0u) base = atomicAdd(&q_ht[2 * lane + 1], my_count);
+    const uint32_t my_base = (uint32_t) __builtin_amdgcn_ds_bpermute(cls << 2, (int) base);     // the base lane `cls` obtained
+    if (valid && cls != B_DONE) q_ids[cls][(my_base + my_rank) & (uint32_t) (WG - 1)] = (uint16_t) pid;
 }
 
 template <bool COUNT, int WG /* paths */, int NT /* threads: fewer threads than paths keeps the rings fuller */>
@@ -944,12 +941,12 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
     static_assert(NT % 64 == 0 && WG % 64 == 0 && NT <= WG, "whole waves");
     __shared__ uint32_t hot_lds[H_COUNT * WG];
     __shared__ uint16_t q_ids[NQ][WG];
-    __shared__ uint32_t q_head[8], q_tail[8], q_misc[2];     // q_misc[0]: finished paths, q_misc[1]: waves running a block
+    __shared__ unsigned long long q_ht64[B_COUNT];           // low word: head, high word: tail
+    uint32_t *const q_ht = (uint32_t *) q_ht64;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wg_base = blockIdx.x * WG;
     for (int c = 0; c < NQ; ++c) for (uint32_t i = tid; i < (uint32_t) WG; i += NT) q_ids[c][i] = 0xFFFFu;
-    if (tid < 8) { q_head[tid] = 0; q_tail[tid] = 0; }
-    if (tid < 2) q_misc[tid] = 0;
+    if (tid < 2u * B_COUNT) q_ht[tid] = 0;
     __syncthreads();
 #pragma unroll 1
     for (uint32_t pid0 = tid; pid0 < (uint32_t) WG; pid0 += NT) {   // ---- initialise the paths (integrator.cpp:198) and queue them
@@ -974,7 +971,7 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         const int cls = vm.classify(p);
         hs.store(p, cls);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        wga_push<WG>(cls, pid0, true, q_ids, q_tail, &q_misc[0], lane);
+        wga_push<WG>(cls, pid0, true, q_ids, q_ht, lane);
     }
 #if defined(MTSAMD_BLOCKSTATS)
     long long bs_t0 = clock64(); unsigned long long bs_loc[24] = {};     // [2c]: executions, [2c+1]: lanes, [16+c]: cycles, [16+7]: claim / push / naps
@@ -982,23 +979,22 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
     for (;;) {
         // ---- pick the fullest ring
         uint32_t hd = 0, avail = 0;
-        if (lane < (uint32_t) NQ) {
-            hd = __atomic_load_n(&q_head[lane], __ATOMIC_RELAXED);
-            avail = __atomic_load_n(&q_tail[lane], __ATOMIC_RELAXED) - hd;
+        if (lane < (uint32_t) B_COUNT) {
+            const unsigned long long ht = __atomic_load_n(&q_ht64[lane], __ATOMIC_RELAXED);
+            hd = (uint32_t) ht; avail = (uint32_t) (ht >> 32) - hd;
         }
         int sel = -1; uint32_t best = 0;
         for (int c = 0; c < NQ; ++c) { const uint32_t v = (uint32_t) __builtin_amdgcn_readlane((int) avail, c); if (v > best) { best = v; sel = c; } }
         if (best == 0) {
-            if (__atomic_load_n(&q_misc[0], __ATOMIC_RELAXED) == (uint32_t) WG) break;       // every path of the workgroup has finished
-            __builtin_amdgcn_s_sleep(4);
+            if ((uint32_t) __builtin_amdgcn_readlane((int) avail, B_DONE) == (uint32_t) WG) break;     // every path of the workgroup has finished
+            __builtin_amdgcn_s_sleep(2);
             continue;
         }
-        if (best < (uint32_t) WGA_MIN_BATCH && __atomic_load_n(&q_misc[1], __ATOMIC_RELAXED) != 0u) { __builtin_amdgcn_s_sleep(4); continue; }
         // ---- claim up to 64 ids
         const uint32_t n = best < 64u ? best : 64u;
         const uint32_t h = (uint32_t) __builtin_amdgcn_readlane((int) hd, sel);
         uint32_t won = 0;
-        if (lane == 0) { won = atomicCAS(&q_head[sel], h, h + n) == h ? 1u : 0u; if (won) atomicAdd(&q_misc[1], 1u); }
+        if (lane == 0) won = atomicCAS(&q_ht[2 * sel], h, h + n) == h ? 1u : 0u;
         if (!__builtin_amdgcn_readfirstlane((int) won)) continue;
         uint32_t pid = 0;
         const bool mine = lane < n;
@@ -1030,8 +1026,7 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         if (COUNT) { long long t = clock64(); bs_loc[16 + sel] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
 #endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        wga_push<WG>(cls, pid, mine, q_ids, q_tail, &q_misc[0], lane);
-        if (lane == 0) atomicSub(&q_misc[1], 1u);
+        wga_push<WG>(cls, pid, mine, q_ids, q_ht, lane);
     }
 #if defined(MTSAMD_BLOCKSTATS)
     if (COUNT) {
