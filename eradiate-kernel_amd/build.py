@@ -36,7 +36,9 @@ def build_backend(force=False, verbose=True, extra=()):
     if not force and not _stale(LIB, deps):
         return LIB
     extra = list(extra) + os.environ.get("MTSAMD_EXTRA_FLAGS", "").split()
-    cmd = [HIPCC] + FLAGS + list(extra) + ["-x", "hip"] + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB]
+    flags = [("-fno-hip-fp32-correctly-rounded-divide-sqrt" if (os.environ.get("MTSAMD_EXP_FASTDIV") and f == "-fhip-fp32-correctly-rounded-divide-sqrt") else f)
+             for f in FLAGS]                                 # MTSAMD_EXP_FASTDIV: measurement only, breaks parity
+    cmd = [HIPCC] + flags + list(extra) + ["-x", "hip"] + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

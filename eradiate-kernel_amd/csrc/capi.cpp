@@ -164,15 +164,14 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             DeviceBuffer<DBlock> d_blocks(blocks.size());
             HIP_CHECK(hipMemcpyAsync(d_blocks.p, blocks.data(), blocks.size() * sizeof(DBlock), hipMemcpyHostToDevice, stream));
             HIP_CHECK(hipEventRecord(ev0, stream));
-            // kernel variant: MTSAMD_KERNEL = nested | flat | wg256 | wg512 | wg1024 (default: see DESIGN.md)
-            int variant = 11024;                                   // default: asynchronous regrouping, 1024 paths served by 768 threads
+            // kernel variant: MTSAMD_KERNEL = nested | flat | wga256 | wga512 | wga1024 (default)
+            int variant = 11024;                                   // asynchronous regrouping, 1024 paths served by 768 threads
             if (const char *kv = getenv("MTSAMD_KERNEL")) {
                 if (!strcmp(kv, "nested")) variant = 0; else if (!strcmp(kv, "flat")) variant = 1;
-                else if (!strcmp(kv, "wg256")) variant = 256; else if (!strcmp(kv, "wg512")) variant = 512; else if (!strcmp(kv, "wg1024")) variant = 1024;
                 else if (!strcmp(kv, "wga256")) variant = 10256; else if (!strcmp(kv, "wga512")) variant = 10512; else if (!strcmp(kv, "wga1024")) variant = 11024;
-                else throw std::runtime_error("MTSAMD_KERNEL must be one of nested, flat, wg256, wg512, wg1024, wga256, wga512, wga1024");
+                else throw std::runtime_error("MTSAMD_KERNEL must be one of nested, flat, wga256, wga512, wga1024");
             }
-            if (variant > 1 && (block_size * block_size) % (uint32_t) (variant % 10000) != 0) variant = 1;     // small blocks: per-lane kernel
+            if (variant > 1 && (block_size * block_size) % (uint32_t) (variant - 10000) != 0) variant = 1;     // small blocks: per-lane kernel
             int wg_threads = variant == 11024 ? 768 : 0;            // MTSAMD_WG_THREADS: threads per workgroup of the wga kernels (<= paths)
             if (const char *tv = getenv("MTSAMD_WG_THREADS")) wg_threads = atoi(tv);
             DeviceBuffer<float> d_ws(render_workspace_floats((uint32_t) blocks.size(), block_size, variant));

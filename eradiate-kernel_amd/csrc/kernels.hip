@@ -72,21 +72,8 @@ __global__ void __launch_bounds__(256) render_kernel(DScene sc, const DBlock *__
     }
 }
 
-// Workgroup-regrouping variant of the volpath render kernel (volpath_flat.h, driver 2).  The parameter list
-// must stay in sync with WgArgs: the block functions re-read it from the kernarg segment with scalar loads.
-template <bool COUNT, int WG>
-__global__ void __launch_bounds__(WG, WG >= 1024 ? 4 : (WG >= 512 ? 4 : 4)) render_kernel_wg(DScene sc, const DBlock *blocks, uint32_t n_blocks, uint32_t block_size,
-                                                        uint32_t sample_count, float *film, float *cold_g, uint32_t cold_stride,
-                                                        unsigned long long *counters) {
-    Counters cnt = {};
-    volpath_workgroup<COUNT, WG>((const MTS_CONST_AS void *) __builtin_amdgcn_kernarg_segment_ptr(), cnt);
-    if (COUNT) {
-        atomicAdd(counters + 0, (unsigned long long) cnt.n_iter);
-        atomicAdd(counters + 1, (unsigned long long) cnt.n_lookup);
-        atomicAdd(counters + 2, (unsigned long long) cnt.n_nee_step);
-    }
-}
-// Asynchronous-regrouping variant (volpath_flat.h, driver 3); same parameter list / WgArgs.  WG paths are served by NT threads;
+// Asynchronous-regrouping variant of the volpath render kernel (volpath_flat.h, driver 2).  The parameter list must stay in
+// sync with WgArgs: the block functions re-read it from the kernarg segment with scalar loads.  WG paths are served by NT threads;
 // WPE = waves per SIMD the register budget is sized for (512 / WPE VGPRs).
 template <bool COUNT, int WG, int NT, int WPE>
 __global__ void __launch_bounds__(NT, WPE) render_kernel_wga(DScene sc, const DBlock *blocks, uint32_t n_blocks, uint32_t block_size,
@@ -168,17 +155,6 @@ hipError_t launch_render(const DScene &sc, const DBlock *d_blocks, uint32_t n_bl
 #undef LAUNCH_WGA
         return hipGetLastError();
     }
-    if (variant >= 256 && sc.integrator.type == MTS_INTEGRATOR_VOLPATH) {          // workgroup-regrouping kernel, variant = workgroup size
-        const uint32_t wg = (uint32_t) variant;
-        const uint32_t grid = (uint32_t) ((threads + wg - 1) / wg);
-        const uint32_t stride = grid * wg;
-#define LAUNCH_WG(C, W) hipLaunchKernelGGL((render_kernel_wg<C, W>), dim3(grid), dim3(W), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters)
-        if (wg == 256) { if (count) LAUNCH_WG(true, 256); else LAUNCH_WG(false, 256); }
-        else if (wg == 512) { if (count) LAUNCH_WG(true, 512); else LAUNCH_WG(false, 512); }
-        else { if (count) LAUNCH_WG(true, 1024); else LAUNCH_WG(false, 1024); }
-#undef LAUNCH_WG
-        return hipGetLastError();
-    }
     const bool flat = variant != 0;
     const uint32_t grid = (uint32_t) ((threads + 255) / 256);
     const bool use_flat = flat && sc.integrator.type == MTS_INTEGRATOR_VOLPATH;
@@ -207,8 +183,8 @@ hipError_t launch_intersect(const DScene &sc, int32_t n, const float *o, const f
 #if defined(MTSAMD_BLOCKSTATS)
 // diagnostic build only (python eradiate-kernel_amd/build.py with MTSAMD_EXTRA_FLAGS=-DMTSAMD_BLOCKSTATS)
 extern "C" int mts_debug_blockstats(unsigned long long *out32, int reset) {
-    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(mtsamd::g_blockstats), 32 * sizeof(unsigned long long)) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[32] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(mtsamd::g_blockstats), z, sizeof(z)) != hipSuccess) return 1; }
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(mtsamd::g_blockstats), 48 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[48] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(mtsamd::g_blockstats), z, sizeof(z)) != hipSuccess) return 1; }
     return 0;
 }
 #endif

@@ -50,6 +50,9 @@ PM_HD float pm_mulsign_neg(float a, float b) { return pm_from_bits(pm_bits(a) ^ 
 
 // Natural logarithm (Cephes-style reduction to [sqrt(1/2), sqrt(2)) + degree-8 polynomial).
 PM_HD float pm_log(float x) {
+#if defined(EXP_FASTMATH) && defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_logf(x) * 0.6931471805599453f;   // measurement only: breaks parity
+#endif
     uint32_t ix = pm_bits(x);
     if (ix >= 0x7f800000u) {            // negative, inf or NaN
         if (ix == 0x7f800000u) return x;                  // +inf
@@ -82,6 +85,9 @@ PM_HD float pm_log(float x) {
 
 // Exponential. Underflows to +0 below ln(FLT_MIN) (flush-to-zero semantics), overflows to +inf.
 PM_HD float pm_exp(float x) {
+#if defined(EXP_FASTMATH) && defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);   // measurement only: breaks parity
+#endif
     if (!(x == x)) return x;
     if (x > 88.7228317f) return pm_inf();
     if (x < -87.3365402f) return 0.0f;

@@ -10,9 +10,10 @@
 // Two drivers schedule the blocks:
 //   1. volpath_pixel_flat: one lane = one pixel, state in registers, per-wave census (__ballot/__popcll)
 //      and a vote for the block most lanes wait for (measured: ~40 % of the lanes served per block).
-//   2. volpath_workgroup: the hot state of the workgroup's paths lives in LDS as struct-of-arrays queues;
-//      every trip the paths are counting-sorted by the block they wait for, so a wave runs one block with
-//      (nearly) all lanes active, and each block is a separate function with its own small register budget.
+//   2. volpath_workgroup_async: the hot state of a workgroup's paths lives in LDS (struct of arrays), one LDS
+//      ring of path ids per block class; a wave claims 64 paths that wait for the same block, runs it with
+//      every lane active, and appends the paths to the rings of their next blocks.  No barriers, no sort.
+//      (A barrier-synchronised counting-sort driver was measured at half the speed and removed.)
 //
 // The random draws happen in exactly the order of the scalar_rgb variant (SURVEY.md 8(a')); results are
 // bit-identical to the nested formulation in integrator_dev.h and to the CPU restatement.
@@ -33,7 +34,7 @@ struct MedStep { float t, mint; F3 p, sigma_t, sigma_s, combined; uint32_t info;
 enum : uint32_t { MI_HOMOGENEOUS = 1, MI_SPECTRAL = 2, MI_SAMPLE_EMITTERS = 4, MI_GREY = 8, MI_PHASE_SHIFT = 8 + 8 };
 
 #if defined(MTSAMD_BLOCKSTATS)
-__device__ unsigned long long g_blockstats[32];    // [2b]: executions, [2b+1]: lanes served, [16+b]: cycles
+__device__ unsigned long long g_blockstats[48];    // [2b]: executions, [2b+1]: lanes served, [16+b]: cycles (b < 8), [24..29]: MEDIUM segments, [30]: idle, [31]: push, [32]: claim / vote
 #endif
 
 // textures/grid3d.cpp:259-341 split in two: cell coordinates / weights (shared by grids with the same
@@ -234,7 +235,8 @@ struct PathEnvT {
     DBlock blk; uint32_t lx, ly, sample_count; MTS_GLOBAL_AS float *film; Cold cold;
 };
 // Scheduling classes: the block a path is waiting for
-enum { B_INT = 0, B_MED, B_SCATTER, B_WSURF, B_SURF, B_PHASE, B_NEW, B_DONE, B_COUNT };
+enum { B_INT = 0, B_MED /* free-flight step of the main path */, B_SCATTER, B_WSURF, B_SURF, B_PHASE, B_NEW,
+       B_MEDW /* free-flight step of an NEE / direct-light walk */, B_DONE, B_COUNT };
 
 template <bool COUNT>
 struct VolpathMachine {
@@ -321,7 +323,7 @@ struct VolpathMachine {
     DEV static int classify(const PathState &p) {
         if (p.st == S_DONE) return B_DONE;
         if (wants_int(p)) return B_INT;
-        if (p.st == S_MED) return B_MED;
+        if (p.st == S_MED) return p.mode == M_MAIN ? B_MED : B_MEDW;
         if (p.st == S_SCATTER) return B_SCATTER;
         if (p.st == S_SURF) return p.mode == M_MAIN ? B_SURF : B_WSURF;
         if (p.st == S_BSDF) return B_SURF;
@@ -362,19 +364,22 @@ struct VolpathMachine {
         p.mode = M_DIR; p.st = S_TOP;
     }
     // ================================================================= MEDIUM: one free-flight step of any of the three loops
-    template <bool DEFER = false, class E> DEV void blk_med(PathState &p, const E &e) const {
+    // MODEK: 0 = lanes of the main path only, 1 = lanes of a walk only (workgroup driver: one class each), -1 = any
+    template <bool DEFER = false, int MODEK = -1, class E> DEV void blk_med(PathState &p, const E &e) const {
         if (p.st != S_MED || (p.flags & FL_NEEDS_INT)) return;
+        if (MODEK == 0 && p.mode != M_MAIN) return;
+        if (MODEK == 1 && p.mode == M_MAIN) return;
         const uint32_t max_depth = (uint32_t) sc.integrator.max_depth;
         const float u = p.rng.next_1d();                       // volpath.cpp:105 / :294 / :391
         MedStep mi;
         WATERFALL_BEGIN(p.medium, mu)
-            mi = medium_step<COUNT>(sc, cload(sc.media + mu), p.ray, u, p.channel, p.mode == M_MAIN, cnt);
+            mi = medium_step<COUNT>(sc, cload(sc.media + mu), p.ray, u, p.channel, MODEK == 0 ? true : (MODEK == 1 ? false : p.mode == M_MAIN), cnt);
         WATERFALL_END
         if (p.si.t < mi.t) mi.t = pm_inf();                    // volpath.cpp:112 / :300 / :397
         const bool spectral = (mi.info & MI_SPECTRAL) != 0, homogeneous = (mi.info & MI_HOMOGENEOUS) != 0, grey = (mi.info & MI_GREY) != 0;
         const F3 sigma_n = homogeneous ? f3s(0.f) : mi.combined - mi.sigma_t;
         const uint32_t channel = p.channel;
-        const bool is_main = p.mode == M_MAIN, is_nee = p.mode == M_NEE;
+        const bool is_main = MODEK == 0 ? true : (MODEK == 1 ? false : p.mode == M_MAIN), is_nee = MODEK == 0 ? false : p.mode == M_NEE;
         // transmittance / free-flight pdf of this step, one formula for the three loops:
         // medium.cpp:77-89 (volpath.cpp:113-117, :401-405) and the NEE variant bounded by remaining_dist (:305-311)
         const float remaining_dist = is_nee ? p.ray.maxt : pm_inf();
@@ -595,11 +600,12 @@ struct VolpathMachine {
         if (p.st == S_ENDNEE) end_nee(p, e);
         else if (p.st == S_ENDDIR0) end_direct(p, e, f3s(0.f), 0.f);
     }
-    template <bool DEFER = false, class E> DEV void run(PathState &p, const E &e, int sel) const {
+    template <bool DEFER = false, bool SPLIT = false, class E> DEV void run(PathState &p, const E &e, int sel) const {
         switch (sel) {
             case B_NEW: blk_new(p, e); break;
             case B_INT: blk_int(p, e); break;
-            case B_MED: blk_med<DEFER>(p, e); break;
+            case B_MED: if (SPLIT) blk_med<DEFER, 0>(p, e); else blk_med<DEFER, -1>(p, e); break;
+            case B_MEDW: if (SPLIT) blk_med<DEFER, 1>(p, e); else blk_med<DEFER, -1>(p, e); break;
             case B_SCATTER: blk_scatter(p, e); break;
             case B_WSURF: blk_wsurf(p, e); break;
             case B_SURF: blk_surf(p, e); blk_bsdf(p, e); break;
@@ -621,51 +627,54 @@ DEV void volpath_pixel_flat(const DScene &sc, Pcg32 &rng, const DBlock &blk, uin
     e.cold.f(C_SAMPLE) = __uint_as_float(0u);
     vm.begin_sample(p, e);
 #if defined(MTSAMD_BLOCKSTATS)
-    long long bs_t0 = clock64(); int bs_prev_sel = 7;
-    unsigned long long bs_loc[24] = {};
+    long long bs_t0 = clock64(); int bs_prev_sel = 8;
+    unsigned long long bs_loc[25] = {};                      // [24]: vote / top
 #endif
     while (__ballot(p.st != S_DONE)) {
 #if defined(MTSAMD_BLOCKSTATS)
-        if (COUNT) { long long t = clock64(); bs_loc[16 + bs_prev_sel] += (unsigned long long) (t - bs_t0); bs_t0 = t; bs_prev_sel = 7; }
+        if (COUNT) { long long t = clock64(); bs_loc[16 + bs_prev_sel] += (unsigned long long) (t - bs_t0); bs_t0 = t; bs_prev_sel = 8; }
 #endif
         vm.top(p, e);
         // census + vote: run the ONE block most lanes of this wave are waiting for
-        const int cls = vm.classify(p);
+        int cls = vm.classify(p);
+        if (cls == B_MEDW) cls = B_MED;                        // this driver runs the generic MEDIUM block for both
         int sel = B_MED, best = -1;
         for (int b = 0; b < B_DONE; ++b) { int v = __popcll(__ballot(cls == b)); if (v > best) { best = v; sel = b; } }
         if (best == 0) continue;
 #if defined(MTSAMD_BLOCKSTATS)
         if (COUNT) {
             bs_loc[2 * sel] += 1ull; bs_loc[2 * sel + 1] += (unsigned long long) best;
-            long long t = clock64(); bs_loc[16 + 7] += (unsigned long long) (t - bs_t0); bs_t0 = t; bs_prev_sel = sel;
+            long long t = clock64(); bs_loc[24] += (unsigned long long) (t - bs_t0); bs_t0 = t; bs_prev_sel = sel;
         }
 #endif
         vm.run(p, e, sel);
     }
 #if defined(MTSAMD_BLOCKSTATS)
     if (COUNT && __builtin_amdgcn_readfirstlane((int) (threadIdx.x & 63)) == (int) (threadIdx.x & 63))
-        for (int k = 0; k < 24; ++k) atomicAdd(&g_blockstats[k], bs_loc[k]);
+        { for (int k = 0; k < 24; ++k) atomicAdd(&g_blockstats[k], bs_loc[k]); atomicAdd(&g_blockstats[32], bs_loc[24]); }
 #endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Driver 2: workgroup-level regrouping.  A workgroup of WG threads owns WG paths (pixels) whose hot state
-// lives in LDS as struct-of-arrays "queues"; cold state lives in HBM.  Every trip the workgroup counting-sorts
-// its paths by the block they wait for (__ballot / __popcll per wave + a tiny LDS histogram), thread t then
-// processes the t-th path of the sorted order, so a wave sees (almost) a single class and runs that block
-// with all 64 lanes active.  Every block is its own function: load the path from LDS, run, store -- nothing
-// stays live across blocks, which keeps the register budget at 128 VGPRs (4 waves / SIMD).
+// Hot path state of the workgroup driver: WG paths (pixels) per workgroup, struct-of-arrays in LDS; cold state lives in HBM.
+// Every block class loads / stores only the fields it can touch (ClassFields), which keeps the blocks' register budget small.
+// depth shares a dword with the packed small fields (15 bits: a path of more than 32767 scattering events would need to
+// survive Russian roulette with probability < 0.95^32000).
 enum { H_RNG = 0, H_O = 2, H_D = 5, H_MINT = 8, H_MAXT = 9, H_SI = 10, H_MEDIUM = 18, H_THR = 19, H_RES = 22, H_ETA = 25,
-       H_DEPTH = 26, H_PACKED = 27, H_TRANS = 28, H_WA = 31, H_WB = 32, H_DRCP = 33, H_COUNT = 36 };
+       H_PACKED = 26 /* st, mode, channel, flags, class, depth */, H_TRANS = 27, H_WA = 30, H_WB = 31, H_DRCP = 32, H_COUNT = 35 };
 
 enum : uint32_t { G_RNG = 1, G_O = 2, G_D = 4 /* d and 1/d */, G_MINT = 8, G_MAXT = 16, G_SIT = 32 /* si.t */, G_SIX = 64 /* rest of si */,
-                  G_MED = 128, G_THR = 256, G_RES = 512, G_ETA = 1024, G_DEPTH = 2048, G_TRANS = 4096, G_WA = 8192, G_WB = 16384, G_ALL = 32767 };
+                  G_MED = 128, G_THR = 256, G_RES = 512, G_ETA = 1024, G_TRANS = 2048, G_WA = 4096, G_WB = 8192, G_ALL = 16383 };
 // What block class C (followed by top()) may read (`load`, a superset of `store`) and write (`store`).  end_nee / end_direct touch
 // almost everything; the classes with partial sets run them deferred (VolpathMachine::finish on the full state).
 template <int C> struct ClassFields { static constexpr uint32_t load = G_ALL, store = G_ALL; static constexpr bool defer = false; };
-template <> struct ClassFields<B_MED> {
-    static constexpr uint32_t load = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_MED | G_THR | G_ETA | G_DEPTH | G_TRANS | G_WA | G_WB,
-                              store = G_RNG | G_O | G_MINT | G_MAXT | G_SIT | G_THR | G_DEPTH | G_TRANS | G_WA;
+template <> struct ClassFields<B_MED> {          // main path: tracks thr
+    static constexpr uint32_t load = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_MED | G_THR | G_ETA,
+                              store = G_RNG | G_O | G_MINT | G_SIT | G_THR;
+    static constexpr bool defer = true; };
+template <> struct ClassFields<B_MEDW> {         // NEE / direct-light walk: tracks trans, the NEE walk also its distance budget
+    static constexpr uint32_t load = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_MED | G_TRANS | G_WA | G_WB,
+                              store = G_RNG | G_O | G_MINT | G_MAXT | G_SIT | G_TRANS | G_WA;
     static constexpr bool defer = true; };
 template <> struct ClassFields<B_INT> {          // every lane of the class wants the intersection: si is written, never read
     static constexpr uint32_t load = G_O | G_D | G_MINT | G_MAXT | G_MED | G_TRANS, store = G_SIT | G_SIX | G_TRANS;
@@ -675,7 +684,7 @@ template <> struct ClassFields<B_SCATTER> {
                               store = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_TRANS | G_WA | G_WB;
     static constexpr bool defer = true; };
 template <> struct ClassFields<B_PHASE> {
-    static constexpr uint32_t load = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_MED | G_THR | G_ETA | G_DEPTH,
+    static constexpr uint32_t load = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_MED | G_THR | G_ETA,
                               store = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_THR;
     static constexpr bool defer = true; };
 
@@ -688,9 +697,12 @@ struct HotStore {
     DEV void put3(int k, F3 v) const { putf(k, v.x); putf(k + 1, v.y); putf(k + 2, v.z); }
     DEV F3 get3(int k) const { return f3(f(k), f(k + 1), f(k + 2)); }
     DEV static uint32_t pack(const PathState &p, int cls) {
-        return p.st | (p.mode << 4) | (p.channel << 6) | (p.flags << 8) | ((uint32_t) cls << 13);
+        return p.st | (p.mode << 4) | (p.channel << 6) | (p.flags << 8) | ((uint32_t) cls << 13) | ((p.depth < 32767u ? p.depth : 32767u) << 17);
     }
-    DEV static int cls_of(uint32_t packed) { return (int) (packed >> 13) & 7; }
+    DEV static int cls_of(uint32_t packed) { return (int) (packed >> 13) & 15; }
+    DEV static void unpack(uint32_t pk, PathState &p) {
+        p.st = pk & 15u; p.mode = (pk >> 4) & 3u; p.channel = (pk >> 6) & 3u; p.flags = (pk >> 8) & 31u; p.depth = pk >> 17;
+    }
     // field groups: a block loads / stores only what it can read / write (ClassFields below)
     template <uint32_t M> DEV void store_m(const PathState &p, int cls) const {
         if (M & G_RNG) { u(H_RNG) = (uint32_t) p.rng.state; u(H_RNG + 1) = (uint32_t) (p.rng.state >> 32); }
@@ -704,7 +716,6 @@ struct HotStore {
         if (M & G_THR) put3(H_THR, p.thr);
         if (M & G_RES) put3(H_RES, p.res);
         if (M & G_ETA) putf(H_ETA, p.eta);
-        if (M & G_DEPTH) u(H_DEPTH) = p.depth;
         if (M & G_TRANS) put3(H_TRANS, p.trans);
         if (M & G_WA) putf(H_WA, p.wa);
         if (M & G_WB) putf(H_WB, p.wb);
@@ -721,41 +732,15 @@ struct HotStore {
         if (M & G_SIX) { p.si.p = get3(H_SI + 1); p.si.uv.x = f(H_SI + 4); p.si.uv.y = f(H_SI + 5); p.si.shape = (int) u(H_SI + 6); p.si.prim = (int) u(H_SI + 7); }
         p.medium = (M & G_MED) ? (int) u(H_MEDIUM) : -1;
         p.thr = (M & G_THR) ? get3(H_THR) : f3s(0.f); p.res = (M & G_RES) ? get3(H_RES) : f3s(0.f);
-        p.eta = (M & G_ETA) ? f(H_ETA) : 1.f; p.depth = (M & G_DEPTH) ? u(H_DEPTH) : 0u;
+        p.eta = (M & G_ETA) ? f(H_ETA) : 1.f;
         p.trans = (M & G_TRANS) ? get3(H_TRANS) : f3s(0.f); p.wa = (M & G_WA) ? f(H_WA) : 0.f; p.wb = (M & G_WB) ? f(H_WB) : 0.f;
-        const uint32_t pk = u(H_PACKED);
-        p.st = pk & 15u; p.mode = (pk >> 4) & 3u; p.channel = (pk >> 6) & 3u; p.flags = (pk >> 8) & 31u;
+        unpack(u(H_PACKED), p);
     }
-    DEV void store(const PathState &p, int cls) const {
-        u(H_RNG) = (uint32_t) p.rng.state; u(H_RNG + 1) = (uint32_t) (p.rng.state >> 32);
-        put3(H_O, p.ray.o); put3(H_D, p.ray.d); put3(H_DRCP, p.ray.d_rcp); putf(H_MINT, p.ray.mint); putf(H_MAXT, p.ray.maxt);
-        putf(H_SI, p.si.t); put3(H_SI + 1, p.si.p); putf(H_SI + 4, p.si.uv.x); putf(H_SI + 5, p.si.uv.y);
-        u(H_SI + 6) = (uint32_t) p.si.shape; u(H_SI + 7) = (uint32_t) p.si.prim;
-        u(H_MEDIUM) = (uint32_t) p.medium; put3(H_THR, p.thr); put3(H_RES, p.res); putf(H_ETA, p.eta);
-        u(H_DEPTH) = p.depth; u(H_PACKED) = pack(p, cls);
-        put3(H_TRANS, p.trans); putf(H_WA, p.wa); putf(H_WB, p.wb);
-    }
-    DEV void load(PathState &p) const {
-        p.rng.state = (uint64_t) u(H_RNG) | ((uint64_t) u(H_RNG + 1) << 32); p.rng.inc = (PCG32_DEFAULT_STREAM << 1u) | 1u;
-        p.ray.o = get3(H_O); p.ray.d = get3(H_D); p.ray.d_rcp = get3(H_DRCP); p.ray.mint = f(H_MINT); p.ray.maxt = f(H_MAXT);
-        p.si.t = f(H_SI); p.si.p = get3(H_SI + 1); p.si.uv.x = f(H_SI + 4); p.si.uv.y = f(H_SI + 5);
-        p.si.shape = (int) u(H_SI + 6); p.si.prim = (int) u(H_SI + 7);
-        p.medium = (int) u(H_MEDIUM); p.thr = get3(H_THR); p.res = get3(H_RES); p.eta = f(H_ETA);
-        p.depth = u(H_DEPTH);
-        const uint32_t pk = u(H_PACKED);
-        p.st = pk & 15u; p.mode = (pk >> 4) & 3u; p.channel = (pk >> 6) & 3u; p.flags = (pk >> 8) & 31u;
-        p.trans = get3(H_TRANS); p.wa = f(H_WA); p.wb = f(H_WB);
-    }
+    DEV void store(const PathState &p, int cls) const { store_m<G_ALL>(p, cls); }
+    DEV void load(PathState &p) const { load_m<G_ALL>(p); }
 };
 
-#ifndef WG_ROUNDS
-#define WG_ROUNDS 6          // block executions of a wave between two re-sorts of the workgroup
-#endif
-#ifndef WG_MIN_LANES
-#define WG_MIN_LANES 28      // ... as long as the winning class still has this many lanes
-#endif
-
-// kernel arguments of render_kernel_wg, re-read by the block functions through the constant address space
+// kernel arguments of render_kernel_wga, re-read by the block functions through the constant address space
 struct WgArgs {
     DScene sc; const DBlock *blocks; uint32_t n_blocks, block_size, sample_count; float *film; float *cold_g; uint32_t cold_stride;
     unsigned long long *counters;
@@ -796,7 +781,7 @@ static __device__ WG_BLOCK_ATTR int wg_block(const MTS_CONST_AS void *kernarg_, 
     if (COUNT && C == B_MED) MTS_SEG_BEGIN(*cnt);
     hs.template load_m<CF::load>(p);
     if (COUNT && C == B_MED) MTS_SEG(*cnt, 0);
-    vm.template run<CF::defer>(p, e, C);
+    vm.template run<CF::defer, true>(p, e, C);
     if (COUNT && C == B_MED) MTS_SEG(*cnt, 3);
     vm.template top<CF::defer>(p, e);
     if (COUNT && C == B_MED) MTS_SEG(*cnt, 4);
@@ -814,103 +799,8 @@ static __device__ WG_BLOCK_ATTR int wg_block(const MTS_CONST_AS void *kernarg_, 
     return cls;
 }
 
-template <bool COUNT, int WG>
-DEV void volpath_workgroup(const MTS_CONST_AS void *kernarg, Counters &cnt) {
-    constexpr int NW = WG / 64;
-    __shared__ uint32_t hot_lds[H_COUNT * WG];
-    __shared__ uint32_t s_cnt[NW][8];
-    __shared__ uint16_t s_perm[WG];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t wg_base = blockIdx.x * WG;                // first global path id of this workgroup
-    {   // ---- initialise the path this thread starts with (integrator.cpp:198)
-        const WgArgs a = cload_k<WgArgs>(kernarg);
-        VolpathMachine<COUNT> vm(a.sc, cnt);
-        PathEnvT<ColdStoreHbm> e; PathState p;
-        HotStore<WG> hs; hs.base = hot_lds + tid;
-        const bool ok = wg_env<WG>(a, wg_base, tid, e);
-        p.rng.state = 0; p.rng.inc = 0;
-        p.ray = make_ray(f3s(0.f), f3(0.f, 0.f, 1.f), 0.f, 0.f); p.si.t = pm_inf(); p.si.p = f3s(0.f); p.si.uv.x = p.si.uv.y = 0.f; p.si.shape = -1; p.si.prim = 0;
-        p.medium = -1; p.thr = p.res = p.trans = f3s(0.f); p.eta = 1.f; p.depth = 0; p.channel = 0; p.mode = M_MAIN; p.flags = 0; p.wa = p.wb = 0.f;
-        p.st = S_DONE;
-        if (ok) {
-            const uint32_t ppb = a.block_size * a.block_size;
-            const uint32_t i = (wg_base % ppb) + tid;
-            p.rng.seed(a.sc.sensor.seed + (uint64_t) e.blk.id * ppb + i, PCG32_DEFAULT_STREAM);     // sampler.cpp:83-96
-            for (int k = 0; k < 5; ++k) e.cold.f(C_ACC + k) = 0.f;
-            e.cold.f(C_SAMPLE) = __uint_as_float(0u);
-            vm.begin_sample(p, e);
-            vm.top(p, e);
-        }
-        hs.store(p, vm.classify(p));
-    }
-#if defined(MTSAMD_BLOCKSTATS)
-    long long bs_t0 = clock64(); unsigned long long bs_loc[24] = {};     // [2c]: executions, [2c+1]: lanes, [16+c]: cycles, [16+7]: sort / barriers / vote
-#endif
-    for (;;) {
-        __syncthreads();
-        // ---- counting sort of the workgroup's paths by class
-        const int home_cls = HotStore<WG>::cls_of(hot_lds[H_PACKED * WG + tid]);
-        unsigned long long my_mask = 0; int my_count = 0;
-        for (int c = 0; c < B_COUNT; ++c) {
-            unsigned long long m = __ballot(home_cls == c);
-            if (home_cls == c) my_mask = m;
-            if ((int) lane == c) my_count = __popcll(m);
-        }
-        if (lane < (uint32_t) B_COUNT) s_cnt[wave][lane] = (uint32_t) my_count;
-        __syncthreads();
-        uint32_t base = 0, done_total = 0;
-        for (int w = 0; w < NW; ++w) {
-            for (int c = 0; c < B_COUNT; ++c) {
-                const uint32_t n = s_cnt[w][c];
-                if (c < home_cls || (c == home_cls && w < (int) wave)) base += n;
-            }
-            done_total += s_cnt[w][B_DONE];
-        }
-        if (done_total == (uint32_t) WG) break;
-        const uint32_t rank = (uint32_t) __popcll(my_mask & ((1ull << lane) - 1ull));
-        s_perm[base + rank] = (uint16_t) tid;
-        __syncthreads();
-        // ---- process the path at this thread's position of the sorted order: right after the sort a wave holds
-        // (almost) one class; it then keeps going for a few rounds on a per-wave vote before the next re-sort,
-        // which amortises the workgroup barriers
-        const uint32_t pid = s_perm[tid];
-#pragma unroll 1
-        for (int round = 0; round < WG_ROUNDS; ++round) {
-            const int cls = HotStore<WG>::cls_of(hot_lds[H_PACKED * WG + pid]);
-            int sel = -1, best = 0;
-            for (int c = 0; c < B_DONE; ++c) { int v = __popcll(__ballot(cls == c)); if (v > best) { best = v; sel = c; } }
-            if (best == 0 || (round > 0 && best < WG_MIN_LANES)) break;
-#if defined(MTSAMD_BLOCKSTATS)
-            if (COUNT) { bs_loc[2 * sel] += 1ull; bs_loc[2 * sel + 1] += (unsigned long long) best;
-                         long long t = clock64(); bs_loc[16 + 7] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
-#endif
-            if (cls == sel) {
-                switch (sel) {
-                    case B_INT: wg_block<COUNT, WG, B_INT>(kernarg, hot_lds, wg_base, pid, &cnt); break;
-                    case B_MED: wg_block<COUNT, WG, B_MED>(kernarg, hot_lds, wg_base, pid, &cnt); break;
-                    case B_SCATTER: wg_block<COUNT, WG, B_SCATTER>(kernarg, hot_lds, wg_base, pid, &cnt); break;
-                    case B_WSURF: wg_block<COUNT, WG, B_WSURF>(kernarg, hot_lds, wg_base, pid, &cnt); break;
-                    case B_SURF: wg_block<COUNT, WG, B_SURF>(kernarg, hot_lds, wg_base, pid, &cnt); break;
-                    case B_PHASE: wg_block<COUNT, WG, B_PHASE>(kernarg, hot_lds, wg_base, pid, &cnt); break;
-                    default: wg_block<COUNT, WG, B_NEW>(kernarg, hot_lds, wg_base, pid, &cnt); break;
-                }
-            }
-#if defined(MTSAMD_BLOCKSTATS)
-            if (COUNT) { long long t = clock64(); bs_loc[16 + sel] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
-#endif
-        }
-    }
-#if defined(MTSAMD_BLOCKSTATS)
-    if (COUNT) {
-        long long t = clock64(); bs_loc[16 + 7] += (unsigned long long) (t - bs_t0);
-        if (lane == 0) for (int k = 0; k < 24; ++k) atomicAdd(&g_blockstats[k], bs_loc[k]);
-    }
-#endif
-}
-
 // ---------------------------------------------------------------------------------------------------------
-// Driver 3: asynchronous regrouping.  Same LDS-resident path state as driver 2, but no workgroup barriers and
-// no sort: one LDS ring of path ids per block class.  A wave claims up to 64 ids from the fullest ring
+// Driver 2: asynchronous regrouping.  No workgroup barriers and no sort: one LDS ring of path ids per block class.  A wave claims up to 64 ids from the fullest ring
 // (compare-and-swap on its head), runs that block with every claimed lane active, and appends each path to
 // the ring of the class it waits for next (wave-aggregated atomic add on the tail).  Waves never wait for
 // each other; a wave that finds every ring empty naps briefly.  A ring slot holds 0xFFFF until its producer has written the id, so a consumer that claimed
@@ -974,7 +864,7 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         wga_push<WG>(cls, pid0, true, q_ids, q_ht, lane);
     }
 #if defined(MTSAMD_BLOCKSTATS)
-    long long bs_t0 = clock64(); unsigned long long bs_loc[24] = {};     // [2c]: executions, [2c+1]: lanes, [16+c]: cycles, [16+7]: claim / push / naps
+    long long bs_t0 = clock64(); unsigned long long bs_loc[25] = {}, bs_idle = 0, bs_push = 0;     // [2c]: executions, [2c+1]: lanes, [16+c]: cycles, [24]: claim
 #endif
     for (;;) {
         // ---- pick the fullest ring
@@ -988,6 +878,9 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         if (best == 0) {
             if ((uint32_t) __builtin_amdgcn_readlane((int) avail, B_DONE) == (uint32_t) WG) break;     // every path of the workgroup has finished
             __builtin_amdgcn_s_sleep(2);
+#if defined(MTSAMD_BLOCKSTATS)
+            if (COUNT) { long long t = clock64(); bs_idle += (unsigned long long) (t - bs_t0); bs_t0 = t; }
+#endif
             continue;
         }
         // ---- claim up to 64 ids
@@ -1008,13 +901,14 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #if defined(MTSAMD_BLOCKSTATS)
         if (COUNT) { bs_loc[2 * sel] += 1ull; bs_loc[2 * sel + 1] += (unsigned long long) n;
-                     long long t = clock64(); bs_loc[16 + 7] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
+                     long long t = clock64(); bs_loc[24] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
 #endif
         int cls = B_DONE;
         if (mine) {
             switch (sel) {
                 case B_INT: cls = wg_block<COUNT, WG, B_INT>(kernarg, hot_lds, wg_base, pid, &cnt); break;
                 case B_MED: cls = wg_block<COUNT, WG, B_MED>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                case B_MEDW: cls = wg_block<COUNT, WG, B_MEDW>(kernarg, hot_lds, wg_base, pid, &cnt); break;
                 case B_SCATTER: cls = wg_block<COUNT, WG, B_SCATTER>(kernarg, hot_lds, wg_base, pid, &cnt); break;
                 case B_WSURF: cls = wg_block<COUNT, WG, B_WSURF>(kernarg, hot_lds, wg_base, pid, &cnt); break;
                 case B_SURF: cls = wg_block<COUNT, WG, B_SURF>(kernarg, hot_lds, wg_base, pid, &cnt); break;
@@ -1027,12 +921,16 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
 #endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         wga_push<WG>(cls, pid, mine, q_ids, q_ht, lane);
+#if defined(MTSAMD_BLOCKSTATS)
+        if (COUNT) { long long t = clock64(); bs_push += (unsigned long long) (t - bs_t0); bs_t0 = t; }
+#endif
     }
 #if defined(MTSAMD_BLOCKSTATS)
     if (COUNT) {
-        long long t = clock64(); bs_loc[16 + 7] += (unsigned long long) (t - bs_t0);
-        if (lane == 0) for (int k = 0; k < 24; ++k) atomicAdd(&g_blockstats[k], bs_loc[k]);
-        if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_blockstats[24 + k], cnt.seg[k]);
+        long long t = clock64(); bs_loc[24] += (unsigned long long) (t - bs_t0);
+        if (lane == 0) { for (int k = 0; k < 24; ++k) atomicAdd(&g_blockstats[k], bs_loc[k]); atomicAdd(&g_blockstats[32], bs_loc[24]); }
+        if (lane == 0) for (int k = 0; k < 6; ++k) atomicAdd(&g_blockstats[24 + k], cnt.seg[k]);
+        if (lane == 0) { atomicAdd(&g_blockstats[30], bs_idle); atomicAdd(&g_blockstats[31], bs_push); }
     }
 #endif
 }

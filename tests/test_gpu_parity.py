@@ -179,6 +179,23 @@ def test_full_size_properties(gpu_rgb):
     assert_parity(gc, ob.OracleScene(dc).render())
 
 
+@pytest.mark.parametrize("kernel,threads", [("nested", None), ("flat", None), ("wga256", None), ("wga512", None), ("wga512", "256"),
+                                            ("wga1024", "1024"), ("wga1024", "768"), ("wga1024", "512")])
+def test_every_kernel_formulation_matches_the_oracle(gpu_rgb, monkeypatch, kernel, threads):
+    """All kernel formulations (nested loops, per-lane state machine, asynchronous regrouping with several workgroup shapes)
+    must produce the oracle's film and loop counters bit for bit: heterogeneous medium + cornell box (area light, BSDF
+    sampling, direct-light walks) + the atmosphere miniature (null surfaces, blend / tabulated phase, RPV)."""
+    monkeypatch.setenv("MTSAMD_KERNEL", kernel)
+    if threads: monkeypatch.setenv("MTSAMD_WG_THREADS", threads)
+    else: monkeypatch.delenv("MTSAMD_WG_THREADS", raising=False)
+    for d in (scenes.c3_heterogeneous(96, 64, 8, res=16), scenes.c1_cornell(64, 64, 4), scenes.c4_atmosphere(48, 32, 4)):
+        gpu, st = gpu_render(gpu_rgb, d, collect_counters=True)
+        o = ob.OracleScene(d); ref = o.render(); so = o.last_stats
+        assert np.array_equal(gpu, ref)
+        if d["integrator"]["type"] == "volpath":
+            assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
+
+
 @pytest.mark.parametrize("setup", ["default", "target_square", "target_square_large", "target_point"])
 @pytest.mark.parametrize("w_e", [[0, 0, -1], [0, 1, -1]])
 def test_reference_call_sequence(gpu_rgb, setup, w_e):
