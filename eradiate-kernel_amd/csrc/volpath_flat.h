@@ -34,7 +34,7 @@ struct MedStep { float t, mint; F3 p, sigma_t, sigma_s, combined; uint32_t info;
 enum : uint32_t { MI_HOMOGENEOUS = 1, MI_SPECTRAL = 2, MI_SAMPLE_EMITTERS = 4, MI_GREY = 8, MI_PHASE_SHIFT = 8 + 8 };
 
 #if defined(MTSAMD_BLOCKSTATS)
-__device__ unsigned long long g_blockstats[48];    // [2b]: executions, [2b+1]: lanes served, [16+b]: cycles (b < 8), [24..29]: MEDIUM segments, [30]: idle, [31]: push, [32]: claim / vote
+__device__ unsigned long long g_blockstats[48];    // class b < 12: [b] executions, [12+b] lanes served, [24+b] cycles; [36..41] MEDIUM segments, [42] idle, [43] push, [44] claim / vote
 #endif
 
 // textures/grid3d.cpp:259-341 split in two: cell coordinates / weights (shared by grids with the same
@@ -520,8 +520,9 @@ struct VolpathMachine {
         if (hit) {
             WATERFALL_BEGIN(p.si.shape, su)
                 const DShape s = cload(sc.shapes + su);
-                complete_surface(sc, s, p.si, p.ray.d, sf);
                 emitter = s.emitter; bsdf_id = s.bsdf;
+                // the shading frame is only read by emitter evaluation and by the NEE of a smooth BSDF: a null boundary needs neither
+                if (s.emitter >= 0 || (cload(sc.bsdfs + s.bsdf).flags & F_Smooth) != 0) complete_surface(sc, s, p.si, p.ray.d, sf);
             WATERFALL_END
         }
         if ((p.flags & FL_SPEC_CHAIN) && emitter >= 0) p.res = p.res + p.thr * emitter_eval(sc, emitter, sf.wi.z);
@@ -608,7 +609,7 @@ struct VolpathMachine {
             case B_MEDW: if (SPLIT) blk_med<DEFER, 1>(p, e); else blk_med<DEFER, -1>(p, e); break;
             case B_SCATTER: blk_scatter(p, e); break;
             case B_WSURF: blk_wsurf(p, e); break;
-            case B_SURF: blk_surf(p, e); blk_bsdf(p, e); break;
+            case B_SURF: blk_surf(p, e); blk_bsdf(p, e); break;     // no NEE at this surface: the BSDF is sampled in the same visit
             case B_PHASE: blk_phase(p, e); break;
             default: break;
         }
@@ -627,12 +628,12 @@ DEV void volpath_pixel_flat(const DScene &sc, Pcg32 &rng, const DBlock &blk, uin
     e.cold.f(C_SAMPLE) = __uint_as_float(0u);
     vm.begin_sample(p, e);
 #if defined(MTSAMD_BLOCKSTATS)
-    long long bs_t0 = clock64(); int bs_prev_sel = 8;
-    unsigned long long bs_loc[25] = {};                      // [24]: vote / top
+    long long bs_t0 = clock64(); int bs_prev_sel = 20;
+    unsigned long long bs_loc[45] = {};                      // laid out like g_blockstats
 #endif
     while (__ballot(p.st != S_DONE)) {
 #if defined(MTSAMD_BLOCKSTATS)
-        if (COUNT) { long long t = clock64(); bs_loc[16 + bs_prev_sel] += (unsigned long long) (t - bs_t0); bs_t0 = t; bs_prev_sel = 8; }
+        if (COUNT) { long long t = clock64(); bs_loc[24 + bs_prev_sel] += (unsigned long long) (t - bs_t0); bs_t0 = t; bs_prev_sel = 20; }
 #endif
         vm.top(p, e);
         // census + vote: run the ONE block most lanes of this wave are waiting for
@@ -643,15 +644,15 @@ DEV void volpath_pixel_flat(const DScene &sc, Pcg32 &rng, const DBlock &blk, uin
         if (best == 0) continue;
 #if defined(MTSAMD_BLOCKSTATS)
         if (COUNT) {
-            bs_loc[2 * sel] += 1ull; bs_loc[2 * sel + 1] += (unsigned long long) best;
-            long long t = clock64(); bs_loc[24] += (unsigned long long) (t - bs_t0); bs_t0 = t; bs_prev_sel = sel;
+            bs_loc[sel] += 1ull; bs_loc[12 + sel] += (unsigned long long) best;
+            long long t = clock64(); bs_loc[44] += (unsigned long long) (t - bs_t0); bs_t0 = t; bs_prev_sel = sel;
         }
 #endif
         vm.run(p, e, sel);
     }
 #if defined(MTSAMD_BLOCKSTATS)
     if (COUNT && __builtin_amdgcn_readfirstlane((int) (threadIdx.x & 63)) == (int) (threadIdx.x & 63))
-        { for (int k = 0; k < 24; ++k) atomicAdd(&g_blockstats[k], bs_loc[k]); atomicAdd(&g_blockstats[32], bs_loc[24]); }
+        for (int k = 0; k < 45; ++k) atomicAdd(&g_blockstats[k], bs_loc[k]);
 #endif
 }
 
@@ -864,7 +865,7 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         wga_push<WG>(cls, pid0, true, q_ids, q_ht, lane);
     }
 #if defined(MTSAMD_BLOCKSTATS)
-    long long bs_t0 = clock64(); unsigned long long bs_loc[25] = {}, bs_idle = 0, bs_push = 0;     // [2c]: executions, [2c+1]: lanes, [16+c]: cycles, [24]: claim
+    long long bs_t0 = clock64(); unsigned long long bs_loc[45] = {};                      // laid out like g_blockstats
 #endif
     for (;;) {
         // ---- pick the fullest ring
@@ -879,7 +880,7 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
             if ((uint32_t) __builtin_amdgcn_readlane((int) avail, B_DONE) == (uint32_t) WG) break;     // every path of the workgroup has finished
             __builtin_amdgcn_s_sleep(2);
 #if defined(MTSAMD_BLOCKSTATS)
-            if (COUNT) { long long t = clock64(); bs_idle += (unsigned long long) (t - bs_t0); bs_t0 = t; }
+            if (COUNT) { long long t = clock64(); bs_loc[42] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
 #endif
             continue;
         }
@@ -900,8 +901,8 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #if defined(MTSAMD_BLOCKSTATS)
-        if (COUNT) { bs_loc[2 * sel] += 1ull; bs_loc[2 * sel + 1] += (unsigned long long) n;
-                     long long t = clock64(); bs_loc[24] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
+        if (COUNT) { bs_loc[sel] += 1ull; bs_loc[12 + sel] += (unsigned long long) n;
+                     long long t = clock64(); bs_loc[44] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
 #endif
         int cls = B_DONE;
         if (mine) {
@@ -917,20 +918,19 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
             }
         }
 #if defined(MTSAMD_BLOCKSTATS)
-        if (COUNT) { long long t = clock64(); bs_loc[16 + sel] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
+        if (COUNT) { long long t = clock64(); bs_loc[24 + sel] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
 #endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         wga_push<WG>(cls, pid, mine, q_ids, q_ht, lane);
 #if defined(MTSAMD_BLOCKSTATS)
-        if (COUNT) { long long t = clock64(); bs_push += (unsigned long long) (t - bs_t0); bs_t0 = t; }
+        if (COUNT) { long long t = clock64(); bs_loc[43] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
 #endif
     }
 #if defined(MTSAMD_BLOCKSTATS)
     if (COUNT) {
-        long long t = clock64(); bs_loc[24] += (unsigned long long) (t - bs_t0);
-        if (lane == 0) { for (int k = 0; k < 24; ++k) atomicAdd(&g_blockstats[k], bs_loc[k]); atomicAdd(&g_blockstats[32], bs_loc[24]); }
-        if (lane == 0) for (int k = 0; k < 6; ++k) atomicAdd(&g_blockstats[24 + k], cnt.seg[k]);
-        if (lane == 0) { atomicAdd(&g_blockstats[30], bs_idle); atomicAdd(&g_blockstats[31], bs_push); }
+        long long t = clock64(); bs_loc[44] += (unsigned long long) (t - bs_t0);
+        for (int k = 0; k < 6; ++k) bs_loc[36 + k] = cnt.seg[k];
+        if (lane == 0) for (int k = 0; k < 45; ++k) atomicAdd(&g_blockstats[k], bs_loc[k]);
     }
 #endif
 }

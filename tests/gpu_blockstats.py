@@ -13,13 +13,14 @@ scene.integrator().render(scene, sensor, collect_counters=True)
 st = scene.integrator().last_stats
 A.lib().mts_debug_blockstats(out, 0)
 names = ["INT", "MED", "SCATTER", "WSURF", "SURF", "PHASE", "NEW", "MEDW"]
-waves = w * h / 64
+waves = w * h / 64          # normalisation unit: one 64-pixel group (the launch may use fewer, fuller waves)
 print("samples/wave-lane", spp, "kernel ms", st["kernel_ms"])
+total = sum(out[24:36]) + out[42] + out[43] + out[44]
 for i, n in enumerate(names):
-    ex, lanes = out[2 * i], out[2 * i + 1]
-    print("%-6s executions/wave/sample %8.2f  lanes/execution %6.2f  lane-visits/sample %7.2f  cycles/execution %8.1f  cycles/wave/sample %9.0f" % (
-        n, ex / waves / spp, lanes / max(ex, 1), lanes / (w * h * spp), out[16 + i] / max(ex, 1), out[16 + i] / waves / spp))
-print("claim (sort/vote/barrier) cycles/wave/sample %9.0f   idle %9.0f   push %9.0f   total %9.0f" % (out[32] / waves / spp, out[30] / waves / spp, out[31] / waves / spp, (sum(out[16:24]) + out[30] + out[31] + out[32]) / waves / spp))
-seg = ["lds load", "rng+free-flight sample", "grid lookup", "transmittance/decide", "top", "lds store", "-", "-"]
-med_exec = max(out[2], 1)
-print("MED segments (cycles / execution):", ", ".join("%s %.0f" % (n, out[24 + i] / med_exec) for i, n in enumerate(seg[:6])))
+    ex, lanes, cyc = out[i], out[12 + i], out[24 + i]
+    print("%-7s executions/wave/sample %7.2f  lanes/execution %6.2f  lane-visits/sample %6.2f  cycles/execution %8.1f  share %5.1f %%" % (
+        n, ex / waves / spp, lanes / max(ex, 1), lanes / (w * h * spp), cyc / max(ex, 1), 100.0 * cyc / max(total, 1)))
+print("claim / vote %5.1f %%   idle %5.1f %%   push %5.1f %%   total cycles/wave/sample %9.0f" % (
+    100.0 * out[44] / max(total, 1), 100.0 * out[42] / max(total, 1), 100.0 * out[43] / max(total, 1), total / waves / spp))
+seg = ["lds load", "rng+free-flight sample", "grid lookup", "transmittance/decide", "top", "lds store"]
+print("MED segments (cycles / execution):", ", ".join("%s %.0f" % (n, out[36 + i] / max(out[1], 1)) for i, n in enumerate(seg)))
