@@ -893,10 +893,10 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         uint32_t pid = 0;
         const bool mine = lane < n;
         if (mine) {
-            volatile uint16_t *slot = &q_ids[sel][(h + lane) & (uint32_t) (WG - 1)];
+            uint16_t *slot = &q_ids[sel][(h + lane) & (uint32_t) (WG - 1)];     // relaxed atomics, not volatile: volatile accesses stay FLAT
             uint32_t v;
-            do { v = *slot; } while (v == 0xFFFFu);
-            *slot = 0xFFFFu;
+            do { v = __atomic_load_n(slot, __ATOMIC_RELAXED); } while (v == 0xFFFFu);
+            __atomic_store_n(slot, (uint16_t) 0xFFFFu, __ATOMIC_RELAXED);
             pid = v;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
