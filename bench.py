@@ -33,9 +33,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=512)
-    ap.add_argument("--height", type=int, default=512)
-    ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4"],
+                    help="BASELINE.json configuration; C3 is the one the metric is quoted on, the others are side measurements")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--res", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU-baseline sample (0 = sized for ~15 s)")
@@ -64,8 +66,22 @@ def main():
     scenes = importlib.import_module("eradiate-kernel_amd.scenes")
     pkg.set_variant("gpu_rgb")
 
+    cfg_w, cfg_h, cfg_spp = {"C1": (256, 256, 64), "C2": (512, 512, 256), "C3": (512, 512, 1024), "C4": (1024, 1024, 4096)}[args.config]
+    args.width, args.height, args.spp = args.width or cfg_w, args.height or cfg_h, args.spp or cfg_spp
     spp_total = args.spp * n
-    d = scenes.c3_heterogeneous(args.width, args.height, spp_total, res=args.res, samples_per_pass=args.spp)
+
+    def make_scene(spp, samples_per_pass=-1):
+        if args.config == "C1":
+            d_ = scenes.c1_cornell(args.width, args.height, spp)
+        elif args.config == "C2":
+            d_ = scenes.c2_homogeneous_slab(args.width, args.height, spp)
+        elif args.config == "C4":
+            d_ = scenes.c4_atmosphere(args.width, args.height, spp, samples_per_pass=samples_per_pass)
+        else:
+            return scenes.c3_heterogeneous(args.width, args.height, spp, res=args.res, samples_per_pass=samples_per_pass)
+        d_["integrator"]["samples_per_pass"] = samples_per_pass
+        return d_
+    d = make_scene(spp_total, args.spp)
     scene = pkg.load_dict(d, device=local_rank)            # grids uploaded to HBM here (outside the timed region)
     sensor = scene.sensors()[0]
     integ = scene.integrator()
@@ -111,13 +127,13 @@ def main():
     bytes_per_launch = bytes_per_sample * samples_rank * (args.steps / max(launches, 1))
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
     kv = os.environ.get("MTSAMD_KERNEL", "wga1024")
-    if kv in ("nested", "flat"):
-        kernel_name = "render_kernel<false, %s>" % ("true" if kv == "flat" else "false")
-    elif kv.startswith("wga"):
+    if d["integrator"]["type"] == "path" or kv == "nested":
+        kernel_name = "render_kernel<false, false>"
+    elif kv == "flat":
+        kernel_name = "render_kernel<false, true>"
+    else:
         paths = int(kv[3:]); nt = int(os.environ.get("MTSAMD_WG_THREADS", "768" if paths == 1024 else str(paths)))
         kernel_name = "render_kernel_wga<false, %d, %d, %d>" % (paths, nt, {1: 4, 0.875: 4, 0.75: 3, 0.625: 3, 0.5: 2}[nt / paths])
-    else:
-        kernel_name = "render_kernel_wg<false, %s>" % kv[2:]
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "kernel": kernel_name, "avg_launch_ms": round(avg_launch_ms, 3),
@@ -126,7 +142,7 @@ def main():
                 "n_lookup_per_sample": round(cs["n_lookup"] / cs["samples"], 3),
                 "n_nee_step_per_sample": round(cs["n_nee_step"] / cs["samples"], 3)}
     traffic_file = os.path.join(ROOT, "profiles", "traffic_bytes_per_launch.json")
-    if os.path.exists(traffic_file):                           # measured HBM bytes per launch from the rocprofv3 --pmc passes
+    if os.path.exists(traffic_file) and args.config == "C3":                           # measured HBM bytes per launch from the rocprofv3 --pmc passes
         try:
             roofline["traffic"] = json.load(open(traffic_file)).get("bytes_per_launch")
         except Exception:
@@ -138,7 +154,7 @@ def main():
         import tests.oracle_binding as ob
         cores = os.cpu_count() or 1
         def cpu_render(spp):
-            osc = ob.OracleScene(scenes.c3_heterogeneous(args.width, args.height, spp, res=args.res))
+            osc = ob.OracleScene(make_scene(spp))
             tc0 = time.perf_counter()
             osc.render(threads=cores)
             return time.perf_counter() - tc0
@@ -152,12 +168,15 @@ def main():
                                                   % (args.width, args.height, cpu_spp, tcpu, cores)}
 
     if rank == 0:
-        out = {"metric": "Msamples/s volpath 512x512x1024spp plane-parallel atmosphere", "value": round(value, 2), "unit": "Msamples/s",
+        workload = {"C1": "C1 path cornell box", "C2": "C2 volpath homogeneous slab", "C4": "C4 volpath layered atmosphere, blend/tabulated phase, RPV ground",
+                    "C3": "C3 volpath heterogeneous %d^3 grid + HG g=0.8" % args.res}[args.config]
+        out = {"metric": "Msamples/s volpath 512x512x1024spp plane-parallel atmosphere" if args.config == "C3" else "Msamples/s %s (side measurement)" % args.config,
+               "value": round(value, 2), "unit": "Msamples/s",
                "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "C3 volpath heterogeneous %d^3 grid + HG g=0.8, %dx%dx%dspp per GPU (%d spp total, passes of %d)"
-                                      % (args.res, args.width, args.height, args.spp, spp_total, args.spp),
-                          "integrator": "volpath", "sampler": "independent seed 0", "block_size": 32, "rfilter": "box",
+               "config": {"workload": "%s, %dx%dx%dspp per GPU (%d spp total, passes of %d)"
+                                      % (workload, args.width, args.height, args.spp, spp_total, args.spp),
+                          "integrator": d["integrator"]["type"], "sampler": "independent seed 0", "block_size": 32, "rfilter": "box",
                           "sharding": "block_id %% %d round-robin + RCCL film reduce" % n if n > 1 else "single GPU"},
                "roofline": roofline, "cpu_baseline": cpu_baseline}
         print(json.dumps(out), flush=True)
