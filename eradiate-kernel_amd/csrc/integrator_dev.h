@@ -386,10 +386,7 @@ DEV float distr_sample(const DPhase &d, float value) {
 }
 
 // Record load: U = the index is wave-uniform (scalar loads), otherwise an ordinary per-lane read
-#ifndef EXP_NO_U
-#define EXP_NO_U 0
-#endif
-template <bool U, typename T> DEV T rload(const T *base, int i) { if (U && !EXP_NO_U) return cload(base + i); return base[i]; }
+template <bool U, typename T> DEV T rload(const T *base, int i) { if (U) return cload(base + i); return base[i]; }
 
 // Leaf phase functions (blendphase recursion is resolved by the two callers below; nesting depth 1)
 DEV float phase_eval_leaf(const DPhase &ph, F3 wi, F3 wo) {
