@@ -171,7 +171,7 @@ class Sensor:
         return self._sampler
 
     def needs_aperture_sample(self):
-        return self._rec.type == A.SENSOR_DISTANT
+        return self._rec.type in (A.SENSOR_DISTANT, A.SENSOR_MDISTANT)
 
 
 class Integrator:

@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MTSAMD_LIB") or os.path.join(HERE, "libmtsamd.so")
 
-MTS_ABI_VERSION = 1
+MTS_ABI_VERSION = 2
 
 # enums (include/mtsamd.h)
 VOLUME_CONST, VOLUME_GRID = 0, 1
@@ -21,7 +21,7 @@ MEDIUM_HOMOGENEOUS, MEDIUM_HETEROGENEOUS = 0, 1
 BSDF_DIFFUSE, BSDF_NULL, BSDF_RPV = 0, 1, 2
 SHAPE_RECTANGLE, SHAPE_CUBE, SHAPE_SPHERE, SHAPE_MESH = 0, 1, 2, 3
 EMITTER_DIRECTIONAL, EMITTER_AREA, EMITTER_CONSTANT = 0, 1, 2
-SENSOR_PERSPECTIVE, SENSOR_DISTANT = 0, 1
+SENSOR_PERSPECTIVE, SENSOR_DISTANT, SENSOR_MRADIANCEMETER, SENSOR_MDISTANT = 0, 1, 2, 3
 RFILTER_BOX, RFILTER_GAUSSIAN = 0, 1
 DISTANT_TARGET_NONE, DISTANT_TARGET_POINT, DISTANT_TARGET_SHAPE = 0, 1, 2
 INTEGRATOR_PATH, INTEGRATOR_VOLPATH = 0, 1
@@ -77,7 +77,8 @@ class Sensor(C.Structure):
                 ("distant_target_point", f32 * 3), ("distant_target_shape", Shape),
                 ("film_width", i32), ("film_height", i32), ("crop_offset", i32 * 2), ("crop_size", i32 * 2),
                 ("rfilter_type", i32), ("rfilter_radius", f32), ("rfilter_stddev", f32),
-                ("sample_count", i32), ("sampler_seed", C.c_uint64), ("medium", i32)]
+                ("sample_count", i32), ("sampler_seed", C.c_uint64), ("medium", i32),
+                ("multi_transforms", C.POINTER(C.c_float)), ("multi_count", i32)]
 
 
 class Integrator(C.Structure):

@@ -89,6 +89,8 @@ struct DSensor {
     DRFilter rfilter;
     int32_t sample_count;
     uint64_t seed;
+    const float *multi;            // mradiancemeter / mdistant: multi_count 4x4 matrices (device pointer)
+    int32_t multi_count;
 };
 
 struct DIntegrator { int32_t type, max_depth, rr_depth, hide_emitters; };

@@ -969,6 +969,34 @@ DEV DRay sensor_sample_ray(const DScene &sc, F2 position_sample, F2 aperture_sam
         weight = f3s(1.f);
         return make_ray(mat_point_affine(se.to_world.m, f3s(0.f)), mat_vector(se.to_world.m, d), se.near_clip * inv_z, se.far_clip * inv_z);
     }
+    if (se.type == MTS_SENSOR_MRADIANCEMETER || se.type == MTS_SENSOR_MDISTANT) {
+        // Int32 sensor_index(position_sample.x() * m_sensor_count), mradiancemeter.cpp:146 / mdistant.cpp:231; the reference
+        // gathers without a bounds check, here the index is clamped (position_sample.x can round up to 1)
+        int index = (int) (position_sample.x * (float) se.multi_count);
+        index = min(max(index, 0), se.multi_count - 1);
+        const MTS_GLOBAL_AS float *gm = as_global(se.multi) + 16 * index;
+        float m[16];
+        for (int k = 0; k < 16; ++k) m[k] = gm[k];
+        F3 d = mat_vector(m, f3(0.f, 0.f, 1.f));
+        if (se.type == MTS_SENSOR_MRADIANCEMETER) {                                               // mradiancemeter.cpp:134-157
+            weight = f3s(1.f);
+            return make_ray(mat_point_affine(m, f3s(0.f)), d, MTS_RAY_EPSILON, pm_inf());
+        }
+        F3 o; float w = 1.f;                                                                      // mdistant.cpp:212-262
+        if (se.target_type == MTS_DISTANT_TARGET_POINT) o = f3(se.target_point) - 2.f * d * se.bsphere_radius;
+        else if (se.target_type == MTS_DISTANT_TARGET_SHAPE) {
+            F3 tp, n; float pdf;
+            shape_sample_position(se.target_shape, aperture_sample, tp, n, pdf);
+            o = tp - 2.f * d * se.bsphere_radius;
+            w = 1.f / (pdf * se.target_area);
+        } else {
+            F2 offset = square_to_uniform_disk_concentric(aperture_sample);
+            F3 perp_offset = mat_vector(m, f3(offset.x, offset.y, 0.f));
+            o = f3(se.bsphere_center) + perp_offset * se.bsphere_radius - d * se.bsphere_radius;
+        }
+        weight = f3s(w);
+        return make_ray(o, d, MTS_RAY_EPSILON, pm_inf());
+    }
     F3 v0 = f3(0.f, 0.f, 1.f);
     if (se.direction_type == 2) v0 = square_to_uniform_hemisphere(position_sample);
     else if (se.direction_type == 1) { float s, c; pm_sincos(MTS_PI * position_sample.x, &s, &c); v0.x = c; v0.z = s; }

@@ -376,6 +376,28 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
             throw std::runtime_error("distant sensor: unknown ray_target type");
         store3(se.bsphere_center, center); se.bsphere_radius = bsphere_radius;
         se.needs_aperture_sample = 1;                                                          // endpoint.h:244
+    } else if (s.type == MTS_SENSOR_MRADIANCEMETER || s.type == MTS_SENSOR_MDISTANT) {        // mradiancemeter.cpp:72-132, mdistant.cpp:147-203
+        if (s.multi_count <= 0 || s.multi_transforms == nullptr) throw std::runtime_error("multi-sensor: no sub-sensors given");
+        if (se.width != s.multi_count || se.height != 1) throw std::runtime_error("Film size must be [sensor_count, 1].");
+        hs.multi_transforms.assign(s.multi_transforms, s.multi_transforms + 16 * (size_t) s.multi_count);
+        se.multi_count = s.multi_count;
+        se.needs_aperture_sample = s.type == MTS_SENSOR_MDISTANT ? 1 : 0;                        // m_needs_sample_3
+        se.target_type = MTS_DISTANT_TARGET_NONE;
+        if (s.type == MTS_SENSOR_MDISTANT) {
+            se.target_type = s.distant_target_type;
+            memcpy(se.target_point, s.distant_target_point, 12);
+            if (se.target_type == MTS_DISTANT_TARGET_SHAPE) {
+                HostScene scratch; DBBox sb; int pc;
+                if (s.distant_target_shape.type != MTS_SHAPE_RECTANGLE && s.distant_target_shape.type != MTS_SHAPE_SPHERE)
+                    throw std::runtime_error("mdistant target shape must be a rectangle or a sphere in this backend");
+                se.target_shape = build_shape(s.distant_target_shape, scratch, sb, pc);
+                se.target_area = se.target_shape.type == MTS_SHAPE_RECTANGLE
+                    ? norm(cross(f3(se.target_shape.frame_s), f3(se.target_shape.frame_t)))
+                    : 4.f * MTS_PI * se.target_shape.radius * se.target_shape.radius;
+            } else if (se.target_type != MTS_DISTANT_TARGET_NONE && se.target_type != MTS_DISTANT_TARGET_POINT)
+                throw std::runtime_error("mdistant sensor: unknown target type");
+            store3(se.bsphere_center, center); se.bsphere_radius = bsphere_radius;               // mdistant.cpp:205-210
+        }
     } else throw std::runtime_error("unknown sensor type");
     // ---- integrator (integrator.cpp:23-39,302-315)
     const mts_integrator &it = d->integrator;
@@ -419,6 +441,7 @@ void upload_host_scene(HostScene &hs, int device) {
     sc.faces = upload(hs, hs.faces);
     sc.tri = upload(hs, hs.tri);
     sc.sensor.rfilter.values = upload(hs, hs.rfilter_values);
+    sc.sensor.multi = upload(hs, hs.multi_transforms);
     HIP_CHECK(hipDeviceSynchronize());
     hs.uploaded = true;
 }

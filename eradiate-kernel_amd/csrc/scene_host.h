@@ -27,6 +27,7 @@ struct HostScene {
     std::vector<float> tri;
     std::vector<float> rfilter_values;
     std::vector<std::vector<float>> grid_data, tab_pdf, tab_cdf;
+    std::vector<float> multi_transforms;            // mradiancemeter / mdistant sub-sensor matrices
     std::vector<std::vector<float>> pair_data;       // per medium: interleaved {sigma_t, albedo} voxels (DMedium::pair_grid), or empty
     std::vector<void *> device_allocs;
     int device = 0;

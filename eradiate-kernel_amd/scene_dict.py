@@ -538,6 +538,53 @@ class SceneBuilder:
                     s.distant_target_point[:] = tuple(float(x) for x in np.asarray(rt, dtype=np.float32))
             if p.has("ray_origin"):
                 raise RuntimeError("distant sensor: 'ray_origin' shapes are not supported by this backend")
+        elif p.type in ("mradiancemeter", "mdistant"):
+            # src/sensors/mradiancemeter.cpp:72-132 / src/sensors/mdistant.cpp:60-98,147-203: N sub-sensors, one per film column
+            multi = p.type == "mradiancemeter"
+            s.type = A.SENSOR_MRADIANCEMETER if multi else A.SENSOR_MDISTANT
+            if multi and p.has("to_world"):
+                raise RuntimeError("This sensor is specified through a set of origin and direction values and cannot use the to_world transform.")
+
+            def tokens(key):                                                   # string::tokenize(props.string(key), " ,")
+                return [t for t in str(p.get(key)).replace(",", " ").split() if t]
+            dirs = tokens("directions")
+            if len(dirs) % 3 != 0:
+                raise RuntimeError("Invalid specification! Number of parameters %d, is not a multiple of three." % len(dirs))
+            count = len(dirs) // 3
+            mats = np.zeros((count, 4, 4), dtype=np.float32)
+            if multi:
+                origs = tokens("origins")
+                if len(origs) % 3 != 0:
+                    raise RuntimeError("Invalid specification! Number of parameters %d, is not a multiple of three." % len(origs))
+                if len(origs) != len(dirs):
+                    raise RuntimeError("Invalid specification! Number of parameters for origins and directions (%d, %d) are not equal."
+                                       % (len(origs), len(dirs)))
+            for i in range(count):
+                direction = np.array([np.float32(x) for x in dirs[3 * i:3 * i + 3]], dtype=np.float32)    # std::stof
+                if multi:
+                    origin = np.array([np.float32(x) for x in origs[3 * i:3 * i + 3]], dtype=np.float32)
+                    up, _ = coordinate_system(direction)                                               # mradiancemeter.cpp:109: first vector
+                    mats[i] = ScalarTransform4f.look_at(origin, (origin + direction).astype(np.float32), up).matrix
+                else:
+                    _, up = coordinate_system(direction)                                               # mdistant.cpp:166-167: second vector
+                    mats[i] = ScalarTransform4f.look_at([0, 0, 0], direction, up).matrix
+            if (s.film_width, s.film_height) != (count, 1):
+                raise RuntimeError("Film size must be [sensor_count, 1]. Expected [%d, 1], got [%d, %d]" % (count, s.film_width, s.film_height))
+            buf = np.ascontiguousarray(mats.reshape(-1), dtype=np.float32)
+            self.keep.append(buf)
+            s.multi_transforms = buf.ctypes.data_as(C.POINTER(C.c_float))
+            s.multi_count = count
+            s.to_world = _xf(ScalarTransform4f())
+            s.distant_target_type = A.DISTANT_TARGET_NONE
+            if not multi and p.has("target"):                                  # mdistant.cpp:71-88,188-198
+                tg = p.get("target")
+                if isinstance(tg, dict):
+                    s.distant_target_type = A.DISTANT_TARGET_SHAPE
+                    rec, _ = self.make_shape(tg, where + ".target", in_scene=False)
+                    s.distant_target_shape = rec
+                else:
+                    s.distant_target_type = A.DISTANT_TARGET_POINT
+                    s.distant_target_point[:] = tuple(float(x) for x in np.asarray(tg, dtype=np.float32))
         else:
             raise RuntimeError("Unknown / unsupported sensor plugin \"%s\"" % p.type)
         p.finish()
@@ -583,7 +630,7 @@ class SceneBuilder:
                 self.add_shape(v, k)
             elif t in ("directional", "constant", "area"):
                 self.add_emitter(v, k)
-            elif t in ("perspective", "distant"):
+            elif t in ("perspective", "distant", "mradiancemeter", "mdistant"):
                 if self.sensor is not None:
                     raise RuntimeError("this backend supports a single sensor per scene")
                 self.set_sensor(v, k)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MTS_ABI_VERSION 1
+#define MTS_ABI_VERSION 2
 
 /* Transform4f: row-major 4x4 matrix and its inverse transpose (transform.h:36-50). */
 typedef struct mts_transform {
@@ -125,7 +125,8 @@ typedef struct mts_emitter {
 
 /* ---- Sensor + film + sampler (src/sensors/{perspective,distant}.cpp, src/films/hdrfilm.cpp,
  *      src/samplers/independent.cpp, src/rfilters/{box,gaussian}.cpp) ---- */
-enum { MTS_SENSOR_PERSPECTIVE = 0, MTS_SENSOR_DISTANT = 1 };
+enum { MTS_SENSOR_PERSPECTIVE = 0, MTS_SENSOR_DISTANT = 1,
+       MTS_SENSOR_MRADIANCEMETER = 2 /* src/sensors/mradiancemeter.cpp */, MTS_SENSOR_MDISTANT = 3 /* src/sensors/mdistant.cpp */ };
 enum { MTS_RFILTER_BOX = 0, MTS_RFILTER_GAUSSIAN = 1 };
 enum { MTS_DISTANT_TARGET_NONE = 0, MTS_DISTANT_TARGET_POINT = 1, MTS_DISTANT_TARGET_SHAPE = 2 };
 typedef struct mts_sensor {
@@ -154,6 +155,12 @@ typedef struct mts_sensor {
     int32_t sample_count;     /* "sample_count", default 4                                       */
     uint64_t sampler_seed;    /* "seed", default 0                                               */
     int32_t medium;           /* sensor medium, -1 = none                                        */
+    /* mradiancemeter / mdistant: one 4x4 matrix (row-major) per sub-sensor, exactly what the constructors store in
+     * m_transforms (mradiancemeter.cpp:95-113: look_at(origin, origin + direction, up = coordinate_system(direction).first);
+     * mdistant.cpp:160-175: look_at(0, direction, up = coordinate_system(direction).second)).  The film must be
+     * multi_count x 1.  mdistant's "target" travels in distant_target_type / _point / _shape. */
+    const float *multi_transforms;
+    int32_t multi_count;
 } mts_sensor;
 
 /* ---- Integrator (src/integrators/{path,volpath}.cpp, src/librender/integrator.cpp:23-39,302-315) */

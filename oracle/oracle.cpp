@@ -924,6 +924,34 @@ static Ray sensor_sample_ray(const Scene &sc, P2 position_sample, P2 aperture_sa
         *weight = v3(1.f, 1.f, 1.f);
         return ray;
     }
+    if (se.type == MTS_SENSOR_MRADIANCEMETER || se.type == MTS_SENSOR_MDISTANT) {
+        // Int32 sensor_index(position_sample.x() * m_sensor_count): mradiancemeter.cpp:146, mdistant.cpp:231 (clamped: the
+        // reference gathers without a bounds check and position_sample.x can round up to 1)
+        int index = (int) (position_sample.x * (float) se.multi_count);
+        index = std::min(std::max(index, 0), se.multi_count - 1);
+        Xf trafo = {}; memcpy(trafo.m, &se.multi[16 * (size_t) index], 64);
+        V3 d = xf_vector(trafo, v3(0.f, 0.f, 1.f));                                       // transform_affine(Vector3f{0, 0, 1})
+        if (se.type == MTS_SENSOR_MRADIANCEMETER) {                                       // mradiancemeter.cpp:134-157
+            *weight = v3(1.f, 1.f, 1.f);
+            return make_ray(xf_point_affine(trafo, v3(0.f, 0.f, 0.f)), d, RayEpsilon, pm_inf());
+        }
+        V3 o; float w = 1.f;                                                              // mdistant.cpp:212-262
+        if (se.target_type == MTS_DISTANT_TARGET_POINT) o = se.target_point - 2.f * d * se.bsphere_radius;
+        else if (se.target_type == MTS_DISTANT_TARGET_SHAPE) {
+            V3 tp, n; float pdf;
+            shape_sample_position(se.target_shape, aperture_sample, &tp, &n, &pdf);
+            float area = se.target_shape.type == MTS_SHAPE_RECTANGLE ? norm(cross(se.target_shape.frame.s, se.target_shape.frame.t))
+                                                                     : 4.f * Pi * se.target_shape.radius * se.target_shape.radius;
+            o = tp - 2.f * d * se.bsphere_radius;
+            w = 1.f / (pdf * area);
+        } else {
+            P2 offset = square_to_uniform_disk_concentric(aperture_sample);
+            V3 perp_offset = xf_vector(trafo, v3(offset.x, offset.y, 0.f));
+            o = se.bsphere_center + perp_offset * se.bsphere_radius - d * se.bsphere_radius;
+        }
+        *weight = v3(w, w, w);
+        return make_ray(o, d, RayEpsilon, pm_inf());
+    }
     // distant.cpp:299-386
     V3 v0 = v3(0.f, 0.f, 1.f);
     if (se.direction_type == 2) v0 = square_to_uniform_hemisphere(position_sample);

@@ -283,6 +283,7 @@ struct Sensor {
     int width, height, crop_x, crop_y, crop_w, crop_h;
     RFilter rfilter;
     int sample_count; uint64_t seed;
+    std::vector<float> multi; int multi_count = 0;   // mradiancemeter / mdistant: m_transforms (mradiancemeter.cpp:95-113, mdistant.cpp:160-175)
 };
 
 // Transform::perspective, transform.h:203-220
@@ -435,6 +436,25 @@ static inline Scene *make_scene(const mts_scene_desc *d) {
             se.principal_point_offset.x = s.principal_point_offset[0] * ((float) se.width / (float) se.crop_w);
             se.principal_point_offset.y = s.principal_point_offset[1] * ((float) se.height / (float) se.crop_h);
             se.needs_aperture_sample = false;                                              // perspective.cpp:122
+        } else if (s.type == MTS_SENSOR_MRADIANCEMETER || s.type == MTS_SENSOR_MDISTANT) {
+            if (s.multi_count <= 0 || !s.multi_transforms) throw std::runtime_error("multi-sensor: no sub-sensors given");
+            if (se.width != s.multi_count || se.height != 1) throw std::runtime_error("Film size must be [sensor_count, 1].");   // mradiancemeter.cpp:115-118
+            se.multi.assign(s.multi_transforms, s.multi_transforms + 16 * (size_t) s.multi_count);
+            se.multi_count = s.multi_count;
+            se.needs_aperture_sample = s.type == MTS_SENSOR_MDISTANT;                      // m_needs_sample_3: mradiancemeter.cpp:126, mdistant.cpp:202
+            se.target_type = MTS_DISTANT_TARGET_NONE;
+            if (s.type == MTS_SENSOR_MDISTANT) {
+                se.target_type = s.distant_target_type;
+                se.target_point = v3(s.distant_target_point[0], s.distant_target_point[1], s.distant_target_point[2]);
+                if (se.target_type == MTS_DISTANT_TARGET_SHAPE) {
+                    se.target_shape = make_shape(s.distant_target_shape);
+                    if (se.target_shape.type != MTS_SHAPE_RECTANGLE && se.target_shape.type != MTS_SHAPE_SPHERE)
+                        throw std::runtime_error("mdistant target shape must be a rectangle or a sphere in this backend");
+                }
+                V3 c = (sc->bbox.max + sc->bbox.min) * .5f;                                // mdistant.cpp:205-210
+                se.bsphere_center = c;
+                se.bsphere_radius = pm_max(RayEpsilon, norm(c - sc->bbox.max) * (1.f + RayEpsilon));
+            }
         } else {
             // distant.cpp:228-238
             se.direction_type = (se.width == 1 && se.height == 1) ? 0 : (se.height == 1 ? 1 : 2);

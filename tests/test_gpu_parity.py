@@ -196,6 +196,31 @@ def test_every_kernel_formulation_matches_the_oracle(gpu_rgb, monkeypatch, kerne
             assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
 
 
+@pytest.mark.parametrize("sensor", ["mradiancemeter", "mdistant_none", "mdistant_point", "mdistant_shape"])
+def test_multi_sensors_match_the_oracle(gpu_rgb, sensor):
+    """Eradiate's multi-sensors (src/sensors/mradiancemeter.cpp, mdistant.cpp): one sub-sensor per film column, over the
+    heterogeneous slab; film and counters bit for bit."""
+    n = 40                                                   # more than one 32-pixel block column
+    ang = np.linspace(0.05, 1.3, n)
+    if sensor == "mradiancemeter":
+        origins = ", ".join("%g, %g, 12" % (4 * np.cos(7 * a), 4 * np.sin(7 * a)) for a in ang)
+        directions = ", ".join("%g, %g, %g" % (np.sin(a) * np.cos(3 * a), np.sin(a) * np.sin(3 * a), -np.cos(a)) for a in ang)
+        sd = {"type": "mradiancemeter", "origins": origins, "directions": directions}
+    else:
+        directions = ", ".join("%g, %g, %g" % (np.sin(a) * np.cos(3 * a), np.sin(a) * np.sin(3 * a), -np.cos(a)) for a in ang)
+        sd = {"type": "mdistant", "directions": directions}
+        if sensor == "mdistant_point": sd["target"] = [1.0, -2.0, 2.0]
+        if sensor == "mdistant_shape": sd["target"] = {"type": "rectangle", "to_world": T.translate([0, 0, 2.0]) @ T.scale(10.0)}
+    d = scenes.c3_heterogeneous(8, 8, 32, res=16)
+    sd.update({"film": {"type": "hdrfilm", "width": n, "height": 1, "rfilter": {"type": "box"}},
+               "sampler": {"type": "independent", "sample_count": 32}})
+    d["sensor"] = sd
+    gpu, st = gpu_render(gpu_rgb, d, collect_counters=True)
+    o = ob.OracleScene(d); ref = o.render(); so = o.last_stats
+    assert gpu.shape == (1, n, 5) and np.array_equal(gpu, ref) and gpu[..., :3].max() > 0
+    assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
+
+
 @pytest.mark.parametrize("setup", ["default", "target_square", "target_square_large", "target_point"])
 @pytest.mark.parametrize("w_e", [[0, 0, -1], [0, 1, -1]])
 def test_reference_call_sequence(gpu_rgb, setup, w_e):

@@ -503,3 +503,121 @@ def test_distant_sensor_render(setup, w_e, w_o):
     expected = {"default": l_o * 2.0 / np.pi, "target_square_large": l_o * 0.25}.get(setup, l_o)
     rtol = {"target_square_large": 2e-2, "default": 2e-2}.get(setup, 5e-3)
     assert np.allclose(rgb, expected, rtol=rtol)
+
+
+# ---------------------------------------------------------------- mradiancemeter / mdistant
+def _mrad_sensor(orig, dirs, pixels):
+    return {"type": "mradiancemeter", "origins": orig, "directions": dirs,
+            "film": {"type": "hdrfilm", "width": pixels, "height": 1, "rfilter": {"type": "box"}}}
+
+
+def _with_sensor(sensor, **extra):
+    d = {"type": "scene", "integrator": {"type": "path"}, "sensor": sensor}
+    d.update(extra)
+    return d
+
+
+def test_mradiancemeter_construct_and_rays():
+    """src/sensors/tests/test_mradiancemeter.py:57-105: instantiation errors and the sub-sensor picked by position_sample.x"""
+    for origins, directions in [(["0, 0, 0"], ["1, 0, 0"]), (["0, 0, 0"] * 2, ["1, 0, 0", "-1, 0, 0"])]:
+        ob.OracleScene(_with_sensor(_mrad_sensor(", ".join(origins), ", ".join(directions), len(origins))))
+    for bad in [("0, 0, 0", "1, 0, 0", 2), ("0, 0", "1, 0", 1), ("0, 0, 0", "1, 0", 1)]:
+        with pytest.raises(RuntimeError):
+            ob.OracleScene(_with_sensor(_mrad_sensor(*bad)))
+    o = ob.OracleScene(_with_sensor(_mrad_sensor("0, 0, 0, 1, 0, 1", "1, 0, 0, 1, 1, 1", 2)))
+    import random
+    random.seed(42)
+    for _ in range(10):
+        random.random()
+        ps = (random.random(), random.random())
+        ro, rd, w = o.sensor_sample_ray([ps], [(0, 0)])
+        if ps[0] < 0.5:
+            assert np.allclose(ro[0], (0, 0, 0)) and np.allclose(rd[0], (1, 0, 0), atol=1e-6)
+        else:
+            assert np.allclose(ro[0], (1, 0, 1)) and np.allclose(rd[0], np.ones(3) / np.sqrt(3.0), atol=1e-6)
+        assert np.allclose(w[0], 1.0)
+
+
+@pytest.mark.parametrize("radiance", [10.0 ** x for x in range(-3, 4)])
+def test_mradiancemeter_render_constant(radiance):
+    """test_mradiancemeter.py:150-163: three radiancemeters inside a constant environment see its radiance"""
+    sensor = _mrad_sensor("1, 0, 0, 0, 1, 0, 0, 0, 1", "1, 0, 0, 0, -1, 0, 0, 0, -1", 3)
+    sensor["sampler"] = {"type": "independent", "sample_count": 1}
+    d = _with_sensor(sensor, emitter={"type": "constant", "radiance": {"type": "uniform", "value": radiance}})
+    img = ob.OracleScene(d).render(threads=1)
+    import tests.transport_cases as tc
+    assert np.allclose(tc.radiance_rgb(img), radiance, rtol=1e-5)
+
+
+def test_mradiancemeter_render_complex():
+    """test_mradiancemeter.py:166-240: three sub-sensors looking at three surfaces with different reflectances under a
+    constant environment of radiance 1 see a radiance equal to the reflectance"""
+    sensor = {"type": "mradiancemeter", "origins": "-2, 0, 1, 0, 0, 1, 2, 0, 1", "directions": "0, 0, -1, 0, 0, -1 0, 0, -1",
+              "film": {"type": "hdrfilm", "width": 3, "height": 1, "pixel_format": "luminance", "rfilter": {"type": "box"}},
+              "sampler": {"type": "independent", "sample_count": 20000}}
+    d = _with_sensor(sensor, emitter={"type": "constant", "radiance": {"type": "uniform", "value": 1.0}})
+    for k, (x, rho) in enumerate([(-2, 0.0), (0, 0.5), (2, 1.0)]):
+        d["rect%d" % k] = {"type": "rectangle", "to_world": T.translate([x, 0, 0]) @ T.scale(0.5),
+                           "bsdf": {"type": "diffuse", "reflectance": {"type": "uniform", "value": rho}}}
+    img = ob.OracleScene(d).render(threads=1)
+    import tests.transport_cases as tc
+    rgb = tc.radiance_rgb(img).reshape(3, 3)
+    assert np.allclose(rgb[:, 0], [0.0, 0.5, 1.0], atol=1e-2)
+
+
+def _mdist_sensor(target=None, directions="0, 0, 1", pixel_count=1, spp=None):
+    s = {"type": "mdistant", "directions": directions,
+         "film": {"type": "hdrfilm", "width": pixel_count, "height": 1, "rfilter": {"type": "box"}}}
+    if target == "point":
+        s["target"] = [0, 0, 0]
+    elif target == "shape":
+        s["target"] = {"type": "rectangle"}
+    elif isinstance(target, dict):
+        s["target"] = target
+    if spp:
+        s["sampler"] = {"type": "independent", "sample_count": spp}
+    return s
+
+
+def test_mdistant_construct_and_directions():
+    """src/sensors/tests/test_mdistant.py:37-132"""
+    directions = ",".join(str(x) for x in [0, 0, 1, 0, 0, -1])
+    unit = {"shape": {"type": "rectangle"}}
+    ob.OracleScene(_with_sensor(_mdist_sensor(directions=directions, pixel_count=2), **unit))
+    with pytest.raises(RuntimeError):
+        ob.OracleScene(_with_sensor({"type": "mdistant"}, **unit))
+    with pytest.raises(RuntimeError):
+        ob.OracleScene(_with_sensor({"type": "mdistant", "directions": directions, "film": {"type": "hdrfilm", "width": 2, "height": 2}}, **unit))
+    for target in (None, "point", "shape"):
+        ob.OracleScene(_with_sensor(_mdist_sensor(target, directions, 2), **unit))
+    with pytest.raises(RuntimeError):
+        ob.OracleScene(_with_sensor(_mdist_sensor({"type": "constant"}, directions, 2), **unit))
+    o = ob.OracleScene(_with_sensor(_mdist_sensor("point", "0, 0, -1, -1, -1, 0, -2, 0, 0", 3), **unit))
+    for s1, s2, expected in [[[0.32, 0.87], [0.16, 0.44], [0, 0, -1]], [[0.17, 0.44], [0.22, 0.81], [0, 0, -1]],
+                             [[0.51, 0.82], [0.99, 0.42], [-1, -1, 0]], [[0.72, 0.40], [0.01, 0.61], [-2, 0, 0]]]:
+        _, rd, _ = o.sensor_sample_ray([s1], [s2])
+        e = np.array(expected, dtype=np.float64)
+        assert np.allclose(rd[0], e / np.linalg.norm(e), atol=1e-6)
+
+
+@pytest.mark.parametrize("setup", ["default", "target_square", "target_square_small", "target_square_large", "target_point"])
+@pytest.mark.parametrize("w_e", [[0, 0, -1], [0, 1, -1]])
+@pytest.mark.parametrize("w_o", [[0, 0, -1], [0, -1, -1]])
+def test_mdistant_render_targets(setup, w_e, w_o):
+    """test_mdistant.py:135-296: path + directional + diffuse under mdistant; L = E cos(theta_e) rho / pi, times (2/pi) cos(theta_o)
+    without target, times 0.25 for a target twice the surface's size.  20000 spp instead of 1e5."""
+    w_e = list(np.array(w_e) / np.linalg.norm(w_e)); w_o = list(np.array(w_o) / np.linalg.norm(w_o))
+    cos_e, cos_o = abs(w_e[2]), abs(w_o[2])
+    target = {"default": None, "target_point": "point"}.get(setup, setup)
+    if isinstance(target, str) and target.startswith("target_square"):
+        scale = {"target_square": 1.0, "target_square_small": 0.5, "target_square_large": 2.0}[setup]
+        target = {"type": "rectangle", "to_world": T.scale(scale)}
+    sensor = _mdist_sensor(target, ",".join(map(str, w_o)), 1, spp=20000)
+    d = _with_sensor(sensor, shape={"type": "rectangle", "to_world": T.scale(1.0), "bsdf": {"type": "diffuse", "reflectance": 1.0}},
+                     emitter={"type": "directional", "direction": w_e, "irradiance": 1.0})
+    img = ob.OracleScene(d).render(threads=1)
+    import tests.transport_cases as tc
+    rgb = tc.radiance_rgb(img).reshape(3)
+    l_o = cos_e / np.pi
+    expected = {"default": l_o * (2.0 / np.pi) * cos_o, "target_square_large": l_o * 0.25}.get(setup, l_o)
+    assert np.allclose(rgb, expected, rtol={"target_square_large": 2e-2, "default": 2e-2}.get(setup, 5e-3))
