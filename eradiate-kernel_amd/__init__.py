@@ -171,7 +171,7 @@ class Sensor:
         return self._sampler
 
     def needs_aperture_sample(self):
-        return self._rec.type in (A.SENSOR_DISTANT, A.SENSOR_MDISTANT)
+        return self._rec.type in (A.SENSOR_DISTANT, A.SENSOR_MDISTANT, A.SENSOR_DISTANTFLUX)
 
 
 class Integrator:

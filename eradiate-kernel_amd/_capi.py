@@ -21,7 +21,7 @@ MEDIUM_HOMOGENEOUS, MEDIUM_HETEROGENEOUS = 0, 1
 BSDF_DIFFUSE, BSDF_NULL, BSDF_RPV = 0, 1, 2
 SHAPE_RECTANGLE, SHAPE_CUBE, SHAPE_SPHERE, SHAPE_MESH = 0, 1, 2, 3
 EMITTER_DIRECTIONAL, EMITTER_AREA, EMITTER_CONSTANT = 0, 1, 2
-SENSOR_PERSPECTIVE, SENSOR_DISTANT, SENSOR_MRADIANCEMETER, SENSOR_MDISTANT = 0, 1, 2, 3
+SENSOR_PERSPECTIVE, SENSOR_DISTANT, SENSOR_MRADIANCEMETER, SENSOR_MDISTANT, SENSOR_DISTANTFLUX = 0, 1, 2, 3, 4
 RFILTER_BOX, RFILTER_GAUSSIAN = 0, 1
 DISTANT_TARGET_NONE, DISTANT_TARGET_POINT, DISTANT_TARGET_SHAPE = 0, 1, 2
 INTEGRATOR_PATH, INTEGRATOR_VOLPATH = 0, 1

@@ -997,6 +997,23 @@ DEV DRay sensor_sample_ray(const DScene &sc, F2 position_sample, F2 aperture_sam
         weight = f3s(w);
         return make_ray(o, d, MTS_RAY_EPSILON, pm_inf());
     }
+    if (se.type == MTS_SENSOR_DISTANTFLUX) {                                                      // distantflux.cpp:189-240
+        F3 d = -mat_vector(se.to_world.m, square_to_uniform_hemisphere(position_sample));
+        const F3 reference_normal = mat_vector(se.to_world.m, f3(0.f, 0.f, 1.f));                 // distantflux.cpp:185-186
+        float w = dot(-d, reference_normal) / (MTS_INV_TWO_PI * (float) ((uint32_t) se.width * (uint32_t) se.height));
+        F3 ray_target = f3(se.target_point);
+        if (se.target_type == MTS_DISTANT_TARGET_SHAPE) {
+            F3 n; float pdf;
+            shape_sample_position(se.target_shape, aperture_sample, ray_target, n, pdf);
+            w *= 1.f / (pdf * se.target_area);
+        } else if (se.target_type == MTS_DISTANT_TARGET_NONE) {
+            F2 offset = square_to_uniform_disk_concentric(aperture_sample);
+            F3 perp_offset = mat_vector(se.to_world.m, f3(offset.x, offset.y, 0.f));
+            ray_target = f3(se.bsphere_center) + perp_offset * se.bsphere_radius;
+        }
+        weight = f3s(w);
+        return make_ray(ray_target - d * 2.f * se.bsphere_radius, d, MTS_RAY_EPSILON, pm_inf());
+    }
     F3 v0 = f3(0.f, 0.f, 1.f);
     if (se.direction_type == 2) v0 = square_to_uniform_hemisphere(position_sample);
     else if (se.direction_type == 1) { float s, c; pm_sincos(MTS_PI * position_sample.x, &s, &c); v0.x = c; v0.z = s; }

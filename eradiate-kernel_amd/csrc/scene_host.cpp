@@ -359,7 +359,7 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
         se.ppo[0] = s.principal_point_offset[0] * ((float) se.width / (float) se.crop_w);      // perspective.cpp:101-106
         se.ppo[1] = s.principal_point_offset[1] * ((float) se.height / (float) se.crop_h);
         se.needs_aperture_sample = 0;                                                          // perspective.cpp:122
-    } else if (s.type == MTS_SENSOR_DISTANT) {                                                 // distant.cpp:225-297
+    } else if (s.type == MTS_SENSOR_DISTANT || s.type == MTS_SENSOR_DISTANTFLUX) {             // distant.cpp:225-297, distantflux.cpp:141-187
         se.direction_type = (se.width == 1 && se.height == 1) ? 0 : (se.height == 1 ? 1 : 2);
         se.flip_directions = s.distant_flip_directions != 0;
         se.target_type = s.distant_target_type;

@@ -538,6 +538,24 @@ class SceneBuilder:
                     s.distant_target_point[:] = tuple(float(x) for x in np.asarray(rt, dtype=np.float32))
             if p.has("ray_origin"):
                 raise RuntimeError("distant sensor: 'ray_origin' shapes are not supported by this backend")
+        elif p.type == "distantflux":                                      # src/sensors/distantflux.cpp:60-105,141-187
+            s.type = A.SENSOR_DISTANTFLUX
+            tw = p.get("to_world")
+            s.to_world = _xf(ScalarTransform4f() if tw is None else tw)
+            s.distant_target_type = A.DISTANT_TARGET_NONE
+            if p.has("target"):
+                tg = p.get("target")
+                if isinstance(tg, dict):
+                    s.distant_target_type = A.DISTANT_TARGET_SHAPE
+                    rec, _ = self.make_shape(tg, where + ".target", in_scene=False)
+                    s.distant_target_shape = rec
+                else:
+                    s.distant_target_type = A.DISTANT_TARGET_POINT
+                    s.distant_target_point[:] = tuple(float(x) for x in np.asarray(tg, dtype=np.float32))
+            if p.has("origin"):
+                if not isinstance(p.get("origin"), dict) or p.get("origin").get("type") not in ("rectangle", "sphere", "cube", "disk"):
+                    raise RuntimeError("Invalid parameter origin, must be a Shape.")
+                raise RuntimeError("distantflux sensor: 'origin' shapes are not supported by this backend")
         elif p.type in ("mradiancemeter", "mdistant"):
             # src/sensors/mradiancemeter.cpp:72-132 / src/sensors/mdistant.cpp:60-98,147-203: N sub-sensors, one per film column
             multi = p.type == "mradiancemeter"
@@ -630,7 +648,7 @@ class SceneBuilder:
                 self.add_shape(v, k)
             elif t in ("directional", "constant", "area"):
                 self.add_emitter(v, k)
-            elif t in ("perspective", "distant", "mradiancemeter", "mdistant"):
+            elif t in ("perspective", "distant", "mradiancemeter", "mdistant", "distantflux"):
                 if self.sensor is not None:
                     raise RuntimeError("this backend supports a single sensor per scene")
                 self.set_sensor(v, k)

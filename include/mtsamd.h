@@ -126,7 +126,8 @@ typedef struct mts_emitter {
 /* ---- Sensor + film + sampler (src/sensors/{perspective,distant}.cpp, src/films/hdrfilm.cpp,
  *      src/samplers/independent.cpp, src/rfilters/{box,gaussian}.cpp) ---- */
 enum { MTS_SENSOR_PERSPECTIVE = 0, MTS_SENSOR_DISTANT = 1,
-       MTS_SENSOR_MRADIANCEMETER = 2 /* src/sensors/mradiancemeter.cpp */, MTS_SENSOR_MDISTANT = 3 /* src/sensors/mdistant.cpp */ };
+       MTS_SENSOR_MRADIANCEMETER = 2 /* src/sensors/mradiancemeter.cpp */, MTS_SENSOR_MDISTANT = 3 /* src/sensors/mdistant.cpp */,
+       MTS_SENSOR_DISTANTFLUX = 4 /* src/sensors/distantflux.cpp: to_world + distant_target_*; "origin" shapes are not supported */ };
 enum { MTS_RFILTER_BOX = 0, MTS_RFILTER_GAUSSIAN = 1 };
 enum { MTS_DISTANT_TARGET_NONE = 0, MTS_DISTANT_TARGET_POINT = 1, MTS_DISTANT_TARGET_SHAPE = 2 };
 typedef struct mts_sensor {

@@ -952,6 +952,26 @@ static Ray sensor_sample_ray(const Scene &sc, P2 position_sample, P2 aperture_sa
         *weight = v3(w, w, w);
         return make_ray(o, d, RayEpsilon, pm_inf());
     }
+    if (se.type == MTS_SENSOR_DISTANTFLUX) {                                              // distantflux.cpp:189-240
+        V3 d = -xf_vector(se.to_world, square_to_uniform_hemisphere(position_sample));
+        V3 reference_normal = xf_vector(se.to_world, v3(0.f, 0.f, 1.f));                  // distantflux.cpp:185-186
+        // dot(-ray.d, n) / (square_to_uniform_hemisphere_pdf(ray.d) * m_npixels), warp.h:312-320 (no domain test: 1 / 2 pi)
+        float w = dot(-d, reference_normal) / (InvTwoPi * (float) ((uint32_t) se.width * (uint32_t) se.height));
+        V3 ray_target = se.target_point;
+        if (se.target_type == MTS_DISTANT_TARGET_SHAPE) {
+            V3 n; float pdf;
+            shape_sample_position(se.target_shape, aperture_sample, &ray_target, &n, &pdf);
+            float area = se.target_shape.type == MTS_SHAPE_RECTANGLE ? norm(cross(se.target_shape.frame.s, se.target_shape.frame.t))
+                                                                     : 4.f * Pi * se.target_shape.radius * se.target_shape.radius;
+            w *= 1.f / (pdf * area);
+        } else if (se.target_type == MTS_DISTANT_TARGET_NONE) {
+            P2 offset = square_to_uniform_disk_concentric(aperture_sample);
+            V3 perp_offset = xf_vector(se.to_world, v3(offset.x, offset.y, 0.f));
+            ray_target = se.bsphere_center + perp_offset * se.bsphere_radius;
+        }
+        *weight = v3(w, w, w);
+        return make_ray(ray_target - d * 2.f * se.bsphere_radius, d, RayEpsilon, pm_inf());
+    }
     // distant.cpp:299-386
     V3 v0 = v3(0.f, 0.f, 1.f);
     if (se.direction_type == 2) v0 = square_to_uniform_hemisphere(position_sample);

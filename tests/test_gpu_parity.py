@@ -196,6 +196,21 @@ def test_every_kernel_formulation_matches_the_oracle(gpu_rgb, monkeypatch, kerne
             assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
 
 
+@pytest.mark.parametrize("target", [None, [1.0, -2.0, 2.0], {"type": "rectangle", "to_world": T.translate([0, 0, 2.0]) @ T.scale(10.0)}])
+def test_distantflux_matches_the_oracle(gpu_rgb, target):
+    """src/sensors/distantflux.cpp over the heterogeneous slab: film and counters bit for bit."""
+    d = scenes.c3_heterogeneous(8, 8, 16, res=16)
+    sd = {"type": "distantflux", "film": {"type": "hdrfilm", "width": 24, "height": 20, "rfilter": {"type": "box"}},
+          "sampler": {"type": "independent", "sample_count": 16}}
+    if target is not None:
+        sd["target"] = target
+    d["sensor"] = sd
+    gpu, st = gpu_render(gpu_rgb, d, collect_counters=True)
+    o = ob.OracleScene(d); ref = o.render(); so = o.last_stats
+    assert np.array_equal(gpu, ref) and gpu[..., :3].max() > 0
+    assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
+
+
 @pytest.mark.parametrize("sensor", ["mradiancemeter", "mdistant_none", "mdistant_point", "mdistant_shape"])
 def test_multi_sensors_match_the_oracle(gpu_rgb, sensor):
     """Eradiate's multi-sensors (src/sensors/mradiancemeter.cpp, mdistant.cpp): one sub-sensor per film column, over the

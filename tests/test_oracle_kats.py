@@ -621,3 +621,60 @@ def test_mdistant_render_targets(setup, w_e, w_o):
     l_o = cos_e / np.pi
     expected = {"default": l_o * (2.0 / np.pi) * cos_o, "target_square_large": l_o * 0.25}.get(setup, l_o)
     assert np.allclose(rgb, expected, rtol={"target_square_large": 2e-2, "default": 2e-2}.get(setup, 5e-3))
+
+
+# ---------------------------------------------------------------- distantflux
+def _flux_sensor(target=None, to_world=None, film="1x1", spp=None):
+    w, h = {"1x1": (1, 1), "16x16": (16, 16), "32x32": (32, 32)}[film]
+    s = {"type": "distantflux", "film": {"type": "hdrfilm", "width": w, "height": h, "rfilter": {"type": "box"}}}
+    if to_world is not None:
+        s["to_world"] = to_world
+    if target == "point":
+        s["target"] = [0, 0, 0]
+    elif target == "shape":
+        s["target"] = {"type": "rectangle"}
+    elif target is not None:
+        s["target"] = target
+    if spp:
+        s["sampler"] = {"type": "independent", "sample_count": spp}
+    return s
+
+
+def test_distantflux_construct_and_rays():
+    """src/sensors/tests/test_distantflux.py:58-106,109-132,184-199: construction, origins outside the bounding sphere, the
+    literal ray directions of the hemisphere warp"""
+    unit = {"shape": {"type": "rectangle"}}
+    for sd in (_flux_sensor(), _flux_sensor(to_world=T.look_at([0, 0, 0], [0, 0, 1], [1, 0, 0])), _flux_sensor("point"), _flux_sensor("shape")):
+        ob.OracleScene(_with_sensor(sd, **unit))
+    with pytest.raises(RuntimeError):
+        ob.OracleScene(_with_sensor(_flux_sensor({"type": "constant"}), **unit))
+    o = ob.OracleScene(_with_sensor(_flux_sensor(), **unit))
+    radius = np.linalg.norm([1.0, 1.0, 0.0])                 # bounding sphere of the unit rectangle
+    for s1, s2 in [[[0.32, 0.87], [0.16, 0.44]], [[0.17, 0.44], [0.22, 0.81]], [[0.12, 0.82], [0.99, 0.42]], [[0.72, 0.40], [0.01, 0.61]]]:
+        ro, _, _ = o.sensor_sample_ray([s1], [s2])
+        assert np.linalg.norm(ro[0]) > radius
+    for s1, s2, expected in [[[0.5, 0.5], [0.16, 0.44], [0, 0, -1]], [[0.0, 0.0], [0.23, 0.40], [0.707107, 0.707107, 0]],
+                             [[1.0, 0.0], [0.22, 0.81], [-0.707107, 0.707107, 0]], [[0.0, 1.0], [0.99, 0.42], [0.707107, -0.707107, 0]],
+                             [[1.0, 1.0], [0.52, 0.31], [-0.707107, -0.707107, 0]]]:
+        _, rd, _ = o.sensor_sample_ray([s1], [s2])
+        assert np.allclose(rd[0], expected, atol=1e-6)
+
+
+@pytest.mark.parametrize("setup", ["default", "target_square", "target_square_small", "target_square_large", "target_point"])
+def test_distantflux_render_targets(setup):
+    """test_distantflux.py:202-369: the film of a distantflux sensor sums to the exitant flux density of a white Lambertian
+    square under unit irradiance (x 2/pi without target, x 0.25 for a target twice as large)"""
+    target = {"default": None, "target_point": "point"}.get(setup, setup)
+    if isinstance(target, str) and target.startswith("target_square"):
+        target = {"type": "rectangle", "to_world": T.scale({"target_square": 1.0, "target_square_small": 0.5, "target_square_large": 2.0}[setup])}
+    spp = 10000 if setup in ("default", "target_square_large") else 100
+    if setup in ("default", "target_square_large"):
+        spp = 2000                                           # 1e4 in the reference; tolerance widened accordingly
+    d = _with_sensor(_flux_sensor(target, film="16x16", spp=spp),
+                     shape={"type": "rectangle", "to_world": T.scale(1.0), "bsdf": {"type": "diffuse", "reflectance": 1.0}},
+                     emitter={"type": "directional", "direction": [0, 0, -1], "irradiance": 1.0})
+    img = ob.OracleScene(d).render()
+    import tests.transport_cases as tc
+    total = tc.radiance_rgb(img)[..., 1].sum()
+    expected = {"default": 2.0 / np.pi, "target_square_large": 0.25}.get(setup, 1.0)
+    assert np.allclose(total, expected, rtol={"default": 1e-2, "target_square_large": 1e-2}.get(setup, 1e-3))
