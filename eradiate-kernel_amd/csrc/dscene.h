@@ -109,6 +109,13 @@ struct DScene {
     const float *positions, *normals, *texcoords;   // world-space mesh data of all meshes
     const uint32_t *faces;
     const float *tri;                               // per primitive (prim order): p0, e1 = p1 - p0, e2 = p2 - p0 (triangles only)
+    // Bounding-volume hierarchy over the primitives, built by the host for scenes with many primitives (NULL otherwise:
+    // the primitive list is walked).  Nodes in depth-first order, 32 bytes each: bmin[3], bmax[3] (conservatively
+    // enlarged), skip = index of the next node when this subtree is missed or done, leaf = (first << 3 | count) into
+    // bvh_prims (0 for inner nodes, whose first child is the next node).  Stack-free traversal.
+    const float *bvh_nodes;
+    const int32_t *bvh_prims;                       // leaf contents: primitive indices (prim order decides ties, kdtree.h:2152-2154)
+    int32_t bvh_node_count;
     int32_t volume_count, phase_count, medium_count, bsdf_count, shape_count, prim_count, emitter_count;
     int32_t environment;
     DBBox bbox;

@@ -158,6 +158,59 @@ DEV float sphere_intersect(const DShape &s, const DRay &ray) {
 // later primitive at the same t replaces the earlier one (`t <= maxt`).  For the handful of
 // primitives of the atmosphere scenes the "acceleration structure" is the primitive list itself,
 // walked with wave-uniform (scalar) loads -- no per-lane memory traffic at all.
+// One primitive addressed per lane (BVH leaves): the same tests as the scalar walk, records fetched with vector loads.
+struct BvhArgs { const float *nodes; const int32_t *leaf_prims; int32_t node_count; const DPrim *prims; const DShape *shapes; const float *tri; };
+DEV float prim_intersect_lane(const BvhArgs &a, int pi, const DRay &ray, F2 &uv, int &shape, int &index) {
+    const MTS_GLOBAL_AS int32_t *pr = (const MTS_GLOBAL_AS int32_t *) as_global(a.prims + pi);
+    shape = pr[0]; index = pr[1];
+    const DShape &s = a.shapes[shape];
+    uv.x = uv.y = 0.f;
+    if (s.type == MTS_SHAPE_RECTANGLE) return rectangle_intersect(s, ray, uv);
+    if (s.type == MTS_SHAPE_SPHERE) return sphere_intersect(s, ray);
+    const MTS_GLOBAL_AS float *t = as_global(a.tri) + 9 * pi;
+    TriRec T;
+    for (int k = 0; k < 9; ++k) T.v[k] = t[k];
+    return triangle_intersect(T, ray, uv);
+}
+// Stack-free traversal of the host-built BVH (dscene.h).  Node boxes are conservative, the exact primitive tests decide;
+// "closest t, ties to the later primitive" is the order-independent form of the sequential rule of kdtree.h:2152-2154.
+// A real function (arguments by value): the traversal loop keeps its registers out of the callers' hot paths, and its
+// callee-saved spills are only paid by scenes that have a BVH.
+template <bool ShadowRay>
+DEV_NOINLINE Hit bvh_intersect(const BvhArgs a, DRay ray) {
+    Hit h; h.t = pm_inf(); h.p = f3s(0.f); h.uv.x = h.uv.y = 0.f; h.shape = -1; h.prim = 0;
+    int best = -1;
+    const MTS_GLOBAL_AS float *nodes = as_global(a.nodes);
+    const MTS_GLOBAL_AS int32_t *leaf_prims = as_global(a.leaf_prims);
+    const int n = a.node_count;
+    int i = 0;
+    while (i < n) {
+        const MTS_GLOBAL_AS float *nd = nodes + 8 * i;
+        const float t1x = (nd[0] - ray.o.x) * ray.d_rcp.x, t2x = (nd[3] - ray.o.x) * ray.d_rcp.x;
+        const float t1y = (nd[1] - ray.o.y) * ray.d_rcp.y, t2y = (nd[4] - ray.o.y) * ray.d_rcp.y;
+        const float t1z = (nd[2] - ray.o.z) * ray.d_rcp.z, t2z = (nd[5] - ray.o.z) * ray.d_rcp.z;
+        // fmin / fmax drop a NaN operand (0 * inf when the origin lies on a slab plane of a ray parallel to it): that axis
+        // then simply does not constrain the interval, which keeps the test conservative
+        const float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)), __builtin_fminf(t1z, t2z));
+        const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)), __builtin_fmaxf(t1z, t2z));
+        const int skip = __float_as_int(nd[6]), leaf = __float_as_int(nd[7]);
+        if (!(tnear <= tfar && tfar >= ray.mint && tnear <= ray.maxt)) { i = skip; continue; }
+        const int count = leaf & 7, first = leaf >> 3;
+        for (int k = 0; k < count; ++k) {
+            const int pi = leaf_prims[first + k];
+            F2 uv; int shape, index;
+            const float t = prim_intersect_lane(a, pi, ray, uv, shape, index);
+            if (t != pm_inf() && (t < h.t || pi > best)) {       // the tests accept t <= ray.maxt == h.t: equal t goes to the later primitive
+                h.t = t; h.uv = uv; h.shape = shape; h.prim = index; best = pi;
+                if (ShadowRay) return h;
+                ray.maxt = t;
+            }
+        }
+        i = i + 1;
+    }
+    return h;
+}
+
 template <bool ShadowRay>
 DEV Hit ray_intersect_preliminary(const DScene &sc, DRay ray) {
     Hit h; h.t = pm_inf(); h.p = f3s(0.f); h.uv.x = h.uv.y = 0.f; h.shape = -1; h.prim = 0;
@@ -165,6 +218,10 @@ DEV Hit ray_intersect_preliminary(const DScene &sc, DRay ray) {
     bbox_ray_intersect(sc.bbox, ray, bmint, bmaxt);
     float mint = pm_max(ray.mint, bmint), maxt = pm_min(ray.maxt, bmaxt);
     if (!(mint <= maxt)) return h;
+    if (sc.bvh_node_count > 0) {
+        BvhArgs a; a.nodes = sc.bvh_nodes; a.leaf_prims = sc.bvh_prims; a.node_count = sc.bvh_node_count; a.prims = sc.prims; a.shapes = sc.shapes; a.tri = sc.tri;
+        return bvh_intersect<ShadowRay>(a, ray);
+    }
     for (int i = 0; i < sc.prim_count; ++i) {
         const DPrim pr = cload(sc.prims + i);
         const DShape s = cload(sc.shapes + pr.shape);

@@ -315,6 +315,7 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
     }
     // ---- emitters + set_scene (scene.cpp:41-52,95-97; directional.cpp:68-73; constant.cpp:35-39; bbox.h:329-332)
     sc.environment = -1;
+    build_bvh(hs);
     F3 center = (f3(sc.bbox.max) + f3(sc.bbox.min)) * .5f;
     float bsphere_radius = pm_max(MTS_RAY_EPSILON, norm(center - f3(sc.bbox.max)) * (1.f + MTS_RAY_EPSILON));
     for (int i = 0; i < d->emitter_count; ++i) {
@@ -412,6 +413,83 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
     return hsp.release();
 }
 
+// ---------------------------------------------------------------- BVH
+// A conservative acceleration structure: every node box is enlarged by a margin far above the rounding error of the slab
+// test, so a primitive the exact tests would accept is never culled; the hit that wins is decided by the exact tests and
+// the order-independent form of the reference's rule (closest t, ties to the later primitive), so results equal the walk
+// over the primitive list bit for bit (which is what the CPU restatement does).
+namespace {
+struct PrimBox { float lo[3], hi[3], c[3]; int32_t prim; };
+struct BvhBuilder {
+    std::vector<PrimBox> &pb; std::vector<float> &nodes; std::vector<int32_t> &prims; float margin;
+    int build(int begin, int end) {
+        const int node = (int) nodes.size() / 8;
+        nodes.resize(nodes.size() + 8);
+        float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY }, clo[3], chi[3];
+        for (int a = 0; a < 3; ++a) { clo[a] = INFINITY; chi[a] = -INFINITY; }
+        for (int i = begin; i < end; ++i) for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], pb[i].lo[a]); hi[a] = std::max(hi[a], pb[i].hi[a]);
+            clo[a] = std::min(clo[a], pb[i].c[a]); chi[a] = std::max(chi[a], pb[i].c[a]);
+        }
+        int32_t leaf = 0;
+        const int count = end - begin;
+        int axis = 0;
+        for (int a = 1; a < 3; ++a) if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
+        if (count <= 4 || !(chi[axis] > clo[axis])) {
+            if (count > 7) {                                                // coincident centroids: split by index
+                const int mid = begin + count / 2;
+                build(begin, mid); build(mid, end);
+            } else {
+                leaf = (int32_t) ((prims.size() << 3) | (size_t) count);
+                for (int i = begin; i < end; ++i) prims.push_back(pb[i].prim);
+            }
+        } else {
+            const int mid = begin + count / 2;
+            std::nth_element(pb.begin() + begin, pb.begin() + mid, pb.begin() + end,
+                             [axis](const PrimBox &x, const PrimBox &y) { return x.c[axis] < y.c[axis]; });
+            build(begin, mid); build(mid, end);
+        }
+        float *n = &nodes[8 * (size_t) node];
+        for (int a = 0; a < 3; ++a) {
+            n[a] = lo[a] - margin - 1e-6f * std::fabs(lo[a]);
+            n[3 + a] = hi[a] + margin + 1e-6f * std::fabs(hi[a]);
+        }
+        const int32_t skip = (int32_t) (nodes.size() / 8);
+        memcpy(&n[6], &skip, 4); memcpy(&n[7], &leaf, 4);
+        return node;
+    }
+};
+}
+
+void build_bvh(HostScene &hs) {
+    hs.bvh_nodes.clear(); hs.bvh_prims.clear();
+    int threshold = 40;                                                    // at or below this the scalar walk over the list is faster (measured: 31 primitives 584 vs 562 Msamples/s)
+    if (const char *e = getenv("MTSAMD_BVH_THRESHOLD")) threshold = atoi(e);
+    const int n = (int) hs.prims.size();
+    if (n <= threshold) return;
+    std::vector<PrimBox> pb((size_t) n);
+    for (int i = 0; i < n; ++i) {
+        const DPrim &pr = hs.prims[(size_t) i]; const DShape &s = hs.shapes[(size_t) pr.shape];
+        PrimBox b; b.prim = i;
+        for (int a = 0; a < 3; ++a) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; }
+        auto add = [&b](F3 p) { const float v[3] = { p.x, p.y, p.z }; for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], v[a]); b.hi[a] = std::max(b.hi[a], v[a]); } };
+        if (s.type == MTS_SHAPE_RECTANGLE) {
+            for (int k = 0; k < 4; ++k) add(mat_point_affine(s.to_world.m, f3((k & 1) ? 1.f : -1.f, (k & 2) ? 1.f : -1.f, 0.f)));
+        } else if (s.type == MTS_SHAPE_SPHERE) {
+            add(f3(s.center) - f3s(s.radius)); add(f3(s.center) + f3s(s.radius));
+        } else {
+            const float *t = &hs.tri[9 * (size_t) i];
+            F3 p0 = f3(t), e1 = f3(t + 3), e2 = f3(t + 6);
+            add(p0); add(p0 + e1); add(p0 + e2);
+        }
+        for (int a = 0; a < 3; ++a) b.c[a] = .5f * (b.lo[a] + b.hi[a]);
+        pb[(size_t) i] = b;
+    }
+    const F3 diag = f3(hs.scene.bbox.max) - f3(hs.scene.bbox.min);
+    BvhBuilder bb{ pb, hs.bvh_nodes, hs.bvh_prims, 1e-5f * norm(diag) + 1e-7f };
+    bb.build(0, n);
+}
+
 // ---------------------------------------------------------------- upload
 #define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
@@ -440,6 +518,8 @@ void upload_host_scene(HostScene &hs, int device) {
     sc.positions = upload(hs, hs.positions); sc.normals = upload(hs, hs.normals); sc.texcoords = upload(hs, hs.texcoords);
     sc.faces = upload(hs, hs.faces);
     sc.tri = upload(hs, hs.tri);
+    sc.bvh_nodes = nullptr; sc.bvh_prims = nullptr; sc.bvh_node_count = (int32_t) (hs.bvh_nodes.size() / 8);
+    if (sc.bvh_node_count > 0) { sc.bvh_nodes = upload(hs, hs.bvh_nodes); sc.bvh_prims = upload(hs, hs.bvh_prims); }
     sc.sensor.rfilter.values = upload(hs, hs.rfilter_values);
     sc.sensor.multi = upload(hs, hs.multi_transforms);
     HIP_CHECK(hipDeviceSynchronize());

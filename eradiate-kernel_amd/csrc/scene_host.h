@@ -25,6 +25,8 @@ struct HostScene {
     std::vector<float> positions, normals, texcoords;
     std::vector<uint32_t> faces;
     std::vector<float> tri;
+    std::vector<float> bvh_nodes;                    // 8 floats per node (DScene::bvh_nodes); empty = no BVH
+    std::vector<int32_t> bvh_prims;
     std::vector<float> rfilter_values;
     std::vector<std::vector<float>> grid_data, tab_pdf, tab_cdf;
     std::vector<float> multi_transforms;            // mradiancemeter / mdistant sub-sensor matrices
@@ -36,6 +38,7 @@ struct HostScene {
 };
 
 HostScene *build_host_scene(const mts_scene_desc *desc);   // throws std::runtime_error
+void build_bvh(HostScene &hs);                 // fills bvh_nodes / bvh_prims when the scene has many primitives
 void upload_host_scene(HostScene &hs, int device);          // throws std::runtime_error
 void free_host_scene(HostScene *hs);
 

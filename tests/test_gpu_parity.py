@@ -196,6 +196,44 @@ def test_every_kernel_formulation_matches_the_oracle(gpu_rgb, monkeypatch, kerne
             assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
 
 
+def _uv_sphere(n_lat, n_lon, radius=1.0, center=(0, 0, 0)):
+    th = np.linspace(0.0, np.pi, n_lat + 1); ph = np.linspace(0.0, 2.0 * np.pi, n_lon, endpoint=False)
+    v = np.array([[np.sin(t) * np.cos(p), np.sin(t) * np.sin(p), np.cos(t)] for t in th for p in ph], dtype=np.float32) * radius + np.asarray(center, np.float32)
+    f = []
+    for i in range(n_lat):
+        for j in range(n_lon):
+            a, b = i * n_lon + j, i * n_lon + (j + 1) % n_lon
+            c, d_ = a + n_lon, b + n_lon
+            if i > 0: f.append((a, c, b))
+            if i < n_lat - 1: f.append((b, c, d_))
+    return v, np.array(f, dtype=np.uint32)
+
+
+@pytest.mark.parametrize("threshold", ["0", "1000000"])
+def test_bvh_equals_the_primitive_walk(gpu_rgb, monkeypatch, threshold):
+    """Scene intersection (Scene::ray_intersect, kdtree.h:2078-2171 semantics): the host-built BVH must select exactly the hits
+    of the walk over the primitive list -- which is what the oracle does.  Threshold 0 forces the BVH for every scene,
+    a huge threshold forces the walk; both must equal the oracle: cornell box (path, shadow rays), heterogeneous slab,
+    atmosphere miniature, and a 2.6k-triangle mesh holding a medium (volpath) / lit by an area light (path)."""
+    monkeypatch.setenv("MTSAMD_BVH_THRESHOLD", threshold)
+    v, f = _uv_sphere(24, 56, 1.5, (0, 0, 1.6))
+    mesh_medium = scenes.c2_homogeneous_slab(40, 40, 4)
+    mesh_medium["blob"] = {"type": "mesh", "vertex_positions": v, "faces": f, "bsdf": {"type": "null"},
+                           "interior": {"type": "homogeneous", "sigma_t": 2.0, "albedo": 0.7, "phase": {"type": "hg", "g": 0.3}}}
+    mesh_medium["sensor"]["to_world"] = T.look_at([0, -9, 3], [0, 0, 1.5], [0, 0, 1])
+    mesh_path = scenes.c1_cornell(40, 40, 4)
+    v2, f2 = _uv_sphere(20, 40, 1.0, (0.5, 0.3, 2.0))
+    mesh_path["ball"] = {"type": "mesh", "vertex_positions": v2, "faces": f2, "bsdf": {"type": "diffuse", "reflectance": 0.7}}
+    cases = [scenes.c1_cornell(48, 48, 4), scenes.c3_heterogeneous(48, 32, 4, res=16), scenes.c4_atmosphere(32, 32, 4), mesh_path]
+    if threshold == "0":
+        cases.append(mesh_medium)                            # the list walk over 2.6k primitives is only the oracle's job
+    for d in cases:
+        gpu, st = gpu_render(gpu_rgb, d, collect_counters=True)
+        o = ob.OracleScene(d); ref = o.render(); so = o.last_stats
+        assert np.array_equal(gpu, ref)
+        assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
+
+
 @pytest.mark.parametrize("target", [None, [1.0, -2.0, 2.0], {"type": "rectangle", "to_world": T.translate([0, 0, 2.0]) @ T.scale(10.0)}])
 def test_distantflux_matches_the_oracle(gpu_rgb, target):
     """src/sensors/distantflux.cpp over the heterogeneous slab: film and counters bit for bit."""
