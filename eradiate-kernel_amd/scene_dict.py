@@ -15,6 +15,7 @@ import numpy as np
 from . import _capi as A
 from .transform import ScalarTransform4f, coordinate_system
 from .volume_io import read_volume
+from .mesh_io import load_mesh
 
 
 def _key_less(a, b):
@@ -352,21 +353,33 @@ class SceneBuilder:
             rec.flip_normals = int(bool(p.get("flip_normals", False)))
             rec.center[:] = tuple(float(x) for x in np.asarray(p.get("center", (0, 0, 0)), dtype=np.float32))
             rec.radius = float(p.get("radius", 1.0))
-        elif p.type == "mesh":
-            # in-memory triangle mesh (extension standing in for the obj / ply loaders)
+        elif p.type in ("mesh", "obj", "ply"):
+            # "mesh": in-memory triangle mesh (extension); "obj" / "ply": src/shapes/obj.cpp, src/shapes/ply.cpp via mesh_io.py,
+            # which applies to_world at load time like the reference's loaders
             rec.type = A.SHAPE_MESH
-            pos = np.ascontiguousarray(p.get("vertex_positions"), dtype=np.float32).reshape(-1, 3)
-            faces = np.ascontiguousarray(p.get("faces"), dtype=np.uint32).reshape(-1, 3)
+            if p.type == "mesh":
+                arrays = {k: p.get(k) for k in ("vertex_positions", "faces", "vertex_normals", "vertex_texcoords") if p.has(k)}
+            else:
+                arrays = load_mesh(p.type, str(p.get("filename")), p.get("to_world"), bool(p.get("face_normals", False)),
+                                   bool(p.get("flip_tex_coords", True)) if p.type == "obj" else True)
+                rec.to_world = _xf(None)
+
+            class _Arr:                                                    # the parsed arrays, read like properties below
+                def has(self, k): return k in arrays
+                def get(self, k): return arrays[k]
+            p_arr = _Arr()
+            pos = np.ascontiguousarray(arrays["vertex_positions"], dtype=np.float32).reshape(-1, 3)
+            faces = np.ascontiguousarray(arrays["faces"], dtype=np.uint32).reshape(-1, 3)
             self.keep += [pos, faces]
             rec.vertex_positions = pos.ctypes.data_as(A.fp)
             rec.faces = faces.ctypes.data_as(C.POINTER(C.c_uint32))
             rec.vertex_count, rec.face_count = pos.shape[0], faces.shape[0]
-            if p.has("vertex_normals"):
-                nor = np.ascontiguousarray(p.get("vertex_normals"), dtype=np.float32).reshape(-1, 3)
+            if p_arr.has("vertex_normals"):
+                nor = np.ascontiguousarray(p_arr.get("vertex_normals"), dtype=np.float32).reshape(-1, 3)
                 self.keep.append(nor)
                 rec.vertex_normals = nor.ctypes.data_as(A.fp)
-            if p.has("vertex_texcoords"):
-                uv = np.ascontiguousarray(p.get("vertex_texcoords"), dtype=np.float32).reshape(-1, 2)
+            if p_arr.has("vertex_texcoords"):
+                uv = np.ascontiguousarray(p_arr.get("vertex_texcoords"), dtype=np.float32).reshape(-1, 2)
                 self.keep.append(uv)
                 rec.vertex_texcoords = uv.ctypes.data_as(A.fp)
         else:
@@ -635,7 +648,7 @@ class SceneBuilder:
     def load(self, d):
         if not isinstance(d, dict) or d.get("type") != "scene":
             raise RuntimeError("load_dict(): the top-level dictionary must have type 'scene' in this backend")
-        SHAPES = ("rectangle", "cube", "sphere", "mesh")
+        SHAPES = ("rectangle", "cube", "sphere", "mesh", "obj", "ply")
         for k, v in sorted_items(d):          # scene.cpp:23: props.objects() order
             if k in ("type", "id"):
                 continue
