@@ -287,6 +287,21 @@ def load_dict(d, device=0):
     return Scene(desc, keep, device)
 
 
+def load_string(string, device=0, **kwargs):
+    """mitsuba.core.xml.load_string(string, variant, **parameters) (src/libcore/python/xml_v.cpp:76-98): the XML is turned into
+    a scene dictionary (xml_io.py), keyword arguments fill `$parameters`."""
+    from .xml_io import xml_to_dict
+    kwargs.pop("variant", None)
+    return load_dict(xml_to_dict(string, kwargs), device)
+
+
+def load_file(path, device=0, **kwargs):
+    """mitsuba.core.xml.load_file(path, variant, update_scene=False, **parameters) (xml_v.cpp:70-75)."""
+    from .xml_io import file_to_dict
+    kwargs.pop("variant", None); kwargs.pop("update_scene", None)
+    return load_dict(file_to_dict(path, kwargs), device)
+
+
 # virtual modules mitsuba.core / mitsuba.core.xml / mitsuba.render (src/python/__init__.py:115-121), registered so
 # that `from mitsuba_amd.core.xml import load_dict` works like the reference's import line
 def _virtual_module(name, **members):
@@ -300,7 +315,7 @@ def _virtual_module(name, **members):
     return mods[0]
 
 
-_xml = _virtual_module("core.xml", load_dict=load_dict)
+_xml = _virtual_module("core.xml", load_dict=load_dict, load_string=load_string, load_file=load_file)
 core = _virtual_module("core", ScalarTransform4f=ScalarTransform4f, Bitmap=Bitmap, Struct=Struct, xml=_xml)
 for _p in ("mitsuba_amd",):
     import sys as _sys
