@@ -133,7 +133,7 @@ def main():
         kernel_name = "render_kernel<false, true>"
     else:
         paths = int(kv[3:]); nt = int(os.environ.get("MTSAMD_WG_THREADS", "768" if paths == 1024 else str(paths)))
-        kernel_name = "render_kernel_wga<false, %d, %d, %d>" % (paths, nt, {1: 4, 0.875: 4, 0.75: 3, 0.625: 3, 0.5: 2}[nt / paths])
+        kernel_name = "render_kernel_wga<false, %d, %d, %d>" % (paths, nt, {1: 4, 0.75: 3, 0.5: 2}[nt / paths])
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "kernel": kernel_name, "avg_launch_ms": round(avg_launch_ms, 3),

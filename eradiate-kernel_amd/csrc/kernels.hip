@@ -144,12 +144,9 @@ hipError_t launch_render(const DScene &sc, const DBlock *d_blocks, uint32_t n_bl
                                  else hipLaunchKernelGGL((render_kernel_wga<false, W, T, E>), dim3(grid), dim3(T), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters); } while (0)
         if (wg == 256 && nt == 256) LAUNCH_WGA(256, 256, 4);
         else if (wg == 512 && nt == 512) LAUNCH_WGA(512, 512, 4);
-        else if (wg == 512 && nt == 384) LAUNCH_WGA(512, 384, 3);
         else if (wg == 512 && nt == 256) LAUNCH_WGA(512, 256, 2);
         else if (wg == 1024 && nt == 1024) LAUNCH_WGA(1024, 1024, 4);
-        else if (wg == 1024 && nt == 896) LAUNCH_WGA(1024, 896, 4);
         else if (wg == 1024 && nt == 768) LAUNCH_WGA(1024, 768, 3);
-        else if (wg == 1024 && nt == 640) LAUNCH_WGA(1024, 640, 3);
         else if (wg == 1024 && nt == 512) LAUNCH_WGA(1024, 512, 2);
         else return hipErrorInvalidConfiguration;
 #undef LAUNCH_WGA
