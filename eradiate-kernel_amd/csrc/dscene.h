@@ -69,6 +69,9 @@ struct DShape {
 };
 
 struct DPrim { int32_t shape, index; };
+// Everything the primitive-list walk needs about one primitive in ONE 64-byte record (one scalar load per primitive instead of a
+// chain prim -> shape -> geometry): triangle: p0, e1, e2; rectangle: rows 0..2 of to_object; sphere: center, radius.
+struct DWalkPrim { int32_t type, shape, index, pad; float f[12]; };
 
 struct DEmitter { int32_t type; DXf to_world; float radiance[3]; int32_t shape; float bsphere_center[3], bsphere_radius; };
 
@@ -105,6 +108,7 @@ struct DScene {
     const DBsdf *bsdfs;
     const DShape *shapes;
     const DPrim *prims;
+    const DWalkPrim *walk;                          // prim order, one record per primitive
     const DEmitter *emitters;
     const float *positions, *normals, *texcoords;   // world-space mesh data of all meshes
     const uint32_t *faces;

@@ -98,8 +98,8 @@ DEV bool bbox_ray_intersect(const DBBox &b, const DRay &ray, float &mint, float 
 
 // ---------------------------------------------------------------- primitives
 // shapes/rectangle.cpp:139-155
-DEV float rectangle_intersect(const DShape &s, const DRay &ray, F2 &uv) {
-    F3 o = mat_point_affine(s.to_object.m, ray.o), d = mat_vector(s.to_object.m, ray.d);
+DEV float rectangle_intersect(const float *to_object /* rows 0..2 suffice */, const DRay &ray, F2 &uv) {
+    F3 o = mat_point_affine(to_object, ray.o), d = mat_vector(to_object, ray.d);
     float t = -o.z * (1.0f / d.z);
     float lx = pm_fma(d.x, t, o.x), ly = pm_fma(d.y, t, o.y);
     bool active = t >= ray.mint && t <= ray.maxt && pm_abs(lx) <= 1.f && pm_abs(ly) <= 1.f;
@@ -128,13 +128,13 @@ DEV float triangle_intersect(const TriRec &T, const DRay &ray, F2 &uv) {
     return active ? t : pm_inf();
 }
 // shapes/sphere.cpp:272-306 in double precision (the reference's CPU path, sphere.cpp:276) + core/math.h:371-411
-DEV float sphere_intersect(const DShape &s, const DRay &ray) {
+DEV float sphere_intersect(const float *center, float radius, const DRay &ray) {
     double mint = ray.mint, maxt = ray.maxt;
-    double ox = (double) ray.o.x - (double) s.center[0], oy = (double) ray.o.y - (double) s.center[1], oz = (double) ray.o.z - (double) s.center[2];
+    double ox = (double) ray.o.x - (double) center[0], oy = (double) ray.o.y - (double) center[1], oz = (double) ray.o.z - (double) center[2];
     double dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
     double A = pm_fma_d(dz, dz, pm_fma_d(dy, dy, dx * dx));
     double B = 2.0 * pm_fma_d(oz, dz, pm_fma_d(oy, dy, ox * dx));
-    double Cc = pm_fma_d(oz, oz, pm_fma_d(oy, oy, ox * ox)) - (double) s.radius * (double) s.radius;
+    double Cc = pm_fma_d(oz, oz, pm_fma_d(oy, oy, ox * ox)) - (double) radius * (double) radius;
     bool linear_case = A == 0.0, valid_linear = linear_case && B != 0.0;
     double x0 = -Cc / B, x1 = x0;
     double discrim = pm_fma_d(B, B, -(4.0 * A * Cc));
@@ -165,8 +165,8 @@ DEV float prim_intersect_lane(const BvhArgs &a, int pi, const DRay &ray, F2 &uv,
     shape = pr[0]; index = pr[1];
     const DShape &s = a.shapes[shape];
     uv.x = uv.y = 0.f;
-    if (s.type == MTS_SHAPE_RECTANGLE) return rectangle_intersect(s, ray, uv);
-    if (s.type == MTS_SHAPE_SPHERE) return sphere_intersect(s, ray);
+    if (s.type == MTS_SHAPE_RECTANGLE) return rectangle_intersect(s.to_object.m, ray, uv);
+    if (s.type == MTS_SHAPE_SPHERE) return sphere_intersect(s.center, s.radius, ray);
     const MTS_GLOBAL_AS float *t = as_global(a.tri) + 9 * pi;
     TriRec T;
     for (int k = 0; k < 9; ++k) T.v[k] = t[k];
@@ -223,14 +223,13 @@ DEV Hit ray_intersect_preliminary(const DScene &sc, DRay ray) {
         return bvh_intersect<ShadowRay>(a, ray);
     }
     for (int i = 0; i < sc.prim_count; ++i) {
-        const DPrim pr = cload(sc.prims + i);
-        const DShape s = cload(sc.shapes + pr.shape);
+        const DWalkPrim w = cload(sc.walk + i);               // one 64-byte scalar load per primitive (fetching one ahead measured slower)
         F2 uv; uv.x = uv.y = 0.f; float t;
-        if (s.type == MTS_SHAPE_RECTANGLE) t = rectangle_intersect(s, ray, uv);
-        else if (s.type == MTS_SHAPE_SPHERE) t = sphere_intersect(s, ray);
-        else t = triangle_intersect(cload((const TriRec *) (sc.tri + 9 * i)), ray, uv);
+        if (w.type == MTS_SHAPE_RECTANGLE) t = rectangle_intersect(w.f, ray, uv);
+        else if (w.type == MTS_SHAPE_SPHERE) t = sphere_intersect(w.f, w.f[3], ray);
+        else { TriRec T; for (int k = 0; k < 9; ++k) T.v[k] = w.f[k]; t = triangle_intersect(T, ray, uv); }
         if (t != pm_inf()) {
-            h.t = t; h.uv = uv; h.shape = pr.shape; h.prim = pr.index;
+            h.t = t; h.uv = uv; h.shape = w.shape; h.prim = w.index;
             if (ShadowRay) return h;
             ray.maxt = t;
         }

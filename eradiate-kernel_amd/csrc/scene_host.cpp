@@ -311,6 +311,12 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
                 store3(rec, p0); store3(rec + 3, e1); store3(rec + 6, e2);
             }
             hs.tri.insert(hs.tri.end(), rec, rec + 9);
+            DWalkPrim w; memset(&w, 0, sizeof(w));
+            w.type = ds.type; w.shape = i; w.index = k;
+            if (ds.type == MTS_SHAPE_RECTANGLE) memcpy(w.f, ds.to_object.m, 48);
+            else if (ds.type == MTS_SHAPE_SPHERE) { memcpy(w.f, ds.center, 12); w.f[3] = ds.radius; }
+            else memcpy(w.f, rec, 36);
+            hs.walk.push_back(w);
         }
     }
     // ---- emitters + set_scene (scene.cpp:41-52,95-97; directional.cpp:68-73; constant.cpp:35-39; bbox.h:329-332)
@@ -513,7 +519,7 @@ void upload_host_scene(HostScene &hs, int device) {
         if (!hs.pair_data[i].empty()) hs.media[i].pair_grid = upload(hs, hs.pair_data[i]);
     DScene &sc = hs.scene;
     sc.volumes = upload(hs, hs.volumes); sc.phases = upload(hs, hs.phases); sc.media = upload(hs, hs.media);
-    sc.bsdfs = upload(hs, hs.bsdfs); sc.shapes = upload(hs, hs.shapes); sc.prims = upload(hs, hs.prims);
+    sc.bsdfs = upload(hs, hs.bsdfs); sc.shapes = upload(hs, hs.shapes); sc.prims = upload(hs, hs.prims); sc.walk = upload(hs, hs.walk);
     sc.emitters = upload(hs, hs.emitters);
     sc.positions = upload(hs, hs.positions); sc.normals = upload(hs, hs.normals); sc.texcoords = upload(hs, hs.texcoords);
     sc.faces = upload(hs, hs.faces);

@@ -21,6 +21,7 @@ struct HostScene {
     std::vector<DBsdf> bsdfs;
     std::vector<DShape> shapes;
     std::vector<DPrim> prims;
+    std::vector<DWalkPrim> walk;
     std::vector<DEmitter> emitters;
     std::vector<float> positions, normals, texcoords;
     std::vector<uint32_t> faces;
