@@ -50,6 +50,10 @@ struct DMedium {
     // uploads them interleaved, voxel by voxel {sigma_t, albedo} (padded by one voxel): the two x-neighbours of both grids are
     // 16 contiguous bytes, so a lookup is 4 wide gathers instead of 16 dword gathers.  NULL otherwise.
     const float *pair_grid;
+    // ... together with a copy of what a lookup needs from the sigma_t volume record (one scalar load for the whole step
+    // instead of the chain medium -> volume): world_to_local, resolution, affine flag.  Valid when pair_grid != NULL.
+    float pair_w2l[16];
+    int32_t pair_nx, pair_ny, pair_nz, pair_affine;
 };
 
 struct DBsdf { int32_t type; float reflectance[3], rho_0[3], k[3], g[3], rho_c[3]; uint32_t flags; };

@@ -268,6 +268,7 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
                 const size_t n = (size_t) a.nx * a.ny * a.nz;
                 pair.assign(2 * (n + 1), 0.f);
                 for (size_t k = 0; k < n; ++k) { pair[2 * k] = ga[k]; pair[2 * k + 1] = gb[k]; }
+                memcpy(dm.pair_w2l, a.w2l, 64); dm.pair_nx = a.nx; dm.pair_ny = a.ny; dm.pair_nz = a.nz; dm.pair_affine = a.affine;
             }
             hs.pair_data.push_back(std::move(pair));
         }

@@ -40,6 +40,17 @@ __device__ unsigned long long g_blockstats[48];    // class b < 12: [b] executio
 // textures/grid3d.cpp:259-341 split in two: cell coordinates / weights (shared by grids with the same
 // transform and resolution) and the 8 gathers + trilinear blend of one grid.
 struct GridCell { int32_t r00, r10, r01, r11, x0, x1; F3 w0, w1; };
+DEV GridCell grid_cell_clamp(const float *w2l, int affine, int nx, int ny, int nz, F3 p_world) {      // clamp mode (pair grids)
+    F3 p = affine ? mat_point_affine(w2l, p_world) : mat_point(w2l, p_world);
+    p = f3(pm_fma(p.x, (float) nx, -.5f), pm_fma(p.y, (float) ny, -.5f), pm_fma(p.z, (float) nz, -.5f));
+    int ix = (int) pm_floor(p.x), iy = (int) pm_floor(p.y), iz = (int) pm_floor(p.z);
+    GridCell c;
+    c.w1 = p - f3((float) ix, (float) iy, (float) iz); c.w0 = f3(1.f - c.w1.x, 1.f - c.w1.y, 1.f - c.w1.z);
+    c.x0 = min(max(ix, 0), nx - 1); c.x1 = min(max(ix + 1, 0), nx - 1);                                  // grid3d.cpp:234-250, clamp
+    int y0 = min(max(iy, 0), ny - 1), y1 = min(max(iy + 1, 0), ny - 1), z0 = min(max(iz, 0), nz - 1), z1 = min(max(iz + 1, 0), nz - 1);
+    c.r00 = (z0 * ny + y0) * nx; c.r10 = (z0 * ny + y1) * nx; c.r01 = (z1 * ny + y0) * nx; c.r11 = (z1 * ny + y1) * nx;
+    return c;
+}
 DEV GridCell grid_cell(const DVolume &v, F3 p_world) {
     F3 p = v.affine ? mat_point_affine(v.w2l, p_world) : mat_point(v.w2l, p_world);
     const int nx = v.nx, ny = v.ny, nz = v.nz;
@@ -100,24 +111,26 @@ DEV MedStep medium_step(const DScene &sc, const DMedium m, const DRay &ray, floa
         if (want_albedo) mi.sigma_s = st * volume_eval(cload(sc.volumes + m.albedo), mi.p);
     } else if (valid_mi) {
         if (COUNT) MTS_SEG(cnt, 1);
-        const DVolume vs = cload(sc.volumes + m.sigma_t), va = cload(sc.volumes + m.albedo);
-        if (m.pair_grid != nullptr) {
-            GridCell c = grid_cell(vs, mi.p);
+        if (m.pair_grid != nullptr) {                          // everything comes from the medium record and the interleaved grid
+            GridCell c = grid_cell_clamp(m.pair_w2l, m.pair_affine, m.pair_nx, m.pair_ny, m.pair_nz, mi.p);
             float st_raw, al_raw;
-            grid_fetch_pair(as_global(m.pair_grid), c, vs.nx, st_raw, al_raw);
+            grid_fetch_pair(as_global(m.pair_grid), c, m.pair_nx, st_raw, al_raw);
             float st = m.scale * st_raw;
             mi.sigma_t = f3s(st);
             if (want_albedo) mi.sigma_s = f3s(st * al_raw);
-        } else if (m.shared_grid && m.grey && vs.filter == MTS_FILTER_TRILINEAR) {
-            // both grids share one cell / one set of weights; single channel: one value serves the three channels
-            GridCell c = grid_cell(vs, mi.p);
-            float st = m.scale * grid_fetch1(as_global(vs.data), c);
-            mi.sigma_t = f3s(st);
-            if (want_albedo) mi.sigma_s = f3s(st * grid_fetch1(as_global(va.data), c));       // the tracking walks never read sigma_s
         } else {
-            F3 st = m.scale * volume_eval(vs, mi.p);
-            mi.sigma_t = st;
-            if (want_albedo) mi.sigma_s = st * volume_eval(va, mi.p);
+            const DVolume vs = cload(sc.volumes + m.sigma_t), va = cload(sc.volumes + m.albedo);
+            if (m.shared_grid && m.grey && vs.filter == MTS_FILTER_TRILINEAR) {
+                // both grids share one cell / one set of weights; single channel: one value serves the three channels
+                GridCell c = grid_cell(vs, mi.p);
+                float st = m.scale * grid_fetch1(as_global(vs.data), c);
+                mi.sigma_t = f3s(st);
+                if (want_albedo) mi.sigma_s = f3s(st * grid_fetch1(as_global(va.data), c));       // the tracking walks never read sigma_s
+            } else {
+                F3 st = m.scale * volume_eval(vs, mi.p);
+                mi.sigma_t = st;
+                if (want_albedo) mi.sigma_s = st * volume_eval(va, mi.p);
+            }
         }
         if (COUNT) cnt.n_lookup++;
         if (COUNT) MTS_SEG(cnt, 2);
