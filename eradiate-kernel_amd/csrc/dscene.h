@@ -70,6 +70,7 @@ struct DShape {
     int32_t vertex_offset, face_offset;           // into the scene-wide mesh arrays
     int32_t has_normals, has_texcoords;
     int32_t is_medium_transition;
+    int32_t bsdf_type; uint32_t bsdf_flags;       // copies of bsdfs[bsdf].type / .flags: spares the surface blocks a dependent record load
 };
 
 struct DPrim { int32_t shape, index; };

@@ -300,6 +300,7 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
         DBBox sb; int prim_count;
         DShape ds = build_shape(s, hs, sb, prim_count);
         if (ds.bsdf < 0) ds.bsdf = ds.emitter >= 0 ? default_emitter_bsdf : default_bsdf;
+        ds.bsdf_type = hs.bsdfs[(size_t) ds.bsdf].type; ds.bsdf_flags = hs.bsdfs[(size_t) ds.bsdf].flags;
         hs.shapes.push_back(ds);
         bbox_expand(sc.bbox, sb);
         for (int k = 0; k < prim_count; ++k) {

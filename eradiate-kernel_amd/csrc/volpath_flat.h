@@ -498,7 +498,7 @@ struct VolpathMachine {
             WATERFALL_BEGIN(p.si.shape, su)
                 const DShape s = cload(sc.shapes + su);
                 if (!is_nee) emitter = s.emitter;
-                nt = cload(sc.bsdfs + s.bsdf).type == MTS_BSDF_NULL ? f3s(1.f) : f3s(0.f);    // null.cpp:70-73, bsdf.cpp:11-14
+                nt = s.bsdf_type == MTS_BSDF_NULL ? f3s(1.f) : f3s(0.f);                      // null.cpp:70-73, bsdf.cpp:11-14
                 is_tr = s.is_medium_transition; ext = s.exterior; inte = s.interior;
                 if (emitter >= 0) complete_surface(sc, s, p.si, p.ray.d, sf);
                 else if (is_tr) sf.n = hit_geo_normal(sc, s, p.si);
@@ -535,7 +535,7 @@ struct VolpathMachine {
                 const DShape s = cload(sc.shapes + su);
                 emitter = s.emitter; bsdf_id = s.bsdf;
                 // the shading frame is only read by emitter evaluation and by the NEE of a smooth BSDF: a null boundary needs neither
-                if (s.emitter >= 0 || (cload(sc.bsdfs + s.bsdf).flags & F_Smooth) != 0) complete_surface(sc, s, p.si, p.ray.d, sf);
+                if (s.emitter >= 0 || (s.bsdf_flags & F_Smooth) != 0) complete_surface(sc, s, p.si, p.ray.d, sf);
             WATERFALL_END
         }
         if ((p.flags & FL_SPEC_CHAIN) && emitter >= 0) p.res = p.res + p.thr * emitter_eval(sc, emitter, sf.wi.z);
