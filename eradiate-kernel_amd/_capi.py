@@ -24,7 +24,7 @@ EMITTER_DIRECTIONAL, EMITTER_AREA, EMITTER_CONSTANT = 0, 1, 2
 SENSOR_PERSPECTIVE, SENSOR_DISTANT, SENSOR_MRADIANCEMETER, SENSOR_MDISTANT, SENSOR_DISTANTFLUX = 0, 1, 2, 3, 4
 RFILTER_BOX, RFILTER_GAUSSIAN = 0, 1
 DISTANT_TARGET_NONE, DISTANT_TARGET_POINT, DISTANT_TARGET_SHAPE = 0, 1, 2
-INTEGRATOR_PATH, INTEGRATOR_VOLPATH = 0, 1
+INTEGRATOR_PATH, INTEGRATOR_VOLPATH, INTEGRATOR_VOLPATHMIS = 0, 1, 2
 
 f32 = C.c_float
 i32 = C.c_int32
@@ -83,7 +83,7 @@ class Sensor(C.Structure):
 
 class Integrator(C.Structure):
     _fields_ = [("type", i32), ("max_depth", i32), ("rr_depth", i32), ("hide_emitters", i32),
-                ("block_size", i32), ("samples_per_pass", i32), ("timeout", f32)]
+                ("block_size", i32), ("samples_per_pass", i32), ("timeout", f32), ("use_spectral_mis", i32)]
 
 
 class SceneDesc(C.Structure):

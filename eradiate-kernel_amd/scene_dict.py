@@ -629,8 +629,11 @@ class SceneBuilder:
             it.type = A.INTEGRATOR_PATH
         elif p.type == "volpath":
             it.type = A.INTEGRATOR_VOLPATH
+        elif p.type == "volpathmis":
+            it.type = A.INTEGRATOR_VOLPATHMIS
         else:
             raise RuntimeError("Unknown / unsupported integrator plugin \"%s\"" % p.type)
+        it.use_spectral_mis = int(bool(p.get("use_spectral_mis", True))) if p.type == "volpathmis" else 1
         it.max_depth = int(p.get("max_depth", -1))
         it.rr_depth = int(p.get("rr_depth", 5))
         it.hide_emitters = int(bool(p.get("hide_emitters", False)))
@@ -665,7 +668,7 @@ class SceneBuilder:
                 if self.sensor is not None:
                     raise RuntimeError("this backend supports a single sensor per scene")
                 self.set_sensor(v, k)
-            elif t in ("path", "volpath"):
+            elif t in ("path", "volpath", "volpathmis"):
                 if self.integrator is not None:
                     raise RuntimeError("Only one integrator can be specified per scene.")
                 self.set_integrator(v, k)

@@ -165,7 +165,7 @@ typedef struct mts_sensor {
 } mts_sensor;
 
 /* ---- Integrator (src/integrators/{path,volpath}.cpp, src/librender/integrator.cpp:23-39,302-315) */
-enum { MTS_INTEGRATOR_PATH = 0, MTS_INTEGRATOR_VOLPATH = 1 };
+enum { MTS_INTEGRATOR_PATH = 0, MTS_INTEGRATOR_VOLPATH = 1, MTS_INTEGRATOR_VOLPATHMIS = 2 /* src/integrators/volpathmis.cpp */ };
 typedef struct mts_integrator {
     int32_t type;
     int32_t max_depth;        /* default -1 (infinite)                                           */
@@ -174,6 +174,7 @@ typedef struct mts_integrator {
     int32_t block_size;       /* default 0 = heuristic; this backend pins 32 (MTS_BLOCK_SIZE)    */
     int32_t samples_per_pass; /* default -1 = all                                                */
     float timeout;            /* seconds, < 0 = none                                             */
+    int32_t use_spectral_mis; /* volpathmis "use_spectral_mis", default true (volpathmis.cpp:29,38)  */
 } mts_integrator;
 
 typedef struct mts_scene_desc {

@@ -857,6 +857,292 @@ static V3 volpath_sample(const Scene &sc, Sampler &sampler, Ray ray, int medium,
     return result;
 }
 
+// ---------------------------------------------------------------- volpathmis
+// src/integrators/volpathmis.cpp: the volumetric path tracer with spectral multiple importance sampling.  WeightMatrix is a
+// 3 x 3 matrix (one row of probability ratios per colour channel) with `use_spectral_mis` (the default, :29,38-46), a single
+// row without.  hsum is evaluated left to right.
+template <bool SPEC> struct MisWeights { V3 r[SPEC ? 3 : 1]; };
+template <bool SPEC> static inline MisWeights<SPEC> mw_full(float v) { MisWeights<SPEC> w; for (auto &x : w.r) x = v3(v, v, v); return w; }
+static inline bool finite3(float x) { return pm_isfinite(x); }
+// volpathmis.cpp:447-466
+template <bool SPEC>
+static inline void update_weights(MisWeights<SPEC> &w, V3 p, V3 f, uint32_t channel, bool active) {
+    if (SPEC) {
+        for (int i = 0; i < 3; ++i) {
+            float fi = idx(f, (uint32_t) i);
+            V3 ratio = v3(p.x / fi, p.y / fi, p.z / fi);
+            ratio = v3(finite3(ratio.x) ? ratio.x : 0.f, finite3(ratio.y) ? ratio.y : 0.f, finite3(ratio.z) ? ratio.z : 0.f);
+            ratio = ratio * w.r[i];
+            if (active) w.r[i] = v3(ratio.x != ratio.x ? 0.f : ratio.x, ratio.y != ratio.y ? 0.f : ratio.y, ratio.z != ratio.z ? 0.f : ratio.z);
+        }
+    } else {
+        float pdf = idx(p, channel);
+        V3 ratio = w.r[0] * v3(pdf / f.x, pdf / f.y, pdf / f.z);
+        if (active) w.r[0] = v3(finite3(ratio.x) ? ratio.x : 0.f, finite3(ratio.y) ? ratio.y : 0.f, finite3(ratio.z) ? ratio.z : 0.f);
+    }
+}
+template <bool SPEC> static inline void update_weights(MisWeights<SPEC> &w, float p, V3 f, uint32_t c, bool a) { update_weights(w, v3(p, p, p), f, c, a); }
+template <bool SPEC> static inline void update_weights(MisWeights<SPEC> &w, V3 p, float f, uint32_t c, bool a) { update_weights(w, p, v3(f, f, f), c, a); }
+template <bool SPEC> static inline void update_weights(MisWeights<SPEC> &w, float p, float f, uint32_t c, bool a) { update_weights(w, v3(p, p, p), v3(f, f, f), c, a); }
+// volpathmis.cpp:468-481
+template <bool SPEC>
+static inline V3 mis_weight_w(const MisWeights<SPEC> &w) {
+    if (SPEC) {
+        float o[3];
+        for (int i = 0; i < 3; ++i) { float sum = (w.r[i].x + w.r[i].y) + w.r[i].z; o[i] = sum == 0.f ? 0.f : 3.f / sum; }
+        return v3(o[0], o[1], o[2]);
+    }
+    V3 a = w.r[0];
+    bool invalid = pm_min(pm_min(pm_abs(a.x), pm_abs(a.y)), pm_abs(a.z)) == 0.f;
+    return invalid ? v3(0.f, 0.f, 0.f) : v3(1.f / a.x, 1.f / a.y, 1.f / a.z);
+}
+// volpathmis.cpp:484-498
+template <bool SPEC>
+static inline V3 mis_weight_w(const MisWeights<SPEC> &a, const MisWeights<SPEC> &b) {
+    if (SPEC) {
+        float o[3];
+        for (int i = 0; i < 3; ++i) { V3 r = a.r[i] + b.r[i]; float sum = (r.x + r.y) + r.z; o[i] = sum == 0.f ? 0.f : 3.f / sum; }
+        return v3(o[0], o[1], o[2]);
+    }
+    V3 sum = a.r[0] + b.r[0];
+    bool zero = pm_min(pm_min(pm_abs(sum.x), pm_abs(sum.y)), pm_abs(sum.z)) == 0.f;
+    return zero ? v3(0.f, 0.f, 0.f) : v3(1.f / sum.x, 1.f / sum.y, 1.f / sum.z);
+}
+
+// volpathmis.cpp:330-445
+template <bool SPEC>
+static V3 volpathmis_sample_emitter(const Scene &sc, V3 ref_p, bool is_medium_interaction, Sampler &sampler, int medium, const MisWeights<SPEC> &p_over_f,
+                                    uint32_t channel, MisWeights<SPEC> *nee_out, MisWeights<SPEC> *uni_out, DirectionSample *ds_out, Counters *cnt) {
+    MisWeights<SPEC> p_over_f_nee = p_over_f, p_over_f_uni = p_over_f;
+    V3 emitter_sample_weight;
+    DirectionSample ds = sample_emitter_direction(sc, ref_p, sampler.next_2d(), false, &emitter_sample_weight);
+    V3 emitter_val = emitter_sample_weight * ds.pdf;
+    if (ds.pdf == 0.f) emitter_val = v3(0.f, 0.f, 0.f);
+    bool active = ds.pdf != 0.f;
+    update_weights(p_over_f_nee, ds.pdf, 1.0f, channel, active);
+    *ds_out = ds;
+    if (!active) { *nee_out = p_over_f_nee; *uni_out = p_over_f_uni; return emitter_val; }
+    Ray ray = spawn_ray(ref_p, ds.d);
+    if (is_medium_interaction) ray.mint = 0.f;
+    float total_dist = 0.f;
+    SurfaceInteraction si; memset(&si, 0, sizeof(si)); si.t = pm_inf(); si.shape = -1;
+    bool needs_intersection = true;
+    while (active) {
+        float remaining_dist = ds.dist * (1.f - ShadowEpsilon) - total_dist;
+        ray.maxt = remaining_dist;
+        active = active && remaining_dist > 0.f;
+        if (!active) break;
+        if (cnt) cnt->n_nee_step++;
+        bool escaped_medium = false, active_medium = medium >= 0, active_surface = !active_medium;
+        if (active_medium) {
+            const Medium &m = sc.media[medium];
+            MediumInteraction mi = medium_sample_interaction(sc, medium, ray, sampler.next_1d(), channel, cnt);
+            if (m.is_homogeneous && mi.is_valid()) ray.maxt = pm_min(mi.t, remaining_dist);
+            if (needs_intersection) si = ray_intersect(sc, ray);
+            if (si.t < mi.t) mi.t = pm_inf();
+            needs_intersection = false;
+            bool is_spectral = m.has_spectral_extinction, not_spectral = !is_spectral;
+            if (is_spectral) {
+                float t = pm_min(remaining_dist, pm_min(mi.t, si.t)) - mi.mint;
+                V3 tr = v3(pm_exp(-t * mi.combined_extinction.x), pm_exp(-t * mi.combined_extinction.y), pm_exp(-t * mi.combined_extinction.z));
+                V3 free_flight_pdf = (si.t < mi.t || mi.t > remaining_dist) ? tr : tr * mi.combined_extinction;
+                update_weights(p_over_f_nee, free_flight_pdf, tr, channel, true);
+                update_weights(p_over_f_uni, free_flight_pdf, tr, channel, true);
+            }
+            if (mi.t > remaining_dist && mi.is_valid()) total_dist = ds.dist;
+            if (mi.t > remaining_dist) mi.t = pm_inf();
+            escaped_medium = !mi.is_valid();
+            active_medium = mi.is_valid();
+            is_spectral = is_spectral && active_medium; not_spectral = not_spectral && active_medium;
+            if (active_medium) {
+                total_dist += mi.t;
+                ray.o = mi.p; ray.mint = 0.f; si.t = si.t - mi.t;
+                if (is_spectral) {
+                    update_weights(p_over_f_nee, 1.f, mi.sigma_n, channel, true);
+                    update_weights(p_over_f_uni, mi.sigma_n / mi.combined_extinction, mi.sigma_n, channel, true);
+                }
+                if (not_spectral) {
+                    update_weights(p_over_f_nee, 1.f, mi.sigma_n / mi.combined_extinction, channel, true);
+                    update_weights(p_over_f_uni, mi.sigma_n, mi.sigma_n, channel, true);
+                }
+            }
+        }
+        bool intersect = active_surface && needs_intersection;
+        if (intersect) si = ray_intersect(sc, ray);
+        active_surface = active_surface || escaped_medium;
+        if (active_surface) total_dist += si.t;
+        active_surface = active_surface && si.is_valid() && active && !active_medium;
+        if (active_surface) {
+            V3 bsdf_val = bsdf_eval_null_transmission(sc.bsdf_of(sc.shapes[si.shape]));
+            update_weights(p_over_f_nee, 1.0f, bsdf_val, channel, true);
+            update_weights(p_over_f_uni, 1.0f, bsdf_val, channel, true);
+        }
+        if (active_surface) ray = spawn_ray(si.p, ray.d);
+        ray.maxt = remaining_dist;
+        needs_intersection = needs_intersection || active_surface;
+        if (SPEC) active = active && (active_medium || active_surface) && any_nonzero(mis_weight_w(p_over_f_uni));
+        else active = active && (active_medium || active_surface) && (any_nonzero(p_over_f_uni.r[0]) || any_nonzero(p_over_f_nee.r[0]));
+        if (active_surface && sc.shapes[si.shape].is_medium_transition()) medium = target_medium(sc, si, ray.d);
+    }
+    *nee_out = p_over_f_nee; *uni_out = p_over_f_uni;
+    return emitter_val;
+}
+
+// volpathmis.cpp:86-328
+template <bool SPEC>
+static V3 volpathmis_sample(const Scene &sc, Sampler &sampler, Ray ray, int medium, bool *valid_out, Counters *cnt) {
+    const uint32_t max_depth = (uint32_t) sc.integrator.max_depth, rr_depth = (uint32_t) sc.integrator.rr_depth;
+    const bool hide_emitters = sc.integrator.hide_emitters != 0;
+    bool valid_ray = !hide_emitters && sc.environment >= 0;
+    float eta = 1.f;
+    V3 result = v3(0.f, 0.f, 0.f);
+    MediumInteraction mi; memset(&mi, 0, sizeof(mi)); mi.t = pm_inf();
+    bool active = true, specular_chain = !hide_emitters;
+    uint32_t depth = 0;
+    MisWeights<SPEC> p_over_f = mw_full<SPEC>(1.f), p_over_f_nee = mw_full<SPEC>(1.f);
+    uint32_t channel = (uint32_t) pm_min(sampler.next_1d() * 3.f, 2.f);                      // volpathmis.cpp:120-124
+    SurfaceInteraction si; memset(&si, 0, sizeof(si)); si.t = pm_inf(); si.shape = -1;
+    bool needs_intersection = true, last_event_was_null = false;
+    V3 last_scatter_p = v3(0.f, 0.f, 0.f);                                                    // last_scatter_event: only .p is read
+    for (;;) {
+        V3 mis_throughput = mis_weight_w(p_over_f);
+        float q = pm_min(hmax(mis_throughput) * (eta * eta), .95f);
+        bool perform_rr = active && !last_event_was_null && (depth > rr_depth);
+        active = active && !(sampler.next_1d() >= q && perform_rr);
+        update_weights(p_over_f, q, 1.0f, channel, perform_rr);
+        last_event_was_null = false;
+        bool exceeded_max_depth = depth >= max_depth;
+        active = active && !exceeded_max_depth;
+        active = active && any_nonzero(mis_weight_w(p_over_f));
+        if (!active) break;
+        if (cnt) cnt->n_iter++;
+        bool active_medium = active && medium >= 0, active_surface = active && !active_medium;
+        bool act_null_scatter = false, act_medium_scatter = false, escaped_medium = false;
+        bool is_spectral = active_medium, not_spectral = false;
+        if (active_medium) { is_spectral = is_spectral && sc.media[medium].has_spectral_extinction; not_spectral = !is_spectral && active_medium; }
+        if (active_medium) {
+            const Medium &m = sc.media[medium];
+            mi = medium_sample_interaction(sc, medium, ray, sampler.next_1d(), channel, cnt);
+            if (m.is_homogeneous && mi.is_valid()) ray.maxt = mi.t;
+            if (needs_intersection) si = ray_intersect(sc, ray);
+            needs_intersection = false;
+            if (si.t < mi.t) mi.t = pm_inf();
+            if (is_spectral) {
+                float t = pm_min(mi.t, si.t) - mi.mint;                                       // medium.cpp:77-89
+                V3 tr = v3(pm_exp(-t * mi.combined_extinction.x), pm_exp(-t * mi.combined_extinction.y), pm_exp(-t * mi.combined_extinction.z));
+                V3 free_flight_pdf = si.t < mi.t ? tr : tr * mi.combined_extinction;
+                update_weights(p_over_f, free_flight_pdf, tr, channel, true);
+                update_weights(p_over_f_nee, free_flight_pdf, tr, channel, true);
+            }
+            escaped_medium = !mi.is_valid();
+            active_medium = mi.is_valid();
+            is_spectral = is_spectral && active_medium; not_spectral = not_spectral && active_medium;
+        }
+        if (active_medium) {
+            bool null_scatter = sampler.next_1d() >= idx(mi.sigma_t, channel) / idx(mi.combined_extinction, channel);
+            act_null_scatter = null_scatter;
+            act_medium_scatter = !act_null_scatter;
+            if (act_medium_scatter) { depth += 1; last_scatter_p = mi.p; }
+            const Medium &m = sc.media[mi.medium];
+            bool sample_emitters = m.sample_emitters;
+            active = active && depth < max_depth;
+            act_medium_scatter = act_medium_scatter && active;
+            specular_chain = specular_chain && !(act_medium_scatter && sample_emitters);
+            if (act_null_scatter) {
+                if (is_spectral) {
+                    update_weights(p_over_f, mi.sigma_n / mi.combined_extinction, mi.sigma_n, channel, true);
+                    update_weights(p_over_f_nee, 1.0f, mi.sigma_n, channel, true);
+                }
+                if (not_spectral) {
+                    update_weights(p_over_f, mi.sigma_n, mi.sigma_n, channel, true);
+                    update_weights(p_over_f_nee, 1.0f, mi.sigma_n / mi.combined_extinction, channel, true);
+                }
+                ray.o = mi.p; ray.mint = 0.f; si.t = si.t - mi.t;
+            }
+            if (act_medium_scatter) {
+                if (is_spectral) update_weights(p_over_f, mi.sigma_t / mi.combined_extinction, mi.sigma_s, channel, true);
+                if (not_spectral) update_weights(p_over_f, mi.sigma_t, mi.sigma_s, channel, true);
+                valid_ray = true;
+                if (sample_emitters) {
+                    MisWeights<SPEC> nee_end, uni_end; DirectionSample ds;
+                    V3 emitted = volpathmis_sample_emitter<SPEC>(sc, mi.p, true, sampler, medium, p_over_f, channel, &nee_end, &uni_end, &ds, cnt);
+                    bool active_e = true;
+                    float phase_val = phase_eval(sc, m.phase, mi, ds.d);
+                    update_weights(nee_end, 1.0f, phase_val, channel, active_e);
+                    update_weights(uni_end, ds.delta ? 0.f : phase_val, phase_val, channel, active_e);
+                    result = result + mis_weight_w(nee_end, uni_end) * emitted;
+                }
+                p_over_f_nee = p_over_f;
+                float s1 = sampler.next_1d(); P2 s2 = sampler.next_2d();                      // left-to-right, SURVEY.md 8(a')
+                V3 wo; float phase_pdf;
+                phase_sample(sc, m.phase, mi, s1, s2, &wo, &phase_pdf);
+                ray = spawn_ray(mi.p, wo); ray.mint = 0.0f;
+                needs_intersection = true;
+                update_weights(p_over_f, phase_pdf, phase_pdf, channel, true);
+                update_weights(p_over_f_nee, 1.f, phase_pdf, channel, true);
+            }
+        }
+        active_surface = active_surface || escaped_medium;
+        bool intersect = active_surface && needs_intersection;
+        if (intersect) si = ray_intersect(sc, ray);
+        if (active_surface) {
+            bool ray_from_camera = depth == 0;
+            bool count_direct = ray_from_camera || specular_chain;
+            int emitter = si_emitter(sc, si);
+            bool active_e = emitter >= 0 && !(depth == 0 && hide_emitters);
+            if (active_e) {
+                if (!count_direct) {
+                    DirectionSample ds; memset(&ds, 0, sizeof(ds));                          // records.h:168-174
+                    ds.p = si.p; ds.n = si.sh_frame.n; ds.d = si.p - last_scatter_p; ds.dist = norm(ds.d); ds.d = ds.d / ds.dist;
+                    if (!si.is_valid()) ds.d = -si.wi;
+                    ds.emitter = emitter;
+                    float emitter_pdf = pdf_emitter_direction(sc, last_scatter_p, ds);
+                    update_weights(p_over_f_nee, emitter_pdf, 1.f, channel, true);
+                }
+                V3 emitted = emitter_eval(sc, emitter, si);
+                V3 contrib = count_direct ? mis_weight_w(p_over_f) * emitted : mis_weight_w(p_over_f, p_over_f_nee) * emitted;
+                result = result + contrib;
+            }
+        }
+        active_surface = active_surface && si.is_valid();
+        if (active_surface) {
+            const Shape &shape = sc.shapes[si.shape];
+            const Bsdf &bsdf = sc.bsdf_of(shape);
+            bool active_e = (bsdf.flags & F_Smooth) != 0 && (depth + 1 < max_depth);
+            if (active_e) {
+                MisWeights<SPEC> nee_end, uni_end; DirectionSample ds;
+                V3 emitted = volpathmis_sample_emitter<SPEC>(sc, si.p, false, sampler, medium, p_over_f, channel, &nee_end, &uni_end, &ds, cnt);
+                V3 wo_local = si.to_local(ds.d);
+                V3 bsdf_val = bsdf_eval(bsdf, si, wo_local);
+                float bpdf = bsdf_pdf(bsdf, si, wo_local);
+                update_weights(nee_end, 1.0f, bsdf_val, channel, true);
+                update_weights(uni_end, ds.delta ? 0.f : bpdf, bsdf_val, channel, true);
+                result = result + mis_weight_w(nee_end, uni_end) * emitted;
+            }
+            float s1 = sampler.next_1d(); P2 s2 = sampler.next_2d();
+            BSDFSample bs;
+            V3 bsdf_weight = bsdf_sample(bsdf, si, s1, s2, &bs);
+            bool invalid_bsdf_sample = bs.pdf == 0.f;
+            active_surface = active_surface && bs.pdf > 0.f;
+            if (active_surface) eta *= bs.eta;
+            Ray bsdf_ray = spawn_ray(si.p, si.to_world(bs.wo));
+            if (active_surface) { ray = bsdf_ray; needs_intersection = true; }
+            bool non_null_bsdf = active_surface && !(bs.sampled_type & F_Null);
+            valid_ray = valid_ray || non_null_bsdf || invalid_bsdf_sample;
+            specular_chain = specular_chain || (non_null_bsdf && (bs.sampled_type & F_Delta));
+            specular_chain = specular_chain && !(active_surface && (bs.sampled_type & F_Smooth));
+            if (non_null_bsdf) { depth += 1; last_scatter_p = si.p; }
+            if (non_null_bsdf) p_over_f_nee = p_over_f;
+            update_weights(p_over_f, bs.pdf, bsdf_weight * bs.pdf, channel, active_surface);
+            update_weights(p_over_f_nee, 1.f, bsdf_weight * bs.pdf, channel, non_null_bsdf);
+            if (active_surface && shape.is_medium_transition()) medium = target_medium(sc, si, ray.d);
+        }
+        active = active && (active_surface || active_medium);
+    }
+    *valid_out = valid_ray;
+    return result;
+}
+
 // path.cpp:100-211
 static V3 path_sample(const Scene &sc, Sampler &sampler, Ray ray, bool *valid_out, Counters *cnt) {
     const int max_depth = sc.integrator.max_depth, rr_depth = sc.integrator.rr_depth;
@@ -910,6 +1196,15 @@ static V3 path_sample(const Scene &sc, Sampler &sampler, Ray ray, bool *valid_ou
     }
     *valid_out = valid_ray;
     return result;
+}
+
+static V3 integrator_sample(const Scene &sc, Sampler &sampler, Ray ray, int medium, bool *valid, Counters *cnt) {
+    switch (sc.integrator.type) {
+        case MTS_INTEGRATOR_VOLPATH: return volpath_sample(sc, sampler, ray, medium, valid, cnt);
+        case MTS_INTEGRATOR_VOLPATHMIS: return sc.integrator.use_spectral_mis ? volpathmis_sample<true>(sc, sampler, ray, medium, valid, cnt)
+                                                                             : volpathmis_sample<false>(sc, sampler, ray, medium, valid, cnt);
+        default: return path_sample(sc, sampler, ray, valid, cnt);
+    }
 }
 
 // ---------------------------------------------------------------- sensors
@@ -1104,8 +1399,7 @@ static void render_sample(const Scene &sc, Sampler &sampler, ImageBlock &block, 
     V3 ray_weight;
     Ray ray = sensor_sample_ray(sc, adjusted, aperture_sample, &ray_weight);
     bool valid;
-    V3 L = sc.integrator.type == MTS_INTEGRATOR_VOLPATH ? volpath_sample(sc, sampler, ray, se.medium, &valid, cnt)
-                                                         : path_sample(sc, sampler, ray, &valid, cnt);
+    V3 L = integrator_sample(sc, sampler, ray, se.medium, &valid, cnt);
     L = ray_weight * L;
     // srgb_to_xyz, spectrum.h:221-227 (matrix * vector = fmadd chain over columns)
     float aovs[5];
@@ -1226,7 +1520,7 @@ int oracle_sample(oracle_scene *s, int32_t n, uint64_t seed_offset, const float 
         Sampler sampler; sampler.base_seed = sc.sensor.seed; sampler.seed(seed_offset + (uint64_t) i);
         Ray ray = make_ray(v3(ox[i], oy[i], oz[i]), v3(dx[i], dy[i], dz[i]), RayEpsilon, pm_inf());
         bool valid;
-        V3 L = sc.integrator.type == MTS_INTEGRATOR_VOLPATH ? volpath_sample(sc, sampler, ray, sc.sensor.medium, &valid, nullptr) : path_sample(sc, sampler, ray, &valid, nullptr);
+        V3 L = integrator_sample(sc, sampler, ray, sc.sensor.medium, &valid, nullptr);
         out_rgb[3 * i] = L.x; out_rgb[3 * i + 1] = L.y; out_rgb[3 * i + 2] = L.z; out_valid[i] = valid;
     }
     _mm_setcsr(csr);

@@ -6,7 +6,8 @@ pkg = importlib.import_module("eradiate-kernel_amd"); A = importlib.import_modul
 scenes = importlib.import_module("eradiate-kernel_amd.scenes")
 pkg.set_variant("gpu_rgb")
 w, h, spp = [int(x) for x in sys.argv[1:4]]
-scene = pkg.load_dict(scenes.c3_heterogeneous(w, h, spp)); sensor = scene.sensors()[0]
+cfg = sys.argv[4] if len(sys.argv) > 4 else "C3"
+scene = pkg.load_dict({"C3": scenes.c3_heterogeneous, "C4": scenes.c4_atmosphere, "C2": scenes.c2_homogeneous_slab}[cfg](w, h, spp)); sensor = scene.sensors()[0]
 out = (C.c_ulonglong * 48)()
 A.lib().mts_debug_blockstats(out, 1)
 scene.integrator().render(scene, sensor, collect_counters=True)
