@@ -491,6 +491,41 @@ DEV F3 phase_sample(const DScene &sc, int phase, const Frame3 &frame, F3 p, floa
     return phase_sample_leaf(rload<U>(sc.phases, ph.child[1]), frame, sample2);
 }
 
+// The same samples with the pdf the phase functions return (volpathmis keeps it; hg.cpp:76, rayleigh.cpp:64, tabphase.cpp:68,
+// isotropic.cpp:39; blendphase.cpp:93-108 returns the pdf of the component it sampled)
+DEV F3 phase_sample_leaf_pdf(const DPhase &ph, const Frame3 &frame, F2 sample2, float &pdf) {
+    float cos_theta;
+    switch (ph.type) {
+        case MTS_PHASE_HG:
+            if (pm_abs(ph.g) < MTS_EPSILON) cos_theta = 1 - 2 * sample2.x;
+            else { float sqr_term = (1 - ph.g * ph.g) / (1 - ph.g + 2 * ph.g * sample2.x); cos_theta = (1 + ph.g * ph.g - sqr_term * sqr_term) / (2 * ph.g); }
+            pdf = eval_hg(ph.g, -cos_theta);
+            break;
+        case MTS_PHASE_RAYLEIGH: {
+            float z = 2.f * (2.f * sample2.x - 1.f), tmp = pm_sqrt(z * z + 1.f);
+            cos_theta = pm_cbrt(z + tmp) + pm_cbrt(z - tmp);
+            pdf = eval_rayleigh(-cos_theta);
+            break;
+        }
+        case MTS_PHASE_TABULATED:
+            cos_theta = distr_sample(ph, sample2.x);
+            pdf = distr_eval_pdf(ph, -cos_theta) * ph.normalization * MTS_INV_TWO_PI;
+            break;
+        default: pdf = MTS_INV_FOUR_PI; return square_to_uniform_sphere(sample2);
+    }
+    float sin_theta = pm_safe_sqrt(1.0f - cos_theta * cos_theta);
+    float sin_phi, cos_phi; pm_sincos(2.f * MTS_PI * sample2.y, &sin_phi, &cos_phi);
+    return to_world(frame, f3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta));
+}
+DEV F3 phase_sample_pdf(const DScene &sc, int phase, const Frame3 &frame, F3 p, float sample1, F2 sample2, float &pdf) {
+    const DPhase &ph = sc.phases[phase];
+    if (ph.type != MTS_PHASE_BLEND) return phase_sample_leaf_pdf(ph, frame, sample2, pdf);
+    float w = volume_eval_1(sc.volumes[ph.weight_volume], p);
+    float weight = pm_min(pm_max(w, 0.f), 1.f);
+    if (sample1 > weight) return phase_sample_leaf_pdf(sc.phases[ph.child[0]], frame, sample2, pdf);
+    return phase_sample_leaf_pdf(sc.phases[ph.child[1]], frame, sample2, pdf);
+}
+
 // ---------------------------------------------------------------- BSDFs
 struct BSDFSample { F3 wo; float pdf, eta; uint32_t sampled_type; };
 DEV float frame_tan_theta(F3 v) { float temp = pm_fma(-v.z, v.z, 1.f); return pm_safe_sqrt(temp) / v.z; }   // core/frame.h:67-70
@@ -952,6 +987,290 @@ DEV F3 volpath_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, bool &
     return result;
 }
 
+// ---------------------------------------------------------------- volpathmis
+// integrators/volpathmis.cpp (nested formulation, statement for statement the CPU restatement in oracle/oracle.cpp).
+// WeightMatrix: 3 rows of probability ratios with `use_spectral_mis` (default), one row without (:38-46).
+template <bool SPEC> struct MisWeights { F3 r[SPEC ? 3 : 1]; };
+template <bool SPEC> DEV MisWeights<SPEC> mw_full(float v) { MisWeights<SPEC> w; for (int i = 0; i < (SPEC ? 3 : 1); ++i) w.r[i] = f3s(v); return w; }
+DEV float mw_fin(float x) { return pm_isfinite(x) ? x : 0.f; }
+DEV float mw_nan0(float x) { return x != x ? 0.f : x; }
+template <bool SPEC>
+DEV void update_weights(MisWeights<SPEC> &w, F3 p, F3 f, uint32_t channel, bool active) {       // volpathmis.cpp:447-466
+    if (SPEC) {
+        for (int i = 0; i < 3; ++i) {
+            float fi = pick(f, (uint32_t) i);
+            F3 ratio = f3(mw_fin(p.x / fi), mw_fin(p.y / fi), mw_fin(p.z / fi));
+            ratio = ratio * w.r[i];
+            if (active) w.r[i] = f3(mw_nan0(ratio.x), mw_nan0(ratio.y), mw_nan0(ratio.z));
+        }
+    } else {
+        float pdf = pick(p, channel);
+        F3 ratio = w.r[0] * f3(pdf / f.x, pdf / f.y, pdf / f.z);
+        if (active) w.r[0] = f3(mw_fin(ratio.x), mw_fin(ratio.y), mw_fin(ratio.z));
+    }
+}
+template <bool SPEC> DEV void update_weights(MisWeights<SPEC> &w, float p, F3 f, uint32_t c, bool a) { update_weights(w, f3s(p), f, c, a); }
+template <bool SPEC> DEV void update_weights(MisWeights<SPEC> &w, F3 p, float f, uint32_t c, bool a) { update_weights(w, p, f3s(f), c, a); }
+template <bool SPEC> DEV void update_weights(MisWeights<SPEC> &w, float p, float f, uint32_t c, bool a) { update_weights(w, f3s(p), f3s(f), c, a); }
+template <bool SPEC>
+DEV F3 mis_weight_w(const MisWeights<SPEC> &w) {                                                 // volpathmis.cpp:468-481
+    if (SPEC) {
+        float o[3];
+        for (int i = 0; i < 3; ++i) { float sum = (w.r[i].x + w.r[i].y) + w.r[i].z; o[i] = sum == 0.f ? 0.f : 3.f / sum; }
+        return f3(o[0], o[1], o[2]);
+    }
+    F3 a = w.r[0];
+    bool invalid = pm_min(pm_min(pm_abs(a.x), pm_abs(a.y)), pm_abs(a.z)) == 0.f;
+    return invalid ? f3s(0.f) : f3(1.f / a.x, 1.f / a.y, 1.f / a.z);
+}
+template <bool SPEC>
+DEV F3 mis_weight_w(const MisWeights<SPEC> &a, const MisWeights<SPEC> &b) {                      // volpathmis.cpp:484-498
+    if (SPEC) {
+        float o[3];
+        for (int i = 0; i < 3; ++i) { F3 r = a.r[i] + b.r[i]; float sum = (r.x + r.y) + r.z; o[i] = sum == 0.f ? 0.f : 3.f / sum; }
+        return f3(o[0], o[1], o[2]);
+    }
+    F3 sum = a.r[0] + b.r[0];
+    bool zero = pm_min(pm_min(pm_abs(sum.x), pm_abs(sum.y)), pm_abs(sum.z)) == 0.f;
+    return zero ? f3s(0.f) : f3(1.f / sum.x, 1.f / sum.y, 1.f / sum.z);
+}
+
+// volpathmis.cpp:330-445
+template <bool COUNT, bool SPEC>
+DEV_NOINLINE F3 volpathmis_sample_emitter(const DScene &sc, F3 ref_p, bool is_medium_interaction, Pcg32 &rng, int medium, const MisWeights<SPEC> &p_over_f,
+                                          uint32_t channel, MisWeights<SPEC> &nee_out, MisWeights<SPEC> &uni_out, DirSample &ds, Counters &cnt) {
+    MisWeights<SPEC> p_over_f_nee = p_over_f, p_over_f_uni = p_over_f;
+    F3 emitter_sample_weight;
+    ds = sample_emitter_direction(sc, ref_p, rng.next_2d(), false, emitter_sample_weight);
+    F3 emitter_val = emitter_sample_weight * ds.pdf;
+    if (ds.pdf == 0.f) emitter_val = f3s(0.f);
+    bool active = ds.pdf != 0.f;
+    update_weights(p_over_f_nee, ds.pdf, 1.0f, channel, active);
+    if (!active) { nee_out = p_over_f_nee; uni_out = p_over_f_uni; return emitter_val; }
+    DRay ray = spawn_ray(ref_p, ds.d);
+    if (is_medium_interaction) ray.mint = 0.f;
+    float total_dist = 0.f;
+    Hit si; si.t = pm_inf(); si.shape = -1; si.prim = 0; si.p = f3s(0.f); si.uv.x = si.uv.y = 0.f;
+    bool needs_intersection = true;
+    while (active) {
+        float remaining_dist = ds.dist * (1.f - MTS_SHADOW_EPSILON) - total_dist;
+        ray.maxt = remaining_dist;
+        active = active && remaining_dist > 0.f;
+        if (!active) break;
+        if (COUNT) cnt.n_nee_step++;
+        bool escaped_medium = false, active_medium = medium >= 0, active_surface = !active_medium;
+        if (active_medium) {
+            const DMedium &m = sc.media[medium];
+            MediumSample mi = medium_sample_interaction<COUNT>(sc, medium, ray, rng.next_1d(), channel, cnt);
+            if (m.is_homogeneous && ms_valid(mi)) ray.maxt = pm_min(mi.t, remaining_dist);
+            if (needs_intersection) si = ray_intersect(sc, ray);
+            if (si.t < mi.t) mi.t = pm_inf();
+            needs_intersection = false;
+            bool is_spectral = m.has_spectral_extinction != 0, not_spectral = !is_spectral;
+            if (is_spectral) {
+                float t = pm_min(remaining_dist, pm_min(mi.t, si.t)) - mi.mint;
+                F3 tr = transmittance_exp(t, mi.combined);
+                F3 free_flight_pdf = (si.t < mi.t || mi.t > remaining_dist) ? tr : tr * mi.combined;
+                update_weights(p_over_f_nee, free_flight_pdf, tr, channel, true);
+                update_weights(p_over_f_uni, free_flight_pdf, tr, channel, true);
+            }
+            if (mi.t > remaining_dist && ms_valid(mi)) total_dist = ds.dist;
+            if (mi.t > remaining_dist) mi.t = pm_inf();
+            escaped_medium = !ms_valid(mi);
+            active_medium = ms_valid(mi);
+            is_spectral = is_spectral && active_medium; not_spectral = not_spectral && active_medium;
+            if (active_medium) {
+                total_dist += mi.t;
+                ray.o = mi.p; ray.mint = 0.f; si.t = si.t - mi.t;
+                if (is_spectral) {
+                    update_weights(p_over_f_nee, 1.f, mi.sigma_n, channel, true);
+                    update_weights(p_over_f_uni, mi.sigma_n / mi.combined, mi.sigma_n, channel, true);
+                }
+                if (not_spectral) {
+                    update_weights(p_over_f_nee, 1.f, mi.sigma_n / mi.combined, channel, true);
+                    update_weights(p_over_f_uni, mi.sigma_n, mi.sigma_n, channel, true);
+                }
+            }
+        }
+        bool intersect = active_surface && needs_intersection;
+        if (intersect) si = ray_intersect(sc, ray);
+        active_surface = active_surface || escaped_medium;
+        if (active_surface) total_dist += si.t;
+        active_surface = active_surface && hit_valid(si) && active && !active_medium;
+        if (active_surface) {
+            F3 bsdf_val = null_transmission(sc, sc.shapes[si.shape]);
+            update_weights(p_over_f_nee, 1.0f, bsdf_val, channel, true);
+            update_weights(p_over_f_uni, 1.0f, bsdf_val, channel, true);
+        }
+        if (active_surface) ray = spawn_ray(si.p, ray.d);
+        ray.maxt = remaining_dist;
+        needs_intersection = needs_intersection || active_surface;
+        if (SPEC) active = active && (active_medium || active_surface) && any_nonzero(mis_weight_w(p_over_f_uni));
+        else active = active && (active_medium || active_surface) && (any_nonzero(p_over_f_uni.r[0]) || any_nonzero(p_over_f_nee.r[0]));
+        if (active_surface && sc.shapes[si.shape].is_medium_transition) medium = target_medium(sc.shapes[si.shape], hit_geo_normal(sc, si), ray.d);
+    }
+    nee_out = p_over_f_nee; uni_out = p_over_f_uni;
+    return emitter_val;
+}
+
+// volpathmis.cpp:86-328
+template <bool COUNT, bool SPEC>
+DEV F3 volpathmis_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, bool &valid_out, Counters &cnt) {
+    const uint32_t max_depth = (uint32_t) sc.integrator.max_depth, rr_depth = (uint32_t) sc.integrator.rr_depth;
+    const bool hide_emitters = sc.integrator.hide_emitters != 0;
+    bool valid_ray = !hide_emitters && sc.environment >= 0;
+    float eta = 1.f;
+    F3 result = f3s(0.f);
+    bool active = true, specular_chain = !hide_emitters;
+    uint32_t depth = 0;
+    MisWeights<SPEC> p_over_f = mw_full<SPEC>(1.f), p_over_f_nee = mw_full<SPEC>(1.f);
+    uint32_t channel = (uint32_t) pm_min(rng.next_1d() * 3.f, 2.f);                          // volpathmis.cpp:120-124
+    Hit si; si.t = pm_inf(); si.shape = -1; si.prim = 0; si.p = f3s(0.f); si.uv.x = si.uv.y = 0.f;
+    bool needs_intersection = true, last_event_was_null = false;
+    F3 last_scatter_p = f3s(0.f);                                                             // last_scatter_event: only .p is read
+    for (;;) {
+        F3 mis_throughput = mis_weight_w(p_over_f);
+        float q = pm_min(hmax(mis_throughput) * (eta * eta), .95f);
+        bool perform_rr = active && !last_event_was_null && (depth > rr_depth);
+        active = active && !(rng.next_1d() >= q && perform_rr);
+        update_weights(p_over_f, q, 1.0f, channel, perform_rr);
+        last_event_was_null = false;
+        bool exceeded_max_depth = depth >= max_depth;
+        active = active && !exceeded_max_depth;
+        active = active && any_nonzero(mis_weight_w(p_over_f));
+        if (!active) break;
+        if (COUNT) cnt.n_iter++;
+        bool active_medium = active && medium >= 0, active_surface = active && !active_medium;
+        bool act_null_scatter = false, act_medium_scatter = false, escaped_medium = false;
+        MediumSample mi; mi.t = pm_inf();
+        bool is_spectral = active_medium, not_spectral = false;
+        if (active_medium) { is_spectral = is_spectral && sc.media[medium].has_spectral_extinction != 0; not_spectral = !is_spectral && active_medium; }
+        if (active_medium) {
+            const DMedium &m = sc.media[medium];
+            mi = medium_sample_interaction<COUNT>(sc, medium, ray, rng.next_1d(), channel, cnt);
+            if (m.is_homogeneous && ms_valid(mi)) ray.maxt = mi.t;
+            if (needs_intersection) si = ray_intersect(sc, ray);
+            needs_intersection = false;
+            if (si.t < mi.t) mi.t = pm_inf();
+            if (is_spectral) {
+                float t = pm_min(mi.t, si.t) - mi.mint;                                       // medium.cpp:77-89
+                F3 tr = transmittance_exp(t, mi.combined);
+                F3 free_flight_pdf = si.t < mi.t ? tr : tr * mi.combined;
+                update_weights(p_over_f, free_flight_pdf, tr, channel, true);
+                update_weights(p_over_f_nee, free_flight_pdf, tr, channel, true);
+            }
+            escaped_medium = !ms_valid(mi);
+            active_medium = ms_valid(mi);
+            is_spectral = is_spectral && active_medium; not_spectral = not_spectral && active_medium;
+        }
+        if (active_medium) {
+            const int mi_medium = medium;
+            bool null_scatter = rng.next_1d() >= pick(mi.sigma_t, channel) / pick(mi.combined, channel);
+            act_null_scatter = null_scatter;
+            act_medium_scatter = !act_null_scatter;
+            if (act_medium_scatter) { depth += 1; last_scatter_p = mi.p; }
+            const DMedium &m = sc.media[mi_medium];
+            bool sample_emitters = m.sample_emitters != 0;
+            active = active && depth < max_depth;
+            act_medium_scatter = act_medium_scatter && active;
+            specular_chain = specular_chain && !(act_medium_scatter && sample_emitters);
+            if (act_null_scatter) {
+                if (is_spectral) {
+                    update_weights(p_over_f, mi.sigma_n / mi.combined, mi.sigma_n, channel, true);
+                    update_weights(p_over_f_nee, 1.0f, mi.sigma_n, channel, true);
+                }
+                if (not_spectral) {
+                    update_weights(p_over_f, mi.sigma_n, mi.sigma_n, channel, true);
+                    update_weights(p_over_f_nee, 1.0f, mi.sigma_n / mi.combined, channel, true);
+                }
+                ray.o = mi.p; ray.mint = 0.f; si.t = si.t - mi.t;
+            }
+            if (act_medium_scatter) {
+                if (is_spectral) update_weights(p_over_f, mi.sigma_t / mi.combined, mi.sigma_s, channel, true);
+                if (not_spectral) update_weights(p_over_f, mi.sigma_t, mi.sigma_s, channel, true);
+                valid_ray = true;
+                F3 wi = -ray.d;
+                if (sample_emitters) {
+                    MisWeights<SPEC> nee_end, uni_end; DirSample ds;
+                    F3 emitted = volpathmis_sample_emitter<COUNT, SPEC>(sc, mi.p, true, rng, medium, p_over_f, channel, nee_end, uni_end, ds, cnt);
+                    float phase_val = phase_eval(sc, m.phase, wi, mi.p, ds.d);
+                    update_weights(nee_end, 1.0f, phase_val, channel, true);
+                    update_weights(uni_end, ds.delta ? 0.f : phase_val, phase_val, channel, true);
+                    result = result + mis_weight_w(nee_end, uni_end) * emitted;
+                }
+                p_over_f_nee = p_over_f;
+                float s1 = rng.next_1d(); F2 s2 = rng.next_2d();                              // left-to-right (SURVEY.md 8(a'))
+                float phase_pdf;
+                F3 wo = phase_sample_pdf(sc, m.phase, make_frame(ray.d), mi.p, s1, s2, phase_pdf);
+                ray = spawn_ray(mi.p, wo); ray.mint = 0.0f;
+                needs_intersection = true;
+                update_weights(p_over_f, phase_pdf, phase_pdf, channel, true);
+                update_weights(p_over_f_nee, 1.f, phase_pdf, channel, true);
+            }
+        }
+        active_surface = active_surface || escaped_medium;
+        bool intersect = active_surface && needs_intersection;
+        if (intersect) si = ray_intersect(sc, ray);
+        Surf sf; sf.wi = -ray.d; sf.sh.n = f3s(0.f);
+        if (active_surface && hit_valid(si)) complete_surface(sc, si, ray.d, sf);
+        if (active_surface) {
+            bool ray_from_camera = depth == 0;
+            bool count_direct = ray_from_camera || specular_chain;
+            int emitter = hit_emitter(sc, si);
+            bool active_e = emitter >= 0 && !(depth == 0 && hide_emitters);
+            if (active_e) {
+                if (!count_direct) {
+                    DirSample ds;                                                             // records.h:168-174
+                    ds.p = si.p; ds.n = sf.sh.n; ds.d = si.p - last_scatter_p; ds.dist = norm(ds.d); ds.d = ds.d / ds.dist;
+                    if (!hit_valid(si)) ds.d = -sf.wi;
+                    ds.emitter = emitter; ds.pdf = 0.f; ds.delta = false;
+                    float emitter_pdf = pdf_emitter_direction(sc, last_scatter_p, ds);
+                    update_weights(p_over_f_nee, emitter_pdf, 1.f, channel, true);
+                }
+                F3 emitted = emitter_eval(sc, emitter, sf.wi.z);
+                F3 contrib = count_direct ? mis_weight_w(p_over_f) * emitted : mis_weight_w(p_over_f, p_over_f_nee) * emitted;
+                result = result + contrib;
+            }
+        }
+        active_surface = active_surface && hit_valid(si);
+        if (active_surface) {
+            const DShape &shape = sc.shapes[si.shape];
+            const DBsdf &bsdf = sc.bsdfs[shape.bsdf];
+            bool active_e = (bsdf.flags & F_Smooth) != 0 && (depth + 1 < max_depth);
+            if (active_e) {
+                MisWeights<SPEC> nee_end, uni_end; DirSample ds;
+                F3 emitted = volpathmis_sample_emitter<COUNT, SPEC>(sc, si.p, false, rng, medium, p_over_f, channel, nee_end, uni_end, ds, cnt);
+                F3 wo_local = to_local(sf.sh, ds.d);
+                F3 bsdf_val = bsdf_eval(bsdf, sf.wi, wo_local);
+                float bpdf = bsdf_pdf(bsdf, sf.wi, wo_local);
+                update_weights(nee_end, 1.0f, bsdf_val, channel, true);
+                update_weights(uni_end, ds.delta ? 0.f : bpdf, bsdf_val, channel, true);
+                result = result + mis_weight_w(nee_end, uni_end) * emitted;
+            }
+            float s1 = rng.next_1d(); F2 s2 = rng.next_2d(); (void) s1;
+            BSDFSample bs;
+            F3 bsdf_weight = bsdf_sample(bsdf, sf.wi, s2, bs);
+            bool invalid_bsdf_sample = bs.pdf == 0.f;
+            active_surface = active_surface && bs.pdf > 0.f;
+            if (active_surface) eta *= bs.eta;
+            DRay bsdf_ray = spawn_ray(si.p, to_world(sf.sh, bs.wo));
+            if (active_surface) { ray = bsdf_ray; needs_intersection = true; }
+            bool non_null_bsdf = active_surface && !(bs.sampled_type & F_Null);
+            valid_ray = valid_ray || non_null_bsdf || invalid_bsdf_sample;
+            specular_chain = specular_chain || (non_null_bsdf && (bs.sampled_type & F_Delta));
+            specular_chain = specular_chain && !(active_surface && (bs.sampled_type & F_Smooth));
+            if (non_null_bsdf) { depth += 1; last_scatter_p = si.p; }
+            if (non_null_bsdf) p_over_f_nee = p_over_f;
+            update_weights(p_over_f, bs.pdf, bsdf_weight * bs.pdf, channel, active_surface);
+            update_weights(p_over_f_nee, 1.f, bsdf_weight * bs.pdf, channel, non_null_bsdf);
+            if (active_surface && shape.is_medium_transition) medium = target_medium(shape, sf.n, ray.d);
+        }
+        active = active && (active_surface || active_medium);
+    }
+    valid_out = valid_ray;
+    return result;
+}
+
 // ---------------------------------------------------------------- path
 // integrators/path.cpp:100-211
 template <bool COUNT>
@@ -1012,6 +1331,16 @@ DEV F3 path_sample(const DScene &sc, Pcg32 &rng, DRay ray, bool &valid_out, Coun
     }
     valid_out = valid_ray;
     return result;
+}
+
+// SamplingIntegrator::sample of the configured integrator (nested formulations)
+template <bool COUNT>
+DEV F3 integrator_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, bool &valid, Counters &cnt) {
+    if (sc.integrator.type == MTS_INTEGRATOR_VOLPATH) return volpath_sample<COUNT>(sc, rng, ray, medium, valid, cnt);
+    if (sc.integrator.type == MTS_INTEGRATOR_VOLPATHMIS)
+        return sc.integrator.use_spectral_mis ? volpathmis_sample<COUNT, true>(sc, rng, ray, medium, valid, cnt)
+                                              : volpathmis_sample<COUNT, false>(sc, rng, ray, medium, valid, cnt);
+    return path_sample<COUNT>(sc, rng, ray, valid, cnt);
 }
 
 // ---------------------------------------------------------------- sensors

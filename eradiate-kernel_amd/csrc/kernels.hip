@@ -32,8 +32,7 @@ __device__ __forceinline__ void render_sample(const DScene &sc, Pcg32 &rng, cons
     F3 ray_weight;
     DRay ray = sensor_sample_ray(sc, adjusted, aperture_sample, ray_weight);
     bool valid;
-    F3 L = sc.integrator.type == MTS_INTEGRATOR_VOLPATH ? volpath_sample<COUNT>(sc, rng, ray, se.medium, valid, cnt)
-                                                         : path_sample<COUNT>(sc, rng, ray, valid, cnt);
+    F3 L = integrator_sample<COUNT>(sc, rng, ray, se.medium, valid, cnt);
     L = ray_weight * L;
     splat_sample_t<false>(sc, blk, lx, ly, position_sample, L, valid, as_global(film), acc);
 }
@@ -97,8 +96,7 @@ __global__ void __launch_bounds__(256) sample_kernel(DScene sc, int32_t n, uint6
     Pcg32 rng; rng.seed(sc.sensor.seed + seed_offset + (uint64_t) i, PCG32_DEFAULT_STREAM);
     DRay ray = make_ray(f3(rays[i], rays[n + i], rays[2 * n + i]), f3(rays[3 * n + i], rays[4 * n + i], rays[5 * n + i]), MTS_RAY_EPSILON, pm_inf());
     bool valid; Counters cnt;
-    F3 L = sc.integrator.type == MTS_INTEGRATOR_VOLPATH ? volpath_sample<false>(sc, rng, ray, sc.sensor.medium, valid, cnt)
-                                                         : path_sample<false>(sc, rng, ray, valid, cnt);
+    F3 L = integrator_sample<false>(sc, rng, ray, sc.sensor.medium, valid, cnt);
     out_rgb[3 * i] = L.x; out_rgb[3 * i + 1] = L.y; out_rgb[3 * i + 2] = L.z; out_valid[i] = valid ? 1 : 0;
 }
 

@@ -196,6 +196,22 @@ def test_every_kernel_formulation_matches_the_oracle(gpu_rgb, monkeypatch, kerne
             assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
 
 
+@pytest.mark.parametrize("spectral", [True, False])
+def test_volpathmis_matches_the_oracle(gpu_rgb, spectral):
+    """src/integrators/volpathmis.cpp (spectral MIS on / off) over chromatic and grey media, heterogeneous grids, the cornell
+    box (area light: the emitter-hit MIS branch) and the atmosphere miniature: film and counters bit for bit."""
+    chroma = scenes.c2_homogeneous_slab(32, 24, 8)
+    chroma["slab"]["interior"] = {"type": "homogeneous", "sigma_t": {"type": "rgb", "value": [0.4, 0.8, 1.6]},
+                                  "albedo": {"type": "rgb", "value": [0.9, 0.7, 0.5]}, "phase": {"type": "hg", "g": 0.5}}
+    for d in (chroma, scenes.c3_heterogeneous(48, 32, 8, res=16), scenes.c1_cornell(32, 32, 8), scenes.c4_atmosphere(32, 32, 4)):
+        d = dict(d)
+        d["integrator"] = dict(d["integrator"], type="volpathmis", use_spectral_mis=spectral)
+        gpu, st = gpu_render(gpu_rgb, d, collect_counters=True)
+        o = ob.OracleScene(d); ref = o.render(); so = o.last_stats
+        assert np.array_equal(gpu, ref) and gpu[..., :3].max() > 0
+        assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
+
+
 def _uv_sphere(n_lat, n_lon, radius=1.0, center=(0, 0, 0)):
     th = np.linspace(0.0, np.pi, n_lat + 1); ph = np.linspace(0.0, 2.0 * np.pi, n_lon, endpoint=False)
     v = np.array([[np.sin(t) * np.cos(p), np.sin(t) * np.sin(p), np.cos(t)] for t in th for p in ph], dtype=np.float32) * radius + np.asarray(center, np.float32)
