@@ -57,10 +57,18 @@ def main():
         n = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the gpu_rgb backend has no CPU fallback)")
+    # Rehearsal switch: MTSAMD_BENCH_BACKEND=gloo runs the N-rank path with all ranks on ONE GPU and the film reduce on the
+    # host (RCCL refuses two ranks on one device); numbers from such a run are not a measurement.
+    backend = os.environ.get("MTSAMD_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if n > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=n, device_id=torch.device("cuda", local_rank))
+        if backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=n)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=n, device_id=torch.device("cuda", local_rank))
 
     pkg = importlib.import_module("eradiate-kernel_amd")
     scenes = importlib.import_module("eradiate-kernel_amd.scenes")
@@ -90,7 +98,9 @@ def main():
 
     def step():
         integ.render(scene, sensor, shard_index=rank, shard_count=n, device_film=film.data_ptr(), stream=stream)
-        if n > 1:
+        if n > 1 and backend == "gloo":
+            host = film.cpu(); dist.reduce(host, dst=0, op=dist.ReduceOp.SUM); film.copy_(host)
+        elif n > 1:
             dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)   # RCCL over xGMI: W*H*5 fp32
         return integ.last_stats
 
@@ -109,7 +119,7 @@ def main():
         kernel_ms += st["kernel_ms"]; launches += st["kernel_launches"]; samples_rank = st["samples"]
     barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
     if n > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
