@@ -18,7 +18,7 @@ FILTER_NEAREST, FILTER_TRILINEAR = 0, 1
 WRAP_REPEAT, WRAP_MIRROR, WRAP_CLAMP = 0, 1, 2
 PHASE_ISOTROPIC, PHASE_HG, PHASE_RAYLEIGH, PHASE_BLEND, PHASE_TABULATED = 0, 1, 2, 3, 4
 MEDIUM_HOMOGENEOUS, MEDIUM_HETEROGENEOUS = 0, 1
-BSDF_DIFFUSE, BSDF_NULL, BSDF_RPV = 0, 1, 2
+BSDF_DIFFUSE, BSDF_NULL, BSDF_RPV, BSDF_BILAMBERTIAN = 0, 1, 2, 3
 SHAPE_RECTANGLE, SHAPE_CUBE, SHAPE_SPHERE, SHAPE_MESH = 0, 1, 2, 3
 EMITTER_DIRECTIONAL, EMITTER_AREA, EMITTER_CONSTANT = 0, 1, 2
 SENSOR_PERSPECTIVE, SENSOR_DISTANT, SENSOR_MRADIANCEMETER, SENSOR_MDISTANT, SENSOR_DISTANTFLUX = 0, 1, 2, 3, 4
@@ -55,7 +55,7 @@ class Medium(C.Structure):
 
 class Bsdf(C.Structure):
     _fields_ = [("type", i32), ("reflectance", f32 * 3), ("rho_0", f32 * 3), ("k", f32 * 3),
-                ("g", f32 * 3), ("rho_c", f32 * 3)]
+                ("g", f32 * 3), ("rho_c", f32 * 3), ("transmittance", f32 * 3)]
 
 
 class Shape(C.Structure):

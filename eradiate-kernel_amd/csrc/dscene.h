@@ -56,7 +56,7 @@ struct DMedium {
     int32_t pair_nx, pair_ny, pair_nz, pair_affine;
 };
 
-struct DBsdf { int32_t type; float reflectance[3], rho_0[3], k[3], g[3], rho_c[3]; uint32_t flags; };
+struct DBsdf { int32_t type; float reflectance[3], rho_0[3], k[3], g[3], rho_c[3]; uint32_t flags; float transmittance[3]; };
 
 // Shapes (shapes/rectangle.cpp, shapes/cube.cpp + librender/mesh.cpp, shapes/sphere.cpp)
 struct DShape {
@@ -133,7 +133,7 @@ struct DScene {
 };
 
 // bsdf.h:38-124
-enum : uint32_t { F_Null = 0x1, F_DiffuseReflection = 0x2, F_GlossyReflection = 0x8,
+enum : uint32_t { F_Null = 0x1, F_DiffuseReflection = 0x2, F_DiffuseTransmission = 0x4, F_GlossyReflection = 0x8,
                   F_FrontSide = 0x8000, F_BackSide = 0x10000,
                   F_Smooth = 0x2 | 0x4 | 0x8 | 0x10, F_Delta = 0x1 | 0x20 | 0x40 };
 

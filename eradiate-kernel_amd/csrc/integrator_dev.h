@@ -560,7 +560,15 @@ DEV F3 eval_rpv(const DBsdf &b, F3 wi, F3 wo) {
     for (int c = 0; c < 3; ++c) { q.rho_0[c] = b.rho_0[c]; q.k[c] = b.k[c]; q.g[c] = b.g[c]; q.rho_c[c] = b.rho_c[c]; }
     return eval_rpv_p(q, wi, wo);
 }
+// bsdfs/bilambertian.cpp:62-190
+DEV float bilambertian_reflection_weight(const DBsdf &b) {
+    F3 r = f3(b.reflectance), t = f3(b.transmittance);
+    F3 q = r / (r + t);
+    return ((q.x + q.y) + q.z) * (1.f / 3.f);                // hmean; NaN when r + t == 0: masked by the callers
+}
+DEV bool same_side(float a, float b) { return (pm_bits(a) >> 31) == (pm_bits(b) >> 31); }      // eq(sign(a), sign(b))
 DEV F3 bsdf_eval(const DBsdf &b, F3 wi, F3 wo) {
+    if (b.type == MTS_BSDF_BILAMBERTIAN) return (same_side(wi.z, wo.z) ? f3(b.reflectance) : f3(b.transmittance)) * (MTS_INV_PI * pm_abs(wo.z));
     bool active = wi.z > 0.f && wo.z > 0.f;
     if (b.type == MTS_BSDF_DIFFUSE) return active ? f3(b.reflectance) * MTS_INV_PI * wo.z : f3s(0.f);     // diffuse.cpp:106-120
     if (b.type == MTS_BSDF_RPV) return active ? eval_rpv(b, wi, wo) * pm_abs(wo.z) : f3s(0.f);             // rpv.cpp:133-142
@@ -568,11 +576,33 @@ DEV F3 bsdf_eval(const DBsdf &b, F3 wi, F3 wo) {
 }
 DEV float bsdf_pdf(const DBsdf &b, F3 wi, F3 wo) {
     if (b.type == MTS_BSDF_NULL) return 0.f;                                                               // null.cpp:65-68
+    if (b.type == MTS_BSDF_BILAMBERTIAN) {
+        float result = MTS_INV_PI * pm_abs(wo.z);
+        float rw = bilambertian_reflection_weight(b), tw = 1.f - rw;
+        if (rw != rw) rw = 0.f;
+        if (tw != tw) tw = 0.f;
+        return result * (same_side(wi.z, wo.z) ? rw : tw);
+    }
     float pdf = MTS_INV_PI * wo.z;                                                                          // warp.h:343-350
     return (wi.z > 0.f && wo.z > 0.f) ? pdf : 0.f;                                                         // diffuse.cpp:122-135, rpv.cpp:144-153
 }
-DEV F3 bsdf_sample(const DBsdf &b, F3 wi, F2 sample2, BSDFSample &bs) {
+DEV F3 bsdf_sample(const DBsdf &b, F3 wi, float sample1, F2 sample2, BSDFSample &bs) {
     bs.wo = f3s(0.f); bs.pdf = 0.f; bs.eta = 0.f; bs.sampled_type = 0;
+    if (b.type == MTS_BSDF_BILAMBERTIAN) {                                                                 // bilambertian.cpp:62-116
+        F3 wo = square_to_cosine_hemisphere(sample2);
+        float rw = bilambertian_reflection_weight(b), tw = 1.f - rw;
+        if (rw != rw) rw = 0.f;
+        if (tw != tw) tw = 0.f;
+        bool selected_r = sample1 < rw;
+        F3 value = selected_r ? f3s(1.f) * (f3(b.reflectance) / rw) : f3s(1.f) * (f3(b.transmittance) / tw);
+        bs.pdf = MTS_INV_PI * wo.z;
+        bs.pdf = selected_r ? bs.pdf * rw : bs.pdf * tw;
+        bs.eta = 1.f;
+        bs.sampled_type = selected_r ? F_DiffuseReflection : F_DiffuseTransmission;
+        if (!(wi.z > 0.f)) wo.z = -wo.z;
+        bs.wo = selected_r ? wo : f3(wo.x, wo.y, -wo.z);
+        return bs.pdf > 0.f ? value : f3s(0.f);
+    }
     if (b.type == MTS_BSDF_NULL) {                                                                         // null.cpp:41-58
         bs.wo = -wi; bs.sampled_type = F_Null; bs.eta = 1.f; bs.pdf = 1.f;
         return f3s(1.f);
@@ -958,9 +988,9 @@ DEV F3 volpath_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, bool &
                 float bpdf = bsdf_pdf(bsdf, sf.wi, wo);
                 result = result + throughput * bsdf_val * mis_weight(ds.pdf, ds.delta ? 0.f : bpdf) * emitted;
             }
-            float s1 = rng.next_1d(); F2 s2 = rng.next_2d(); (void) s1;
+            float s1 = rng.next_1d(); F2 s2 = rng.next_2d();
             BSDFSample bs;
-            F3 bsdf_val = bsdf_sample(bsdf, sf.wi, s2, bs);
+            F3 bsdf_val = bsdf_sample(bsdf, sf.wi, s1, s2, bs);
             throughput = throughput * bsdf_val;
             eta *= bs.eta;
             ray = spawn_ray(si.p, to_world(sf.sh, bs.wo));
@@ -1247,9 +1277,9 @@ DEV F3 volpathmis_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, boo
                 update_weights(uni_end, ds.delta ? 0.f : bpdf, bsdf_val, channel, true);
                 result = result + mis_weight_w(nee_end, uni_end) * emitted;
             }
-            float s1 = rng.next_1d(); F2 s2 = rng.next_2d(); (void) s1;
+            float s1 = rng.next_1d(); F2 s2 = rng.next_2d();
             BSDFSample bs;
-            F3 bsdf_weight = bsdf_sample(bsdf, sf.wi, s2, bs);
+            F3 bsdf_weight = bsdf_sample(bsdf, sf.wi, s1, s2, bs);
             bool invalid_bsdf_sample = bs.pdf == 0.f;
             active_surface = active_surface && bs.pdf > 0.f;
             if (active_surface) eta *= bs.eta;
@@ -1306,9 +1336,9 @@ DEV F3 path_sample(const DScene &sc, Pcg32 &rng, DRay ray, bool &valid_out, Coun
             float mis = ds.delta ? 1.f : mis_weight(ds.pdf, bpdf);
             if (active_e) result = result + mis * throughput * bsdf_val * emitter_val;
         }
-        float s1 = rng.next_1d(); F2 s2 = rng.next_2d(); (void) s1;
+        float s1 = rng.next_1d(); F2 s2 = rng.next_2d();
         BSDFSample bs;
-        F3 bsdf_val = bsdf_sample(bsdf, sf.wi, s2, bs);
+        F3 bsdf_val = bsdf_sample(bsdf, sf.wi, s1, s2, bs);
         throughput = throughput * bsdf_val;
         active = active && any_nonzero(throughput);
         if (!active) break;

@@ -60,6 +60,7 @@ static const uint32_t CUBE_TRIANGLES[12][3] = {
 static uint32_t bsdf_flags(int type) {
     if (type == MTS_BSDF_DIFFUSE) return F_DiffuseReflection | F_FrontSide;                // diffuse.cpp:55
     if (type == MTS_BSDF_NULL) return F_Null | F_FrontSide | F_BackSide;                   // null.cpp:26
+    if (type == MTS_BSDF_BILAMBERTIAN) return F_DiffuseReflection | F_DiffuseTransmission | F_FrontSide | F_BackSide;   // bilambertian.cpp:55-60
     return F_GlossyReflection | F_FrontSide;                                               // rpv.cpp:66
 }
 
@@ -277,10 +278,10 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
     // ---- BSDFs
     for (int i = 0; i < d->bsdf_count; ++i) {
         const mts_bsdf &b = d->bsdfs[i];
-        if (b.type < MTS_BSDF_DIFFUSE || b.type > MTS_BSDF_RPV) throw std::runtime_error("unknown BSDF type");
+        if (b.type < MTS_BSDF_DIFFUSE || b.type > MTS_BSDF_BILAMBERTIAN) throw std::runtime_error("unknown BSDF type");
         DBsdf db; memset(&db, 0, sizeof(db));
         db.type = b.type; memcpy(db.reflectance, b.reflectance, 12); memcpy(db.rho_0, b.rho_0, 12); memcpy(db.k, b.k, 12);
-        memcpy(db.g, b.g, 12); memcpy(db.rho_c, b.rho_c, 12); db.flags = bsdf_flags(b.type);
+        memcpy(db.g, b.g, 12); memcpy(db.rho_c, b.rho_c, 12); memcpy(db.transmittance, b.transmittance, 12); db.flags = bsdf_flags(b.type);
         hs.bsdfs.push_back(db);
     }
     // default BSDFs appended after the user's (shape.cpp:74-80): diffuse 0.5, and diffuse 0 for emitters

@@ -574,11 +574,11 @@ struct VolpathMachine {
             complete_surface(sc, s, p.si, p.ray.d, sf);
             bsdf_id = s.bsdf; is_tr = s.is_medium_transition; ext = s.exterior; inte = s.interior;
         WATERFALL_END
-        const float s1 = p.rng.next_1d(); const F2 s2 = p.rng.next_2d(); (void) s1;
+        const float s1 = p.rng.next_1d(); const F2 s2 = p.rng.next_2d();
         BSDFSample bs; F3 bsdf_val;
         WATERFALL_BEGIN(bsdf_id, bu)
             const DBsdf bsdf = cload(sc.bsdfs + bu);
-            bsdf_val = bsdf_sample(bsdf, sf.wi, s2, bs);
+            bsdf_val = bsdf_sample(bsdf, sf.wi, s1, s2, bs);
         WATERFALL_END
         p.thr = p.thr * bsdf_val;
         p.eta *= bs.eta;

@@ -323,6 +323,10 @@ class SceneBuilder:
             rec.reflectance[:] = _color(p.get("reflectance"), where, default=0.5)
         elif p.type == "null":
             rec.type = A.BSDF_NULL
+        elif p.type == "bilambertian":                                   # src/bsdfs/bilambertian.cpp:51-60
+            rec.type = A.BSDF_BILAMBERTIAN
+            rec.reflectance[:] = _color(p.get("reflectance"), where, default=0.5)
+            rec.transmittance[:] = _color(p.get("transmittance"), where, default=0.5)
         elif p.type == "rpv":
             rec.type = A.BSDF_RPV
             rec.rho_0[:] = _color(p.get("rho_0"), where, default=0.1)
@@ -390,7 +394,7 @@ class SceneBuilder:
                 continue
             t = v.get("type")
             kind = self.instances.get(v.get("id"), ("",))[0] if t == "ref" else None
-            if t in ("diffuse", "null", "rpv") or kind == "bsdf":
+            if t in ("diffuse", "null", "rpv", "bilambertian") or kind == "bsdf":
                 if rec.bsdf >= 0:
                     raise RuntimeError("Only a single BSDF child object can be specified per shape.")
                 p.queried.add(k)
@@ -672,7 +676,7 @@ class SceneBuilder:
                 if self.integrator is not None:
                     raise RuntimeError("Only one integrator can be specified per scene.")
                 self.set_integrator(v, k)
-            elif t in ("diffuse", "null", "rpv"):
+            elif t in ("diffuse", "null", "rpv", "bilambertian"):
                 self.add_bsdf(v, k)
             elif t in ("homogeneous", "heterogeneous"):
                 self.add_medium(v, k)

@@ -86,12 +86,13 @@ typedef struct mts_medium {
     int32_t has_spectral_extinction; /* default true (homogeneous.cpp:27, heterogeneous.cpp:27) */
 } mts_medium;
 
-/* ---- BSDFs (src/bsdfs/{diffuse,null,rpv}.cpp) ---- */
-enum { MTS_BSDF_DIFFUSE = 0, MTS_BSDF_NULL = 1, MTS_BSDF_RPV = 2 };
+/* ---- BSDFs (src/bsdfs/{diffuse,null,rpv,bilambertian}.cpp) ---- */
+enum { MTS_BSDF_DIFFUSE = 0, MTS_BSDF_NULL = 1, MTS_BSDF_RPV = 2, MTS_BSDF_BILAMBERTIAN = 3 };
 typedef struct mts_bsdf {
     int32_t type;
     float reflectance[3];     /* diffuse "reflectance" (rgb), default 0.5                        */
     float rho_0[3], k[3], g[3], rho_c[3];  /* rpv parameters (rpv.cpp:60-70)                     */
+    float transmittance[3];   /* bilambertian "transmittance" (with "reflectance"), default 0.5 (bilambertian.cpp:52-53) */
 } mts_bsdf;
 
 /* ---- Shapes (src/shapes/{rectangle,cube,sphere}.cpp, src/librender/mesh.cpp) ---- */

@@ -441,7 +441,17 @@ static inline V3 eval_rpv(const Bsdf &b, V3 wi, V3 wo) {
     }
     return v3(out[0], out[1], out[2]);
 }
+// bilambertian.cpp:62-190: reflection and transmission lobes, both Lambertian, on both sides
+static inline float bilambertian_reflection_weight(const Bsdf &b) {
+    V3 r = b.reflectance, t = b.transmittance;
+    V3 q = r / (r + t);
+    return ((q.x + q.y) + q.z) * (1.f / 3.f);                                                         // hmean; NaN when r + t == 0: masked by the callers
+}
 static V3 bsdf_eval(const Bsdf &b, const SurfaceInteraction &si, V3 wo) {
+    if (b.type == MTS_BSDF_BILAMBERTIAN) {                                                            // bilambertian.cpp:118-146
+        bool same = std::signbit(si.wi.z) == std::signbit(wo.z);
+        return (same ? b.reflectance : b.transmittance) * (InvPi * pm_abs(wo.z));
+    }
     float cos_theta_i = si.wi.z, cos_theta_o = wo.z;
     bool active = cos_theta_i > 0.f && cos_theta_o > 0.f;
     switch (b.type) {
@@ -452,12 +462,35 @@ static V3 bsdf_eval(const Bsdf &b, const SurfaceInteraction &si, V3 wo) {
 }
 static float bsdf_pdf(const Bsdf &b, const SurfaceInteraction &si, V3 wo) {
     if (b.type == MTS_BSDF_NULL) return 0.f;                                                          // null.cpp:65-68
+    if (b.type == MTS_BSDF_BILAMBERTIAN) {                                                            // bilambertian.cpp:148-190
+        float result = InvPi * pm_abs(wo.z);
+        float rw = bilambertian_reflection_weight(b), tw = 1.f - rw;
+        if (rw != rw) rw = 0.f;
+        if (tw != tw) tw = 0.f;
+        bool same = std::signbit(si.wi.z) == std::signbit(wo.z);
+        return result * (same ? rw : tw);
+    }
     float cos_theta_i = si.wi.z, cos_theta_o = wo.z;
     float pdf = InvPi * wo.z;                                                                          // warp.h:343-350
     return (cos_theta_i > 0.f && cos_theta_o > 0.f) ? pdf : 0.f;                                      // diffuse.cpp:122-135, rpv.cpp:144-153
 }
-static V3 bsdf_sample(const Bsdf &b, const SurfaceInteraction &si, float /*sample1*/, P2 sample2, BSDFSample *bs) {
+static V3 bsdf_sample(const Bsdf &b, const SurfaceInteraction &si, float sample1, P2 sample2, BSDFSample *bs) {
     bs->wo = v3(0, 0, 0); bs->pdf = 0.f; bs->eta = 0.f; bs->sampled_type = 0;
+    if (b.type == MTS_BSDF_BILAMBERTIAN) {                                                            // bilambertian.cpp:62-116
+        V3 wo = square_to_cosine_hemisphere(sample2);
+        float rw = bilambertian_reflection_weight(b), tw = 1.f - rw;
+        if (rw != rw) rw = 0.f;
+        if (tw != tw) tw = 0.f;
+        bool selected_r = sample1 < rw;
+        V3 value = selected_r ? v3(1.f, 1.f, 1.f) * (b.reflectance / rw) : v3(1.f, 1.f, 1.f) * (b.transmittance / tw);
+        bs->pdf = InvPi * wo.z;
+        bs->pdf = selected_r ? bs->pdf * rw : bs->pdf * tw;
+        bs->eta = 1.f;
+        bs->sampled_type = selected_r ? F_DiffuseReflection : F_DiffuseTransmission;
+        if (!(si.wi.z > 0.f)) wo.z = -wo.z;
+        bs->wo = selected_r ? wo : v3(wo.x, wo.y, -wo.z);
+        return bs->pdf > 0.f ? value : v3(0, 0, 0);
+    }
     if (b.type == MTS_BSDF_NULL) {                                                                    // null.cpp:41-58
         bs->wo = -si.wi; bs->sampled_type = F_Null; bs->eta = 1.f; bs->pdf = 1.f;
         return v3(1.f, 1.f, 1.f);

@@ -118,7 +118,7 @@ struct Medium {
 };
 
 // ---------------------------------------------------------------- BSDF
-struct Bsdf { int type; V3 reflectance, rho_0, k, g, rho_c; uint32_t flags; };
+struct Bsdf { int type; V3 reflectance, rho_0, k, g, rho_c; uint32_t flags; V3 transmittance; };
 // bsdf.h:38-124
 enum : uint32_t { F_Null = 0x1, F_DiffuseReflection = 0x2, F_DiffuseTransmission = 0x4, F_GlossyReflection = 0x8,
                   F_GlossyTransmission = 0x10, F_DeltaReflection = 0x20, F_DeltaTransmission = 0x40,
@@ -334,6 +334,7 @@ struct Scene {
 static inline uint32_t bsdf_flags(int type) {
     if (type == MTS_BSDF_DIFFUSE) return F_DiffuseReflection | F_FrontSide;              // diffuse.cpp:55
     if (type == MTS_BSDF_NULL) return F_Null | F_FrontSide | F_BackSide;                 // null.cpp:26
+    if (type == MTS_BSDF_BILAMBERTIAN) return F_DiffuseReflection | F_DiffuseTransmission | F_FrontSide | F_BackSide;   // bilambertian.cpp:55-60
     return F_GlossyReflection | F_FrontSide;                                             // rpv.cpp:66
 }
 
@@ -381,6 +382,7 @@ static inline Scene *make_scene(const mts_scene_desc *d) {
             bs.rho_0 = v3(b.rho_0[0], b.rho_0[1], b.rho_0[2]); bs.k = v3(b.k[0], b.k[1], b.k[2]);
             bs.g = v3(b.g[0], b.g[1], b.g[2]); bs.rho_c = v3(b.rho_c[0], b.rho_c[1], b.rho_c[2]);
             bs.flags = bsdf_flags(b.type);
+            bs.transmittance = v3(b.transmittance[0], b.transmittance[1], b.transmittance[2]);
             sc->bsdfs.push_back(bs);
         }
         sc->default_bsdf = Bsdf{ MTS_BSDF_DIFFUSE, v3(.5f, .5f, .5f), {}, {}, {}, {}, bsdf_flags(MTS_BSDF_DIFFUSE) };

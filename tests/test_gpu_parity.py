@@ -212,6 +212,29 @@ def test_volpathmis_matches_the_oracle(gpu_rgb, spectral):
         assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
 
 
+@pytest.mark.parametrize("integrator", ["path", "volpath", "volpathmis"])
+def test_bilambertian_canopy_matches_the_oracle(gpu_rgb, integrator):
+    """Eradiate's leaf BSDF (src/bsdfs/bilambertian.cpp): a small canopy of two-sided reflecting / transmitting leaves over a
+    Lambertian ground, lit by the sun and a constant sky; film bit for bit under the three integrators."""
+    rng = np.random.default_rng(7)
+    d = {"type": "scene", "integrator": {"type": integrator, "max_depth": 12},
+         "sensor": {"type": "perspective", "to_world": T.look_at([0, -6, 5], [0, 0, 1], [0, 0, 1]), "fov": 40,
+                    "film": {"type": "hdrfilm", "width": 40, "height": 32, "rfilter": {"type": "box"}},
+                    "sampler": {"type": "independent", "sample_count": 8}},
+         "ground": {"type": "rectangle", "to_world": T.scale(6.0), "bsdf": {"type": "diffuse", "reflectance": 0.3}},
+         "sun": {"type": "directional", "direction": [0.3, 0.2, -1.0], "irradiance": 3.0},
+         "sky": {"type": "constant", "radiance": 0.2}}
+    for k in range(45):
+        c = rng.uniform([-2, -2, 0.5], [2, 2, 2.5])
+        d["leaf%02d" % k] = {"type": "rectangle",
+                             "to_world": T.translate(c) @ T.rotate(rng.normal(size=3), float(rng.uniform(0, 180))) @ T.scale(0.35),
+                             "bsdf": {"type": "bilambertian", "reflectance": {"type": "rgb", "value": [0.1, 0.45, 0.08]},
+                                      "transmittance": {"type": "rgb", "value": [0.05, 0.4, 0.04]}}}
+    gpu, _ = gpu_render(gpu_rgb, d)
+    ref = ob.OracleScene(d).render()
+    assert np.array_equal(gpu, ref) and gpu[..., 1].max() > 0
+
+
 def _uv_sphere(n_lat, n_lon, radius=1.0, center=(0, 0, 0)):
     th = np.linspace(0.0, np.pi, n_lat + 1); ph = np.linspace(0.0, 2.0 * np.pi, n_lon, endpoint=False)
     v = np.array([[np.sin(t) * np.cos(p), np.sin(t) * np.sin(p), np.cos(t)] for t in th for p in ph], dtype=np.float32) * radius + np.asarray(center, np.float32)

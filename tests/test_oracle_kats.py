@@ -678,3 +678,49 @@ def test_distantflux_render_targets(setup):
     total = tc.radiance_rgb(img)[..., 1].sum()
     expected = {"default": 2.0 / np.pi, "target_square_large": 0.25}.get(setup, 1.0)
     assert np.allclose(total, expected, rtol={"default": 1e-2, "target_square_large": 1e-2}.get(setup, 1e-3))
+
+
+# ---------------------------------------------------------------- bilambertian (Eradiate's leaf BSDF)
+@pytest.mark.parametrize("r,t", [(0.2, 0.4), (0.4, 0.2), (0.1, 0.9), (0.9, 0.1), (0.4, 0.6), (0.6, 0.4)])
+def test_bilambertian_eval_pdf(r, t):
+    """src/bsdfs/tests/test_bilambertian.py:23-63: reflection on the side of wi, transmission on the other, from both sides"""
+    d = {"type": "scene", "integrator": {"type": "path"}, "sensor": {"type": "perspective", "film": {"type": "hdrfilm", "width": 1, "height": 1}},
+         "leaf": {"type": "rectangle", "bsdf": {"type": "bilambertian", "reflectance": r, "transmittance": t}}}
+    o = ob.OracleScene(d)
+    albedo = r + t
+    for wi in ([0, 0, 1], [0, 0, -1]):
+        for i in range(20):
+            theta = i / 19.0 * np.pi
+            wo = [np.sin(theta), 0, np.cos(theta)]
+            v, pdf = o.bsdf_eval(0, wi, wo)
+            k = r if np.dot(wi, wo) > 0 else t
+            assert np.allclose(v, k * abs(wo[2]) / np.pi, atol=1e-7) and np.isclose(pdf, k / albedo * abs(wo[2]) / np.pi, atol=1e-7)
+
+
+@pytest.mark.parametrize("r,t", [(0.6, 0.2), (0.2, 0.6), (0.9, 0.1), (1.0, 0.0), (0.0, 1.0), (0.0, 0.0)])
+def test_bilambertian_sample_matches_its_pdf(r, t):
+    """test_bilambertian.py:66-95 runs a chi^2 test; here: sample() reports the pdf pdf() reports for its direction, the weight is
+    value / pdf, and the lobe frequencies follow the sampling weights (both sides)."""
+    d = {"type": "scene", "integrator": {"type": "path"}, "sensor": {"type": "perspective", "film": {"type": "hdrfilm", "width": 1, "height": 1}},
+         "leaf": {"type": "rectangle", "bsdf": {"type": "bilambertian", "reflectance": r, "transmittance": t}}}
+    o = ob.OracleScene(d)
+    rng = np.random.default_rng(3)
+    for wi in ([0.3, -0.2, 0.93], [0.1, 0.4, -0.91]):
+        wi = np.array(wi) / np.linalg.norm(wi)
+        refl = 0
+        n = 400
+        for _ in range(n):
+            s1, s2 = rng.random(), rng.random(2)
+            wo, pdf, wgt, st = o.bsdf_sample(0, wi, s1, s2)
+            if r + t == 0:
+                assert np.all(wgt == 0)
+                continue
+            assert st in (0x2, 0x4) and np.isclose(np.linalg.norm(wo), 1.0, atol=1e-5)
+            refl += st == 0x2
+            assert (st == 0x2) == (wo[2] * wi[2] > 0)
+            v, p2 = o.bsdf_eval(0, wi, wo)
+            assert np.isclose(p2, pdf, rtol=1e-5, atol=1e-8)
+            if pdf > 0:
+                assert np.allclose(wgt, v / pdf, rtol=1e-4)
+        if r + t > 0:
+            assert abs(refl / n - r / (r + t)) < 0.08
