@@ -555,6 +555,32 @@ class SceneBuilder:
                     s.distant_target_point[:] = tuple(float(x) for x in np.asarray(rt, dtype=np.float32))
             if p.has("ray_origin"):
                 raise RuntimeError("distant sensor: 'ray_origin' shapes are not supported by this backend")
+        elif p.type == "radiancemeter":
+            # src/sensors/radiancemeter.cpp:60-98: one ray along +z of to_world (or of look_at(origin, origin + direction)); it is the
+            # one-sub-sensor case of mradiancemeter (same ray arithmetic, :124-127 vs mradiancemeter.cpp:150-153)
+            s.type = A.SENSOR_MRADIANCEMETER
+            p.get("srf")                                                   # ignored outside spectral variants (radiancemeter.cpp:61-68)
+            if p.has("to_world"):
+                p.get("direction"); p.get("origin")
+                m = p.get("to_world").matrix
+            else:
+                if p.has("direction") != p.has("origin"):
+                    raise RuntimeError("If the sensor is specified through origin and direction both values must be set!")
+                if p.has("direction"):
+                    origin = np.asarray(p.get("origin"), dtype=np.float32)
+                    direction = np.asarray(p.get("direction"), dtype=np.float32)
+                    up, _ = coordinate_system(direction)
+                    m = ScalarTransform4f.look_at(origin, (origin + direction).astype(np.float32), up).matrix
+                else:
+                    m = ScalarTransform4f().matrix
+            if (s.film_width, s.film_height) != (1, 1):
+                raise RuntimeError("This sensor only supports films of size 1x1 Pixels!")
+            buf = np.ascontiguousarray(np.asarray(m, dtype=np.float32).reshape(-1))
+            self.keep.append(buf)
+            s.multi_transforms = buf.ctypes.data_as(C.POINTER(C.c_float))
+            s.multi_count = 1
+            s.to_world = _xf(ScalarTransform4f())
+            s.distant_target_type = A.DISTANT_TARGET_NONE
         elif p.type == "distantflux":                                      # src/sensors/distantflux.cpp:60-105,141-187
             s.type = A.SENSOR_DISTANTFLUX
             tw = p.get("to_world")
@@ -668,7 +694,7 @@ class SceneBuilder:
                 self.add_shape(v, k)
             elif t in ("directional", "constant", "area"):
                 self.add_emitter(v, k)
-            elif t in ("perspective", "distant", "mradiancemeter", "mdistant", "distantflux"):
+            elif t in ("perspective", "distant", "mradiancemeter", "mdistant", "distantflux", "radiancemeter"):
                 if self.sensor is not None:
                     raise RuntimeError("this backend supports a single sensor per scene")
                 self.set_sensor(v, k)

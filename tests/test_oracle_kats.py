@@ -724,3 +724,40 @@ def test_bilambertian_sample_matches_its_pdf(r, t):
                 assert np.allclose(wgt, v / pdf, rtol=1e-4)
         if r + t > 0:
             assert abs(refl / n - r / (r + t)) < 0.08
+
+
+# ---------------------------------------------------------------- radiancemeter
+def _radiancemeter(origin=None, direction=None, to_world=None, pixels=1):
+    d = {"type": "radiancemeter", "film": {"type": "hdrfilm", "width": pixels, "height": pixels, "rfilter": {"type": "box"}}}
+    if origin is not None: d["origin"] = origin
+    if direction is not None: d["direction"] = direction
+    if to_world is not None: d["to_world"] = to_world
+    return d
+
+
+def test_radiancemeter_construct_and_rays():
+    """src/sensors/tests/test_radiancemeter.py:32-111"""
+    look = T.look_at([0, 0, 0], [0, 1, 0], [0, 0, 1])
+    o = ob.OracleScene(_with_sensor(_radiancemeter(to_world=look)))
+    ro, rd, _ = o.sensor_sample_ray([[0.32, 0.87]], [[0.16, 0.44]])
+    assert np.allclose(ro[0], 0) and np.allclose(rd[0], [0, 1, 0], atol=1e-6)
+    o = ob.OracleScene(_with_sensor(_radiancemeter(to_world=look, origin=[1, 0, 0], direction=[4, 1, 0])))      # to_world wins
+    ro, rd, _ = o.sensor_sample_ray([[0.5, 0.5]], [[0.5, 0.5]])
+    assert np.allclose(ro[0], 0) and np.allclose(rd[0], [0, 1, 0], atol=1e-6)
+    for bad in (dict(direction=[0, 1, 0]), dict(origin=[0, 1, 0]), dict(pixels=2)):
+        with pytest.raises(RuntimeError):
+            ob.OracleScene(_with_sensor(_radiancemeter(**bad)))
+    for direction in ([0.0, 0.0, 1.0], [-1.0, -1.0, 0.0], [2.0, 0.0, 0.0]):
+        for origin in ([0.0, 0.0, 0.0], [-1.0, -1.0, 0.5], [4.0, 1.0, 0.0]):
+            o = ob.OracleScene(_with_sensor(_radiancemeter(origin, direction)))
+            ro, rd, w = o.sensor_sample_ray([[0.32, 0.87]], [[0.16, 0.44]])
+            assert np.allclose(ro[0], origin) and np.allclose(rd[0], np.array(direction) / np.linalg.norm(direction), atol=1e-6) and np.allclose(w, 1)
+
+
+@pytest.mark.parametrize("radiance", [10.0 ** x for x in range(-3, 4)])
+def test_radiancemeter_render(radiance):
+    """test_radiancemeter.py:114-150: a radiancemeter inside a constant environment measures its radiance"""
+    s = _radiancemeter([1, 0, 0], [1, 0, 0]); s["sampler"] = {"type": "independent", "sample_count": 1}
+    d = _with_sensor(s, emitter={"type": "constant", "radiance": {"type": "uniform", "value": radiance}})
+    import tests.transport_cases as tc
+    assert np.allclose(tc.radiance_rgb(ob.OracleScene(d).render(threads=1)), radiance, rtol=1e-5)
