@@ -19,7 +19,7 @@ WRAP_REPEAT, WRAP_MIRROR, WRAP_CLAMP = 0, 1, 2
 PHASE_ISOTROPIC, PHASE_HG, PHASE_RAYLEIGH, PHASE_BLEND, PHASE_TABULATED = 0, 1, 2, 3, 4
 MEDIUM_HOMOGENEOUS, MEDIUM_HETEROGENEOUS = 0, 1
 BSDF_DIFFUSE, BSDF_NULL, BSDF_RPV, BSDF_BILAMBERTIAN = 0, 1, 2, 3
-SHAPE_RECTANGLE, SHAPE_CUBE, SHAPE_SPHERE, SHAPE_MESH = 0, 1, 2, 3
+SHAPE_RECTANGLE, SHAPE_CUBE, SHAPE_SPHERE, SHAPE_MESH, SHAPE_DISK = 0, 1, 2, 3, 4
 EMITTER_DIRECTIONAL, EMITTER_AREA, EMITTER_CONSTANT = 0, 1, 2
 SENSOR_PERSPECTIVE, SENSOR_DISTANT, SENSOR_MRADIANCEMETER, SENSOR_MDISTANT, SENSOR_DISTANTFLUX = 0, 1, 2, 3, 4
 RFILTER_BOX, RFILTER_GAUSSIAN = 0, 1

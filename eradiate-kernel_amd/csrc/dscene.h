@@ -65,6 +65,7 @@ struct DShape {
     int32_t bsdf, interior, exterior, emitter;   // bsdf always resolved (default diffuse appended by the host)
     float frame_s[3], frame_t[3], frame_n[3];     // rectangle.cpp:66-74
     float inv_surface_area;
+    float surface_area;                           // disk (disk.cpp:108-111)
     float center[3], radius;                      // sphere
     int32_t flip_normals;
     int32_t vertex_offset, face_offset;           // into the scene-wide mesh arrays

@@ -106,6 +106,15 @@ DEV float rectangle_intersect(const float *to_object /* rows 0..2 suffice */, co
     uv.x = lx; uv.y = ly;
     return active ? t : pm_inf();
 }
+// shapes/disk.cpp:136-153
+DEV float disk_intersect(const float *to_object, const DRay &ray, F2 &uv) {
+    F3 o = mat_point_affine(to_object, ray.o), d = mat_vector(to_object, ray.d);
+    float t = -o.z * (1.0f / d.z);
+    float lx = pm_fma(d.x, t, o.x), ly = pm_fma(d.y, t, o.y);
+    bool active = t >= ray.mint && t <= ray.maxt && lx * lx + ly * ly <= 1.f;
+    uv.x = lx; uv.y = ly;
+    return active ? t : pm_inf();
+}
 // render/mesh.h:195-226 with p0 / e1 / e2 precomputed per primitive (same subtraction, done once on the host).
 // The two `__ballot(...) == 0` exits skip the rest of the test when NO lane of the wave can still hit this
 // triangle; a lane's own result never depends on them.
@@ -166,6 +175,7 @@ DEV float prim_intersect_lane(const BvhArgs &a, int pi, const DRay &ray, F2 &uv,
     const DShape &s = a.shapes[shape];
     uv.x = uv.y = 0.f;
     if (s.type == MTS_SHAPE_RECTANGLE) return rectangle_intersect(s.to_object.m, ray, uv);
+    if (s.type == MTS_SHAPE_DISK) return disk_intersect(s.to_object.m, ray, uv);
     if (s.type == MTS_SHAPE_SPHERE) return sphere_intersect(s.center, s.radius, ray);
     const MTS_GLOBAL_AS float *t = as_global(a.tri) + 9 * pi;
     TriRec T;
@@ -226,6 +236,7 @@ DEV Hit ray_intersect_preliminary(const DScene &sc, DRay ray) {
         const DWalkPrim w = cload(sc.walk + i);               // one 64-byte scalar load per primitive (fetching one ahead measured slower)
         F2 uv; uv.x = uv.y = 0.f; float t;
         if (w.type == MTS_SHAPE_RECTANGLE) t = rectangle_intersect(w.f, ray, uv);
+        else if (w.type == MTS_SHAPE_DISK) t = disk_intersect(w.f, ray, uv);
         else if (w.type == MTS_SHAPE_SPHERE) t = sphere_intersect(w.f, w.f[3], ray);
         else { TriRec T; for (int k = 0; k < 9; ++k) T.v[k] = w.f[k]; t = triangle_intersect(T, ray, uv); }
         if (t != pm_inf()) {
@@ -239,7 +250,7 @@ DEV Hit ray_intersect_preliminary(const DScene &sc, DRay ray) {
 
 // Hit point: rectangle.cpp:181-185, mesh.cpp:470-483, sphere.cpp:325-327
 DEV void hit_point(const DScene &sc, const DShape &s, const DRay &ray, Hit &h) {
-    if (s.type == MTS_SHAPE_RECTANGLE) {
+    if (s.type == MTS_SHAPE_RECTANGLE || s.type == MTS_SHAPE_DISK) {                          // rectangle.cpp:181-185 == disk.cpp:186-188
         F3 p = ray_at(ray, h.t), n = f3(s.frame_n);
         float dist = dot(f3(s.to_world.m[3], s.to_world.m[7], s.to_world.m[11]) - p, n);
         h.p = fmadd(n, dist, p);
@@ -274,6 +285,11 @@ DEV void complete_surface(const DScene &sc, const DShape &s, const Hit &h, F3 d,
     F3 dp_du, dp_dv, shn;
     if (s.type == MTS_SHAPE_RECTANGLE) {
         sf.n = f3(s.frame_n); shn = sf.n; dp_du = f3(s.frame_s);
+    } else if (s.type == MTS_SHAPE_DISK) {                                                    // disk.cpp:190-207, h.uv = prim_uv
+        sf.n = f3(s.frame_n); shn = sf.n;
+        float r = pm_sqrt(pm_fma(h.uv.y, h.uv.y, h.uv.x * h.uv.x)), inv_r = pm_rcp(r);
+        float cos_phi = r != 0.f ? h.uv.x * inv_r : 1.f, sin_phi = r != 0.f ? h.uv.y * inv_r : 0.f;
+        dp_du = mat_vector(s.to_world.m, f3(cos_phi, sin_phi, 0.f));
     } else if (s.type == MTS_SHAPE_SPHERE) {
         // hit_point() parked the unit normal normalize(ray(t) - center) in (uv.x, uv.y, bits(prim))
         shn = f3(h.uv.x, h.uv.y, pm_from_bits((uint32_t) h.prim));
@@ -628,6 +644,10 @@ DEV void shape_sample_position(const DShape &s, F2 sample, F3 &p, F3 &n, float &
     if (s.type == MTS_SHAPE_RECTANGLE) {
         p = mat_point_affine(s.to_world.m, f3(sample.x * 2.f - 1.f, sample.y * 2.f - 1.f, 0.f));
         n = f3(s.frame_n);
+    } else if (s.type == MTS_SHAPE_DISK) {                                                    // disk.cpp:114-128
+        F2 q = square_to_uniform_disk_concentric(sample);
+        p = mat_point_affine(s.to_world.m, f3(q.x, q.y, 0.f));
+        n = f3(s.frame_n);
     } else {
         F3 local = square_to_uniform_sphere(sample);
         p = fmadd(local, s.radius, f3(s.center));
@@ -638,7 +658,7 @@ DEV void shape_sample_position(const DShape &s, F2 sample, F3 &p, F3 &n, float &
 // librender/shape.cpp:293-310 ; shapes/sphere.cpp (sample_direction)
 DEV_NOINLINE DirSample shape_sample_direction(const DShape &s, F3 ref_p, F2 sample) {
     DirSample ds; ds.delta = false; ds.emitter = -1;
-    if (s.type == MTS_SHAPE_RECTANGLE) {
+    if (s.type == MTS_SHAPE_RECTANGLE || s.type == MTS_SHAPE_DISK) {
         shape_sample_position(s, sample, ds.p, ds.n, ds.pdf);
         ds.d = ds.p - ref_p;
         float dist_squared = squared_norm(ds.d);
@@ -679,7 +699,7 @@ DEV_NOINLINE DirSample shape_sample_direction(const DShape &s, F3 ref_p, F2 samp
     return ds;
 }
 DEV float shape_pdf_direction(const DShape &s, F3 ref_p, const DirSample &ds) {
-    if (s.type == MTS_SHAPE_RECTANGLE) {                                                      // shape.cpp:312-323
+    if (s.type == MTS_SHAPE_RECTANGLE || s.type == MTS_SHAPE_DISK) {                          // shape.cpp:312-323
         float pdf = s.inv_surface_area, dp = pm_abs(dot(ds.d, ds.n));
         pdf *= (dp != 0.f) ? (ds.dist * ds.dist) / dp : 0.f;
         return pdf;
@@ -754,7 +774,7 @@ DEV float mis_weight(float pdf_a, float pdf_b) { pdf_a *= pdf_a; pdf_b *= pdf_b;
 
 // Geometric normal of a hit without the full shading frame (only needed for medium transitions)
 DEV F3 hit_geo_normal(const DScene &sc, const DShape &s, const Hit &h) {
-    if (s.type == MTS_SHAPE_RECTANGLE) return f3(s.frame_n);
+    if (s.type == MTS_SHAPE_RECTANGLE || s.type == MTS_SHAPE_DISK) return f3(s.frame_n);
     Surf sf; complete_surface(sc, s, h, f3(0.f, 0.f, 1.f), sf);
     return sf.n;
 }

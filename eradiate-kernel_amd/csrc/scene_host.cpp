@@ -85,6 +85,23 @@ static DShape build_shape(const mts_shape &d, HostScene &hs, DBBox &shape_bbox, 
         bbox_expand(shape_bbox, mat_point_affine(s.to_world.m, f3(1.f, 1.f, 0.f)));
         bbox_expand(shape_bbox, mat_point_affine(s.to_world.m, f3(-1.f, 1.f, 0.f)));
         prim_count = 1;
+    } else if (d.type == MTS_SHAPE_DISK) {                                                     // disk.cpp:74-111
+        if (d.flip_normals) s.to_world = xf_mul(s.to_world, xf_scale(f3(1.f, 1.f, -1.f)));
+        s.to_object = xf_inverse(s.to_world);
+        F3 dp_du = mat_vector(s.to_world.m, f3(1.f, 0.f, 0.f)), dp_dv = mat_vector(s.to_world.m, f3(0.f, 1.f, 0.f));
+        float du = norm(dp_du), dv = norm(dp_dv);
+        F3 n = normalize(mat_vector(s.to_world.it, f3(0.f, 0.f, 1.f)));
+        F3 fs = dp_du / du, ft = dp_dv / dv;
+        store3(s.frame_s, fs); store3(s.frame_t, ft); store3(s.frame_n, n);
+        float dts = dot(ft * dv, fs);
+        float h = pm_sqrt(dv * dv - dts * dts);
+        s.surface_area = MTS_PI * du * h;
+        s.inv_surface_area = 1.f / s.surface_area;
+        bbox_expand(shape_bbox, mat_point_affine(s.to_world.m, f3(-1.f, -1.f, 0.f)));
+        bbox_expand(shape_bbox, mat_point_affine(s.to_world.m, f3(-1.f, 1.f, 0.f)));
+        bbox_expand(shape_bbox, mat_point_affine(s.to_world.m, f3(1.f, -1.f, 0.f)));
+        bbox_expand(shape_bbox, mat_point_affine(s.to_world.m, f3(1.f, 1.f, 0.f)));
+        prim_count = 1;
     } else if (d.type == MTS_SHAPE_CUBE || d.type == MTS_SHAPE_MESH) {
         s.to_object = xf_inverse(s.to_world);
         int nv, nf; const float *pos, *nor, *uv; const uint32_t *fc;
@@ -316,7 +333,7 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
             hs.tri.insert(hs.tri.end(), rec, rec + 9);
             DWalkPrim w; memset(&w, 0, sizeof(w));
             w.type = ds.type; w.shape = i; w.index = k;
-            if (ds.type == MTS_SHAPE_RECTANGLE) memcpy(w.f, ds.to_object.m, 48);
+            if (ds.type == MTS_SHAPE_RECTANGLE || ds.type == MTS_SHAPE_DISK) memcpy(w.f, ds.to_object.m, 48);
             else if (ds.type == MTS_SHAPE_SPHERE) { memcpy(w.f, ds.center, 12); w.f[3] = ds.radius; }
             else memcpy(w.f, rec, 36);
             hs.walk.push_back(w);
@@ -376,10 +393,10 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
         memcpy(se.target_point, s.distant_target_point, 12);
         if (se.target_type == MTS_DISTANT_TARGET_SHAPE) {
             HostScene scratch; DBBox sb; int pc;
-            if (s.distant_target_shape.type != MTS_SHAPE_RECTANGLE && s.distant_target_shape.type != MTS_SHAPE_SPHERE)
-                throw std::runtime_error("distant ray_target shape must be a rectangle or a sphere in this backend");
+            if (s.distant_target_shape.type != MTS_SHAPE_RECTANGLE && s.distant_target_shape.type != MTS_SHAPE_SPHERE && s.distant_target_shape.type != MTS_SHAPE_DISK)
+                throw std::runtime_error("distant ray_target shape must be a rectangle, a disk or a sphere in this backend");
             se.target_shape = build_shape(s.distant_target_shape, scratch, sb, pc);
-            se.target_area = se.target_shape.type == MTS_SHAPE_RECTANGLE
+            se.target_area = se.target_shape.type == MTS_SHAPE_DISK ? se.target_shape.surface_area : se.target_shape.type == MTS_SHAPE_RECTANGLE
                 ? norm(cross(f3(se.target_shape.frame_s), f3(se.target_shape.frame_t)))
                 : 4.f * MTS_PI * se.target_shape.radius * se.target_shape.radius;
         } else if (se.target_type != MTS_DISTANT_TARGET_NONE && se.target_type != MTS_DISTANT_TARGET_POINT)
@@ -398,10 +415,10 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
             memcpy(se.target_point, s.distant_target_point, 12);
             if (se.target_type == MTS_DISTANT_TARGET_SHAPE) {
                 HostScene scratch; DBBox sb; int pc;
-                if (s.distant_target_shape.type != MTS_SHAPE_RECTANGLE && s.distant_target_shape.type != MTS_SHAPE_SPHERE)
-                    throw std::runtime_error("mdistant target shape must be a rectangle or a sphere in this backend");
+                if (s.distant_target_shape.type != MTS_SHAPE_RECTANGLE && s.distant_target_shape.type != MTS_SHAPE_SPHERE && s.distant_target_shape.type != MTS_SHAPE_DISK)
+                    throw std::runtime_error("mdistant target shape must be a rectangle, a disk or a sphere in this backend");
                 se.target_shape = build_shape(s.distant_target_shape, scratch, sb, pc);
-                se.target_area = se.target_shape.type == MTS_SHAPE_RECTANGLE
+                se.target_area = se.target_shape.type == MTS_SHAPE_DISK ? se.target_shape.surface_area : se.target_shape.type == MTS_SHAPE_RECTANGLE
                     ? norm(cross(f3(se.target_shape.frame_s), f3(se.target_shape.frame_t)))
                     : 4.f * MTS_PI * se.target_shape.radius * se.target_shape.radius;
             } else if (se.target_type != MTS_DISTANT_TARGET_NONE && se.target_type != MTS_DISTANT_TARGET_POINT)
@@ -483,7 +500,7 @@ void build_bvh(HostScene &hs) {
         PrimBox b; b.prim = i;
         for (int a = 0; a < 3; ++a) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; }
         auto add = [&b](F3 p) { const float v[3] = { p.x, p.y, p.z }; for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], v[a]); b.hi[a] = std::max(b.hi[a], v[a]); } };
-        if (s.type == MTS_SHAPE_RECTANGLE) {
+        if (s.type == MTS_SHAPE_RECTANGLE || s.type == MTS_SHAPE_DISK) {
             for (int k = 0; k < 4; ++k) add(mat_point_affine(s.to_world.m, f3((k & 1) ? 1.f : -1.f, (k & 2) ? 1.f : -1.f, 0.f)));
         } else if (s.type == MTS_SHAPE_SPHERE) {
             add(f3(s.center) - f3s(s.radius)); add(f3(s.center) + f3s(s.radius));

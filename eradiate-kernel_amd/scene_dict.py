@@ -350,6 +350,9 @@ class SceneBuilder:
         if p.type == "rectangle":
             rec.type = A.SHAPE_RECTANGLE
             rec.flip_normals = int(bool(p.get("flip_normals", False)))
+        elif p.type == "disk":                                           # src/shapes/disk.cpp:74-81
+            rec.type = A.SHAPE_DISK
+            rec.flip_normals = int(bool(p.get("flip_normals", False)))
         elif p.type == "cube":
             rec.type = A.SHAPE_CUBE
         elif p.type == "sphere":
@@ -681,7 +684,7 @@ class SceneBuilder:
     def load(self, d):
         if not isinstance(d, dict) or d.get("type") != "scene":
             raise RuntimeError("load_dict(): the top-level dictionary must have type 'scene' in this backend")
-        SHAPES = ("rectangle", "cube", "sphere", "mesh", "obj", "ply")
+        SHAPES = ("rectangle", "cube", "sphere", "mesh", "obj", "ply", "disk")
         for k, v in sorted_items(d):          # scene.cpp:23: props.objects() order
             if k in ("type", "id"):
                 continue

@@ -95,8 +95,8 @@ typedef struct mts_bsdf {
     float transmittance[3];   /* bilambertian "transmittance" (with "reflectance"), default 0.5 (bilambertian.cpp:52-53) */
 } mts_bsdf;
 
-/* ---- Shapes (src/shapes/{rectangle,cube,sphere}.cpp, src/librender/mesh.cpp) ---- */
-enum { MTS_SHAPE_RECTANGLE = 0, MTS_SHAPE_CUBE = 1, MTS_SHAPE_SPHERE = 2, MTS_SHAPE_MESH = 3 };
+/* ---- Shapes (src/shapes/{rectangle,cube,sphere,disk}.cpp, src/librender/mesh.cpp) ---- */
+enum { MTS_SHAPE_RECTANGLE = 0, MTS_SHAPE_CUBE = 1, MTS_SHAPE_SPHERE = 2, MTS_SHAPE_MESH = 3, MTS_SHAPE_DISK = 4 /* src/shapes/disk.cpp */ };
 typedef struct mts_shape {
     int32_t type;
     mts_transform to_world;

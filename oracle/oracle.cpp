@@ -69,6 +69,15 @@ static inline float rectangle_intersect(const Shape &s, const Ray &ray_, P2 *uv)
     uv->x = local.x; uv->y = local.y;
     return active ? t : pm_inf();
 }
+// disk.cpp:136-153
+static inline float disk_intersect(const Shape &s, const Ray &ray_, P2 *uv) {
+    Ray ray = xf_ray_affine(s.to_object, ray_);
+    float t = -ray.o.z * ray.d_rcp.z;
+    V3 local = ray(t);
+    bool active = t >= ray.mint && t <= ray.maxt && local.x * local.x + local.y * local.y <= 1.f;
+    uv->x = local.x; uv->y = local.y;
+    return active ? t : pm_inf();
+}
 // mesh.h:195-226 (Moeller-Trumbore)
 static inline float triangle_intersect(const Shape &s, int index, const Ray &ray, P2 *uv) {
     const uint32_t *fi = &s.faces[3 * index];
@@ -136,6 +145,7 @@ static inline PreliminaryIntersection ray_intersect_preliminary(const Scene &sc,
         const Shape &s = sc.shapes[sc.prims[i].shape];
         P2 uv = { 0.f, 0.f }; float t;
         if (s.type == MTS_SHAPE_RECTANGLE) t = rectangle_intersect(s, ray, &uv);
+        else if (s.type == MTS_SHAPE_DISK) t = disk_intersect(s, ray, &uv);
         else if (s.type == MTS_SHAPE_SPHERE) t = sphere_intersect(s, ray);
         else t = triangle_intersect(s, sc.prims[i].index, ray, &uv);
         if (t != pm_inf()) {
@@ -155,6 +165,18 @@ static inline void rectangle_fill(const Shape &s, const Ray &ray, const Prelimin
     si.n = s.frame.n; si.sh_frame.n = s.frame.n;
     si.dp_du = s.frame.s; si.dp_dv = s.frame.t;
     si.uv.x = pm_fma(pi.prim_uv.x, .5f, .5f); si.uv.y = pm_fma(pi.prim_uv.y, .5f, .5f);
+}
+// disk.cpp:168-211 (si.uv = (r, phi / 2 pi) is not produced: nothing on this path reads texture coordinates of a disk)
+static inline void disk_fill(const Shape &s, const Ray &ray, const PreliminaryIntersection &pi, SurfaceInteraction &si) {
+    V3 p = ray(pi.t);
+    float dist = dot(xf_translation(s.to_world) - p, s.frame.n);
+    si.p = fmadd(s.frame.n, dist, p);
+    float r = pm_sqrt(pm_fma(pi.prim_uv.y, pi.prim_uv.y, pi.prim_uv.x * pi.prim_uv.x)), inv_r = pm_rcp(r);
+    float cos_phi = r != 0.f ? pi.prim_uv.x * inv_r : 1.f, sin_phi = r != 0.f ? pi.prim_uv.y * inv_r : 0.f;
+    si.dp_du = xf_vector(s.to_world, v3(cos_phi, sin_phi, 0.f));
+    si.dp_dv = xf_vector(s.to_world, v3(-sin_phi, cos_phi, 0.f));
+    si.uv.x = r; si.uv.y = 0.f;
+    si.n = s.frame.n; si.sh_frame.n = s.frame.n;
 }
 // mesh.cpp:448-545
 static inline void mesh_fill(const Shape &s, const PreliminaryIntersection &pi, SurfaceInteraction &si) {
@@ -214,6 +236,7 @@ static inline SurfaceInteraction ray_intersect(const Scene &sc, const Ray &ray) 
     const Shape &s = sc.shapes[pi.shape];
     si.t = pi.t;
     if (s.type == MTS_SHAPE_RECTANGLE) rectangle_fill(s, ray, pi, si);
+    else if (s.type == MTS_SHAPE_DISK) disk_fill(s, ray, pi, si);
     else if (s.type == MTS_SHAPE_SPHERE) sphere_fill(s, ray, pi, si);
     else mesh_fill(s, pi, si);
     si.prim_index = pi.prim_index; si.shape = pi.shape;
@@ -519,6 +542,10 @@ static inline void shape_sample_position(const Shape &s, P2 sample, V3 *p, V3 *n
     if (s.type == MTS_SHAPE_RECTANGLE) {
         *p = xf_point_affine(s.to_world, v3(sample.x * 2.f - 1.f, sample.y * 2.f - 1.f, 0.f));
         *n = s.frame.n; *pdf = s.inv_surface_area;
+    } else if (s.type == MTS_SHAPE_DISK) {                                                // disk.cpp:114-128
+        P2 q = square_to_uniform_disk_concentric(sample);
+        *p = xf_point_affine(s.to_world, v3(q.x, q.y, 0.f));
+        *n = s.frame.n; *pdf = s.inv_surface_area;
     } else {
         V3 local = square_to_uniform_sphere(sample);
         *p = fmadd(local, s.radius, s.center);
@@ -528,7 +555,7 @@ static inline void shape_sample_position(const Shape &s, P2 sample, V3 *p, V3 *n
 // shape.cpp:293-310 (generic), sphere.cpp sample_direction
 static inline DirectionSample shape_sample_direction(const Shape &s, V3 ref_p, P2 sample) {
     DirectionSample ds; memset(&ds, 0, sizeof(ds));
-    if (s.type == MTS_SHAPE_RECTANGLE) {
+    if (s.type == MTS_SHAPE_RECTANGLE || s.type == MTS_SHAPE_DISK) {
         shape_sample_position(s, sample, &ds.p, &ds.n, &ds.pdf);
         ds.d = ds.p - ref_p;
         float dist_squared = squared_norm(ds.d);
@@ -569,7 +596,7 @@ static inline DirectionSample shape_sample_direction(const Shape &s, V3 ref_p, P
     return ds;
 }
 static inline float shape_pdf_direction(const Shape &s, V3 ref_p, const DirectionSample &ds) {
-    if (s.type == MTS_SHAPE_RECTANGLE) {                                                   // shape.cpp:312-323
+    if (s.type == MTS_SHAPE_RECTANGLE || s.type == MTS_SHAPE_DISK) {                       // shape.cpp:312-323
         float pdf = s.inv_surface_area, dp = pm_abs(dot(ds.d, ds.n));
         pdf *= (dp != 0.f) ? (ds.dist * ds.dist) / dp : 0.f;
         return pdf;
@@ -1268,7 +1295,7 @@ static Ray sensor_sample_ray(const Scene &sc, P2 position_sample, P2 aperture_sa
         else if (se.target_type == MTS_DISTANT_TARGET_SHAPE) {
             V3 tp, n; float pdf;
             shape_sample_position(se.target_shape, aperture_sample, &tp, &n, &pdf);
-            float area = se.target_shape.type == MTS_SHAPE_RECTANGLE ? norm(cross(se.target_shape.frame.s, se.target_shape.frame.t))
+            float area = se.target_shape.type == MTS_SHAPE_DISK ? se.target_shape.surface_area : se.target_shape.type == MTS_SHAPE_RECTANGLE ? norm(cross(se.target_shape.frame.s, se.target_shape.frame.t))
                                                                      : 4.f * Pi * se.target_shape.radius * se.target_shape.radius;
             o = tp - 2.f * d * se.bsphere_radius;
             w = 1.f / (pdf * area);
@@ -1289,7 +1316,7 @@ static Ray sensor_sample_ray(const Scene &sc, P2 position_sample, P2 aperture_sa
         if (se.target_type == MTS_DISTANT_TARGET_SHAPE) {
             V3 n; float pdf;
             shape_sample_position(se.target_shape, aperture_sample, &ray_target, &n, &pdf);
-            float area = se.target_shape.type == MTS_SHAPE_RECTANGLE ? norm(cross(se.target_shape.frame.s, se.target_shape.frame.t))
+            float area = se.target_shape.type == MTS_SHAPE_DISK ? se.target_shape.surface_area : se.target_shape.type == MTS_SHAPE_RECTANGLE ? norm(cross(se.target_shape.frame.s, se.target_shape.frame.t))
                                                                      : 4.f * Pi * se.target_shape.radius * se.target_shape.radius;
             w *= 1.f / (pdf * area);
         } else if (se.target_type == MTS_DISTANT_TARGET_NONE) {
@@ -1310,7 +1337,7 @@ static Ray sensor_sample_ray(const Scene &sc, P2 position_sample, P2 aperture_sa
     else if (se.target_type == MTS_DISTANT_TARGET_SHAPE) {
         V3 n; float pdf;
         shape_sample_position(se.target_shape, aperture_sample, &ray_target, &n, &pdf);
-        float area = se.target_shape.type == MTS_SHAPE_RECTANGLE ? norm(cross(se.target_shape.frame.s, se.target_shape.frame.t))
+        float area = se.target_shape.type == MTS_SHAPE_DISK ? se.target_shape.surface_area : se.target_shape.type == MTS_SHAPE_RECTANGLE ? norm(cross(se.target_shape.frame.s, se.target_shape.frame.t))
                                                                  : 4.f * Pi * se.target_shape.radius * se.target_shape.radius;
         float w = 1.f / pdf / area;
         ray_weight = v3(w, w, w);

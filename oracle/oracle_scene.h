@@ -134,6 +134,7 @@ struct Shape {
     // rectangle (rectangle.cpp:66-74)
     Frame frame;
     float inv_surface_area;
+    float surface_area = 0.f;                    // disk (disk.cpp:108-111)
     // sphere (sphere.cpp:80-105)
     V3 center; float radius; bool flip_normals;
     // mesh (mesh.cpp, cube.cpp:54-112): world-space vertex data
@@ -177,6 +178,22 @@ static inline Shape make_shape(const mts_shape &d) {
         bbox_expand(s.bbox, xf_point_affine(s.to_world, v3(1.f, -1.f, 0.f)));
         bbox_expand(s.bbox, xf_point_affine(s.to_world, v3(1.f, 1.f, 0.f)));
         bbox_expand(s.bbox, xf_point_affine(s.to_world, v3(-1.f, 1.f, 0.f)));
+        s.prim_count = 1;
+    } else if (d.type == MTS_SHAPE_DISK) {                                                   // disk.cpp:74-111
+        if (d.flip_normals) s.to_world = xf_mul(s.to_world, xf_scale(v3(1.f, 1.f, -1.f)));
+        s.to_object = xf_inverse(s.to_world);
+        V3 dp_du = xf_vector(s.to_world, v3(1.f, 0.f, 0.f)), dp_dv = xf_vector(s.to_world, v3(0.f, 1.f, 0.f));
+        float du = norm(dp_du), dv = norm(dp_dv);
+        V3 n = normalize(xf_normal(s.to_world, v3(0.f, 0.f, 1.f)));
+        s.frame.s = dp_du / du; s.frame.t = dp_dv / dv; s.frame.n = n;
+        float dts = dot(s.frame.t * dv, s.frame.s);
+        float h = pm_sqrt(dv * dv - dts * dts);
+        s.surface_area = Pi * du * h;
+        s.inv_surface_area = 1.f / s.surface_area;
+        bbox_expand(s.bbox, xf_point_affine(s.to_world, v3(-1.f, -1.f, 0.f)));
+        bbox_expand(s.bbox, xf_point_affine(s.to_world, v3(-1.f, 1.f, 0.f)));
+        bbox_expand(s.bbox, xf_point_affine(s.to_world, v3(1.f, -1.f, 0.f)));
+        bbox_expand(s.bbox, xf_point_affine(s.to_world, v3(1.f, 1.f, 0.f)));
         s.prim_count = 1;
     } else if (d.type == MTS_SHAPE_CUBE || d.type == MTS_SHAPE_MESH) {
         s.to_object = xf_inverse(s.to_world);
@@ -450,7 +467,7 @@ static inline Scene *make_scene(const mts_scene_desc *d) {
                 se.target_point = v3(s.distant_target_point[0], s.distant_target_point[1], s.distant_target_point[2]);
                 if (se.target_type == MTS_DISTANT_TARGET_SHAPE) {
                     se.target_shape = make_shape(s.distant_target_shape);
-                    if (se.target_shape.type != MTS_SHAPE_RECTANGLE && se.target_shape.type != MTS_SHAPE_SPHERE)
+                    if (se.target_shape.type != MTS_SHAPE_RECTANGLE && se.target_shape.type != MTS_SHAPE_SPHERE && se.target_shape.type != MTS_SHAPE_DISK)
                         throw std::runtime_error("mdistant target shape must be a rectangle or a sphere in this backend");
                 }
                 V3 c = (sc->bbox.max + sc->bbox.min) * .5f;                                // mdistant.cpp:205-210
@@ -465,7 +482,7 @@ static inline Scene *make_scene(const mts_scene_desc *d) {
             se.target_point = v3(s.distant_target_point[0], s.distant_target_point[1], s.distant_target_point[2]);
             if (se.target_type == MTS_DISTANT_TARGET_SHAPE) {
                 se.target_shape = make_shape(s.distant_target_shape);
-                if (se.target_shape.type != MTS_SHAPE_RECTANGLE && se.target_shape.type != MTS_SHAPE_SPHERE)
+                if (se.target_shape.type != MTS_SHAPE_RECTANGLE && se.target_shape.type != MTS_SHAPE_SPHERE && se.target_shape.type != MTS_SHAPE_DISK)
                     throw std::runtime_error("distant ray_target shape must be a rectangle or a sphere in this backend");
             }
             V3 c = (sc->bbox.max + sc->bbox.min) * .5f;                                    // distant.cpp:292-297

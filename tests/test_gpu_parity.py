@@ -235,6 +235,28 @@ def test_bilambertian_canopy_matches_the_oracle(gpu_rgb, integrator):
     assert np.array_equal(gpu, ref) and gpu[..., 1].max() > 0
 
 
+def test_disk_shapes_match_the_oracle(gpu_rgb):
+    """src/shapes/disk.cpp: disks as leaves (bilambertian), as an area light, as a medium boundary and as an mdistant target."""
+    rng = np.random.default_rng(11)
+    d = scenes.c2_homogeneous_slab(40, 32, 8)
+    for k in range(30):
+        c = rng.uniform([-4, -4, 2.2], [4, 4, 4.0])
+        d["leaf%02d" % k] = {"type": "disk", "to_world": T.translate(c) @ T.rotate(rng.normal(size=3), float(rng.uniform(0, 180))) @ T.scale([0.6, 0.4, 1.0]),
+                             "bsdf": {"type": "bilambertian", "reflectance": 0.4, "transmittance": 0.3}}
+    d["lamp"] = {"type": "disk", "to_world": T.translate([0, 0, 6]) @ T.rotate([1, 0, 0], 180) @ T.scale(1.5),
+                 "emitter": {"type": "area", "radiance": 4.0}}
+    cases = [d]
+    e = scenes.c3_heterogeneous(8, 8, 16, res=16)
+    e["sensor"] = {"type": "mdistant", "directions": "0, 0, -1, 0.3, 0.1, -1", "target": {"type": "disk", "to_world": T.translate([0, 0, 2.0]) @ T.scale(8.0)},
+                   "film": {"type": "hdrfilm", "width": 2, "height": 1, "rfilter": {"type": "box"}}, "sampler": {"type": "independent", "sample_count": 64}}
+    cases.append(e)
+    for sc in cases:
+        gpu, st = gpu_render(gpu_rgb, sc, collect_counters=True)
+        o = ob.OracleScene(sc); ref = o.render(); so = o.last_stats
+        assert np.array_equal(gpu, ref) and gpu[..., :3].max() > 0
+        assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
+
+
 def _uv_sphere(n_lat, n_lon, radius=1.0, center=(0, 0, 0)):
     th = np.linspace(0.0, np.pi, n_lat + 1); ph = np.linspace(0.0, 2.0 * np.pi, n_lon, endpoint=False)
     v = np.array([[np.sin(t) * np.cos(p), np.sin(t) * np.sin(p), np.cos(t)] for t in th for p in ph], dtype=np.float32) * radius + np.asarray(center, np.float32)

@@ -761,3 +761,35 @@ def test_radiancemeter_render(radiance):
     d = _with_sensor(s, emitter={"type": "constant", "radiance": {"type": "uniform", "value": radiance}})
     import tests.transport_cases as tc
     assert np.allclose(tc.radiance_rgb(ob.OracleScene(d).render(threads=1)), radiance, rtol=1e-5)
+
+
+# ---------------------------------------------------------------- disk shape
+def test_disk_hits_and_targets():
+    """src/shapes/tests/test_disk.py:37-65: rays along +z through a grid of points hit iff x^2 + y^2 <= r^2; the hit lies on the
+    disk's plane with the disk's normal.  Also: a disk as sensor target (test_mdistant.py "target_disk")."""
+    for r in (1, 3, 5):
+        for translate in ([0.0, 0.0, 0.0], [1.0, -5.0, 0.0]):
+            d = {"type": "scene", "integrator": {"type": "path"},
+                 "sensor": {"type": "perspective", "film": {"type": "hdrfilm", "width": 4, "height": 4, "rfilter": {"type": "box"}}},
+                 "foo": {"type": "disk", "to_world": T.translate(translate) @ T.scale([r, r, 1.0])}}
+            o = ob.OracleScene(d)
+            g = np.linspace(-1, 1, 10, dtype=np.float32)
+            xs = (1.1 * r * (g[:, None] - translate[0]) + 0 * g[None, :]).reshape(-1)
+            ys = (1.1 * r * (g[None, :] - translate[1]) + 0 * g[:, None]).reshape(-1)
+            orig = np.stack([xs, ys, np.full(xs.size, -10.0)], 1).astype(np.float32)
+            dirs = np.tile(np.array([0, 0, 1], np.float32), (xs.size, 1))
+            res = o.ray_intersect(orig, dirs, mint=np.zeros(xs.size, np.float32))
+            found = np.isfinite(res["t"])
+            lx, ly = (xs - translate[0]) / r, (ys - translate[1]) / r
+            expect = lx.astype(np.float32) ** 2 + ly.astype(np.float32) ** 2 <= 1
+            margin = np.abs(lx ** 2 + ly ** 2 - 1) > 1e-4
+            assert np.array_equal(found[margin], expect[margin]) and (~found).any()
+            assert found.any() == (translate[1] == 0.0)      # the reference's second grid (test_disk.py:52-53) misses the translated disk entirely
+            assert np.allclose(res["t"][found], 10) and np.allclose(res["n"][found], [0, 0, 1])
+    # surface area pi sx sy (test_disk.py:7-34) through the area-sampling pdf of an emitter on a disk
+    sensor = _mdist_sensor({"type": "disk", "to_world": T.scale(1.0)}, "0, 0, -1", 1, spp=20000)
+    d = _with_sensor(sensor, shape={"type": "rectangle", "to_world": T.scale(1.0), "bsdf": {"type": "diffuse", "reflectance": 1.0}},
+                     emitter={"type": "directional", "direction": [0, 0, -1], "irradiance": 1.0})
+    import tests.transport_cases as tc
+    rgb = tc.radiance_rgb(ob.OracleScene(d).render(threads=1)).reshape(3)
+    assert np.allclose(rgb, 1.0 / np.pi, rtol=5e-3)        # test_mdistant.py:135-296, "target_disk": every ray lands on the square
