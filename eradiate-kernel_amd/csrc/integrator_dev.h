@@ -348,8 +348,15 @@ DEV float trilerp(float d000, float d100, float d010, float d110, float d001, fl
     return pm_fma(w0.z, v0, w1.z * v1);
 }
 // textures/grid3d.cpp:220-232,259-360 ; textures/constant3d.cpp
+// The grid lookup with its wrap modes, channel counts and filters is a real function: it is off the hot paths (the metric scene
+// reads its grids through the pair-grid fast path, constant volumes return above), and inlining its ~25 copies of the repeat /
+// mirror index arithmetic into every block was costing instruction-cache space.
+DEV_NOINLINE F3 volume_eval_grid(const DVolume v, F3 p_world);
 DEV F3 volume_eval(const DVolume &v, F3 p_world) {
     if (v.type == MTS_VOLUME_CONST) return f3(v.value);
+    return volume_eval_grid(v, p_world);
+}
+DEV_NOINLINE F3 volume_eval_grid(const DVolume v, F3 p_world) {
     F3 p = v.affine ? mat_point_affine(v.w2l, p_world) : mat_point(v.w2l, p_world);    // x / 1 == x
     const MTS_GLOBAL_AS float *D = as_global(v.data); const int nx = v.nx, ny = v.ny, nz = v.nz, ch = v.channels;
     if (v.filter == MTS_FILTER_TRILINEAR) {
