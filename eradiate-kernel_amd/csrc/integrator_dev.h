@@ -137,7 +137,11 @@ DEV float triangle_intersect(const TriRec &T, const DRay &ray, F2 &uv) {
     return active ? t : pm_inf();
 }
 // shapes/sphere.cpp:272-306 in double precision (the reference's CPU path, sphere.cpp:276) + core/math.h:371-411
-DEV float sphere_intersect(const float *center, float radius, const DRay &ray) {
+// (a real function: double-precision code that only scenes with spheres execute)
+DEV_NOINLINE float sphere_intersect_v(float cx, float cy, float cz, float radius, const DRay ray);
+DEV float sphere_intersect(const float *center, float radius, const DRay &ray) { return sphere_intersect_v(center[0], center[1], center[2], radius, ray); }
+DEV_NOINLINE float sphere_intersect_v(float cx, float cy, float cz, float radius, const DRay ray) {
+    const float center[3] = { cx, cy, cz };
     double mint = ray.mint, maxt = ray.maxt;
     double ox = (double) ray.o.x - (double) center[0], oy = (double) ray.o.y - (double) center[1], oz = (double) ray.o.z - (double) center[2];
     double dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
