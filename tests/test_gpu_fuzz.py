@@ -1,0 +1,113 @@
+"""Differential fuzzing of the HIP path against the oracle: random scenes assembled from every supported plugin (shapes, BSDFs,
+media, phase functions, emitters, sensors, integrators), small films, bit-for-bit comparison of film and loop counters."""
+import importlib
+
+import numpy as np
+import pytest
+
+import tests.oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+T = importlib.import_module("eradiate-kernel_amd.transform").ScalarTransform4f
+scenes = importlib.import_module("eradiate-kernel_amd.scenes")
+
+
+def _bsdf(rng):
+    k = rng.integers(0, 4)
+    if k == 0:
+        return {"type": "diffuse", "reflectance": {"type": "rgb", "value": rng.uniform(0.05, 0.95, 3).tolist()}}
+    if k == 1:
+        return {"type": "bilambertian", "reflectance": float(rng.uniform(0, 0.6)), "transmittance": float(rng.uniform(0, 0.4))}
+    if k == 2:
+        return {"type": "rpv", "rho_0": float(rng.uniform(0.05, 0.3)), "k": float(rng.uniform(0.4, 0.9)), "g": float(rng.uniform(-0.3, 0.1))}
+    return {"type": "diffuse", "reflectance": float(rng.uniform(0.1, 0.9))}
+
+
+def _phase(rng):
+    k = rng.integers(0, 5)
+    if k == 0: return {"type": "isotropic"}
+    if k == 1: return {"type": "hg", "g": float(rng.uniform(-0.8, 0.9))}
+    if k == 2: return {"type": "rayleigh"}
+    if k == 3: return {"type": "tabphase", "values": scenes.hg_table(float(rng.uniform(0.1, 0.8)), 61)}
+    return {"type": "blendphase", "phase_0": {"type": "rayleigh"}, "phase_1": {"type": "hg", "g": 0.6}, "weight": float(rng.uniform(0.1, 0.9))}
+
+
+def _medium(rng):
+    if rng.random() < 0.5:
+        chroma = rng.random() < 0.4
+        st = rng.uniform(0.2, 2.0, 3) if chroma else np.full(3, rng.uniform(0.2, 2.0))
+        return {"type": "homogeneous", "sigma_t": {"type": "rgb", "value": st.tolist()}, "albedo": float(rng.uniform(0.3, 0.95)), "phase": _phase(rng)}
+    res = int(rng.choice([4, 8, 12]))
+    grid_xf = T.translate([-3, -3, 0]) @ T.scale([6, 6, 2])
+    sig = rng.uniform(0.1, 2.5, (res, res, res)).astype(np.float32)
+    alb = rng.uniform(0.3, 0.95, (res, res, res)).astype(np.float32) if rng.random() < 0.7 else np.full((res, res, res), 0.8, np.float32)
+    m = {"type": "heterogeneous", "sigma_t": {"type": "gridvolume", "data": sig, "to_world": grid_xf},
+         "albedo": {"type": "gridvolume", "data": alb, "to_world": grid_xf}, "phase": _phase(rng), "scale": float(rng.uniform(0.5, 1.5))}
+    if rng.random() < 0.3:
+        m["sigma_t"]["filter_type"] = "nearest"; m["albedo"]["filter_type"] = "nearest"
+    return m
+
+
+def _scene(seed):
+    rng = np.random.default_rng(seed)
+    integrator = str(rng.choice(["volpath", "volpath", "volpathmis", "path"]))
+    d = {"type": "scene", "integrator": {"type": integrator, "max_depth": int(rng.choice([-1, 3, 8])), "rr_depth": int(rng.choice([2, 5])), "block_size": 32}}
+    if integrator == "volpathmis":
+        d["integrator"]["use_spectral_mis"] = bool(rng.random() < 0.6)
+    w, h, spp = int(rng.integers(5, 40)), int(rng.integers(4, 36)), int(rng.choice([2, 4, 6]))
+    film = {"type": "hdrfilm", "width": w, "height": h, "rfilter": {"type": "box"} if rng.random() < 0.8 else {"type": "gaussian"}}
+    st = rng.integers(0, 4)
+    if st == 0:
+        d["sensor"] = {"type": "perspective", "to_world": T.look_at([rng.uniform(-1, 1), -9, rng.uniform(3, 7)], [0, 0, 1], [0, 0, 1]), "fov": 45, "film": film}
+    elif st == 1:
+        d["sensor"] = {"type": "distant", "direction": [0.2, -0.1, -1], "film": film}
+        if rng.random() < 0.5: d["sensor"]["ray_target"] = {"type": "rectangle", "to_world": T.translate([0, 0, 2.1]) @ T.scale(3.0)}
+    elif st == 2:
+        n = int(rng.integers(2, 6)); film["width"], film["height"] = n, 1
+        dirs = ", ".join("%g, %g, -1" % (rng.uniform(-.5, .5), rng.uniform(-.5, .5)) for _ in range(n))
+        d["sensor"] = {"type": "mdistant", "directions": dirs, "film": film, "target": [0.0, 0.0, 1.0]}
+    else:
+        film["width"], film["height"] = 6, 5
+        d["sensor"] = {"type": "distantflux", "film": film, "target": {"type": "disk", "to_world": T.translate([0, 0, 2.1]) @ T.scale(2.5)}}
+    d["sensor"]["sampler"] = {"type": "independent", "sample_count": spp, "seed": int(rng.integers(0, 1000))}
+    d["ground"] = {"type": "rectangle", "to_world": T.translate([0, 0, -0.01]) @ T.scale(8.0), "bsdf": _bsdf(rng)}
+    if integrator != "path":
+        d["slab"] = {"type": "cube", "to_world": T.translate([0, 0, 1]) @ T.scale([3, 3, 1]), "bsdf": {"type": "null"}, "interior": _medium(rng)}
+    for k in range(int(rng.integers(0, 9))):
+        c = rng.uniform([-2.5, -2.5, 2.2], [2.5, 2.5, 4.5])
+        xf = T.translate(c) @ T.rotate(rng.normal(size=3), float(rng.uniform(0, 180))) @ T.scale(rng.uniform(0.2, 0.7, 3))
+        kind = str(rng.choice(["rectangle", "disk", "cube", "sphere"]))
+        shape = {"type": kind, "bsdf": _bsdf(rng)}
+        if kind == "sphere":
+            shape.update(center=c.tolist(), radius=float(rng.uniform(0.2, 0.6)))
+        else:
+            shape["to_world"] = xf
+        d["obj%d" % k] = shape
+    et = rng.integers(0, 3)
+    if et == 0:
+        d["sun"] = {"type": "directional", "direction": [float(rng.uniform(-.5, .5)), float(rng.uniform(-.5, .5)), -1.0], "irradiance": 2.0}
+    elif et == 1:
+        d["sky"] = {"type": "constant", "radiance": 0.7}
+        d["sun"] = {"type": "directional", "direction": [0.1, 0.3, -1.0], "irradiance": 1.0}
+    else:
+        d["lamp"] = {"type": str(rng.choice(["rectangle", "disk"])), "to_world": T.translate([0.5, 0, 6]) @ T.rotate([1, 0, 0], 180) @ T.scale(1.5),
+                     "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [4.0, 3.5, 3.0]}}}
+    return d
+
+
+@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("bvh", [False, True])
+def test_random_scene(gpu_rgb, monkeypatch, seed, bvh):
+    if bvh:
+        monkeypatch.setenv("MTSAMD_BVH_THRESHOLD", "0")
+    d = _scene(seed)
+    scene = gpu_rgb.load_dict(d)
+    sensor = scene.sensors()[0]
+    assert scene.integrator().render(scene, sensor, collect_counters=True)
+    gpu = np.array(sensor.film().bitmap(raw=True)); st = scene.integrator().last_stats
+    o = ob.OracleScene(d); ref = o.render(); so = o.last_stats
+    if d["sensor"]["film"]["rfilter"]["type"] == "gaussian":          # neighbouring pixels are reached by atomics in arbitrary order
+        assert np.allclose(gpu, ref, rtol=2e-4, atol=1e-6)
+    else:
+        assert np.array_equal(gpu, ref), (seed, float(np.abs(gpu - ref).max()))
+    assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
