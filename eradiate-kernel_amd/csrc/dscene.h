@@ -8,6 +8,9 @@
 
 namespace mtsamd {
 
+#define MTS_BVH_TOP_DEPTH 8           // levels 0..8 (at most 511 nodes, 16 KB) are laid out breadth-first and staged in LDS
+#define MTS_BVH_LDS_NODES 511
+
 struct DXf { float m[16]; float it[16]; };            // Transform4f: matrix + inverse transpose (transform.h:36-50)
 
 struct DBBox { float min[3], max[3]; };
@@ -119,13 +122,15 @@ struct DScene {
     const float *positions, *normals, *texcoords;   // world-space mesh data of all meshes
     const uint32_t *faces;
     const float *tri;                               // per primitive (prim order): p0, e1 = p1 - p0, e2 = p2 - p0 (triangles only)
-    // Bounding-volume hierarchy over the primitives, built by the host for scenes with many primitives (NULL otherwise:
-    // the primitive list is walked).  Nodes in depth-first order, 32 bytes each: bmin[3], bmax[3] (conservatively
-    // enlarged), skip = index of the next node when this subtree is missed or done, leaf = (first << 3 | count) into
-    // bvh_prims (0 for inner nodes, whose first child is the next node).  Stack-free traversal.
+    // Bounding-volume hierarchy over the primitives, built by the host for scenes with many primitives (NULL otherwise: the
+    // primitive list is walked).  32-byte nodes: bmin[3], bmax[3] (conservatively enlarged), skip = the node to visit when this
+    // subtree is missed or done, link = (first << 3 | count) into bvh_prims for a leaf, minus the index of the left child for an
+    // inner node (the right child is left.skip).  The top MTS_BVH_TOP_DEPTH levels come first, in breadth-first order: the
+    // per-lane kernels stage them in LDS (bvh_lds / bvh_lds_count, set by the kernel on its copy of this record).
     const float *bvh_nodes;
     const int32_t *bvh_prims;                       // leaf contents: primitive indices (prim order decides ties, kdtree.h:2152-2154)
     int32_t bvh_node_count;
+    const float *bvh_lds; int32_t bvh_lds_count;
     int32_t volume_count, phase_count, medium_count, bsdf_count, shape_count, prim_count, emitter_count;
     int32_t environment;
     DBBox bbox;

@@ -172,7 +172,8 @@ DEV_NOINLINE float sphere_intersect_v(float cx, float cy, float cz, float radius
 // primitives of the atmosphere scenes the "acceleration structure" is the primitive list itself,
 // walked with wave-uniform (scalar) loads -- no per-lane memory traffic at all.
 // One primitive addressed per lane (BVH leaves): the same tests as the scalar walk, records fetched with vector loads.
-struct BvhArgs { const float *nodes; const int32_t *leaf_prims; int32_t node_count; const DPrim *prims; const DShape *shapes; const float *tri; };
+struct BvhArgs { const float *nodes; const int32_t *leaf_prims; int32_t node_count; const DPrim *prims; const DShape *shapes; const float *tri;
+                 const float *lds_nodes; int32_t lds_count; };
 DEV float prim_intersect_lane(const BvhArgs &a, int pi, const DRay &ray, F2 &uv, int &shape, int &index) {
     const MTS_GLOBAL_AS int32_t *pr = (const MTS_GLOBAL_AS int32_t *) as_global(a.prims + pi);
     shape = pr[0]; index = pr[1];
@@ -199,7 +200,9 @@ DEV_NOINLINE Hit bvh_intersect(const BvhArgs a, DRay ray) {
     const int n = a.node_count;
     int i = 0;
     while (i < n) {
-        const MTS_GLOBAL_AS float *nd = nodes + 8 * i;
+        float nd[8];                                          // the top levels come from LDS when the kernel staged them
+        if (i < a.lds_count) { for (int k = 0; k < 8; ++k) nd[k] = a.lds_nodes[8 * i + k]; }
+        else { for (int k = 0; k < 8; ++k) nd[k] = nodes[8 * i + k]; }
         const float t1x = (nd[0] - ray.o.x) * ray.d_rcp.x, t2x = (nd[3] - ray.o.x) * ray.d_rcp.x;
         const float t1y = (nd[1] - ray.o.y) * ray.d_rcp.y, t2y = (nd[4] - ray.o.y) * ray.d_rcp.y;
         const float t1z = (nd[2] - ray.o.z) * ray.d_rcp.z, t2z = (nd[5] - ray.o.z) * ray.d_rcp.z;
@@ -207,9 +210,10 @@ DEV_NOINLINE Hit bvh_intersect(const BvhArgs a, DRay ray) {
         // then simply does not constrain the interval, which keeps the test conservative
         const float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)), __builtin_fminf(t1z, t2z));
         const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)), __builtin_fmaxf(t1z, t2z));
-        const int skip = __float_as_int(nd[6]), leaf = __float_as_int(nd[7]);
+        const int skip = __float_as_int(nd[6]), link = __float_as_int(nd[7]);
         if (!(tnear <= tfar && tfar >= ray.mint && tnear <= ray.maxt)) { i = skip; continue; }
-        const int count = leaf & 7, first = leaf >> 3;
+        if (link < 0) { i = -link; continue; }                // inner node: descend into the left child
+        const int count = link & 7, first = link >> 3;
         for (int k = 0; k < count; ++k) {
             const int pi = leaf_prims[first + k];
             F2 uv; int shape, index;
@@ -220,7 +224,7 @@ DEV_NOINLINE Hit bvh_intersect(const BvhArgs a, DRay ray) {
                 ray.maxt = t;
             }
         }
-        i = i + 1;
+        i = skip;
     }
     return h;
 }
@@ -233,7 +237,7 @@ DEV Hit ray_intersect_preliminary(const DScene &sc, DRay ray) {
     float mint = pm_max(ray.mint, bmint), maxt = pm_min(ray.maxt, bmaxt);
     if (!(mint <= maxt)) return h;
     if (sc.bvh_node_count > 0) {
-        BvhArgs a; a.nodes = sc.bvh_nodes; a.leaf_prims = sc.bvh_prims; a.node_count = sc.bvh_node_count; a.prims = sc.prims; a.shapes = sc.shapes; a.tri = sc.tri;
+        BvhArgs a; a.nodes = sc.bvh_nodes; a.leaf_prims = sc.bvh_prims; a.node_count = sc.bvh_node_count; a.prims = sc.prims; a.shapes = sc.shapes; a.tri = sc.tri; a.lds_nodes = sc.bvh_lds; a.lds_count = sc.bvh_lds_count;
         return bvh_intersect<ShadowRay>(a, ray);
     }
     for (int i = 0; i < sc.prim_count; ++i) {

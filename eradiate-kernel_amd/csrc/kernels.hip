@@ -43,6 +43,18 @@ __device__ __forceinline__ void render_sample(const DScene &sc, Pcg32 &rng, cons
 template <bool COUNT, bool FLAT>
 __global__ void __launch_bounds__(256) render_kernel(DScene sc, const DBlock *__restrict__ blocks, uint32_t n_blocks, uint32_t block_size,
                                                      uint32_t sample_count, float *__restrict__ film, unsigned long long *__restrict__ counters) {
+    // LDS-staged BVH top: the breadth-first top levels of the host-built BVH (dscene.h), shared by the workgroup's traversals
+    __shared__ float bvh_top[MTS_BVH_LDS_NODES * 8];
+    {
+#if defined(EXP_NO_BVH_LDS)
+        const int staged = 0;                                 // measurement only
+#else
+        const int staged = min(sc.bvh_node_count, MTS_BVH_LDS_NODES);
+#endif
+        for (int k = (int) threadIdx.x; k < staged * 8; k += (int) blockDim.x) bvh_top[k] = sc.bvh_nodes[k];
+        __syncthreads();
+        sc.bvh_lds = bvh_top; sc.bvh_lds_count = staged;
+    }
     const uint32_t ppb = block_size * block_size;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t b = gid / ppb, i = gid - b * ppb;

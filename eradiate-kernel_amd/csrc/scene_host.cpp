@@ -447,43 +447,70 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
 // over the primitive list bit for bit (which is what the CPU restatement does).
 namespace {
 struct PrimBox { float lo[3], hi[3], c[3]; int32_t prim; };
+struct TmpNode { float lo[3], hi[3]; int left = -1, right = -1, first = 0, count = 0, depth = 0, final_index = -1; };
 struct BvhBuilder {
-    std::vector<PrimBox> &pb; std::vector<float> &nodes; std::vector<int32_t> &prims; float margin;
-    int build(int begin, int end) {
-        const int node = (int) nodes.size() / 8;
-        nodes.resize(nodes.size() + 8);
+    std::vector<PrimBox> &pb; std::vector<TmpNode> &tmp; std::vector<int32_t> &prims;
+    int build(int begin, int end, int depth) {
+        const int node = (int) tmp.size();
+        tmp.emplace_back();
         float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY }, clo[3], chi[3];
         for (int a = 0; a < 3; ++a) { clo[a] = INFINITY; chi[a] = -INFINITY; }
         for (int i = begin; i < end; ++i) for (int a = 0; a < 3; ++a) {
             lo[a] = std::min(lo[a], pb[i].lo[a]); hi[a] = std::max(hi[a], pb[i].hi[a]);
             clo[a] = std::min(clo[a], pb[i].c[a]); chi[a] = std::max(chi[a], pb[i].c[a]);
         }
-        int32_t leaf = 0;
         const int count = end - begin;
         int axis = 0;
         for (int a = 1; a < 3; ++a) if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
-        if (count <= 4 || !(chi[axis] > clo[axis])) {
-            if (count > 7) {                                                // coincident centroids: split by index
-                const int mid = begin + count / 2;
-                build(begin, mid); build(mid, end);
-            } else {
-                leaf = (int32_t) ((prims.size() << 3) | (size_t) count);
-                for (int i = begin; i < end; ++i) prims.push_back(pb[i].prim);
-            }
+        int left = -1, right = -1, first = 0, leaf_count = 0;
+        const bool splittable = chi[axis] > clo[axis];
+        if (count <= 4 || (!splittable && count <= 7)) {
+            first = (int) prims.size(); leaf_count = count;
+            for (int i = begin; i < end; ++i) prims.push_back(pb[i].prim);
         } else {
             const int mid = begin + count / 2;
-            std::nth_element(pb.begin() + begin, pb.begin() + mid, pb.begin() + end,
-                             [axis](const PrimBox &x, const PrimBox &y) { return x.c[axis] < y.c[axis]; });
-            build(begin, mid); build(mid, end);
+            if (splittable)
+                std::nth_element(pb.begin() + begin, pb.begin() + mid, pb.begin() + end,
+                                 [axis](const PrimBox &x, const PrimBox &y) { return x.c[axis] < y.c[axis]; });
+            left = build(begin, mid, depth + 1); right = build(mid, end, depth + 1);       // coincident centroids: split by index
         }
-        float *n = &nodes[8 * (size_t) node];
-        for (int a = 0; a < 3; ++a) {
-            n[a] = lo[a] - margin - 1e-6f * std::fabs(lo[a]);
-            n[3 + a] = hi[a] + margin + 1e-6f * std::fabs(hi[a]);
-        }
-        const int32_t skip = (int32_t) (nodes.size() / 8);
-        memcpy(&n[6], &skip, 4); memcpy(&n[7], &leaf, 4);
+        TmpNode &n = tmp[(size_t) node];
+        for (int a = 0; a < 3; ++a) { n.lo[a] = lo[a]; n.hi[a] = hi[a]; }
+        n.left = left; n.right = right; n.first = first; n.count = leaf_count; n.depth = depth;
         return node;
+    }
+};
+// Final layout: the top levels in breadth-first order (they are what the kernels stage in LDS), every subtree below them in
+// depth-first order.  A node stores `skip` (where to go when its subtree is missed or done) and `link`: for a leaf
+// (first << 3 | count) into bvh_prims, for an inner node minus the index of its left child; the right child is left.skip.
+struct BvhLayout {
+    std::vector<TmpNode> &tmp; int next = 0;
+    void dfs(int n) { tmp[(size_t) n].final_index = next++; if (tmp[(size_t) n].left >= 0) { dfs(tmp[(size_t) n].left); dfs(tmp[(size_t) n].right); } }
+    void assign(int root, int top_depth) {
+        std::vector<int> level{ root }, below;
+        while (!level.empty()) {
+            std::vector<int> nxt;
+            for (int n : level) {
+                tmp[(size_t) n].final_index = next++;
+                if (tmp[(size_t) n].left < 0) continue;
+                if (tmp[(size_t) n].depth < top_depth) { nxt.push_back(tmp[(size_t) n].left); nxt.push_back(tmp[(size_t) n].right); }
+                else { below.push_back(tmp[(size_t) n].left); below.push_back(tmp[(size_t) n].right); }
+            }
+            level.swap(nxt);
+        }
+        for (int n : below) dfs(n);
+    }
+    void emit(int n, int skip, float margin, std::vector<float> &out) {
+        const TmpNode &t = tmp[(size_t) n];
+        float *o = &out[8 * (size_t) t.final_index];
+        for (int a = 0; a < 3; ++a) {
+            o[a] = t.lo[a] - margin - 1e-6f * std::fabs(t.lo[a]);
+            o[3 + a] = t.hi[a] + margin + 1e-6f * std::fabs(t.hi[a]);
+        }
+        const int32_t sk = skip;
+        const int32_t link = t.left < 0 ? (int32_t) (((uint32_t) t.first << 3) | (uint32_t) t.count) : -(int32_t) tmp[(size_t) t.left].final_index;
+        memcpy(&o[6], &sk, 4); memcpy(&o[7], &link, 4);
+        if (t.left >= 0) { emit(t.left, tmp[(size_t) t.right].final_index, margin, out); emit(t.right, skip, margin, out); }
     }
 };
 }
@@ -513,8 +540,13 @@ void build_bvh(HostScene &hs) {
         pb[(size_t) i] = b;
     }
     const F3 diag = f3(hs.scene.bbox.max) - f3(hs.scene.bbox.min);
-    BvhBuilder bb{ pb, hs.bvh_nodes, hs.bvh_prims, 1e-5f * norm(diag) + 1e-7f };
-    bb.build(0, n);
+    std::vector<TmpNode> tmp;
+    BvhBuilder bb{ pb, tmp, hs.bvh_prims };
+    const int root = bb.build(0, n, 0);
+    BvhLayout layout{ tmp };
+    layout.assign(root, MTS_BVH_TOP_DEPTH);
+    hs.bvh_nodes.assign(8 * tmp.size(), 0.f);
+    layout.emit(root, (int) tmp.size(), 1e-5f * norm(diag) + 1e-7f, hs.bvh_nodes);
 }
 
 // ---------------------------------------------------------------- upload
@@ -546,6 +578,7 @@ void upload_host_scene(HostScene &hs, int device) {
     sc.faces = upload(hs, hs.faces);
     sc.tri = upload(hs, hs.tri);
     sc.bvh_nodes = nullptr; sc.bvh_prims = nullptr; sc.bvh_node_count = (int32_t) (hs.bvh_nodes.size() / 8);
+    sc.bvh_lds = nullptr; sc.bvh_lds_count = 0;
     if (sc.bvh_node_count > 0) { sc.bvh_nodes = upload(hs, hs.bvh_nodes); sc.bvh_prims = upload(hs, hs.bvh_prims); }
     sc.sensor.rfilter.values = upload(hs, hs.rfilter_values);
     sc.sensor.multi = upload(hs, hs.multi_transforms);
