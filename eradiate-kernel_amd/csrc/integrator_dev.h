@@ -172,19 +172,24 @@ DEV_NOINLINE float sphere_intersect_v(float cx, float cy, float cz, float radius
 // primitives of the atmosphere scenes the "acceleration structure" is the primitive list itself,
 // walked with wave-uniform (scalar) loads -- no per-lane memory traffic at all.
 // One primitive addressed per lane (BVH leaves): the same tests as the scalar walk, records fetched with vector loads.
-struct BvhArgs { const float *nodes; const int32_t *leaf_prims; int32_t node_count; const DPrim *prims; const DShape *shapes; const float *tri;
+struct BvhArgs { const float *nodes; const int32_t *leaf_prims; int32_t node_count; const DWalkPrim *walk;
                  const float *lds_nodes; int32_t lds_count; };
+// One primitive addressed per lane (BVH leaves): the same tests as the scalar walk on the same 64-byte record, fetched with
+// four 16-byte vector loads (no prim -> shape -> geometry chain of dependent loads).
 DEV float prim_intersect_lane(const BvhArgs &a, int pi, const DRay &ray, F2 &uv, int &shape, int &index) {
-    const MTS_GLOBAL_AS int32_t *pr = (const MTS_GLOBAL_AS int32_t *) as_global(a.prims + pi);
-    shape = pr[0]; index = pr[1];
-    const DShape &s = a.shapes[shape];
+    typedef int mts_int4 __attribute__((ext_vector_type(4)));
+    const MTS_GLOBAL_AS mts_int4 *rec = (const MTS_GLOBAL_AS mts_int4 *) as_global(a.walk + pi);
+    const mts_int4 hd = rec[0], g0 = rec[1], g1 = rec[2], g2 = rec[3];
+    shape = hd.y; index = hd.z;
+    float f[12] = { __int_as_float(g0.x), __int_as_float(g0.y), __int_as_float(g0.z), __int_as_float(g0.w),
+                    __int_as_float(g1.x), __int_as_float(g1.y), __int_as_float(g1.z), __int_as_float(g1.w),
+                    __int_as_float(g2.x), __int_as_float(g2.y), __int_as_float(g2.z), __int_as_float(g2.w) };
     uv.x = uv.y = 0.f;
-    if (s.type == MTS_SHAPE_RECTANGLE) return rectangle_intersect(s.to_object.m, ray, uv);
-    if (s.type == MTS_SHAPE_DISK) return disk_intersect(s.to_object.m, ray, uv);
-    if (s.type == MTS_SHAPE_SPHERE) return sphere_intersect(s.center, s.radius, ray);
-    const MTS_GLOBAL_AS float *t = as_global(a.tri) + 9 * pi;
+    if (hd.x == MTS_SHAPE_RECTANGLE) return rectangle_intersect(f, ray, uv);
+    if (hd.x == MTS_SHAPE_DISK) return disk_intersect(f, ray, uv);
+    if (hd.x == MTS_SHAPE_SPHERE) return sphere_intersect(f, f[3], ray);
     TriRec T;
-    for (int k = 0; k < 9; ++k) T.v[k] = t[k];
+    for (int k = 0; k < 9; ++k) T.v[k] = f[k];
     return triangle_intersect(T, ray, uv);
 }
 // Stack-free traversal of the host-built BVH (dscene.h).  Node boxes are conservative, the exact primitive tests decide;
@@ -237,7 +242,7 @@ DEV Hit ray_intersect_preliminary(const DScene &sc, DRay ray) {
     float mint = pm_max(ray.mint, bmint), maxt = pm_min(ray.maxt, bmaxt);
     if (!(mint <= maxt)) return h;
     if (sc.bvh_node_count > 0) {
-        BvhArgs a; a.nodes = sc.bvh_nodes; a.leaf_prims = sc.bvh_prims; a.node_count = sc.bvh_node_count; a.prims = sc.prims; a.shapes = sc.shapes; a.tri = sc.tri; a.lds_nodes = sc.bvh_lds; a.lds_count = sc.bvh_lds_count;
+        BvhArgs a; a.nodes = sc.bvh_nodes; a.leaf_prims = sc.bvh_prims; a.node_count = sc.bvh_node_count; a.walk = sc.walk; a.lds_nodes = sc.bvh_lds; a.lds_count = sc.bvh_lds_count;
         return bvh_intersect<ShadowRay>(a, ray);
     }
     for (int i = 0; i < sc.prim_count; ++i) {
