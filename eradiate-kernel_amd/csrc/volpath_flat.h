@@ -818,8 +818,8 @@ static __device__ WG_BLOCK_ATTR int wg_block(const MTS_CONST_AS void *kernarg_, 
 // (compare-and-swap on its head), runs that block with every claimed lane active, and appends each path to
 // the ring of the class it waits for next (wave-aggregated atomic add on the tail).  Waves never wait for
 // each other; a wave that finds every ring empty naps briefly.  A ring slot holds 0xFFFF until its producer has written the id, so a consumer that claimed
-// the slot early spins for the few cycles the write takes.  There are WG paths and WG slots per ring, and a
-// path sits in at most one ring, so a slot is never overwritten before it has been consumed.
+// the slot early spins for the few cycles the write takes, and a producer whose slot still holds an unread id of the previous lap
+// waits for its consumer: a live id is never overwritten (there are WG paths and WG slots per ring, so neither wait can last).
 // q_ht[2c] / q_ht[2c + 1]: head / tail of ring c (monotonic counters, slot = counter mod WG); "ring" B_DONE has no slots, its
 // tail counts the finished paths.  One LDS atomic per push: lane c adds the number of paths this wave appends to ring c.
 template <int WG>
@@ -835,7 +835,13 @@ DEV void wga_push(int cls, uint32_t pid, bool valid, uint16_t (*q_ids)[WG], uint
     uint32_t base = 0;
     if (lane < (uint32_t) B_COUNT && my_count != 0u) base = atomicAdd(&q_ht[2 * lane + 1], my_count);
     const uint32_t my_base = (uint32_t) __builtin_amdgcn_ds_bpermute(cls << 2, (int) base);     // the base lane `cls` obtained
-    if (valid && cls != B_DONE) q_ids[cls][(my_base + my_rank) & (uint32_t) (WG - 1)] = (uint16_t) pid;
+    if (valid && cls != B_DONE) {
+        uint16_t *slot = &q_ids[cls][(my_base + my_rank) & (uint32_t) (WG - 1)];
+        // The slot may still hold an id of the previous lap that its consumer has claimed but not read yet (the consumer resets
+        // it to 0xFFFF right after reading): wait for that, never overwrite a live id.
+        while (__atomic_load_n(slot, __ATOMIC_RELAXED) != 0xFFFFu) { }
+        __atomic_store_n(slot, (uint16_t) pid, __ATOMIC_RELAXED);
+    }
 }
 
 template <bool COUNT, int WG /* paths */, int NT /* threads: fewer threads than paths keeps the rings fuller */>
