@@ -75,6 +75,7 @@ struct DShape {
     int32_t has_normals, has_texcoords;
     int32_t is_medium_transition;
     int32_t bsdf_type; uint32_t bsdf_flags;       // copies of bsdfs[bsdf].type / .flags: spares the surface blocks a dependent record load
+    int32_t prim_offset;                          // index of this shape's first primitive in prim order (DScene::tri_attr)
 };
 
 struct DPrim { int32_t shape, index; };
@@ -122,6 +123,8 @@ struct DScene {
     const float *positions, *normals, *texcoords;   // world-space mesh data of all meshes
     const uint32_t *faces;
     const float *tri;                               // per primitive (prim order): p0, e1 = p1 - p0, e2 = p2 - p0 (triangles only)
+    const float *tri_attr;                          // per primitive, 24 floats: p0 p1 p2, n0 n1 n2, uv0 uv1 uv2 of a triangle -- what hit_point()
+                                                    // and complete_surface() need, in one place instead of behind the face indices
     // Bounding-volume hierarchy over the primitives, built by the host for scenes with many primitives (NULL otherwise: the
     // primitive list is walked).  32-byte nodes: bmin[3], bmax[3] (conservatively enlarged), skip = the node to visit when this
     // subtree is missed or done, link = (first << 3 | count) into bvh_prims for a leaf, minus the index of the left child for an

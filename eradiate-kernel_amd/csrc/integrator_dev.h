@@ -272,9 +272,8 @@ DEV void hit_point(const DScene &sc, const DShape &s, const DRay &ray, Hit &h) {
         h.p = fmadd(n, s.radius, f3(s.center));
         h.uv.x = n.x; h.uv.y = n.y; h.prim = (int32_t) pm_bits(n.z);     // keep the exact normal for complete_surface()
     } else {
-        const MTS_GLOBAL_AS uint32_t *fi = as_global(sc.faces) + 3 * (s.face_offset + h.prim);
-        const MTS_GLOBAL_AS float *P = as_global(sc.positions) + 3 * s.vertex_offset;
-        F3 p0 = f3(P + 3 * fi[0]), p1 = f3(P + 3 * fi[1]), p2 = f3(P + 3 * fi[2]);
+        const MTS_GLOBAL_AS float *A = as_global(sc.tri_attr) + 24 * (s.prim_offset + h.prim);
+        F3 p0 = f3(A), p1 = f3(A + 3), p2 = f3(A + 6);
         float b1 = h.uv.x, b2 = h.uv.y, b0 = 1.f - b1 - b2;
         h.p = p0 * b0 + p1 * b1 + p2 * b2;
     }
@@ -311,24 +310,21 @@ DEV void complete_surface(const DScene &sc, const DShape &s, const Hit &h, F3 d,
         if (s.flip_normals) shn = -shn;
         sf.n = shn;
     } else {
-        const MTS_GLOBAL_AS uint32_t *fi = as_global(sc.faces) + 3 * (s.face_offset + h.prim);
-        const MTS_GLOBAL_AS float *P = as_global(sc.positions) + 3 * s.vertex_offset;
-        F3 p0 = f3(P + 3 * fi[0]), p1 = f3(P + 3 * fi[1]), p2 = f3(P + 3 * fi[2]);
+        const MTS_GLOBAL_AS float *A = as_global(sc.tri_attr) + 24 * (s.prim_offset + h.prim);
+        F3 p0 = f3(A), p1 = f3(A + 3), p2 = f3(A + 6);
         float b1 = h.uv.x, b2 = h.uv.y, b0 = 1.f - b1 - b2;
         F3 dp0 = p1 - p0, dp1 = p2 - p0;
         sf.n = normalize(cross(dp0, dp1));
         coordinate_system(sf.n, dp_du, dp_dv);
         if (s.has_texcoords) {
-            const MTS_GLOBAL_AS float *T = as_global(sc.texcoords) + 2 * s.vertex_offset;
-            float u0x = T[2 * fi[0]], u0y = T[2 * fi[0] + 1], u1x = T[2 * fi[1]], u1y = T[2 * fi[1] + 1], u2x = T[2 * fi[2]], u2y = T[2 * fi[2] + 1];
+            float u0x = A[18], u0y = A[19], u1x = A[20], u1y = A[21], u2x = A[22], u2y = A[23];
             float d0x = u1x - u0x, d0y = u1y - u0y, d1x = u2x - u0x, d1y = u2y - u0y;
             float det = pm_fma(d0x, d1y, -(d0y * d1x)), inv_det = pm_rcp(det);
             if (det != 0.f)
                 dp_du = f3(pm_fma(d1y, dp0.x, -(d0y * dp1.x)), pm_fma(d1y, dp0.y, -(d0y * dp1.y)), pm_fma(d1y, dp0.z, -(d0y * dp1.z))) * inv_det;
         }
         if (s.has_normals) {
-            const MTS_GLOBAL_AS float *N = as_global(sc.normals) + 3 * s.vertex_offset;
-            F3 n0 = f3(N + 3 * fi[0]), n1 = f3(N + 3 * fi[1]), n2 = f3(N + 3 * fi[2]);
+            F3 n0 = f3(A + 9), n1 = f3(A + 12), n2 = f3(A + 15);
             shn = normalize(n0 * b0 + n1 * b1 + n2 * b2);
         } else shn = sf.n;
     }

@@ -319,6 +319,7 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
         DShape ds = build_shape(s, hs, sb, prim_count);
         if (ds.bsdf < 0) ds.bsdf = ds.emitter >= 0 ? default_emitter_bsdf : default_bsdf;
         ds.bsdf_type = hs.bsdfs[(size_t) ds.bsdf].type; ds.bsdf_flags = hs.bsdfs[(size_t) ds.bsdf].flags;
+        ds.prim_offset = (int32_t) hs.prims.size();
         hs.shapes.push_back(ds);
         bbox_expand(sc.bbox, sb);
         for (int k = 0; k < prim_count; ++k) {
@@ -331,6 +332,16 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
                 store3(rec, p0); store3(rec + 3, e1); store3(rec + 6, e2);
             }
             hs.tri.insert(hs.tri.end(), rec, rec + 9);
+            float attr[24] = { 0 };
+            if (ds.type == MTS_SHAPE_CUBE || ds.type == MTS_SHAPE_MESH) {
+                const uint32_t *fi = &hs.faces[3 * (ds.face_offset + k)];
+                for (int c = 0; c < 3; ++c) {
+                    memcpy(attr + 3 * c, &hs.positions[3 * (ds.vertex_offset + fi[c])], 12);
+                    memcpy(attr + 9 + 3 * c, &hs.normals[3 * (ds.vertex_offset + fi[c])], 12);
+                    memcpy(attr + 18 + 2 * c, &hs.texcoords[2 * (ds.vertex_offset + fi[c])], 8);
+                }
+            }
+            hs.tri_attr.insert(hs.tri_attr.end(), attr, attr + 24);
             DWalkPrim w; memset(&w, 0, sizeof(w));
             w.type = ds.type; w.shape = i; w.index = k;
             if (ds.type == MTS_SHAPE_RECTANGLE || ds.type == MTS_SHAPE_DISK) memcpy(w.f, ds.to_object.m, 48);
@@ -577,6 +588,7 @@ void upload_host_scene(HostScene &hs, int device) {
     sc.positions = upload(hs, hs.positions); sc.normals = upload(hs, hs.normals); sc.texcoords = upload(hs, hs.texcoords);
     sc.faces = upload(hs, hs.faces);
     sc.tri = upload(hs, hs.tri);
+    sc.tri_attr = upload(hs, hs.tri_attr);
     sc.bvh_nodes = nullptr; sc.bvh_prims = nullptr; sc.bvh_node_count = (int32_t) (hs.bvh_nodes.size() / 8);
     sc.bvh_lds = nullptr; sc.bvh_lds_count = 0;
     if (sc.bvh_node_count > 0) { sc.bvh_nodes = upload(hs, hs.bvh_nodes); sc.bvh_prims = upload(hs, hs.bvh_prims); }
