@@ -29,7 +29,7 @@ from . import volume_io
 
 __version__ = "0.1.0"
 ERADIATE_KERNEL = True          # src/python/__init__.py:191-193
-_VARIANTS = ["gpu_rgb"]
+_VARIANTS = ["gpu_rgb", "gpu_mono"]      # gpu_mono: the semantics of scalar_mono (one channel, luminance of every colour)
 _tls = threading.local()
 
 
@@ -128,9 +128,10 @@ class Bitmap:
 class Film:
     """hdrfilm (src/films/hdrfilm.cpp): owns the XYZAW storage the integrator writes."""
 
-    def __init__(self, sensor_rec):
+    def __init__(self, sensor_rec, mono=False):
         self._rec = sensor_rec
         self._storage = None
+        self._mono = mono            # hdrfilm.cpp:122-128: monochrome variants force the 'luminance' output format
 
     def size(self):
         return (self._rec.film_width, self._rec.film_height)
@@ -147,7 +148,7 @@ class Film:
         src = Bitmap(self._storage, PixelFormat.XYZAW)
         if raw:
             return src
-        return src.convert(PixelFormat.RGB)
+        return src.convert(PixelFormat.Y if self._mono else PixelFormat.RGB)
 
 
 class Sampler:
@@ -159,9 +160,9 @@ class Sampler:
 
 
 class Sensor:
-    def __init__(self, rec):
+    def __init__(self, rec, mono=False):
         self._rec = rec
-        self._film = Film(rec)
+        self._film = Film(rec, mono)
         self._sampler = Sampler(rec)
 
     def film(self):
@@ -247,7 +248,7 @@ class Scene:
         h = C.c_void_p()
         A.check(A.lib().mts_scene_create(C.byref(desc), device, C.byref(h)))
         self._handle = h
-        self._sensor = Sensor(desc.sensor)
+        self._sensor = Sensor(desc.sensor, bool(desc.integrator.monochrome))
         self._integrator = Integrator(self)
 
     def sensors(self):
@@ -283,7 +284,7 @@ class Scene:
 def load_dict(d, device=0):
     """mitsuba.core.xml.load_dict (src/libcore/python/xml_v.cpp:23-68,100-272)."""
     _require_variant()
-    desc, keep = build_scene_desc(d)
+    desc, keep = build_scene_desc(d, mono=(variant() == "gpu_mono"))
     return Scene(desc, keep, device)
 
 

@@ -83,7 +83,7 @@ class Sensor(C.Structure):
 
 class Integrator(C.Structure):
     _fields_ = [("type", i32), ("max_depth", i32), ("rr_depth", i32), ("hide_emitters", i32),
-                ("block_size", i32), ("samples_per_pass", i32), ("timeout", f32), ("use_spectral_mis", i32)]
+                ("block_size", i32), ("samples_per_pass", i32), ("timeout", f32), ("use_spectral_mis", i32), ("monochrome", i32)]
 
 
 class SceneDesc(C.Structure):

@@ -106,7 +106,7 @@ struct DSensor {
     int32_t multi_count;
 };
 
-struct DIntegrator { int32_t type, max_depth, rr_depth, hide_emitters, use_spectral_mis; };
+struct DIntegrator { int32_t type, max_depth, rr_depth, hide_emitters, use_spectral_mis, monochrome; };
 
 // One spiral block (librender/spiral.cpp:27-72) assigned to this launch
 struct DBlock { int32_t ox, oy, sx, sy; uint32_t id; };

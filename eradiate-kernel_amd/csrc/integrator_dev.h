@@ -940,7 +940,7 @@ DEV F3 volpath_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, bool &
     F3 throughput = f3s(1.f), result = f3s(0.f);
     bool active = true, specular_chain = !hide_emitters;
     uint32_t depth = 0;
-    uint32_t channel = (uint32_t) pm_min(rng.next_1d() * 3.f, 2.f);                          // volpath.cpp:63-67
+    uint32_t channel = sc.integrator.monochrome ? 0u : (uint32_t) pm_min(rng.next_1d() * 3.f, 2.f);   // volpath.cpp:63-67 (rgb variants only)
     Hit si; si.t = pm_inf(); si.shape = -1; si.prim = 0; si.p = f3s(0.f); si.uv.x = si.uv.y = 0.f;
     bool needs_intersection = true;
     for (;;) {
@@ -1190,7 +1190,7 @@ DEV F3 volpathmis_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, boo
     bool active = true, specular_chain = !hide_emitters;
     uint32_t depth = 0;
     MisWeights<SPEC> p_over_f = mw_full<SPEC>(1.f), p_over_f_nee = mw_full<SPEC>(1.f);
-    uint32_t channel = (uint32_t) pm_min(rng.next_1d() * 3.f, 2.f);                          // volpathmis.cpp:120-124
+    uint32_t channel = sc.integrator.monochrome ? 0u : (uint32_t) pm_min(rng.next_1d() * 3.f, 2.f);   // volpathmis.cpp:120-124
     Hit si; si.t = pm_inf(); si.shape = -1; si.prim = 0; si.p = f3s(0.f); si.uv.x = si.uv.y = 0.f;
     bool needs_intersection = true, last_event_was_null = false;
     F3 last_scatter_p = f3s(0.f);                                                             // last_scatter_event: only .p is read

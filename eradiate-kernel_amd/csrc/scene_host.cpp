@@ -444,6 +444,7 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
     if (it.max_depth < 0 && it.max_depth != -1) throw std::runtime_error("\"max_depth\" must be set to -1 (infinite) or a value >= 0");
     sc.integrator.type = it.type; sc.integrator.max_depth = it.max_depth; sc.integrator.rr_depth = it.rr_depth; sc.integrator.hide_emitters = it.hide_emitters != 0;
     sc.integrator.use_spectral_mis = it.use_spectral_mis != 0;
+    sc.integrator.monochrome = it.monochrome != 0;
     hs.integrator = it;
     sc.volume_count = (int) hs.volumes.size(); sc.phase_count = (int) hs.phases.size(); sc.medium_count = (int) hs.media.size();
     sc.bsdf_count = (int) hs.bsdfs.size(); sc.shape_count = (int) hs.shapes.size(); sc.prim_count = (int) hs.prims.size();

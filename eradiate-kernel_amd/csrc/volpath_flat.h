@@ -158,6 +158,8 @@ DEV void splat_sample_t(const DScene &sc, const DBlock &blk, uint32_t lx, uint32
     v[0] = pm_fma(0.180423f, L.z, pm_fma(0.357580f, L.y, 0.412453f * L.x));
     v[1] = pm_fma(0.072169f, L.z, pm_fma(0.715160f, L.y, 0.212671f * L.x));
     v[2] = pm_fma(0.950227f, L.z, pm_fma(0.119193f, L.y, 0.019334f * L.x));
+    if (sc.integrator.monochrome)                               // integrator.cpp:270-271: xyz = spec_u.x()
+        v[0] = v[1] = v[2] = L.x;
     v[3] = valid ? 1.f : 0.f;
     v[4] = 1.f;
     bool ok = true;                                             // imageblock.cpp:85-109: invalid samples are dropped
@@ -281,7 +283,7 @@ struct VolpathMachine {
         e.cold.f(C_POS) = position_sample.x; e.cold.f(C_POS + 1) = position_sample.y; e.cold.f(C_RAYW) = rw.x;   // grey weight
         p.medium = se.medium;
         p.thr = f3s(1.f); p.res = f3s(0.f); p.eta = 1.f; p.depth = 0;
-        p.channel = (uint32_t) pm_min(p.rng.next_1d() * 3.f, 2.f);
+        p.channel = sc.integrator.monochrome ? 0u : (uint32_t) pm_min(p.rng.next_1d() * 3.f, 2.f);     // volpath.cpp:64-67: rgb variants only
         p.si.p = f3s(0.f); p.si.uv.x = p.si.uv.y = 0.f; p.si.prim = 0;
         const bool hide_emitters = sc.integrator.hide_emitters != 0;
         p.flags = FL_ALIVE | ((!hide_emitters && sc.environment >= 0) ? FL_VALID_RAY : 0u) | (!hide_emitters ? FL_SPEC_CHAIN : 0u);

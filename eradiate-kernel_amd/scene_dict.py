@@ -75,8 +75,20 @@ def _xf(t):
     return r
 
 
+_MONO = False      # set by build_scene_desc(mono=True): colours become their luminance (src/spectra/srgb.cpp in *_mono variants)
+
+
 def _color(v, where, default=None):
     """float | [r,g,b] | {"type":"rgb","value":..} | {"type":"spectrum"/"uniform","value":x} -> (r,g,b)."""
+    c = _color_rgb(v, where, default)
+    if _MONO and not (c[0] == c[1] == c[2]):
+        f = np.float32
+        lum = float(f(f(f(c[0]) * f(0.212671) + f(c[1]) * f(0.715160)) + f(c[2]) * f(0.072169)))      # spectrum.h:246-248
+        return (lum, lum, lum)
+    return c
+
+
+def _color_rgb(v, where, default=None):
     if v is None:
         v = default
     if isinstance(v, dict):
@@ -206,6 +218,14 @@ class SceneBuilder:
                 data = np.ascontiguousarray(data, dtype=np.float32)
                 if data.ndim != 4:
                     raise RuntimeError("gridvolume: data must have shape (nz, ny, nx, channels)")
+                mono_max = None
+                if _MONO and data.shape[3] == 3:
+                    # grid3d.cpp:178-179: *_mono variants return the luminance of the interpolated colour. Luminance is
+                    # linear, so it is applied per voxel here; the majorant stays the file's maximum (volume metadata).
+                    mono_max = float(data.max()) if data.size else 0.0
+                    f = np.float32
+                    data = np.ascontiguousarray(((data[..., 0] * f(0.212671) + data[..., 1] * f(0.715160))
+                                                 + data[..., 2] * f(0.072169))[..., None], dtype=np.float32)
                 self.keep.append(data)
                 rec.data = data.ctypes.data_as(A.fp)
                 rec.nz, rec.ny, rec.nx, rec.channels = data.shape
@@ -222,6 +242,9 @@ class SceneBuilder:
                 if p.has("max_value"):
                     rec.has_max_value = 1
                     rec.max_value = float(p.get("max_value"))
+                elif mono_max is not None:
+                    rec.has_max_value = 1
+                    rec.max_value = mono_max
             p.finish()
         else:
             # float / rgb given where a volume is expected -> constvolume (properties.h:319-366)
@@ -741,8 +764,15 @@ class SceneBuilder:
         return desc
 
 
-def build_scene_desc(d):
-    """Returns (SceneDesc, keepalive). The keepalive object owns every buffer the description points to."""
+def build_scene_desc(d, mono=False):
+    """Returns (SceneDesc, keepalive). The keepalive object owns every buffer the description points to.
+    mono: build the scene with the semantics of the *_mono variants."""
+    global _MONO
     b = SceneBuilder()
-    desc = b.load(d)
+    _MONO = bool(mono)
+    try:
+        desc = b.load(d)
+    finally:
+        _MONO = False
+    desc.integrator.monochrome = int(bool(mono))
     return desc, b

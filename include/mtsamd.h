@@ -176,6 +176,9 @@ typedef struct mts_integrator {
     int32_t samples_per_pass; /* default -1 = all                                                */
     float timeout;            /* seconds, < 0 = none                                             */
     int32_t use_spectral_mis; /* volpathmis "use_spectral_mis", default true (volpathmis.cpp:29,38)  */
+    int32_t monochrome;       /* 1: the semantics of the *_mono variants (is_monochromatic_v): no colour-channel draw
+                                 (volpath.cpp:64-67), film X = Y = Z = L (integrator.cpp:270-271); the caller passes every
+                                 colour as its luminance in all three channels.  0: *_rgb.                                */
 } mts_integrator;
 
 typedef struct mts_scene_desc {

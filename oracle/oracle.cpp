@@ -806,7 +806,7 @@ static V3 volpath_sample(const Scene &sc, Sampler &sampler, Ray ray, int medium,
     MediumInteraction mi; memset(&mi, 0, sizeof(mi)); mi.t = pm_inf();
     bool active = true, specular_chain = !hide_emitters;
     uint32_t depth = 0;
-    uint32_t channel = (uint32_t) pm_min(sampler.next_1d() * 3.f, 2.f);                      // volpath.cpp:63-67
+    uint32_t channel = sc.integrator.monochrome ? 0u : (uint32_t) pm_min(sampler.next_1d() * 3.f, 2.f);   // volpath.cpp:63-67 (rgb variants only)
     SurfaceInteraction si; memset(&si, 0, sizeof(si)); si.t = pm_inf(); si.shape = -1;
     bool needs_intersection = true;
     for (;;) {
@@ -1060,7 +1060,7 @@ static V3 volpathmis_sample(const Scene &sc, Sampler &sampler, Ray ray, int medi
     bool active = true, specular_chain = !hide_emitters;
     uint32_t depth = 0;
     MisWeights<SPEC> p_over_f = mw_full<SPEC>(1.f), p_over_f_nee = mw_full<SPEC>(1.f);
-    uint32_t channel = (uint32_t) pm_min(sampler.next_1d() * 3.f, 2.f);                      // volpathmis.cpp:120-124
+    uint32_t channel = sc.integrator.monochrome ? 0u : (uint32_t) pm_min(sampler.next_1d() * 3.f, 2.f);   // volpathmis.cpp:120-124
     SurfaceInteraction si; memset(&si, 0, sizeof(si)); si.t = pm_inf(); si.shape = -1;
     bool needs_intersection = true, last_event_was_null = false;
     V3 last_scatter_p = v3(0.f, 0.f, 0.f);                                                    // last_scatter_event: only .p is read
@@ -1466,6 +1466,8 @@ static void render_sample(const Scene &sc, Sampler &sampler, ImageBlock &block, 
     aovs[0] = pm_fma(0.180423f, L.z, pm_fma(0.357580f, L.y, 0.412453f * L.x));
     aovs[1] = pm_fma(0.072169f, L.z, pm_fma(0.715160f, L.y, 0.212671f * L.x));
     aovs[2] = pm_fma(0.950227f, L.z, pm_fma(0.119193f, L.y, 0.019334f * L.x));
+    if (sc.integrator.monochrome)                              // integrator.cpp:270-271: xyz = spec_u.x()
+        aovs[0] = aovs[1] = aovs[2] = L.x;
     aovs[3] = valid ? 1.f : 0.f;
     aovs[4] = 1.f;
     block.put(position_sample, aovs);

@@ -70,9 +70,9 @@ def _p(a):
 class OracleScene:
     """Scene built from a Mitsuba-style dict (or a ready SceneDesc) and rendered by the CPU restatement."""
 
-    def __init__(self, scene_dict=None, desc=None, keep=None):
+    def __init__(self, scene_dict=None, desc=None, keep=None, mono=False):
         if desc is None:
-            desc, keep = SD.build_scene_desc(scene_dict)
+            desc, keep = SD.build_scene_desc(scene_dict, mono=mono)
         self.desc, self.keep = desc, keep
         h = C.c_void_p()
         _check(lib().oracle_scene_create(C.byref(desc), C.byref(h)))

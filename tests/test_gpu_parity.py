@@ -212,6 +212,35 @@ def test_volpathmis_matches_the_oracle(gpu_rgb, spectral):
         assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
 
 
+@pytest.mark.parametrize("kernel", [None, "nested", "flat"])
+def test_mono_variant_matches_the_oracle(gpu_rgb, monkeypatch, kernel):
+    """gpu_mono (the semantics of scalar_mono: no colour-channel draw, colours as luminance, film X = Y = Z = L,
+    integrator.cpp:270-271) over path, volpath and volpathmis: film and counters bit for bit, luminance bitmap out."""
+    if kernel:
+        monkeypatch.setenv("MTSAMD_KERNEL", kernel)
+    chroma = scenes.c2_homogeneous_slab(32, 24, 8)
+    chroma["slab"]["interior"] = {"type": "homogeneous", "sigma_t": {"type": "rgb", "value": [0.4, 0.8, 1.6]},
+                                  "albedo": {"type": "rgb", "value": [0.9, 0.7, 0.5]}, "phase": {"type": "hg", "g": 0.5}}
+    mis = dict(scenes.c3_heterogeneous(40, 32, 8, res=16))
+    mis["integrator"] = dict(mis["integrator"], type="volpathmis")
+    gpu_rgb.set_variant("gpu_mono")
+    try:
+        for d in (chroma, scenes.c3_heterogeneous(48, 32, 8, res=16), scenes.c1_cornell(32, 32, 8), scenes.c4_atmosphere(24, 24, 4), mis):
+            scene = gpu_rgb.load_dict(d)
+            sensor = scene.sensors()[0]
+            assert scene.integrator().render(scene, sensor, collect_counters=True)
+            gpu, st = np.array(sensor.film().bitmap(raw=True)), scene.integrator().last_stats
+            o = ob.OracleScene(d, mono=True); ref = o.render(); so = o.last_stats
+            assert np.array_equal(gpu, ref) and gpu[..., 1].max() > 0
+            assert np.array_equal(gpu[..., 0], gpu[..., 1]) and np.array_equal(gpu[..., 1], gpu[..., 2])
+            assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
+            lum = np.array(sensor.film().bitmap())
+            assert lum.shape == gpu.shape[:2] + (1,)
+            assert not np.array_equal(ref, ob.OracleScene(d).render())
+    finally:
+        gpu_rgb.set_variant("gpu_rgb")
+
+
 @pytest.mark.parametrize("integrator", ["path", "volpath", "volpathmis"])
 def test_bilambertian_canopy_matches_the_oracle(gpu_rgb, integrator):
     """Eradiate's leaf BSDF (src/bsdfs/bilambertian.cpp): a small canopy of two-sided reflecting / transmitting leaves over a

@@ -115,6 +115,22 @@ def test_volume_file_roundtrip(tmp_path):
 
 
 def test_variant_handling():
-    assert pkg.variants() == ["gpu_rgb"]
+    assert pkg.variants() == ["gpu_rgb", "gpu_mono"]
     with pytest.raises(ImportError):
         pkg.set_variant("scalar_rgb")          # only the HIP backend exists; no CPU path in the product
+
+
+def test_mono_scene_description():
+    """gpu_mono: colours become their luminance (srgb.cpp:38-39), 3-channel grids their per-voxel luminance with the file's
+    maximum kept as majorant (grid3d.cpp:178-179), and the integrator record carries the flag."""
+    d = base(v={"type": "gridvolume", "data": np.stack([np.full((2, 2, 2), c, np.float32) for c in (0.2, 0.6, 1.0)], -1)})
+    desc, keep = SD.build_scene_desc(d, mono=True)
+    assert desc.integrator.monochrome == 1
+    v = desc.volumes[0]
+    lum = np.float32(np.float32(np.float32(0.2) * np.float32(0.212671) + np.float32(0.6) * np.float32(0.715160))
+                     + np.float32(1.0) * np.float32(0.072169))
+    assert v.channels == 1 and v.has_max_value == 1 and v.max_value == pytest.approx(1.0)
+    assert np.ctypeslib.as_array(v.data, (8,)).tolist() == [float(lum)] * 8
+    desc, keep = SD.build_scene_desc(d)
+    assert desc.integrator.monochrome == 0 and desc.volumes[0].channels == 3
+    assert np.allclose(SD._color([0.2, 0.6, 1.0], "t"), (0.2, 0.6, 1.0))          # the switch does not leak
