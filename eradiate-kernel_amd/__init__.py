@@ -122,16 +122,21 @@ class Bitmap:
             return Bitmap(np.concatenate([xyz, alpha], -1), pixel_format)
         if pixel_format == PixelFormat.Y:
             return Bitmap(xyz[..., 1:2], pixel_format)
+        if pixel_format == PixelFormat.YA:
+            return Bitmap(np.concatenate([xyz[..., 1:2], alpha], -1), pixel_format)
         raise RuntimeError("Bitmap.convert(): unsupported target pixel format")
 
 
 class Film:
     """hdrfilm (src/films/hdrfilm.cpp): owns the XYZAW storage the integrator writes."""
 
-    def __init__(self, sensor_rec, mono=False):
+    _FORMATS = {"luminance": PixelFormat.Y, "luminance_alpha": PixelFormat.YA, "rgb": PixelFormat.RGB, "rgba": PixelFormat.RGBA,
+                "xyz": PixelFormat.XYZ, "xyza": PixelFormat.XYZA}
+
+    def __init__(self, sensor_rec, pixel_format="rgba"):
         self._rec = sensor_rec
         self._storage = None
-        self._mono = mono            # hdrfilm.cpp:122-128: monochrome variants force the 'luminance' output format
+        self._pixel_format = self._FORMATS[pixel_format]      # hdrfilm.cpp:122-151 (monochrome variants force 'luminance')
 
     def size(self):
         return (self._rec.film_width, self._rec.film_height)
@@ -148,7 +153,7 @@ class Film:
         src = Bitmap(self._storage, PixelFormat.XYZAW)
         if raw:
             return src
-        return src.convert(PixelFormat.Y if self._mono else PixelFormat.RGB)
+        return src.convert(self._pixel_format)                # hdrfilm.cpp:277-297
 
 
 class Sampler:
@@ -160,9 +165,9 @@ class Sampler:
 
 
 class Sensor:
-    def __init__(self, rec, mono=False):
+    def __init__(self, rec, pixel_format="rgba"):
         self._rec = rec
-        self._film = Film(rec, mono)
+        self._film = Film(rec, pixel_format)
         self._sampler = Sampler(rec)
 
     def film(self):
@@ -248,7 +253,7 @@ class Scene:
         h = C.c_void_p()
         A.check(A.lib().mts_scene_create(C.byref(desc), device, C.byref(h)))
         self._handle = h
-        self._sensor = Sensor(desc.sensor, bool(desc.integrator.monochrome))
+        self._sensor = Sensor(desc.sensor, getattr(keep, "film_pixel_format", "rgba"))
         self._integrator = Integrator(self)
 
     def sensors(self):

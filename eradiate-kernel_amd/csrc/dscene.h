@@ -76,6 +76,7 @@ struct DShape {
     int32_t is_medium_transition;
     int32_t bsdf_type; uint32_t bsdf_flags;       // copies of bsdfs[bsdf].type / .flags: spares the surface blocks a dependent record load
     int32_t prim_offset;                          // index of this shape's first primitive in prim order (DScene::tri_attr)
+    int32_t area_lo, area_hi;                     // meshes: first / last face with a non-zero area (distr_1d.h:60-75); -1 = none
 };
 
 struct DPrim { int32_t shape, index; };
@@ -125,6 +126,8 @@ struct DScene {
     const float *tri;                               // per primitive (prim order): p0, e1 = p1 - p0, e2 = p2 - p0 (triangles only)
     const float *tri_attr;                          // per primitive, 24 floats: p0 p1 p2, n0 n1 n2, uv0 uv1 uv2 of a triangle -- what hit_point()
                                                     // and complete_surface() need, in one place instead of behind the face indices
+    const float *area_pmf, *area_cdf;               // per primitive (prim order): face area and its running sum within the mesh
+                                                    // (Mesh::build_pmf, mesh.cpp:285-312); 0 for other primitives
     // Bounding-volume hierarchy over the primitives, built by the host for scenes with many primitives (NULL otherwise: the
     // primitive list is walked).  32-byte nodes: bmin[3], bmax[3] (conservatively enlarged), skip = the node to visit when this
     // subtree is missed or done, link = (first << 3 | count) into bvh_prims for a leaf, minus the index of the left child for an

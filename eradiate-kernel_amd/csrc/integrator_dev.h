@@ -656,8 +656,25 @@ DEV F3 bsdf_sample(const DBsdf &b, F3 wi, float sample1, F2 sample2, BSDFSample 
 struct DirSample { F3 p, n, d; float pdf, dist; bool delta; int32_t emitter; };
 
 // shapes/rectangle.cpp:111-124 ; shapes/sphere.cpp (sample_position)
-DEV void shape_sample_position(const DShape &s, F2 sample, F3 &p, F3 &n, float &pdf) {
-    if (s.type == MTS_SHAPE_RECTANGLE) {
+DEV void shape_sample_position(const DScene &sc, const DShape &s, F2 sample, F3 &p, F3 &n, float &pdf) {
+    if (s.type == MTS_SHAPE_CUBE || s.type == MTS_SHAPE_MESH) {                               // mesh.cpp:352-397
+        // DiscreteDistribution::sample_reuse (distr_1d.h:141-151,187-197): first face whose running area reaches sample.y * sum
+        const MTS_GLOBAL_AS float *cdf = as_global(sc.area_cdf) + s.prim_offset;
+        const float value = sample.y * s.surface_area;
+        int lo = s.area_lo, hi = s.area_hi;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] < value) lo = mid + 1; else hi = mid; }
+        const float pmf = as_global(sc.area_pmf)[s.prim_offset + lo] * s.inv_surface_area, c = lo > 0 ? cdf[lo - 1] * s.inv_surface_area : 0.f;
+        sample.y = (sample.y - c) / pmf;
+        const MTS_GLOBAL_AS float *A = as_global(sc.tri_attr) + 24 * (s.prim_offset + lo);
+        F3 p0 = f3(A), p1 = f3(A + 3), p2 = f3(A + 6);
+        F3 e0 = p1 - p0, e1 = p2 - p0;
+        float t = pm_safe_sqrt(1.f - sample.x), bx = 1.f - t, by = t * sample.y;             // warp.h:153-156
+        p = p0 + e0 * bx + e1 * by;
+        if (s.has_normals) {
+            F3 n0 = f3(A + 9), n1 = f3(A + 12), n2 = f3(A + 15);
+            n = normalize(n0 * (1.f - bx - by) + n1 * bx + n2 * by);
+        } else n = normalize(cross(e0, e1));
+    } else if (s.type == MTS_SHAPE_RECTANGLE) {
         p = mat_point_affine(s.to_world.m, f3(sample.x * 2.f - 1.f, sample.y * 2.f - 1.f, 0.f));
         n = f3(s.frame_n);
     } else if (s.type == MTS_SHAPE_DISK) {                                                    // disk.cpp:114-128
@@ -672,10 +689,10 @@ DEV void shape_sample_position(const DShape &s, F2 sample, F3 &p, F3 &n, float &
     pdf = s.inv_surface_area;
 }
 // librender/shape.cpp:293-310 ; shapes/sphere.cpp (sample_direction)
-DEV_NOINLINE DirSample shape_sample_direction(const DShape &s, F3 ref_p, F2 sample) {
+DEV_NOINLINE DirSample shape_sample_direction(const DScene &sc, const DShape &s, F3 ref_p, F2 sample) {
     DirSample ds; ds.delta = false; ds.emitter = -1;
-    if (s.type == MTS_SHAPE_RECTANGLE || s.type == MTS_SHAPE_DISK) {
-        shape_sample_position(s, sample, ds.p, ds.n, ds.pdf);
+    if (s.type != MTS_SHAPE_SPHERE) {
+        shape_sample_position(sc, s, sample, ds.p, ds.n, ds.pdf);
         ds.d = ds.p - ref_p;
         float dist_squared = squared_norm(ds.d);
         ds.dist = pm_sqrt(dist_squared);
@@ -715,7 +732,7 @@ DEV_NOINLINE DirSample shape_sample_direction(const DShape &s, F3 ref_p, F2 samp
     return ds;
 }
 DEV float shape_pdf_direction(const DShape &s, F3 ref_p, const DirSample &ds) {
-    if (s.type == MTS_SHAPE_RECTANGLE || s.type == MTS_SHAPE_DISK) {                          // shape.cpp:312-323
+    if (s.type != MTS_SHAPE_SPHERE) {                                                         // shape.cpp:312-323 (mesh.cpp:417-419)
         float pdf = s.inv_surface_area, dp = pm_abs(dot(ds.d, ds.n));
         pdf *= (dp != 0.f) ? (ds.dist * ds.dist) / dp : 0.f;
         return pdf;
@@ -739,7 +756,7 @@ DEV DirSample emitter_sample_direction(const DScene &sc, int ei, F3 ref_p, F2 sa
         ds.p = ref_p + d * dist; ds.n = -d; ds.pdf = MTS_INV_FOUR_PI; ds.delta = false; ds.d = d; ds.dist = dist;
         spec = f3(e.radiance) / ds.pdf;
     } else {
-        ds = shape_sample_direction(sc.shapes[e.shape], ref_p, sample);
+        ds = shape_sample_direction(sc, sc.shapes[e.shape], ref_p, sample);
         bool active = dot(ds.d, ds.n) < 0.f && ds.pdf != 0.f;
         spec = active ? f3(e.radiance) / ds.pdf : f3s(0.f);
     }
@@ -1437,7 +1454,7 @@ DEV DRay sensor_sample_ray(const DScene &sc, F2 position_sample, F2 aperture_sam
         if (se.target_type == MTS_DISTANT_TARGET_POINT) o = f3(se.target_point) - 2.f * d * se.bsphere_radius;
         else if (se.target_type == MTS_DISTANT_TARGET_SHAPE) {
             F3 tp, n; float pdf;
-            shape_sample_position(se.target_shape, aperture_sample, tp, n, pdf);
+            shape_sample_position(sc, se.target_shape, aperture_sample, tp, n, pdf);
             o = tp - 2.f * d * se.bsphere_radius;
             w = 1.f / (pdf * se.target_area);
         } else {
@@ -1455,7 +1472,7 @@ DEV DRay sensor_sample_ray(const DScene &sc, F2 position_sample, F2 aperture_sam
         F3 ray_target = f3(se.target_point);
         if (se.target_type == MTS_DISTANT_TARGET_SHAPE) {
             F3 n; float pdf;
-            shape_sample_position(se.target_shape, aperture_sample, ray_target, n, pdf);
+            shape_sample_position(sc, se.target_shape, aperture_sample, ray_target, n, pdf);
             w *= 1.f / (pdf * se.target_area);
         } else if (se.target_type == MTS_DISTANT_TARGET_NONE) {
             F2 offset = square_to_uniform_disk_concentric(aperture_sample);
@@ -1473,7 +1490,7 @@ DEV DRay sensor_sample_ray(const DScene &sc, F2 position_sample, F2 aperture_sam
     float w = 1.f;
     if (se.target_type == MTS_DISTANT_TARGET_SHAPE) {
         F3 n; float pdf;
-        shape_sample_position(se.target_shape, aperture_sample, ray_target, n, pdf);
+        shape_sample_position(sc, se.target_shape, aperture_sample, ray_target, n, pdf);
         w = 1.f / pdf / se.target_area;
     } else if (se.target_type == MTS_DISTANT_TARGET_NONE) {
         F2 offset = square_to_uniform_disk_concentric(aperture_sample);

@@ -348,7 +348,20 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
             else if (ds.type == MTS_SHAPE_SPHERE) { memcpy(w.f, ds.center, 12); w.f[3] = ds.radius; }
             else memcpy(w.f, rec, 36);
             hs.walk.push_back(w);
+            // mesh.h:108-116: face area
+            hs.area_pmf.push_back((ds.type == MTS_SHAPE_CUBE || ds.type == MTS_SHAPE_MESH) ? 0.5f * norm(cross(f3(rec + 3), f3(rec + 6))) : 0.f);
         }
+        if (ds.type == MTS_SHAPE_CUBE || ds.type == MTS_SHAPE_MESH) {
+            // Mesh::build_pmf (mesh.cpp:285-312) + DiscreteDistribution::update (distr_1d.h:49-83): running sum in double precision
+            DShape &sh = hs.shapes.back();
+            double sum = 0.0; sh.area_lo = sh.area_hi = -1;
+            for (int k = 0; k < prim_count; ++k) {
+                float a = hs.area_pmf[(size_t) sh.prim_offset + k];
+                sum += (double) a; hs.area_cdf.push_back((float) sum);
+                if (a > 0.f) { if (sh.area_lo < 0) sh.area_lo = k; sh.area_hi = k; }
+            }
+            sh.surface_area = (float) sum; sh.inv_surface_area = (float) (1.0 / sum);         // mesh.cpp:346-350,373
+        } else for (int k = 0; k < prim_count; ++k) hs.area_cdf.push_back(0.f);
     }
     // ---- emitters + set_scene (scene.cpp:41-52,95-97; directional.cpp:68-73; constant.cpp:35-39; bbox.h:329-332)
     sc.environment = -1;
@@ -361,8 +374,8 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
         de.type = e.type; de.to_world = xf_from_abi(e.to_world); memcpy(de.radiance, e.radiance, 12); de.shape = e.shape;
         if (e.type == MTS_EMITTER_AREA) {
             check_index(e.shape, d->shape_count, "area emitter shape", false);
-            if (hs.shapes[e.shape].type == MTS_SHAPE_CUBE || hs.shapes[e.shape].type == MTS_SHAPE_MESH)
-                throw std::runtime_error("area emitters on meshes are not supported by this backend");
+            if ((hs.shapes[e.shape].type == MTS_SHAPE_CUBE || hs.shapes[e.shape].type == MTS_SHAPE_MESH) && hs.shapes[e.shape].area_lo < 0)
+                throw std::runtime_error("DiscreteDistribution: no probability mass found!");   // distr_1d.h:78-79
         } else if (e.type == MTS_EMITTER_CONSTANT) {
             if (sc.environment >= 0) throw std::runtime_error("Only one environment emitter can be specified per scene.");
             sc.environment = i;
@@ -590,6 +603,7 @@ void upload_host_scene(HostScene &hs, int device) {
     sc.faces = upload(hs, hs.faces);
     sc.tri = upload(hs, hs.tri);
     sc.tri_attr = upload(hs, hs.tri_attr);
+    sc.area_pmf = upload(hs, hs.area_pmf); sc.area_cdf = upload(hs, hs.area_cdf);
     sc.bvh_nodes = nullptr; sc.bvh_prims = nullptr; sc.bvh_node_count = (int32_t) (hs.bvh_nodes.size() / 8);
     sc.bvh_lds = nullptr; sc.bvh_lds_count = 0;
     if (sc.bvh_node_count > 0) { sc.bvh_nodes = upload(hs, hs.bvh_nodes); sc.bvh_prims = upload(hs, hs.bvh_prims); }

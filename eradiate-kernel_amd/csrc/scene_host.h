@@ -27,6 +27,7 @@ struct HostScene {
     std::vector<uint32_t> faces;
     std::vector<float> tri;
     std::vector<float> tri_attr;
+    std::vector<float> area_pmf, area_cdf;           // prim order (DScene::area_pmf / area_cdf)
     std::vector<float> bvh_nodes;                    // 8 floats per node (DScene::bvh_nodes); empty = no BVH
     std::vector<int32_t> bvh_prims;
     std::vector<float> rfilter_values;

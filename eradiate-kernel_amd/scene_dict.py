@@ -508,8 +508,22 @@ class SceneBuilder:
         if (s.crop_offset[0] < 0 or s.crop_offset[1] < 0 or s.crop_size[0] <= 0 or s.crop_size[1] <= 0 or
                 s.crop_offset[0] + s.crop_size[0] > s.film_width or s.crop_offset[1] + s.crop_size[1] > s.film_height):
             raise RuntimeError("Invalid crop window specification!")
-        for k in ("pixel_format", "component_format", "file_format", "high_quality_edges"):
-            fp_.get(k)
+        # hdrfilm.cpp:100-151: the format strings are validated even though only Film.bitmap() consumes the pixel format here
+        ff = str(fp_.get("file_format", "openexr")).lower()
+        if ff not in ("openexr", "exr", "rgbe", "pfm"):
+            raise RuntimeError("The \"file_format\" parameter must either be equal to \"openexr\", \"pfm\", or \"rgbe\", found %s instead." % ff)
+        pf = str(fp_.get("pixel_format", "rgba")).lower()
+        if pf not in ("luminance", "luminance_alpha", "rgb", "rgba", "xyz", "xyza"):
+            raise RuntimeError("The \"pixel_format\" parameter must either be equal to \"luminance\", \"luminance_alpha\", \"rgb\", "
+                               "\"rgba\",  \"xyz\", \"xyza\". Found %s." % pf)
+        cf = str(fp_.get("component_format", "float16")).lower()
+        if cf not in ("float16", "float32", "uint32"):
+            raise RuntimeError("The \"component_format\" parameter must either be equal to \"float16\", \"float32\", or \"uint32\". "
+                               "Found %s instead." % cf)
+        if ff in ("rgbe", "pfm") and not (ff == "pfm" and pf == "luminance"):
+            pf = "rgb"                                                     # hdrfilm.cpp:153-176
+        self.film_pixel_format = "luminance" if _MONO else pf             # hdrfilm.cpp:122-128
+        fp_.get("high_quality_edges"); fp_.get("filename")
         rf = fp_.get("rfilter", {"type": "gaussian"})
         rp = Props(rf, where + ".film.rfilter")
         s.rfilter_radius, s.rfilter_stddev = 0.5, 0.5

@@ -546,6 +546,26 @@ static inline void shape_sample_position(const Shape &s, P2 sample, V3 *p, V3 *n
         P2 q = square_to_uniform_disk_concentric(sample);
         *p = xf_point_affine(s.to_world, v3(q.x, q.y, 0.f));
         *n = s.frame.n; *pdf = s.inv_surface_area;
+    } else if (s.type == MTS_SHAPE_CUBE || s.type == MTS_SHAPE_MESH) {                    // mesh.cpp:352-397
+        // DiscreteDistribution::sample_reuse (distr_1d.h:141-151,187-197): first face whose running area reaches sample.y * sum
+        float value = sample.y * s.surface_area;
+        int lo = s.area_lo, hi = s.area_hi;
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (s.area_cdf[mid] < value) lo = mid + 1; else hi = mid; }
+        float pmf = s.area_pmf[lo] * s.inv_surface_area, cdf = lo > 0 ? s.area_cdf[lo - 1] * s.inv_surface_area : 0.f;
+        sample.y = (sample.y - cdf) / pmf;
+        const float *P = s.positions.data(); const uint32_t *f = &s.faces[3 * lo];
+        V3 p0 = v3(P[3 * f[0]], P[3 * f[0] + 1], P[3 * f[0] + 2]), p1 = v3(P[3 * f[1]], P[3 * f[1] + 1], P[3 * f[1] + 2]),
+           p2 = v3(P[3 * f[2]], P[3 * f[2] + 1], P[3 * f[2] + 2]);
+        V3 e0 = p1 - p0, e1 = p2 - p0;
+        float t = pm_safe_sqrt(1.f - sample.x), bx = 1.f - t, by = t * sample.y;           // warp.h:153-156
+        *p = p0 + e0 * bx + e1 * by;
+        if (!s.normals.empty()) {
+            const float *N = s.normals.data();
+            V3 n0 = v3(N[3 * f[0]], N[3 * f[0] + 1], N[3 * f[0] + 2]), n1 = v3(N[3 * f[1]], N[3 * f[1] + 1], N[3 * f[1] + 2]),
+               n2 = v3(N[3 * f[2]], N[3 * f[2] + 1], N[3 * f[2] + 2]);
+            *n = normalize(n0 * (1.f - bx - by) + n1 * bx + n2 * by);
+        } else *n = normalize(cross(e0, e1));
+        *pdf = s.inv_surface_area;
     } else {
         V3 local = square_to_uniform_sphere(sample);
         *p = fmadd(local, s.radius, s.center);
@@ -555,7 +575,7 @@ static inline void shape_sample_position(const Shape &s, P2 sample, V3 *p, V3 *n
 // shape.cpp:293-310 (generic), sphere.cpp sample_direction
 static inline DirectionSample shape_sample_direction(const Shape &s, V3 ref_p, P2 sample) {
     DirectionSample ds; memset(&ds, 0, sizeof(ds));
-    if (s.type == MTS_SHAPE_RECTANGLE || s.type == MTS_SHAPE_DISK) {
+    if (s.type != MTS_SHAPE_SPHERE) {
         shape_sample_position(s, sample, &ds.p, &ds.n, &ds.pdf);
         ds.d = ds.p - ref_p;
         float dist_squared = squared_norm(ds.d);
@@ -596,7 +616,7 @@ static inline DirectionSample shape_sample_direction(const Shape &s, V3 ref_p, P
     return ds;
 }
 static inline float shape_pdf_direction(const Shape &s, V3 ref_p, const DirectionSample &ds) {
-    if (s.type == MTS_SHAPE_RECTANGLE || s.type == MTS_SHAPE_DISK) {                       // shape.cpp:312-323
+    if (s.type != MTS_SHAPE_SPHERE) {                                                       // shape.cpp:312-323 (mesh.cpp:417-419)
         float pdf = s.inv_surface_area, dp = pm_abs(dot(ds.d, ds.n));
         pdf *= (dp != 0.f) ? (ds.dist * ds.dist) / dp : 0.f;
         return pdf;

@@ -141,6 +141,9 @@ struct Shape {
     std::vector<float> positions, normals, texcoords;
     std::vector<uint32_t> faces;
     int prim_count;
+    // mesh area distribution (mesh.cpp:285-312, distr_1d.h:49-83): unnormalised pmf / cdf over the faces, first / last non-empty face
+    std::vector<float> area_pmf, area_cdf;
+    int area_lo = -1, area_hi = -1;
     bool is_medium_transition() const { return interior >= 0 || exterior >= 0; }   // shape.h:341
 };
 
@@ -216,6 +219,20 @@ static inline Shape make_shape(const mts_shape &d) {
         s.faces.assign(fc, fc + 3 * nf);
         for (int i = 0; i < 3 * nf; ++i) if (s.faces[i] >= (uint32_t) nv) throw std::runtime_error("mesh: face index out of range");
         s.prim_count = nf;
+        // Mesh::build_pmf (mesh.cpp:285-312) + DiscreteDistribution::update (distr_1d.h:49-83): face areas (mesh.h:108-116),
+        // running sum in double precision
+        s.area_pmf.resize(nf); s.area_cdf.resize(nf);
+        double sum = 0.0;
+        for (int i = 0; i < nf; ++i) {
+            const float *P = s.positions.data(); const uint32_t *f = &s.faces[3 * i];
+            V3 p0 = v3(P[3 * f[0]], P[3 * f[0] + 1], P[3 * f[0] + 2]), p1 = v3(P[3 * f[1]], P[3 * f[1] + 1], P[3 * f[1] + 2]),
+               p2 = v3(P[3 * f[2]], P[3 * f[2] + 1], P[3 * f[2] + 2]);
+            float a = 0.5f * norm(cross(p1 - p0, p2 - p0));
+            s.area_pmf[i] = a; sum += (double) a; s.area_cdf[i] = (float) sum;
+            if (a > 0.f) { if (s.area_lo < 0) s.area_lo = i; s.area_hi = i; }
+        }
+        s.surface_area = (float) sum;                                                          // mesh.cpp:346-350
+        s.inv_surface_area = (float) (1.0 / sum);
     } else if (d.type == MTS_SHAPE_SPHERE) {
         // sphere.cpp:80-105: to_world * translate(center) * scale(radius); must be a uniform scale without shear.
         Xf tw = xf_mul(s.to_world, xf_mul(xf_translate(v3(d.center[0], d.center[1], d.center[2])), xf_scale(v3(d.radius, d.radius, d.radius))));
@@ -423,8 +440,8 @@ static inline Scene *make_scene(const mts_scene_desc *d) {
             em.radiance = v3(e.radiance[0], e.radiance[1], e.radiance[2]); em.shape = e.shape;
             if (e.type == MTS_EMITTER_AREA) {
                 check_index(e.shape, d->shape_count, "area emitter shape", false);
-                if (sc->shapes[e.shape].type == MTS_SHAPE_CUBE || sc->shapes[e.shape].type == MTS_SHAPE_MESH)
-                    throw std::runtime_error("area emitters on meshes are not supported by this backend");
+                if ((sc->shapes[e.shape].type == MTS_SHAPE_CUBE || sc->shapes[e.shape].type == MTS_SHAPE_MESH) && sc->shapes[e.shape].area_lo < 0)
+                    throw std::runtime_error("DiscreteDistribution: no probability mass found!");   // distr_1d.h:78-79
             }
             if (em.is_environment()) {
                 if (sc->environment >= 0) throw std::runtime_error("Only one environment emitter can be specified per scene.");   // scene.cpp:48-50

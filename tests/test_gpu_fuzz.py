@@ -90,7 +90,7 @@ def _scene(seed):
         d["sky"] = {"type": "constant", "radiance": 0.7}
         d["sun"] = {"type": "directional", "direction": [0.1, 0.3, -1.0], "irradiance": 1.0}
     else:
-        d["lamp"] = {"type": str(rng.choice(["rectangle", "disk"])), "to_world": T.translate([0.5, 0, 6]) @ T.rotate([1, 0, 0], 180) @ T.scale(1.5),
+        d["lamp"] = {"type": str(rng.choice(["rectangle", "disk", "cube", "sphere"])), "to_world": T.translate([0.5, 0, 6]) @ T.rotate([1, 0, 0], 180) @ T.scale(1.5),
                      "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [4.0, 3.5, 3.0]}}}
     return d
 

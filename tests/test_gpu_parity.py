@@ -234,11 +234,35 @@ def test_mono_variant_matches_the_oracle(gpu_rgb, monkeypatch, kernel):
             assert np.array_equal(gpu, ref) and gpu[..., 1].max() > 0
             assert np.array_equal(gpu[..., 0], gpu[..., 1]) and np.array_equal(gpu[..., 1], gpu[..., 2])
             assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
-            lum = np.array(sensor.film().bitmap())
+            lum = np.array(sensor.film().bitmap())                 # hdrfilm.cpp:122-128: luminance in monochrome variants
             assert lum.shape == gpu.shape[:2] + (1,)
             assert not np.array_equal(ref, ob.OracleScene(d).render())
     finally:
         gpu_rgb.set_variant("gpu_rgb")
+
+
+@pytest.mark.parametrize("integrator", ["path", "volpath", "volpathmis"])
+def test_mesh_area_emitters_match_the_oracle(gpu_rgb, integrator):
+    """Area emitters on triangle meshes (Mesh::sample_position, mesh.cpp:352-397: face chosen by area with sample reuse,
+    distr_1d.h:187-197, then a uniform point in the triangle): a two-triangle ceiling light with vertex normals, a lit cube
+    (cube.cpp) and a lit uv-sphere mesh of 96 faces, next to a rectangle light -- bit for bit."""
+    d = dict(scenes.c1_cornell(40, 32, 8))
+    d["integrator"] = dict(d["integrator"], type=integrator)
+    xf = np.asarray(d["light"]["to_world"].matrix)
+    quad = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], np.float32)
+    world = np.array([xf[:3, :3] @ v + xf[:3, 3] for v in quad], np.float32)
+    d["light"] = {"type": "mesh", "vertex_positions": world, "faces": np.array([[0, 1, 2], [0, 2, 3]], np.uint32),
+                  "vertex_normals": np.tile([0.0, 0.0, -1.0], (4, 1)).astype(np.float32),
+                  "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [3.0, 2.5, 2.0]}}}
+    d["lamp"] = {"type": "cube", "to_world": T.translate([2.5, 1.0, 1.0]) @ T.rotate([0, 0, 1], 30) @ T.scale([0.5, 0.8, 1.0]),
+                 "emitter": {"type": "area", "radiance": 1.5}}
+    pos, faces = _uv_sphere(6, 8, 0.7, (-2.5, -1.0, 2.0))
+    d["ball"] = {"type": "mesh", "vertex_positions": pos, "faces": faces, "emitter": {"type": "area", "radiance": 0.8}}
+    d["panel"] = {"type": "rectangle", "to_world": T.translate([0, 4.9, 3.5]) @ T.rotate([1, 0, 0], 90) @ T.scale(0.5),
+                  "emitter": {"type": "area", "radiance": 2.0}}
+    gpu, st = gpu_render(gpu_rgb, d, collect_counters=True)
+    o = ob.OracleScene(d); ref = o.render()
+    assert np.array_equal(gpu, ref) and gpu[..., :3].max() > 0
 
 
 @pytest.mark.parametrize("integrator", ["path", "volpath", "volpathmis"])

@@ -1,0 +1,257 @@
+"""More pins from the reference's in-tree tests for components on the hot path: perspective sensor, sphere,
+cube, area and constant emitters, PLY triangle fixture, empty-scene render, film crop window.  Each test names the reference
+test it restates; literals and the triangle fixture are data, the checks are restated."""
+import importlib
+import math
+
+import numpy as np
+import pytest
+
+import tests.oracle_binding as ob
+
+T = importlib.import_module("eradiate-kernel_amd.transform").ScalarTransform4f
+SD = importlib.import_module("eradiate-kernel_amd.scene_dict")
+mesh_io = importlib.import_module("eradiate-kernel_amd.mesh_io")
+
+FILM4 = {"type": "hdrfilm", "width": 4, "height": 4, "rfilter": {"type": "box"}}
+
+
+def scene(**objects):
+    d = {"type": "scene", "integrator": {"type": "path"}}
+    if "sensor" not in objects:
+        d["sensor"] = {"type": "perspective", "film": FILM4}
+    d.update(objects)
+    return d
+
+
+# ---------------------------------------------------------------- perspective sensor
+def camera(o, d, fov=34, fov_axis="x"):
+    """create_camera() of src/sensors/tests/test_perspective.py:7-35 (the shutter is closed: motion blur is not on this path)."""
+    return {"type": "perspective", "near_clip": 1.0, "far_clip": 35.0, "focus_distance": 15.0, "fov": fov, "fov_axis": fov_axis,
+            "to_world": T.look_at(origin=o, target=[o[0] + d[0], o[1] + d[1], o[2] + d[2]], up=[0, 1, 0]),
+            "film": {"type": "hdrfilm", "width": 512, "height": 256}}
+
+
+@pytest.mark.parametrize("origin", [[1.0, 0.0, 1.5], [1.0, 4.0, 1.5]])
+@pytest.mark.parametrize("direction", [[0.0, 0.0, 1.0], [1.0, 0.0, 0.0]])
+def test_perspective_sample_ray(origin, direction):
+    """src/sensors/tests/test_perspective.py:45-62 (construction), :66-90 (sample_ray): rays start at the camera origin, the
+    film centre looks along the camera direction, no aperture sample is needed, the spectral weight is 1 in rgb."""
+    desc, keep = SD.build_scene_desc(scene(sensor=camera(origin, direction)))
+    assert np.isclose(desc.sensor.near_clip, 1) and np.isclose(desc.sensor.far_clip, 35)
+    o = ob.OracleScene(scene(sensor=camera(origin, direction)))
+    ro, rd, w = o.sensor_sample_ray([[0.2, 0.6], [0.1, 0.9], [0.5, 0.5]], [[0, 0]] * 3)
+    assert np.allclose(ro, origin)
+    assert np.allclose(rd[2], direction, atol=1e-7)
+    assert np.allclose(np.linalg.norm(rd, axis=1), 1, atol=1e-6) and np.allclose(w, 1)
+
+
+@pytest.mark.parametrize("direction", [[0.0, 0.0, 1.0], [1.0, 0.0, 0.0]])
+@pytest.mark.parametrize("fov", [34, 80])
+def test_perspective_fov_axis(direction, fov):
+    """src/sensors/tests/test_perspective.py:128-160: at the extremities of the unit square along the fov axis the ray makes
+    an angle of fov / 2 with the camera direction (aspect 2: 'larger' is x, 'smaller' is y, 'diagonal' the four corners)."""
+    origin = [1.0, 0.0, 1.5]
+
+    def check(axis, samples):
+        o = ob.OracleScene(scene(sensor=camera(origin, direction, fov=fov, fov_axis=axis)))
+        _, rd, _ = o.sensor_sample_ray(samples, [[0, 0]] * len(samples))
+        ang = np.degrees(np.arccos(np.clip(rd @ np.asarray(direction, np.float32), -1, 1)))
+        assert np.allclose(ang, fov / 2, rtol=1e-4), (axis, ang)
+    for axis in ("x", "larger"):
+        check(axis, [[0.0, 0.5], [1.0, 0.5]])
+    for axis in ("y", "smaller"):
+        check(axis, [[0.5, 0.0], [0.5, 1.0]])
+    check("diagonal", [[0.0, 0.0], [0.0, 1.0], [1.0, 0.0], [1.0, 1.0]])
+
+
+# ---------------------------------------------------------------- sphere
+@pytest.mark.parametrize("r", [1, 3])
+def test_sphere_ray_intersect_transform(r):
+    """src/shapes/tests/test_sphere.py:52-76: a 21 x 21 grid of parallel rays hits the (rotated, translated) sphere exactly
+    where x^2 + y^2 <= r^2."""
+    o = ob.OracleScene(scene(s={"type": "sphere", "radius": r, "to_world": T.translate([0, 1, 0]) @ T.rotate([0, 1, 0], 30.0)}))
+    n = 21
+    xs = np.array([[r * (2 * (x / n) - 1), r * (2 * (y / n) - 1)] for x in range(n) for y in range(n)])
+    org = np.stack([xs[:, 0], xs[:, 1] + 1, np.full(len(xs), -8.0)], -1)
+    res = o.ray_intersect(org, np.tile([0.0, 0.0, 1.0], (len(xs), 1)))
+    found = np.isfinite(res["t"])
+    rr = xs[:, 0] ** 2 + xs[:, 1] ** 2
+    ok = (found == (rr <= r * r)) | (np.abs(rr - r * r) < 1e-8)
+    assert ok.all()
+    # the hit lies on the sphere and the normal points away from its centre
+    p, nn = res["p"][found], res["n"][found]
+    assert np.allclose(np.linalg.norm(p - np.array([0, 1, 0]), axis=1), r, rtol=1e-5)
+    assert np.allclose(nn, (p - np.array([0, 1, 0])) / r, atol=1e-5)
+
+
+def test_sphere_sample_direction_is_cone_sampling():
+    """src/shapes/tests/test_sphere.py:96-124: from outside, Sphere::sample_direction samples the subtended cone uniformly;
+    direction, distance and point agree with a ray cast along the analytic cone direction.  (Probed through an area emitter on
+    the sphere: with one emitter Scene::sample_emitter_direction forwards the sample unchanged, scene.cpp:144-170.)"""
+    o = ob.OracleScene(scene(s={"type": "sphere", "emitter": {"type": "area", "radiance": 1.0}}))
+    ref = np.array([0, 0, -3.0])
+    sin_cone = 1.0 / ref[2]
+    cos_cone = math.sqrt(1 - sin_cone ** 2)
+
+    def sample_cone(s, cos_theta_max):
+        cos_theta = (1 - s[1]) + s[1] * cos_theta_max
+        sin_theta = math.sqrt(1 - cos_theta * cos_theta)
+        phi = 2 * math.pi * s[0]
+        return np.array([math.cos(phi) * sin_theta, math.sin(phi) * sin_theta, cos_theta])
+    for xi_1 in np.linspace(0, 1, 10):
+        for xi_2 in np.linspace(1e-3, 1 - 1e-3, 10):
+            d, dist, pdf, spec = o.emitter_sample_direction(ref, float(xi_2), float(1 - xi_1))
+            expect = sample_cone([xi_1, xi_2], cos_cone)
+            its = o.ray_intersect([ref], [expect])
+            assert np.allclose(expect, d, atol=1e-5, rtol=1e-5)
+            assert np.isclose(its["t"][0], dist, atol=1e-5, rtol=1e-5)
+            assert np.isclose(pdf, 1.0 / (2 * math.pi * (1 - cos_cone)), rtol=1e-4)        # sphere.cpp:177-180: uniform cone pdf
+
+
+# ---------------------------------------------------------------- cube
+def test_cube_bounding_boxes():
+    """src/shapes/tests/test_cube.py:33-66: bounding boxes of transformed cubes, measured with axis-parallel rays (first hit
+    from outside along +-x, +-y, +-z)."""
+    def bbox(to_world):
+        o = ob.OracleScene(scene(c={"type": "cube", "to_world": to_world}))
+        lo, hi = np.zeros(3), np.zeros(3)
+        for ax in range(3):
+            # sweep a grid of rays along the axis and keep the extreme hit coordinates
+            g = np.linspace(-4.5, 4.5, 61)
+            a, b = np.meshgrid(g, g, indexing="ij")
+            other = [k for k in range(3) if k != ax]
+            for sign, store in ((1.0, lo), (-1.0, hi)):
+                org = np.zeros((a.size, 3)); org[:, other[0]] = a.ravel(); org[:, other[1]] = b.ravel(); org[:, ax] = -50.0 * sign
+                dr = np.zeros((a.size, 3)); dr[:, ax] = sign
+                res = o.ray_intersect(org, dr)
+                hit = np.isfinite(res["t"])
+                coord = res["p"][hit][:, ax]
+                store[ax] = coord.min() if sign > 0 else coord.max()
+        return lo, hi
+    for xf, mn, mx in ((T(), [-1, -1, -1], [1, 1, 1]),
+                       (T.translate([1, 2, 3]), [0, 1, 2], [2, 3, 4]),
+                       (T.scale([1, 2, 3]), [-1, -2, -3], [1, 2, 3]),
+                       (T.translate([1, 0, 0]) @ T.scale([2, 2, 2]), [-1, -2, -2], [3, 2, 2])):
+        lo, hi = bbox(xf)
+        assert np.allclose(lo, mn, atol=1e-4) and np.allclose(hi, mx, atol=1e-4)
+    lo, hi = bbox(T.rotate([0, 0, 1], 45))                                                  # test_cube.py:55-59
+    assert np.allclose([lo[2], hi[2]], [-1, 1], atol=1e-4)
+    assert lo[0] < -1.35 and hi[0] > 1.35 and lo[0] >= -1.41422 and hi[0] <= 1.41422     # the apex lies between grid rays
+
+
+# ---------------------------------------------------------------- emitters
+TRIANGLE_PLY = b"""ply
+format ascii 1.0
+comment this file contains a triangle
+element vertex 3
+property float x
+property float y
+property float z
+element face 1
+property list uchar int vertex_index
+end_header
+0 0 0
+0 0 1
+0 1 0
+3 0 1 2
+"""      # the data of src/emitters/tests/data/triangle.ply == src/librender/tests/data/triangle.ply
+
+
+def test_ply_triangle_fixture(tmp_path):
+    """src/librender/tests/test_mesh.py:35-77: positions, faces and the computed vertex normals (-1, 0, 0) of triangle.ply."""
+    f = tmp_path / "triangle.ply"
+    f.write_bytes(TRIANGLE_PLY)
+    m = mesh_io.load_mesh("ply", str(f), None, True, True)
+    assert "vertex_normals" not in m                                                        # face_normals = true
+    assert np.allclose(np.asarray(m["vertex_positions"]).reshape(-1), [0, 0, 0, 0, 0, 1, 0, 1, 0])
+    assert np.asarray(m["faces"]).reshape(-1).tolist() == [0, 1, 2]
+    m = mesh_io.load_mesh("ply", str(f), None, False, True)
+    assert np.allclose(np.asarray(m["vertex_normals"]).reshape(-1, 3), [[-1, 0, 0]] * 3)
+
+
+def test_vertex_normal_weighting_scheme():
+    """src/librender/tests/test_mesh.py:79-107: vertex normals are weighted by the face angle at the vertex."""
+    a, b = 1.0, 0.5
+    pos = np.array([0, 0, 0, -a, 1, 0, a, 1, 0, -b, 0, 1, b, 0, 1], np.float32).reshape(-1, 3)
+    faces = np.array([[0, 1, 2], [0, 3, 4]], np.uint32)
+    n0, n1 = np.array([0.0, 0.0, -1.0]), np.array([0.0, 1.0, 0.0])
+    n2 = n0 * (math.pi / 2.0) + n1 * math.acos(3.0 / 5.0)
+    n2 /= np.linalg.norm(n2)
+    n = mesh_io.compute_vertex_normals(pos, faces)
+    assert np.allclose(n, np.vstack([n2, n0, n0, n1, n1]), atol=5e-4)
+
+
+def test_area_emitter_on_the_triangle(tmp_path):
+    """src/emitters/tests/test_area.py:21-37,116-139: the area emitter's direction sampling is the shape's (uniform over the
+    triangle, converted to solid angle), its value the radiance divided by that density; nothing is emitted towards the back."""
+    f = tmp_path / "triangle.ply"
+    f.write_bytes(TRIANGLE_PLY)
+    o = ob.OracleScene(scene(t={"type": "ply", "filename": str(f), "to_world": T.translate([10, -1, 2]),
+                                "emitter": {"type": "area", "radiance": 2.5}}))
+    v = np.array([[0, 0, 0], [0, 0, 1], [0, 1, 0]], np.float64) + [10, -1, 2]
+    nrm = np.array([-1.0, 0, 0])
+    for ref in ([0.2, 0.1, 0.2], [0.6, -0.9, 0.2], [0.4, 0.9, -0.2]):
+        for s in ([0.4, 0.1], [0.5, 0.4], [0.3, 0.9]):
+            d, dist, pdf, spec = o.emitter_sample_direction(ref, s[0], s[1])
+            t = math.sqrt(1 - s[0])                                                        # warp.h square_to_uniform_triangle
+            bu, bv = 1 - t, t * s[1]
+            p = v[0] * (1 - bu - bv) + v[1] * bu + v[2] * bv
+            assert np.allclose(d, (p - ref) / np.linalg.norm(p - ref), atol=1e-5)
+            assert np.isclose(dist, np.linalg.norm(p - ref), rtol=1e-5)
+            cos = abs(np.dot(d, nrm))
+            assert np.isclose(pdf, dist * dist / (0.5 * cos), rtol=1e-4)                   # shape.cpp:79-93: area 1/2
+            assert np.allclose(spec, 2.5 / pdf, rtol=1e-4)                                 # the emitting side faces -x
+    d, dist, pdf, spec = o.emitter_sample_direction([20.0, 0, 2.5], 0.4, 0.5)              # behind the triangle: area.cpp:56-60
+    assert np.allclose(spec, 0)
+
+
+def test_constant_emitter_sample_direction():
+    """src/emitters/tests/test_constant.py:73-100: uniform sphere sampling, density 1 / (4 pi), value radiance * 4 pi."""
+    o = ob.OracleScene(scene(s={"type": "sphere"}, e={"type": "constant", "radiance": 0.7}))
+    for ref in ([-0.5, 0.3, -0.1], [0.8, -0.3, -0.2], [-0.2, 0.6, -0.6]):
+        for s in ([0.4, 0.1], [0.5, 0.4], [0.3, 0.9]):
+            d, dist, pdf, spec = o.emitter_sample_direction(ref, s[0], s[1])
+            z = 1 - 2 * s[1]; r = math.sqrt(max(0.0, 1 - z * z)); phi = 2 * math.pi * s[0]     # warp.h:163-170
+            assert np.allclose(d, [r * math.cos(phi), r * math.sin(phi), z], atol=1e-6)
+            assert np.isclose(pdf, 1 / (4 * math.pi), rtol=1e-6)
+            assert np.allclose(spec, 0.7 * 4 * math.pi, rtol=1e-5)
+
+
+# ---------------------------------------------------------------- renders and film
+@pytest.mark.parametrize("integrator", ["path", "volpath", "volpathmis"])
+def test_empty_scene_renders_black(integrator):
+    """src/librender/tests/test_integrator.py:107-110 with python/test/scenes.py:12-29,273-278 ('empty': all averages 0,
+    alpha 0): a 151 x 146 perspective view of nothing."""
+    d = {"type": "scene", "integrator": {"type": integrator},
+         "sensor": {"type": "perspective", "film": {"type": "hdrfilm", "width": 151, "height": 146},
+                    "sampler": {"type": "independent", "sample_count": 2}}}
+    film = ob.OracleScene(d).render()
+    assert film.shape == (146, 151, 5)
+    assert np.all(film[..., :4] == 0) and np.all(film[..., 4] > 0)
+
+
+def test_film_crop_window_checks():
+    """src/films/tests/test_hdrfilm.py:35-70: crop size / offset are taken as given; a window that leaves the film is an error."""
+    film = {"type": "hdrfilm", "width": 32, "height": 21, "crop_width": 11, "crop_height": 5, "crop_offset_x": 2,
+            "crop_offset_y": 3, "high_quality_edges": True, "pixel_format": "rgba"}
+    desc, keep = SD.build_scene_desc(scene(sensor={"type": "perspective", "film": film}))
+    s = desc.sensor
+    assert (s.film_width, s.film_height) == (32, 21) and tuple(s.crop_size) == (11, 5) and tuple(s.crop_offset) == (2, 3)
+    incomplete = {"type": "hdrfilm", "width": 32, "height": 21, "crop_offset_x": 30, "crop_offset_y": 20}
+    with pytest.raises(RuntimeError):
+        SD.build_scene_desc(scene(sensor={"type": "perspective", "film": incomplete}))
+    desc, keep = SD.build_scene_desc(scene(sensor={"type": "perspective", "film": dict(incomplete, crop_width=2, crop_height=1)}))
+    s = desc.sensor
+    assert (s.film_width, s.film_height) == (32, 21) and tuple(s.crop_size) == (2, 1) and tuple(s.crop_offset) == (30, 20)
+    for bad in ({"component_format": "uint8"}, {"pixel_format": "brga"}):                   # test_hdrfilm.py:24-31
+        with pytest.raises(RuntimeError):
+            SD.build_scene_desc(scene(sensor={"type": "perspective", "film": dict({"type": "hdrfilm"}, **bad)}))
+
+
+def test_integrator_parameter_checks():
+    """src/librender/tests/test_integrator.py:92-104: rr_depth / max_depth are read; max_depth < -1 is an error."""
+    desc, keep = SD.build_scene_desc(scene(integrator={"type": "path", "rr_depth": 5, "max_depth": -1}))
+    assert desc.integrator.rr_depth == 5 and desc.integrator.max_depth == -1
+    with pytest.raises(RuntimeError):
+        ob.OracleScene(scene(integrator={"type": "path", "max_depth": -2}))

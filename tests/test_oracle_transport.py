@@ -177,3 +177,23 @@ def test_mono_agrees_with_rgb_on_a_grey_scene():
     y_mono = (mono[..., 1] / mono[..., 4]).mean()
     assert not np.array_equal(rgb[..., 1], mono[..., 1])
     assert abs(y_rgb - y_mono) < 0.02 * y_rgb, (y_rgb, y_mono)
+
+
+def test_mesh_area_light_agrees_with_the_rectangle_light():
+    """Mesh::sample_position (mesh.cpp:352-397: face by area, then uniform in the triangle) against rectangle.cpp:111-124 on the
+    same light geometry: two estimators of the same image."""
+    import importlib
+    scenes = importlib.import_module("eradiate-kernel_amd.scenes")
+    T = tc.T
+    d = scenes.c1_cornell(16, 16, 1024)
+    xf = d["light"]["to_world"]
+    quad = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], np.float32)
+    world = np.array([np.asarray(xf.matrix)[:3, :3] @ v + np.asarray(xf.matrix)[:3, 3] for v in quad], np.float32)
+    m = dict(d)
+    m["light"] = {"type": "mesh", "vertex_positions": world, "faces": np.array([[0, 1, 2], [0, 2, 3]], np.uint32),
+                  "emitter": d["light"]["emitter"]}
+    a = tc.radiance_rgb(ob.OracleScene(d).render())
+    b = tc.radiance_rgb(ob.OracleScene(m).render())
+    assert not np.array_equal(a, b)
+    assert abs(a.mean() - b.mean()) < 0.02 * a.mean(), (a.mean(), b.mean())
+    assert np.abs(a.mean((0, 1)) - b.mean((0, 1))).max() < 0.03 * a.mean()
