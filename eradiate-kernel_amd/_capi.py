@@ -20,7 +20,7 @@ PHASE_ISOTROPIC, PHASE_HG, PHASE_RAYLEIGH, PHASE_BLEND, PHASE_TABULATED = 0, 1, 
 MEDIUM_HOMOGENEOUS, MEDIUM_HETEROGENEOUS = 0, 1
 BSDF_DIFFUSE, BSDF_NULL, BSDF_RPV, BSDF_BILAMBERTIAN = 0, 1, 2, 3
 SHAPE_RECTANGLE, SHAPE_CUBE, SHAPE_SPHERE, SHAPE_MESH, SHAPE_DISK = 0, 1, 2, 3, 4
-EMITTER_DIRECTIONAL, EMITTER_AREA, EMITTER_CONSTANT = 0, 1, 2
+EMITTER_DIRECTIONAL, EMITTER_AREA, EMITTER_CONSTANT, EMITTER_POINT = 0, 1, 2, 3
 SENSOR_PERSPECTIVE, SENSOR_DISTANT, SENSOR_MRADIANCEMETER, SENSOR_MDISTANT, SENSOR_DISTANTFLUX = 0, 1, 2, 3, 4
 RFILTER_BOX, RFILTER_GAUSSIAN = 0, 1
 DISTANT_TARGET_NONE, DISTANT_TARGET_POINT, DISTANT_TARGET_SHAPE = 0, 1, 2

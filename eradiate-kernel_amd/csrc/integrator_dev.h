@@ -755,6 +755,12 @@ DEV DirSample emitter_sample_direction(const DScene &sc, int ei, F3 ref_p, F2 sa
         float dist = 2.f * e.bsphere_radius;
         ds.p = ref_p + d * dist; ds.n = -d; ds.pdf = MTS_INV_FOUR_PI; ds.delta = false; ds.d = d; ds.dist = dist;
         spec = f3(e.radiance) / ds.pdf;
+    } else if (e.type == MTS_EMITTER_POINT) {                                                    // point.cpp:80-107
+        ds.p = f3(e.to_world.m[3], e.to_world.m[7], e.to_world.m[11]); ds.n = f3s(0.f); ds.pdf = 1.f; ds.delta = true;
+        ds.d = ds.p - ref_p; ds.dist = norm(ds.d);
+        float inv_dist = pm_rcp(ds.dist);
+        ds.d = ds.d * inv_dist;
+        spec = f3(e.radiance) * (inv_dist * inv_dist);
     } else {
         ds = shape_sample_direction(sc, sc.shapes[e.shape], ref_p, sample);
         bool active = dot(ds.d, ds.n) < 0.f && ds.pdf != 0.f;
@@ -786,7 +792,7 @@ DEV DirSample sample_emitter_direction(const DScene &sc, F3 ref_p, F2 sample, bo
 DEV float pdf_emitter_direction(const DScene &sc, F3 ref_p, const DirSample &ds) {
     const DEmitter &e = sc.emitters[ds.emitter];
     float value;
-    if (e.type == MTS_EMITTER_DIRECTIONAL) value = 0.f;
+    if (e.type == MTS_EMITTER_DIRECTIONAL || e.type == MTS_EMITTER_POINT) value = 0.f;
     else if (e.type == MTS_EMITTER_CONSTANT) value = MTS_INV_FOUR_PI;
     else { float dp = dot(ds.d, ds.n); value = dp < 0.f ? shape_pdf_direction(sc.shapes[e.shape], ref_p, ds) : 0.f; }
     if (sc.emitter_count == 1) return value;

@@ -379,7 +379,7 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
         } else if (e.type == MTS_EMITTER_CONSTANT) {
             if (sc.environment >= 0) throw std::runtime_error("Only one environment emitter can be specified per scene.");
             sc.environment = i;
-        } else if (e.type != MTS_EMITTER_DIRECTIONAL) throw std::runtime_error("unknown emitter type");
+        } else if (e.type != MTS_EMITTER_DIRECTIONAL && e.type != MTS_EMITTER_POINT) throw std::runtime_error("unknown emitter type");
         store3(de.bsphere_center, center); de.bsphere_radius = bsphere_radius;
         hs.emitters.push_back(de);
     }

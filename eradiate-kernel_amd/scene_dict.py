@@ -481,6 +481,15 @@ class SceneBuilder:
             e.type = A.EMITTER_CONSTANT
             e.to_world = _xf(None)
             e.radiance[:] = _color(p.get("radiance"), where, default=1.0)
+        elif p.type == "point":                                             # point.cpp:45-58
+            e.type = A.EMITTER_POINT
+            if p.has("position"):
+                if p.has("to_world"):
+                    raise RuntimeError("Only one of the parameters 'position' and 'to_world' can be specified at the same time!'")
+                e.to_world = _xf(ScalarTransform4f.translate(np.asarray(p.get("position"), dtype=np.float32)))
+            else:
+                e.to_world = _xf(p.get("to_world"))
+            e.radiance[:] = _color(p.get("intensity"), where, default=1.0)
         elif p.type == "area":
             raise RuntimeError("Can't sample from an area emitter without an associated Shape.")
         else:
@@ -732,7 +741,7 @@ class SceneBuilder:
                 raise RuntimeError("Reference found at the scene level: %s" % k)
             if t in SHAPES:
                 self.add_shape(v, k)
-            elif t in ("directional", "constant", "area"):
+            elif t in ("directional", "constant", "area", "point"):
                 self.add_emitter(v, k)
             elif t in ("perspective", "distant", "mradiancemeter", "mdistant", "distantflux", "radiancemeter"):
                 if self.sensor is not None:

@@ -116,7 +116,8 @@ typedef struct mts_shape {
 } mts_shape;
 
 /* ---- Emitters (src/emitters/{directional,area,constant}.cpp) ---- */
-enum { MTS_EMITTER_DIRECTIONAL = 0, MTS_EMITTER_AREA = 1, MTS_EMITTER_CONSTANT = 2 };
+enum { MTS_EMITTER_DIRECTIONAL = 0, MTS_EMITTER_AREA = 1, MTS_EMITTER_CONSTANT = 2,
+       MTS_EMITTER_POINT = 3 /* src/emitters/point.cpp: position = translation of to_world, `radiance` holds the intensity */ };
 typedef struct mts_emitter {
     int32_t type;
     mts_transform to_world;   /* directional: local +z is the direction of propagation           */

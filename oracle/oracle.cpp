@@ -639,6 +639,12 @@ static inline DirectionSample emitter_sample_direction(const Scene &sc, int ei, 
         float dist = 2.f * e.bsphere_radius;
         ds.p = ref_p + d * dist; ds.n = -d; ds.pdf = InvFourPi; ds.delta = false; ds.d = d; ds.dist = dist;
         *spec = e.radiance / ds.pdf;
+    } else if (e.type == MTS_EMITTER_POINT) {                                                // point.cpp:80-107
+        ds.p = xf_translation(e.to_world); ds.n = v3(0, 0, 0); ds.pdf = 1.f; ds.delta = true;
+        ds.d = ds.p - ref_p; ds.dist = norm(ds.d);
+        float inv_dist = pm_rcp(ds.dist);
+        ds.d = ds.d * inv_dist;
+        *spec = e.radiance * (inv_dist * inv_dist);
     } else {
         ds = shape_sample_direction(sc.shapes[e.shape], ref_p, sample);
         bool active = dot(ds.d, ds.n) < 0.f && ds.pdf != 0.f;
@@ -672,7 +678,7 @@ static inline DirectionSample sample_emitter_direction(const Scene &sc, V3 ref_p
 static inline float pdf_emitter_direction(const Scene &sc, V3 ref_p, const DirectionSample &ds) {
     const Emitter &e = sc.emitters[ds.emitter];
     float value;
-    if (e.type == MTS_EMITTER_DIRECTIONAL) value = 0.f;                                    // directional.cpp:143-147
+    if (e.type == MTS_EMITTER_DIRECTIONAL || e.type == MTS_EMITTER_POINT) value = 0.f;     // directional.cpp:143-147, point.cpp:109-112
     else if (e.type == MTS_EMITTER_CONSTANT) value = InvFourPi;                            // constant.cpp:113-117
     else { float dp = dot(ds.d, ds.n); value = dp < 0.f ? shape_pdf_direction(sc.shapes[e.shape], ref_p, ds) : 0.f; }   // area.cpp:168-186
     if (sc.emitters.size() == 1) return value;

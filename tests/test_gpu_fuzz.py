@@ -83,12 +83,15 @@ def _scene(seed):
         else:
             shape["to_world"] = xf
         d["obj%d" % k] = shape
-    et = rng.integers(0, 3)
+    et = rng.integers(0, 4)
     if et == 0:
         d["sun"] = {"type": "directional", "direction": [float(rng.uniform(-.5, .5)), float(rng.uniform(-.5, .5)), -1.0], "irradiance": 2.0}
     elif et == 1:
         d["sky"] = {"type": "constant", "radiance": 0.7}
         d["sun"] = {"type": "directional", "direction": [0.1, 0.3, -1.0], "irradiance": 1.0}
+    elif et == 3:
+        d["bulb"] = {"type": "point", "position": [float(rng.uniform(-2, 2)), float(rng.uniform(-2, 2)), 5.5], "intensity": {"type": "rgb", "value": [30.0, 25.0, 20.0]}}
+        if rng.random() < 0.5: d["sky"] = {"type": "constant", "radiance": 0.2}
     else:
         d["lamp"] = {"type": str(rng.choice(["rectangle", "disk", "cube", "sphere"])), "to_world": T.translate([0.5, 0, 6]) @ T.rotate([1, 0, 0], 180) @ T.scale(1.5),
                      "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [4.0, 3.5, 3.0]}}}

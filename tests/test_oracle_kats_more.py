@@ -255,3 +255,35 @@ def test_integrator_parameter_checks():
     assert desc.integrator.rr_depth == 5 and desc.integrator.max_depth == -1
     with pytest.raises(RuntimeError):
         ob.OracleScene(scene(integrator={"type": "path", "max_depth": -2}))
+
+
+def test_point_emitter_sample_direction():
+    """src/emitters/tests/test_point.py:64-120: a delta light at `position`: density 1, direction towards it, value
+    intensity / distance^2."""
+    pos = [10, -1, 2]
+    o = ob.OracleScene(scene(s={"type": "sphere"}, e={"type": "point", "position": pos, "intensity": 2.0}))
+    for ref in ([0.0, -2.0, 4.5], [0.0, 0.0, 0.0], [-2.0, 0.0, -2.0], [4.5, 4.5, 0.0]):
+        d, dist, pdf, spec = o.emitter_sample_direction(ref, 0.1, 0.5)
+        v = np.array(pos, np.float64) - ref
+        assert pdf == 1.0 and np.isclose(dist, np.linalg.norm(v), rtol=1e-6)
+        assert np.allclose(d, v / np.linalg.norm(v), atol=1e-6)
+        assert np.allclose(spec, 2.0 / np.dot(v, v), rtol=1e-5)
+    with pytest.raises(RuntimeError):                                                       # point.cpp:46-49
+        SD.build_scene_desc(scene(e={"type": "point", "position": pos, "to_world": T.translate([1, 0, 0])}))
+
+
+@pytest.mark.parametrize("integrator", ["path", "volpath", "volpathmis"])
+def test_point_light_over_a_diffuse_floor(integrator):
+    """Closed form: a point light of intensity I at height h over a Lambertian floor seen by a radiancemeter looking straight
+    down at the foot point: L = rho / pi * I / h^2."""
+    d = {"type": "scene", "integrator": {"type": integrator},
+         "sensor": {"type": "radiancemeter", "origin": [0.3, 0.2, 1.0], "direction": [0, 0, -1],
+                    "film": {"type": "hdrfilm", "width": 1, "height": 1, "rfilter": {"type": "box"}},
+                    "sampler": {"type": "independent", "sample_count": 16}},
+         "floor": {"type": "rectangle", "to_world": T.scale(10.0), "bsdf": {"type": "diffuse", "reflectance": 0.6}},
+         "lamp": {"type": "point", "position": [0.3, 0.2, 2.5], "intensity": 7.0}}
+    film = ob.OracleScene(d).render()
+    rgb = (film[..., :3] / film[..., 4:5])
+    import tests.transport_cases as tc
+    L = tc.radiance_rgb(film).reshape(3)
+    assert np.allclose(L, 0.6 / math.pi * 7.0 / 2.5 ** 2, rtol=1e-5)
