@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MTSAMD_LIB") or os.path.join(HERE, "libmtsamd.so")
 
-MTS_ABI_VERSION = 2
+MTS_ABI_VERSION = 3
 
 # enums (include/mtsamd.h)
 VOLUME_CONST, VOLUME_GRID = 0, 1
@@ -78,7 +78,8 @@ class Sensor(C.Structure):
                 ("film_width", i32), ("film_height", i32), ("crop_offset", i32 * 2), ("crop_size", i32 * 2),
                 ("rfilter_type", i32), ("rfilter_radius", f32), ("rfilter_stddev", f32),
                 ("sample_count", i32), ("sampler_seed", C.c_uint64), ("medium", i32),
-                ("multi_transforms", C.POINTER(C.c_float)), ("multi_count", i32)]
+                ("multi_transforms", C.POINTER(C.c_float)), ("multi_count", i32),
+                ("shutter_open_time", f32)]
 
 
 class Integrator(C.Structure):

@@ -25,6 +25,7 @@ __device__ __forceinline__ void render_sample(const DScene &sc, Pcg32 &rng, cons
     F2 position_sample; position_sample.x = px + u.x; position_sample.y = py + u.y;
     F2 aperture_sample; aperture_sample.x = .5f; aperture_sample.y = .5f;
     if (se.needs_aperture_sample) aperture_sample = rng.next_2d();
+    if (se.shutter_open_time > 0.f) (void) rng.next_1d();        // time sample (integrator.cpp:248-250)
     (void) rng.next_1d();                                       // wavelength sample (integrator.cpp:252), unused in rgb
     F2 adjusted;
     adjusted.x = (position_sample.x - (float) se.crop_x) / (float) se.crop_w;

@@ -394,7 +394,7 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
     se.rfilter = build_rfilter(s.rfilter_type, s.rfilter_radius, s.rfilter_stddev, hs.rfilter_values);
     if (se.rfilter.radius > 16.f) throw std::runtime_error("reconstruction filter radius too large");
     if (s.sample_count <= 0) throw std::runtime_error("sampler: sample_count must be positive");
-    se.sample_count = s.sample_count; se.seed = s.sampler_seed; se.medium = s.medium;
+    se.sample_count = s.sample_count; se.seed = s.sampler_seed; se.medium = s.medium; se.shutter_open_time = s.shutter_open_time;
     check_index(s.medium, d->medium_count, "sensor medium", true);
     if (s.type == MTS_SENSOR_PERSPECTIVE) {
         se.near_clip = s.near_clip; se.far_clip = s.far_clip;

@@ -554,8 +554,10 @@ class SceneBuilder:
         s.sample_count = int(sp.get("sample_count", 4))
         s.sampler_seed = int(sp.get("seed", 0))
         sp.finish()
-        if float(p.get("shutter_open", 0.0)) != float(p.get("shutter_close", 0.0)):
-            raise RuntimeError("motion blur (shutter_open != shutter_close) is not supported")
+        shutter_open, shutter_close = float(p.get("shutter_open", 0.0)), float(p.get("shutter_close", 0.0))      # sensor.cpp:20-27
+        if shutter_close < shutter_open:
+            raise RuntimeError("Shutter opening time must be less than or equal to the shutter closing time!")
+        s.shutter_open_time = shutter_close - shutter_open
         if p.has("medium"):
             s.medium = self.add_medium(p.get("medium"), where + ".medium")
         if p.type == "perspective":

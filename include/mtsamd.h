@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MTS_ABI_VERSION 2
+#define MTS_ABI_VERSION 3
 
 /* Transform4f: row-major 4x4 matrix and its inverse transpose (transform.h:36-50). */
 typedef struct mts_transform {
@@ -164,6 +164,9 @@ typedef struct mts_sensor {
      * multi_count x 1.  mdistant's "target" travels in distant_target_type / _point / _shape. */
     const float *multi_transforms;
     int32_t multi_count;
+    float shutter_open_time;  /* "shutter_close" - "shutter_open" (sensor.cpp:20-27).  Nothing on this path is animated, so
+                                 the only effect is the reference's: one more sampler draw per sample when it is > 0
+                                 (integrator.cpp:248-250) */
 } mts_sensor;
 
 /* ---- Integrator (src/integrators/{path,volpath}.cpp, src/librender/integrator.cpp:23-39,302-315) */

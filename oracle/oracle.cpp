@@ -1479,7 +1479,7 @@ static void render_sample(const Scene &sc, Sampler &sampler, ImageBlock &block, 
     P2 position_sample = { px + u.x, py + u.y };
     P2 aperture_sample = { .5f, .5f };
     if (se.needs_aperture_sample) aperture_sample = sampler.next_2d();
-    /* time: shutter_open_time == 0 for every supported sensor (no draw) */
+    if (se.shutter_open_time > 0.f) (void) sampler.next_1d();      // integrator.cpp:248-250: the time sample (nothing is animated)
     float wavelength_sample = sampler.next_1d(); (void) wavelength_sample;
     P2 adjusted = { (position_sample.x - (float) se.crop_x) / (float) se.crop_w, (position_sample.y - (float) se.crop_y) / (float) se.crop_h };
     V3 ray_weight;

@@ -312,6 +312,7 @@ struct Sensor {
     int target_type; V3 target_point; Shape target_shape;
     V3 bsphere_center; float bsphere_radius;
     bool needs_aperture_sample;
+    float shutter_open_time = 0.f;
     int medium;
     // film
     int width, height, crop_x, crop_y, crop_w, crop_h;
@@ -462,7 +463,7 @@ static inline Scene *make_scene(const mts_scene_desc *d) {
         se.crop_x = s.crop_offset[0]; se.crop_y = s.crop_offset[1]; se.crop_w = s.crop_size[0]; se.crop_h = s.crop_size[1];
         if (se.width <= 0 || se.height <= 0 || se.crop_w <= 0 || se.crop_h <= 0) throw std::runtime_error("film: invalid size");
         se.rfilter = make_rfilter(s.rfilter_type, s.rfilter_radius, s.rfilter_stddev);
-        se.sample_count = s.sample_count; se.seed = s.sampler_seed; se.medium = s.medium;
+        se.sample_count = s.sample_count; se.seed = s.sampler_seed; se.medium = s.medium; se.shutter_open_time = s.shutter_open_time;
         check_index(s.medium, d->medium_count, "sensor medium", true);
         if (s.type == MTS_SENSOR_PERSPECTIVE) {
             se.near_clip = s.near_clip; se.far_clip = s.far_clip;

@@ -265,6 +265,20 @@ def test_mesh_area_emitters_match_the_oracle(gpu_rgb, integrator):
     assert np.array_equal(gpu, ref) and gpu[..., :3].max() > 0
 
 
+@pytest.mark.parametrize("kernel", [None, "nested"])
+def test_open_shutter_matches_the_oracle(gpu_rgb, monkeypatch, kernel):
+    """integrator.cpp:248-250: an open shutter adds the time draw to every sample (both kernel formulations)."""
+    if kernel:
+        monkeypatch.setenv("MTSAMD_KERNEL", kernel)
+    for d in (scenes.c3_heterogeneous(40, 24, 8, res=16), scenes.c1_cornell(24, 24, 8)):
+        d = dict(d); d["sensor"] = dict(d["sensor"], shutter_open=1.0, shutter_close=1.5)
+        gpu, st = gpu_render(gpu_rgb, d, collect_counters=True)
+        ref = ob.OracleScene(d).render()
+        assert np.array_equal(gpu, ref) and gpu[..., :3].max() > 0
+        d["sensor"] = dict(d["sensor"], shutter_close=1.0)
+        assert not np.array_equal(ref, ob.OracleScene(d).render())
+
+
 @pytest.mark.parametrize("integrator", ["path", "volpath", "volpathmis"])
 def test_bilambertian_canopy_matches_the_oracle(gpu_rgb, integrator):
     """Eradiate's leaf BSDF (src/bsdfs/bilambertian.cpp): a small canopy of two-sided reflecting / transmitting leaves over a
