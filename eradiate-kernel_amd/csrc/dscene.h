@@ -100,6 +100,8 @@ struct DSensor {
     float bsphere_center[3], bsphere_radius;
     int32_t needs_aperture_sample, medium;
     float shutter_open_time;       // > 0: one more draw per sample (integrator.cpp:248-250)
+    int32_t origin_type;           // distant / distantflux: 1 = project the target onto origin_shape (distant.cpp:368-375)
+    DShape origin_shape;
     int32_t width, height, crop_x, crop_y, crop_w, crop_h;
     DRFilter rfilter;
     int32_t sample_count;

@@ -1433,6 +1433,17 @@ DEV F3 integrator_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, boo
 }
 
 // ---------------------------------------------------------------- sensors
+// Shape::ray_intersect (shape.cpp:344-352) of a stand-alone analytic shape, reduced to the hit point the distant sensors read
+DEV bool shape_hit_point(const DScene &sc, const DShape &s, const DRay &ray, F3 &p) {
+    F2 uv; Hit h; h.uv.x = h.uv.y = 0.f; h.shape = -1; h.prim = 0;
+    if (s.type == MTS_SHAPE_RECTANGLE) h.t = rectangle_intersect(s.to_object.m, ray, uv);
+    else if (s.type == MTS_SHAPE_DISK) h.t = disk_intersect(s.to_object.m, ray, uv);
+    else h.t = sphere_intersect(s.center, s.radius, ray);
+    if (h.t == pm_inf()) return false;
+    hit_point(sc, s, ray, h);
+    p = h.p;
+    return true;
+}
 // sensors/perspective.cpp:210-252 ; sensors/distant.cpp:299-386
 DEV DRay sensor_sample_ray(const DScene &sc, F2 position_sample, F2 aperture_sample, F3 &weight) {
     const DSensor &se = sc.sensor;
@@ -1485,8 +1496,12 @@ DEV DRay sensor_sample_ray(const DScene &sc, F2 position_sample, F2 aperture_sam
             F3 perp_offset = mat_vector(se.to_world.m, f3(offset.x, offset.y, 0.f));
             ray_target = f3(se.bsphere_center) + perp_offset * se.bsphere_radius;
         }
+        F3 o = ray_target - d * 2.f * se.bsphere_radius;
+        if (se.origin_type != 0) {                                                                // distantflux.cpp:244-252
+            if (!shape_hit_point(sc, se.origin_shape, make_ray(ray_target, -d, MTS_RAY_EPSILON, pm_inf()), o)) { o = f3s(pm_nan()); w = 0.f; }
+        }
         weight = f3s(w);
-        return make_ray(ray_target - d * 2.f * se.bsphere_radius, d, MTS_RAY_EPSILON, pm_inf());
+        return make_ray(o, d, MTS_RAY_EPSILON, pm_inf());
     }
     F3 v0 = f3(0.f, 0.f, 1.f);
     if (se.direction_type == 2) v0 = square_to_uniform_hemisphere(position_sample);
@@ -1504,7 +1519,9 @@ DEV DRay sensor_sample_ray(const DScene &sc, F2 position_sample, F2 aperture_sam
         ray_target = f3(se.bsphere_center) + perp_offset * se.bsphere_radius;
         w = 1.f / dot(-d, f3(0.f, 0.f, 1.f));
     }
-    if (se.target_type == MTS_DISTANT_TARGET_NONE) o = ray_target - d * se.bsphere_radius;
+    if (se.origin_type != 0) {                                                                    // distant.cpp:368-375
+        if (!shape_hit_point(sc, se.origin_shape, make_ray(ray_target, -d, MTS_RAY_EPSILON, pm_inf()), o)) { o = f3s(pm_nan()); w = 0.f; }
+    } else if (se.target_type == MTS_DISTANT_TARGET_NONE) o = ray_target - d * se.bsphere_radius;
     else o = ray_target - d * 2.f * se.bsphere_radius;
     weight = f3s(w);
     return make_ray(o, d, MTS_RAY_EPSILON, pm_inf());

@@ -425,6 +425,13 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
                 : 4.f * MTS_PI * se.target_shape.radius * se.target_shape.radius;
         } else if (se.target_type != MTS_DISTANT_TARGET_NONE && se.target_type != MTS_DISTANT_TARGET_POINT)
             throw std::runtime_error("distant sensor: unknown ray_target type");
+        if (s.distant_origin_type != 0) {                                                      // distant.cpp:280-289, distantflux.cpp:172-184
+            HostScene scratch; DBBox sb; int pc;
+            if (s.distant_origin_shape.type != MTS_SHAPE_RECTANGLE && s.distant_origin_shape.type != MTS_SHAPE_SPHERE && s.distant_origin_shape.type != MTS_SHAPE_DISK)
+                throw std::runtime_error("distant sensor: the ray origin shape must be a rectangle, a disk or a sphere in this backend");
+            se.origin_type = 1;
+            se.origin_shape = build_shape(s.distant_origin_shape, scratch, sb, pc);
+        }
         store3(se.bsphere_center, center); se.bsphere_radius = bsphere_radius;
         se.needs_aperture_sample = 1;                                                          // endpoint.h:244
     } else if (s.type == MTS_SENSOR_MRADIANCEMETER || s.type == MTS_SENSOR_MDISTANT) {        // mradiancemeter.cpp:72-132, mdistant.cpp:147-203

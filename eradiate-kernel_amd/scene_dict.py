@@ -150,6 +150,9 @@ def parse_fov(p, aspect):
     return float(np.float32(result))
 
 
+SHAPE_PLUGINS = ("rectangle", "cube", "sphere", "mesh", "obj", "ply", "disk")
+
+
 class SceneBuilder:
     """Accumulates plugin records; keeps every numpy buffer alive for the lifetime of the description."""
 
@@ -505,6 +508,8 @@ class SceneBuilder:
         s.medium = -1
         s.distant_target_shape.bsdf = s.distant_target_shape.interior_medium = -1
         s.distant_target_shape.exterior_medium = s.distant_target_shape.emitter = -1
+        s.distant_origin_shape.bsdf = s.distant_origin_shape.interior_medium = -1
+        s.distant_origin_shape.exterior_medium = s.distant_origin_shape.emitter = -1
         # film (src/librender/film.cpp:14-50, src/films/hdrfilm.cpp)
         fd = p.get("film", {"type": "hdrfilm"})
         fp_ = Props(fd, where + ".film")
@@ -604,8 +609,13 @@ class SceneBuilder:
                 else:
                     s.distant_target_type = A.DISTANT_TARGET_POINT
                     s.distant_target_point[:] = tuple(float(x) for x in np.asarray(rt, dtype=np.float32))
-            if p.has("ray_origin"):
-                raise RuntimeError("distant sensor: 'ray_origin' shapes are not supported by this backend")
+            if p.has("ray_origin"):                                         # distant.cpp:280-289
+                ro = p.get("ray_origin")
+                if not isinstance(ro, dict) or ro.get("type") not in SHAPE_PLUGINS:
+                    raise RuntimeError("Invalid parameter ray_origin, must be a Shape.")
+                s.distant_origin_type = 1
+                rec, _ = self.make_shape(ro, where + ".ray_origin", in_scene=False)
+                s.distant_origin_shape = rec
         elif p.type == "radiancemeter":
             # src/sensors/radiancemeter.cpp:60-98: one ray along +z of to_world (or of look_at(origin, origin + direction)); it is the
             # one-sub-sensor case of mradiancemeter (same ray arithmetic, :124-127 vs mradiancemeter.cpp:150-153)
@@ -646,10 +656,13 @@ class SceneBuilder:
                 else:
                     s.distant_target_type = A.DISTANT_TARGET_POINT
                     s.distant_target_point[:] = tuple(float(x) for x in np.asarray(tg, dtype=np.float32))
-            if p.has("origin"):
-                if not isinstance(p.get("origin"), dict) or p.get("origin").get("type") not in ("rectangle", "sphere", "cube", "disk"):
+            if p.has("origin"):                                             # distantflux.cpp:172-184
+                ro = p.get("origin")
+                if not isinstance(ro, dict) or ro.get("type") not in SHAPE_PLUGINS:
                     raise RuntimeError("Invalid parameter origin, must be a Shape.")
-                raise RuntimeError("distantflux sensor: 'origin' shapes are not supported by this backend")
+                s.distant_origin_type = 1
+                rec, _ = self.make_shape(ro, where + ".origin", in_scene=False)
+                s.distant_origin_shape = rec
         elif p.type in ("mradiancemeter", "mdistant"):
             # src/sensors/mradiancemeter.cpp:72-132 / src/sensors/mdistant.cpp:60-98,147-203: N sub-sensors, one per film column
             multi = p.type == "mradiancemeter"

@@ -167,6 +167,11 @@ typedef struct mts_sensor {
     float shutter_open_time;  /* "shutter_close" - "shutter_open" (sensor.cpp:20-27).  Nothing on this path is animated, so
                                  the only effect is the reference's: one more sampler draw per sample when it is > 0
                                  (integrator.cpp:248-250) */
+    /* distant "ray_origin" / distantflux "origin" (distant.cpp:126-130,280-289,367-383; distantflux.cpp:172-184,244-255):
+     * 0 = ray origins on the scene's bounding sphere, 1 = the target point is projected onto this shape against the ray
+     * direction (rectangle, disk or sphere; a miss gives the sample a zero weight) */
+    int32_t distant_origin_type;
+    mts_shape distant_origin_shape;
 } mts_sensor;
 
 /* ---- Integrator (src/integrators/{path,volpath}.cpp, src/librender/integrator.cpp:23-39,302-315) */

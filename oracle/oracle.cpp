@@ -210,6 +210,18 @@ static inline void mesh_fill(const Shape &s, const PreliminaryIntersection &pi, 
         si.sh_frame.n = normalize(n0 * b0 + n1 * b1 + n2 * b2);
     } else si.sh_frame.n = si.n;
 }
+// Shape::ray_intersect (shape.cpp:344-352) of a stand-alone analytic shape, reduced to what the distant sensors read: the hit
+// point (rectangle.cpp:181-185, disk.cpp:186-188, sphere.cpp:325-327)
+static inline bool shape_hit_point(const Shape &s, const Ray &ray, V3 *p) {
+    P2 uv; float t;
+    if (s.type == MTS_SHAPE_RECTANGLE) t = rectangle_intersect(s, ray, &uv);
+    else if (s.type == MTS_SHAPE_DISK) t = disk_intersect(s, ray, &uv);
+    else t = sphere_intersect(s, ray);
+    if (t == pm_inf()) return false;
+    if (s.type == MTS_SHAPE_SPHERE) { V3 n = normalize(ray(t) - s.center); *p = fmadd(n, s.radius, s.center); }
+    else { V3 q = ray(t); float dist = dot(xf_translation(s.to_world) - q, s.frame.n); *p = fmadd(s.frame.n, dist, q); }
+    return true;
+}
 // sphere.cpp:308-380 (uv is not needed by any supported BSDF / emitter and is left at zero)
 static inline void sphere_fill(const Shape &s, const Ray &ray, const PreliminaryIntersection &pi, SurfaceInteraction &si) {
     si.sh_frame.n = normalize(ray(pi.t) - s.center);
@@ -1350,8 +1362,12 @@ static Ray sensor_sample_ray(const Scene &sc, P2 position_sample, P2 aperture_sa
             V3 perp_offset = xf_vector(se.to_world, v3(offset.x, offset.y, 0.f));
             ray_target = se.bsphere_center + perp_offset * se.bsphere_radius;
         }
+        V3 o = ray_target - d * 2.f * se.bsphere_radius;
+        if (se.origin_is_shape) {                                                         // distantflux.cpp:244-252
+            if (!shape_hit_point(se.origin_shape, make_ray(ray_target, -d, RayEpsilon, pm_inf()), &o)) { o = v3(pm_nan(), pm_nan(), pm_nan()); w = 0.f; }
+        }
         *weight = v3(w, w, w);
-        return make_ray(ray_target - d * 2.f * se.bsphere_radius, d, RayEpsilon, pm_inf());
+        return make_ray(o, d, RayEpsilon, pm_inf());
     }
     // distant.cpp:299-386
     V3 v0 = v3(0.f, 0.f, 1.f);
@@ -1374,7 +1390,9 @@ static Ray sensor_sample_ray(const Scene &sc, P2 position_sample, P2 aperture_sa
         float w = 1.f / dot(-d, v3(0.f, 0.f, 1.f));
         ray_weight = v3(w, w, w);
     }
-    if (se.target_type == MTS_DISTANT_TARGET_NONE) o = ray_target - d * se.bsphere_radius;
+    if (se.origin_is_shape) {                                                             // distant.cpp:368-375
+        if (!shape_hit_point(se.origin_shape, make_ray(ray_target, -d, RayEpsilon, pm_inf()), &o)) { o = v3(pm_nan(), pm_nan(), pm_nan()); ray_weight = v3(0.f, 0.f, 0.f); }
+    } else if (se.target_type == MTS_DISTANT_TARGET_NONE) o = ray_target - d * se.bsphere_radius;
     else o = ray_target - d * 2.f * se.bsphere_radius;
     *weight = ray_weight;
     Ray ray; ray.o = o; ray.d = d; ray.d_rcp = vrcp(d); ray.mint = RayEpsilon; ray.maxt = pm_inf();   // ray.h:33-34 defaults

@@ -313,6 +313,7 @@ struct Sensor {
     V3 bsphere_center; float bsphere_radius;
     bool needs_aperture_sample;
     float shutter_open_time = 0.f;
+    bool origin_is_shape = false; Shape origin_shape;      // distant.cpp:280-289, distantflux.cpp:172-184
     int medium;
     // film
     int width, height, crop_x, crop_y, crop_w, crop_h;
@@ -464,6 +465,12 @@ static inline Scene *make_scene(const mts_scene_desc *d) {
         if (se.width <= 0 || se.height <= 0 || se.crop_w <= 0 || se.crop_h <= 0) throw std::runtime_error("film: invalid size");
         se.rfilter = make_rfilter(s.rfilter_type, s.rfilter_radius, s.rfilter_stddev);
         se.sample_count = s.sample_count; se.seed = s.sampler_seed; se.medium = s.medium; se.shutter_open_time = s.shutter_open_time;
+        if ((s.type == MTS_SENSOR_DISTANT || s.type == MTS_SENSOR_DISTANTFLUX) && s.distant_origin_type != 0) {
+            se.origin_is_shape = true;
+            se.origin_shape = make_shape(s.distant_origin_shape);
+            if (se.origin_shape.type != MTS_SHAPE_RECTANGLE && se.origin_shape.type != MTS_SHAPE_SPHERE && se.origin_shape.type != MTS_SHAPE_DISK)
+                throw std::runtime_error("distant sensor: the ray origin shape must be a rectangle, a disk or a sphere in this backend");
+        }
         check_index(s.medium, d->medium_count, "sensor medium", true);
         if (s.type == MTS_SENSOR_PERSPECTIVE) {
             se.near_clip = s.near_clip; se.far_clip = s.far_clip;

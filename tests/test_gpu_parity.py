@@ -279,6 +279,29 @@ def test_open_shutter_matches_the_oracle(gpu_rgb, monkeypatch, kernel):
         assert not np.array_equal(ref, ob.OracleScene(d).render())
 
 
+@pytest.mark.parametrize("sensor", ["distant", "distantflux"])
+@pytest.mark.parametrize("origin", ["rectangle", "disk", "sphere", "unreachable"])
+def test_ray_origin_shapes_match_the_oracle(gpu_rgb, sensor, origin):
+    """distant `ray_origin` / distantflux `origin` (distant.cpp:367-383, distantflux.cpp:244-255): the target is projected onto
+    the origin shape; samples whose projection misses it carry a zero weight (and still consume their random numbers)."""
+    d = scenes.c2_homogeneous_slab(8, 6, 16)
+    shape = {"rectangle": {"type": "rectangle", "to_world": T.translate([0, 0, 2.5]) @ T.scale(40.0)},
+             "disk": {"type": "disk", "to_world": T.translate([0, 0, 3.0]) @ T.rotate([1, 0, 0], 10) @ T.scale(6.0)},
+             "sphere": {"type": "sphere", "center": [0, 0, 1], "radius": 30.0},
+             "unreachable": {"type": "rectangle", "to_world": T.translate([0, 0, -5.0])}}[origin]
+    film = dict(d["sensor"]["film"]); sampler = d["sensor"]["sampler"]
+    if sensor == "distant":
+        d["sensor"] = {"type": "distant", "film": film, "sampler": sampler, "ray_origin": shape,
+                       "ray_target": {"type": "rectangle", "to_world": T.translate([0, 0, 2.0]) @ T.scale(2.0)}}
+    else:
+        d["sensor"] = {"type": "distantflux", "film": film, "sampler": sampler, "origin": shape, "target": [0.0, 0.0, 2.0]}
+    gpu, st = gpu_render(gpu_rgb, d, collect_counters=True)
+    o = ob.OracleScene(d); ref = o.render(); so = o.last_stats
+    assert np.array_equal(gpu, ref)
+    assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
+    assert (gpu[..., :3].max() > 0) == (origin != "unreachable")
+
+
 @pytest.mark.parametrize("integrator", ["path", "volpath", "volpathmis"])
 def test_bilambertian_canopy_matches_the_oracle(gpu_rgb, integrator):
     """Eradiate's leaf BSDF (src/bsdfs/bilambertian.cpp): a small canopy of two-sided reflecting / transmitting leaves over a

@@ -307,3 +307,80 @@ def test_shutter_time_costs_one_draw_per_sample():
     assert abs(a - b) < 0.03 * a
     with pytest.raises(RuntimeError):                                                       # sensor.cpp:23-25
         SD.build_scene_desc(scene(sensor={"type": "perspective", "shutter_open": 2.0, "shutter_close": 1.0, "film": FILM4}))
+
+
+# ---------------------------------------------------------------- ray origins of the distant sensors
+ORIGIN_SAMPLES = [[[0.32, 0.87], [0.16, 0.44]], [[0.17, 0.44], [0.22, 0.81]], [[0.12, 0.82], [0.99, 0.42]], [[0.72, 0.40], [0.01, 0.61]]]
+FILM1 = {"type": "hdrfilm", "width": 1, "height": 1, "rfilter": {"type": "box"}}
+
+
+def test_distant_ray_origin_shape():
+    """src/sensors/tests/test_distant.py:214-297: without `ray_origin` the rays start on the bounding sphere; with a shape the
+    target point is projected onto it against the ray direction (here a plane at z = 3.42); an origin surface that cannot be
+    reached gives an invalid origin and a zero weight."""
+    base = {"type": "scene", "integrator": {"type": "path"}, "shape": {"type": "rectangle"}}
+    o = ob.OracleScene(dict(base, sensor={"type": "distant", "direction": [0, 0, 1], "film": FILM1}))
+    radius = np.sqrt(2.0)
+    for s1, s2 in ORIGIN_SAMPLES:
+        ro, rd, w = o.sensor_sample_ray([s1], [s2])
+        assert np.isclose(ro[0, 2], radius, rtol=1e-3)
+    z_offset = 3.42
+    for direction in ([0, 0, 1], [0, 2, 1]):
+        o = ob.OracleScene(dict(base, sensor={"type": "distant", "direction": direction, "film": FILM1,
+                                              "ray_origin": {"type": "rectangle", "to_world": T.translate([0, 0, z_offset]) @ T.scale(10)}}))
+        for s1, s2 in ORIGIN_SAMPLES:
+            ro, rd, w = o.sensor_sample_ray([s1], [s2])
+            assert np.isclose(ro[0, 2], z_offset, rtol=1e-6) and np.all(w > 0)
+            # the origin lies on the ray through the target: stepping along d from it reaches the bounding-sphere disk point
+            dn = np.asarray(direction, np.float64) / np.linalg.norm(direction)
+            assert np.allclose(rd[0], -dn, atol=1e-6)
+    o = ob.OracleScene(dict(base, sensor={"type": "distant", "direction": [0, 0, 1], "film": FILM1,
+                                          "ray_origin": {"type": "rectangle", "to_world": T.translate([0, 0, -1.0])}}))
+    for s1, s2 in ORIGIN_SAMPLES:
+        ro, rd, w = o.sensor_sample_ray([s1], [s2])
+        assert np.isnan(ro).any() and np.allclose(w, 0.0)
+    with pytest.raises(RuntimeError):                                                       # test_distant.py:134-136
+        SD.build_scene_desc(dict(base, sensor={"type": "distant", "film": FILM1, "ray_origin": {"type": "constant"}}))
+
+
+def test_distantflux_origin_shape():
+    """src/sensors/tests/test_distantflux.py:109-178 (the reference expects infinite rather than NaN coordinates for the
+    unreachable origin; this backend reports NaN for both sensors -- the weight is zero either way)."""
+    base = {"type": "scene", "integrator": {"type": "path"}, "shape": {"type": "rectangle"}}
+    film = {"type": "hdrfilm", "width": 4, "height": 4, "rfilter": {"type": "box"}}
+    o = ob.OracleScene(dict(base, sensor={"type": "distantflux", "film": film}))
+    for s1, s2 in ORIGIN_SAMPLES:
+        ro, rd, w = o.sensor_sample_ray([s1], [s2])
+        assert np.linalg.norm(ro[0]) > np.sqrt(2.0)
+    z_offset = 3.42
+    o = ob.OracleScene(dict(base, sensor={"type": "distantflux", "film": film,
+                                          "origin": {"type": "rectangle", "to_world": T.translate([0, 0, z_offset]) @ T.scale(10)}}))
+    for s1, s2 in ORIGIN_SAMPLES:
+        ro, rd, w = o.sensor_sample_ray([s1], [s2])
+        assert np.isclose(ro[0, 2], z_offset, rtol=1e-6)
+    o = ob.OracleScene(dict(base, sensor={"type": "distantflux", "film": film,
+                                          "origin": {"type": "rectangle", "to_world": T.translate([0, 0, -1.0])}}))
+    for s1, s2 in ORIGIN_SAMPLES:
+        ro, rd, w = o.sensor_sample_ray([s1], [s2])
+        assert not np.isfinite(ro).all() and np.allclose(w, 0.0)
+    with pytest.raises(RuntimeError):                                                       # test_distantflux.py:99-101
+        SD.build_scene_desc(dict(base, sensor={"type": "distantflux", "film": film, "origin": {"type": "constant"}}))
+
+
+def test_origin_shape_leaves_the_radiance_alone():
+    """The origin only moves the ray start along its line: with nothing between the two origins the image is unchanged, sample
+    for sample (the draws are the same)."""
+    base = {"type": "scene", "integrator": {"type": "path"},
+            "shape": {"type": "rectangle", "bsdf": {"type": "diffuse", "reflectance": 0.5}},
+            "sun": {"type": "directional", "direction": [0.3, 0.2, -1], "irradiance": 1.0}}
+    film = {"type": "hdrfilm", "width": 6, "height": 6, "rfilter": {"type": "box"}}
+    sensor = {"type": "distant", "film": film, "ray_target": {"type": "rectangle", "to_world": T.scale(0.5)},
+              "sampler": {"type": "independent", "sample_count": 32}}
+    a = ob.OracleScene(dict(base, sensor=sensor)).render()
+    b = ob.OracleScene(dict(base, sensor=dict(sensor, ray_origin={"type": "sphere", "radius": 4.0}))).render()
+    assert a[..., :3].max() > 0
+    assert np.allclose(a, b, rtol=1e-5, atol=1e-7)
+    one = dict(sensor, film=FILM1, direction=[0.2, 0.1, 1.0])                               # a single direction that reaches the disk
+    a = ob.OracleScene(dict(base, sensor=one)).render()
+    c = ob.OracleScene(dict(base, sensor=dict(one, ray_origin={"type": "disk", "to_world": T.translate([0, 0, 2.0]) @ T.scale(3.0)}))).render()
+    assert a[..., :3].max() > 0 and np.allclose(a, c, rtol=1e-5, atol=1e-7)
