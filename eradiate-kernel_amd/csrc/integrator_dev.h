@@ -656,7 +656,11 @@ DEV F3 bsdf_sample(const DBsdf &b, F3 wi, float sample1, F2 sample2, BSDFSample 
 struct DirSample { F3 p, n, d; float pdf, dist; bool delta; int32_t emitter; };
 
 // shapes/rectangle.cpp:111-124 ; shapes/sphere.cpp (sample_position)
-DEV void shape_sample_position(const DScene &sc, const DShape &s, F2 sample, F3 &p, F3 &n, float &pdf) {
+// The mesh tables travel as three pointers, not as the scene record: shape_sample_direction() is a real function, and a reference
+// to the kernel-argument record would force a copy of all of it into scratch memory.
+struct MeshTables { const float *area_pmf, *area_cdf, *tri_attr; };
+DEV MeshTables mesh_tables(const DScene &sc) { MeshTables m; m.area_pmf = sc.area_pmf; m.area_cdf = sc.area_cdf; m.tri_attr = sc.tri_attr; return m; }
+DEV void shape_sample_position(const MeshTables sc, const DShape &s, F2 sample, F3 &p, F3 &n, float &pdf) {
     if (s.type == MTS_SHAPE_CUBE || s.type == MTS_SHAPE_MESH) {                               // mesh.cpp:352-397
         // DiscreteDistribution::sample_reuse (distr_1d.h:141-151,187-197): first face whose running area reaches sample.y * sum
         const MTS_GLOBAL_AS float *cdf = as_global(sc.area_cdf) + s.prim_offset;
@@ -689,7 +693,7 @@ DEV void shape_sample_position(const DScene &sc, const DShape &s, F2 sample, F3 
     pdf = s.inv_surface_area;
 }
 // librender/shape.cpp:293-310 ; shapes/sphere.cpp (sample_direction)
-DEV_NOINLINE DirSample shape_sample_direction(const DScene &sc, const DShape &s, F3 ref_p, F2 sample) {
+DEV_NOINLINE DirSample shape_sample_direction(const MeshTables sc, const DShape &s, F3 ref_p, F2 sample) {
     DirSample ds; ds.delta = false; ds.emitter = -1;
     if (s.type != MTS_SHAPE_SPHERE) {
         shape_sample_position(sc, s, sample, ds.p, ds.n, ds.pdf);
@@ -762,7 +766,7 @@ DEV DirSample emitter_sample_direction(const DScene &sc, int ei, F3 ref_p, F2 sa
         ds.d = ds.d * inv_dist;
         spec = f3(e.radiance) * (inv_dist * inv_dist);
     } else {
-        ds = shape_sample_direction(sc, sc.shapes[e.shape], ref_p, sample);
+        ds = shape_sample_direction(mesh_tables(sc), sc.shapes[e.shape], ref_p, sample);
         bool active = dot(ds.d, ds.n) < 0.f && ds.pdf != 0.f;
         spec = active ? f3(e.radiance) / ds.pdf : f3s(0.f);
     }
@@ -1471,7 +1475,7 @@ DEV DRay sensor_sample_ray(const DScene &sc, F2 position_sample, F2 aperture_sam
         if (se.target_type == MTS_DISTANT_TARGET_POINT) o = f3(se.target_point) - 2.f * d * se.bsphere_radius;
         else if (se.target_type == MTS_DISTANT_TARGET_SHAPE) {
             F3 tp, n; float pdf;
-            shape_sample_position(sc, se.target_shape, aperture_sample, tp, n, pdf);
+            shape_sample_position(mesh_tables(sc), se.target_shape, aperture_sample, tp, n, pdf);
             o = tp - 2.f * d * se.bsphere_radius;
             w = 1.f / (pdf * se.target_area);
         } else {
@@ -1489,7 +1493,7 @@ DEV DRay sensor_sample_ray(const DScene &sc, F2 position_sample, F2 aperture_sam
         F3 ray_target = f3(se.target_point);
         if (se.target_type == MTS_DISTANT_TARGET_SHAPE) {
             F3 n; float pdf;
-            shape_sample_position(sc, se.target_shape, aperture_sample, ray_target, n, pdf);
+            shape_sample_position(mesh_tables(sc), se.target_shape, aperture_sample, ray_target, n, pdf);
             w *= 1.f / (pdf * se.target_area);
         } else if (se.target_type == MTS_DISTANT_TARGET_NONE) {
             F2 offset = square_to_uniform_disk_concentric(aperture_sample);
@@ -1511,7 +1515,7 @@ DEV DRay sensor_sample_ray(const DScene &sc, F2 position_sample, F2 aperture_sam
     float w = 1.f;
     if (se.target_type == MTS_DISTANT_TARGET_SHAPE) {
         F3 n; float pdf;
-        shape_sample_position(sc, se.target_shape, aperture_sample, ray_target, n, pdf);
+        shape_sample_position(mesh_tables(sc), se.target_shape, aperture_sample, ray_target, n, pdf);
         w = 1.f / pdf / se.target_area;
     } else if (se.target_type == MTS_DISTANT_TARGET_NONE) {
         F2 offset = square_to_uniform_disk_concentric(aperture_sample);

@@ -52,3 +52,32 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(A, "LIB_PATH", "/nonexistent/libmtsamd.so")
     with pytest.raises(A.BackendError):
         A.lib()
+
+
+def test_default_kernel_resource_budget(tmp_path):
+    """Guards the default render kernel against silent code-generation regressions (a reference to the kernel-argument record
+    handed to a real function once put the whole record in scratch memory and cost 2.4x): reads the code object's own metadata."""
+    import re
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip("ROCm LLVM tools not found")
+    lib = os.environ.get("MTSAMD_LIB") or os.path.join(ROOT, "eradiate-kernel_amd", "libmtsamd.so")
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
+    subprocess.run([tools[0], "-O", "binary", "--only-section=.hip_fatbin", lib, fat], check=True)
+    subprocess.run([tools[1], "--unbundle", "--type=o", "--input=" + fat, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co],
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    notes = subprocess.run([tools[2], "--notes", co], check=True, capture_output=True, text=True).stdout
+    kernels = {}
+    for block in notes.split("- .agpr_count")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        kernels[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, block).group(1))
+                         for k in ("private_segment_fixed_size", "vgpr_count", "vgpr_spill_count", "sgpr_spill_count")}
+    default = [v for k, v in kernels.items() if "render_kernel_wgaILb0ELi1024ELi768ELi3E" in k]
+    assert len(default) == 1, sorted(kernels)
+    d = default[0]
+    assert d["vgpr_count"] <= 170                       # 3 waves per SIMD (launch bounds 768 threads x 3)
+    assert d["private_segment_fixed_size"] <= 256 and d["vgpr_spill_count"] <= 8, d
+    assert d["sgpr_spill_count"] <= 400, d

@@ -467,6 +467,19 @@ def test_reference_call_sequence(gpu_rgb, setup, w_e):
     assert np.array_equal(np.array(sensor.film().bitmap(raw=True)), ref)
 
 
+def test_metric_scene_throughput_floor(gpu_rgb):
+    """A floor, not a benchmark: the metric scene at 64 spp runs at about 400 Msamples/s on an MI355X; anything below 200 means
+    the kernel lost its footing (scratch traffic, occupancy) and must not pass for green."""
+    scene = gpu_rgb.load_dict(scenes.c3_heterogeneous(512, 512, 64))
+    sensor = scene.sensors()[0]
+    best = 0.0
+    for _ in range(3):
+        assert scene.integrator().render(scene, sensor)
+        st = scene.integrator().last_stats
+        best = max(best, st["samples"] / (st["kernel_ms"] * 1e-3) / 1e6)
+    assert best > 200.0, best
+
+
 def test_cancel_and_timeout(gpu_rgb):
     d = scenes.c3_heterogeneous(64, 64, 64, res=16, samples_per_pass=1)
     d["integrator"]["timeout"] = 1e-6
