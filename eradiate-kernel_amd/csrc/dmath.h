@@ -27,7 +27,7 @@ DM_HD F3 operator-(F3 a) { return f3(-a.x, -a.y, -a.z); }
 DM_HD F3 operator*(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
 DM_HD F3 operator*(float s, F3 a) { return f3(a.x * s, a.y * s, a.z * s); }
 DM_HD F3 operator*(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
-DM_HD F3 operator/(F3 a, float s) { return f3(a.x / s, a.y / s, a.z / s); }
+DM_HD F3 operator/(F3 a, float s) { const float r = 1.0f / s; return f3(a.x * r, a.y * r, a.z * r); }   // enoki: array / scalar = reciprocal, then multiply
 DM_HD F3 operator/(F3 a, F3 b) { return f3(a.x / b.x, a.y / b.y, a.z / b.z); }
 DM_HD float dot(F3 a, F3 b) { return pm_fma(a.z, b.z, pm_fma(a.y, b.y, a.x * b.x)); }
 DM_HD float squared_norm(F3 a) { return dot(a, a); }

@@ -1516,7 +1516,7 @@ DEV DRay sensor_sample_ray(const DScene &sc, F2 position_sample, F2 aperture_sam
     if (se.target_type == MTS_DISTANT_TARGET_SHAPE) {
         F3 n; float pdf;
         shape_sample_position(mesh_tables(sc), se.target_shape, aperture_sample, ray_target, n, pdf);
-        w = 1.f / pdf / se.target_area;
+        w = (1.f / pdf) * (1.f / se.target_area);                                                 // Spectrum / Float / Float: each a reciprocal-multiply
     } else if (se.target_type == MTS_DISTANT_TARGET_NONE) {
         F2 offset = square_to_uniform_disk_concentric(aperture_sample);
         F3 perp_offset = mat_vector(se.to_world.m, f3(offset.x, offset.y, 0.f));

@@ -1381,7 +1381,7 @@ static Ray sensor_sample_ray(const Scene &sc, P2 position_sample, P2 aperture_sa
         shape_sample_position(se.target_shape, aperture_sample, &ray_target, &n, &pdf);
         float area = se.target_shape.type == MTS_SHAPE_DISK ? se.target_shape.surface_area : se.target_shape.type == MTS_SHAPE_RECTANGLE ? norm(cross(se.target_shape.frame.s, se.target_shape.frame.t))
                                                                  : 4.f * Pi * se.target_shape.radius * se.target_shape.radius;
-        float w = 1.f / pdf / area;
+        float w = (1.f / pdf) * (1.f / area);                                               // Spectrum / Float / Float: each a reciprocal-multiply
         ray_weight = v3(w, w, w);
     } else {
         P2 offset = square_to_uniform_disk_concentric(aperture_sample);

@@ -6,8 +6,10 @@
 // (paths relative to /root/reference).
 //
 // Decisions where the reference is ambiguous at the bit level (enoki is absent):
-//   * rcp(x) = 1/x, rsqrt(x) = 1/sqrt(x), array/scalar = true division (enoki's SSE paths use
-//     rcpps/rsqrtps + Newton steps whose bits are hardware dependent);
+//   * rcp(x) = 1/x, rsqrt(x) = 1/sqrt(x) (enoki's SSE paths use rcpps/rsqrtps + Newton steps whose bits are hardware
+//     dependent); array / scalar = array * (1 / scalar), as enoki's operator/ routes a division by a lower-depth operand
+//     ("reciprocal, then multiply", enoki array_router.h -- restated from the published source, the submodule is absent);
+//     array / array = component-wise true division;
 //   * dot(a,b) = fma chain a.x*b.x -> fma(a.y,b.y,.) -> fma(a.z,b.z,.) (enoki generic dot_);
 //   * fmadd/fmsub/fnmadd in the reference source are fused; plain `a*b+c` is not;
 //   * transcendental functions come from csrc/pmath.h (shared, bit-identical host/device).
@@ -27,7 +29,7 @@ static inline V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
 static inline V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
 static inline V3 operator*(float s, V3 a) { return v3(a.x * s, a.y * s, a.z * s); }
 static inline V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
-static inline V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+static inline V3 operator/(V3 a, float s) { float r = 1.0f / s; return v3(a.x * r, a.y * r, a.z * r); }   // enoki: reciprocal, then multiply
 static inline V3 operator/(V3 a, V3 b) { return v3(a.x / b.x, a.y / b.y, a.z / b.z); }
 static inline float dot(V3 a, V3 b) { return pm_fma(a.z, b.z, pm_fma(a.y, b.y, a.x * b.x)); }
 static inline float squared_norm(V3 a) { return dot(a, a); }
