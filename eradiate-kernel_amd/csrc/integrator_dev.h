@@ -834,7 +834,7 @@ DEV F3 transmittance_exp(float t, F3 combined) { return f3(pm_exp(-t * combined.
 // ---------------------------------------------------------------- volpath
 // integrators/volpath.cpp:261-367: NEE with ratio tracking through media and null surfaces
 template <bool COUNT>
-DEV_NOINLINE F3 volpath_sample_emitter(const DScene &sc, F3 ref_p, bool is_medium_interaction, Pcg32 &rng, int medium, uint32_t channel, DirSample &ds, Counters &cnt) {
+DEV F3 volpath_sample_emitter(const DScene &sc, F3 ref_p, bool is_medium_interaction, Pcg32 &rng, int medium, uint32_t channel, DirSample &ds, Counters &cnt) {
     F3 transmittance = f3s(1.f), emitter_val;
     ds = sample_emitter_direction(sc, ref_p, rng.next_2d(), false, emitter_val);
     if (ds.pdf == 0.f) return f3s(0.f);
@@ -898,7 +898,7 @@ DEV_NOINLINE F3 volpath_sample_emitter(const DScene &sc, F3 ref_p, bool is_mediu
 
 // integrators/volpath.cpp:370-465
 template <bool COUNT>
-DEV_NOINLINE F3 volpath_evaluate_direct_light(const DScene &sc, F3 ref_p, Pcg32 &rng, int medium, DRay ray, Hit si, uint32_t channel, bool active, float &emitter_pdf, Counters &cnt) {
+DEV F3 volpath_evaluate_direct_light(const DScene &sc, F3 ref_p, Pcg32 &rng, int medium, DRay ray, Hit si, uint32_t channel, bool active, float &emitter_pdf, Counters &cnt) {
     F3 emitter_val = f3s(0.f), transmittance = f3s(1.f);
     bool needs_intersection = false;
     emitter_pdf = 0.f;
@@ -1130,7 +1130,7 @@ DEV F3 mis_weight_w(const MisWeights<SPEC> &a, const MisWeights<SPEC> &b) {     
 
 // volpathmis.cpp:330-445
 template <bool COUNT, bool SPEC>
-DEV_NOINLINE F3 volpathmis_sample_emitter(const DScene &sc, F3 ref_p, bool is_medium_interaction, Pcg32 &rng, int medium, const MisWeights<SPEC> &p_over_f,
+DEV F3 volpathmis_sample_emitter(const DScene &sc, F3 ref_p, bool is_medium_interaction, Pcg32 &rng, int medium, const MisWeights<SPEC> &p_over_f,
                                           uint32_t channel, MisWeights<SPEC> &nee_out, MisWeights<SPEC> &uni_out, DirSample &ds, Counters &cnt) {
     MisWeights<SPEC> p_over_f_nee = p_over_f, p_over_f_uni = p_over_f;
     F3 emitter_sample_weight;
@@ -1427,8 +1427,15 @@ DEV F3 path_sample(const DScene &sc, Pcg32 &rng, DRay ray, bool &valid_out, Coun
 }
 
 // SamplingIntegrator::sample of the configured integrator (nested formulations)
-template <bool COUNT>
+// INTEG: -1 = decided at run time from the scene record (the probe kernel), otherwise the integrator is fixed at compile time
+// (NI_*: one render-kernel instantiation each, so that `path` does not carry the registers of the volumetric integrators)
+enum { NI_ANY = -1, NI_PATH = 0, NI_VOLPATH = 1, NI_VOLPATHMIS = 2, NI_VOLPATHMIS_NOSPEC = 3 };
+template <bool COUNT, int INTEG = NI_ANY>
 DEV F3 integrator_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, bool &valid, Counters &cnt) {
+    if (INTEG == NI_PATH) return path_sample<COUNT>(sc, rng, ray, valid, cnt);
+    if (INTEG == NI_VOLPATH) return volpath_sample<COUNT>(sc, rng, ray, medium, valid, cnt);
+    if (INTEG == NI_VOLPATHMIS) return volpathmis_sample<COUNT, true>(sc, rng, ray, medium, valid, cnt);
+    if (INTEG == NI_VOLPATHMIS_NOSPEC) return volpathmis_sample<COUNT, false>(sc, rng, ray, medium, valid, cnt);
     if (sc.integrator.type == MTS_INTEGRATOR_VOLPATH) return volpath_sample<COUNT>(sc, rng, ray, medium, valid, cnt);
     if (sc.integrator.type == MTS_INTEGRATOR_VOLPATHMIS)
         return sc.integrator.use_spectral_mis ? volpathmis_sample<COUNT, true>(sc, rng, ray, medium, valid, cnt)

@@ -16,7 +16,7 @@ namespace mtsamd {
 // straight into the film.  With the default box filter a sample lands in its own pixel and is summed
 // in registers in sample order (bit-identical to the reference's block accumulation); the rare
 // sample that falls on the left/top pixel edge (u == 0) goes to the neighbour through an atomic.
-template <bool COUNT>
+template <bool COUNT, int INTEG>
 __device__ __forceinline__ void render_sample(const DScene &sc, Pcg32 &rng, const DBlock &blk, uint32_t lx, uint32_t ly,
                                               float *__restrict__ film, float acc[5], Counters &cnt) {
     const DSensor &se = sc.sensor;
@@ -33,15 +33,16 @@ __device__ __forceinline__ void render_sample(const DScene &sc, Pcg32 &rng, cons
     F3 ray_weight;
     DRay ray = sensor_sample_ray(sc, adjusted, aperture_sample, ray_weight);
     bool valid;
-    F3 L = integrator_sample<COUNT>(sc, rng, ray, se.medium, valid, cnt);
+    F3 L = integrator_sample<COUNT, INTEG>(sc, rng, ray, se.medium, valid, cnt);
     L = ray_weight * L;
     splat_sample_t<false>(sc, blk, lx, ly, position_sample, L, valid, as_global(film), acc);
 }
 
 // librender/integrator.cpp:181-209 (scalar branch) for every block of this launch at once.
 // FLAT = true: volpath as the flat state machine of volpath_flat.h (the production kernel of the metric);
-// FLAT = false: the nested formulation of integrator_dev.h (path integrator; volpath cross-check, MTSAMD_NESTED=1).
-template <bool COUNT, bool FLAT>
+// FLAT = false: the nested formulation of integrator_dev.h (path and volpathmis; volpath cross-check, MTSAMD_KERNEL=nested),
+// one instantiation per integrator (INTEG = NI_*).
+template <bool COUNT, bool FLAT, int INTEG>
 __global__ void __launch_bounds__(256) render_kernel(DScene sc, const DBlock *__restrict__ blocks, uint32_t n_blocks, uint32_t block_size,
                                                      uint32_t sample_count, float *__restrict__ film, unsigned long long *__restrict__ counters) {
     // LDS-staged BVH top: the breadth-first top levels of the host-built BVH (dscene.h), shared by the workgroup's traversals
@@ -73,7 +74,7 @@ __global__ void __launch_bounds__(256) render_kernel(DScene sc, const DBlock *__
     } else {
         float acc[5] = { 0.f, 0.f, 0.f, 0.f, 0.f };
         for (uint32_t j = 0; j < sample_count; ++j)
-            render_sample<COUNT>(sc, rng, blk, lx, ly, film, acc, cnt);
+            render_sample<COUNT, INTEG>(sc, rng, blk, lx, ly, film, acc, cnt);
         float *dst = film + 5 * ((size_t) (blk.oy + (int) ly - sc.sensor.crop_y) * sc.sensor.crop_w + (blk.ox + (int) lx - sc.sensor.crop_x));
         for (int k = 0; k < 5; ++k) atomicAdd(dst + k, acc[k]);
     }
@@ -166,9 +167,14 @@ hipError_t launch_render(const DScene &sc, const DBlock *d_blocks, uint32_t n_bl
     const bool flat = variant != 0;
     const uint32_t grid = (uint32_t) ((threads + 255) / 256);
     const bool use_flat = flat && sc.integrator.type == MTS_INTEGRATOR_VOLPATH;
-#define LAUNCH(C, F) hipLaunchKernelGGL((render_kernel<C, F>), dim3(grid), dim3(256), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_counters)
-    if (use_flat) { if (count) LAUNCH(true, true); else LAUNCH(false, true); }
-    else { if (count) LAUNCH(true, false); else LAUNCH(false, false); }
+#define LAUNCH(C, F, I) hipLaunchKernelGGL((render_kernel<C, F, I>), dim3(grid), dim3(256), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_counters)
+#define LAUNCH_C(F, I) do { if (count) LAUNCH(true, F, I); else LAUNCH(false, F, I); } while (0)
+    if (use_flat) LAUNCH_C(true, NI_VOLPATH);
+    else if (sc.integrator.type == MTS_INTEGRATOR_PATH) LAUNCH_C(false, NI_PATH);
+    else if (sc.integrator.type == MTS_INTEGRATOR_VOLPATH) LAUNCH_C(false, NI_VOLPATH);
+    else if (sc.integrator.use_spectral_mis) LAUNCH_C(false, NI_VOLPATHMIS);
+    else LAUNCH_C(false, NI_VOLPATHMIS_NOSPEC);
+#undef LAUNCH_C
 #undef LAUNCH
     return hipGetLastError();
 }
