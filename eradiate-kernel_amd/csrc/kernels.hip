@@ -42,8 +42,14 @@ __device__ __forceinline__ void render_sample(const DScene &sc, Pcg32 &rng, cons
 // FLAT = true: volpath as the flat state machine of volpath_flat.h (the production kernel of the metric);
 // FLAT = false: the nested formulation of integrator_dev.h (path and volpathmis; volpath cross-check, MTSAMD_KERNEL=nested),
 // one instantiation per integrator (INTEG = NI_*).
+#ifndef MTS_NESTED_WAVES
+#define MTS_NESTED_WAVES 1
+#endif
+#ifndef MTS_PATH_WAVES
+#define MTS_PATH_WAVES 4      // measured on the cornell box: 1 -> 1631, 3 -> 1717, 4 -> 2355, 5 -> 1870, 6 -> 1241 Msamples/s
+#endif
 template <bool COUNT, bool FLAT, int INTEG>
-__global__ void __launch_bounds__(256) render_kernel(DScene sc, const DBlock *__restrict__ blocks, uint32_t n_blocks, uint32_t block_size,
+__global__ void __launch_bounds__(256, FLAT ? 1 : (INTEG == NI_PATH ? MTS_PATH_WAVES : MTS_NESTED_WAVES)) render_kernel(DScene sc, const DBlock *__restrict__ blocks, uint32_t n_blocks, uint32_t block_size,
                                                      uint32_t sample_count, float *__restrict__ film, unsigned long long *__restrict__ counters) {
     // LDS-staged BVH top: the breadth-first top levels of the host-built BVH (dscene.h), shared by the workgroup's traversals
     __shared__ float bvh_top[MTS_BVH_LDS_NODES * 8];
