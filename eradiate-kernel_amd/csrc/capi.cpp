@@ -19,7 +19,33 @@ static thread_local std::string g_error;
 #define API_CATCH } catch (const std::exception &e) { g_error = e.what(); return 1; } catch (...) { g_error = "unknown error"; return 1; } return 0;
 #define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
-struct mts_scene { HostScene *hs; std::mutex render_mutex; };
+// Device buffers and events a render needs besides the scene; they are kept with the handle and only grow, so that a sequence of
+// renders of one scene (passes, sensors swept by the caller, benchmark steps) pays for hipMalloc / hipFree -- which synchronise
+// the device -- once.  Guarded by render_mutex.
+struct RenderCache {
+    void *ptr[4] = { nullptr, nullptr, nullptr, nullptr };         // 0: film (host-film renders), 1: counters, 2: blocks, 3: workspace
+    size_t cap[4] = { 0, 0, 0, 0 };
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void *get(int k, size_t bytes) {
+        bytes = std::max<size_t>(bytes, 16);
+        if (cap[k] < bytes) {
+            if (ptr[k]) { (void) hipFree(ptr[k]); ptr[k] = nullptr; cap[k] = 0; }
+            hipError_t e = hipMalloc(&ptr[k], bytes);
+            if (e != hipSuccess) throw std::runtime_error(std::string("hipMalloc failed: ") + hipGetErrorString(e));
+            cap[k] = bytes;
+        }
+        return ptr[k];
+    }
+    void events() {
+        if (!ev0) { if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) throw std::runtime_error("hipEventCreate failed"); }
+    }
+    void release() {
+        for (int k = 0; k < 4; ++k) if (ptr[k]) { (void) hipFree(ptr[k]); ptr[k] = nullptr; cap[k] = 0; }
+        if (ev0) { (void) hipEventDestroy(ev0); ev0 = nullptr; }
+        if (ev1) { (void) hipEventDestroy(ev1); ev1 = nullptr; }
+    }
+};
+struct mts_scene { HostScene *hs; std::mutex render_mutex; RenderCache cache; };
 
 // librender/spiral.cpp:11-72
 namespace {
@@ -92,7 +118,7 @@ int mts_scene_create(const mts_scene_desc *desc, int device, mts_scene **out) {
 }
 
 int mts_scene_destroy(mts_scene *scene) {
-    if (scene) { free_host_scene(scene->hs); delete scene; }
+    if (scene) { (void) hipSetDevice(scene->hs->device); scene->cache.release(); free_host_scene(scene->hs); delete scene; }
     return 0;
 }
 
@@ -145,14 +171,14 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             samples += (uint64_t) b.sx * b.sy * samples_per_pass;
         }
     const size_t film_floats = (size_t) se.crop_w * se.crop_h * 5;
+    RenderCache &rc = scene->cache;
     float *d_film = film;
-    std::unique_ptr<DeviceBuffer<float>> film_buf;
-    if (!opts.film_on_device) { film_buf.reset(new DeviceBuffer<float>(film_floats)); d_film = film_buf->p; }
-    DeviceBuffer<unsigned long long> d_counters(4);
+    if (!opts.film_on_device) d_film = (float *) rc.get(0, film_floats * sizeof(float));
+    unsigned long long *d_counters = (unsigned long long *) rc.get(1, 4 * sizeof(unsigned long long));
     HIP_CHECK(hipMemsetAsync(d_film, 0, film_floats * sizeof(float), stream));               // hdrfilm.cpp:201-203 (storage cleared by prepare())
-    HIP_CHECK(hipMemsetAsync(d_counters.p, 0, 4 * sizeof(unsigned long long), stream));
-    hipEvent_t ev0, ev1;
-    HIP_CHECK(hipEventCreate(&ev0)); HIP_CHECK(hipEventCreate(&ev1));
+    HIP_CHECK(hipMemsetAsync(d_counters, 0, 4 * sizeof(unsigned long long), stream));
+    rc.events();
+    hipEvent_t ev0 = rc.ev0, ev1 = rc.ev1;
     double kernel_ms = 0.0; int launches = 0; bool cancelled = false;
     const float timeout = hs.integrator.timeout;
     try {
@@ -161,8 +187,8 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             if (hs.stop.load() || (timeout > 0.f && std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count() > timeout)) { cancelled = true; break; }
             const std::vector<DBlock> &blocks = pass_blocks[pass];
             if (blocks.empty()) continue;
-            DeviceBuffer<DBlock> d_blocks(blocks.size());
-            HIP_CHECK(hipMemcpyAsync(d_blocks.p, blocks.data(), blocks.size() * sizeof(DBlock), hipMemcpyHostToDevice, stream));
+            DBlock *d_blocks = (DBlock *) rc.get(2, blocks.size() * sizeof(DBlock));
+            HIP_CHECK(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(DBlock), hipMemcpyHostToDevice, stream));
             HIP_CHECK(hipEventRecord(ev0, stream));
             // kernel variant: MTSAMD_KERNEL = nested | flat | wga256 | wga512 | wga1024 (default)
             int variant = 11024;                                   // asynchronous regrouping, 1024 paths served by 768 threads
@@ -174,9 +200,9 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             if (variant > 1 && (block_size * block_size) % (uint32_t) (variant - 10000) != 0) variant = 1;     // small blocks: per-lane kernel
             int wg_threads = variant == 11024 ? 768 : 0;            // MTSAMD_WG_THREADS: threads per workgroup of the wga kernels (<= paths)
             if (const char *tv = getenv("MTSAMD_WG_THREADS")) wg_threads = atoi(tv);
-            DeviceBuffer<float> d_ws(render_workspace_floats((uint32_t) blocks.size(), block_size, variant));
-            HIP_CHECK(launch_render(hs.scene, d_blocks.p, (uint32_t) blocks.size(), block_size, (uint32_t) samples_per_pass, d_film, d_counters.p,
-                                    opts.collect_counters != 0, variant, wg_threads, d_ws.p, stream));
+            float *d_ws = (float *) rc.get(3, render_workspace_floats((uint32_t) blocks.size(), block_size, variant) * sizeof(float));
+            HIP_CHECK(launch_render(hs.scene, d_blocks, (uint32_t) blocks.size(), block_size, (uint32_t) samples_per_pass, d_film, d_counters,
+                                    opts.collect_counters != 0, variant, wg_threads, d_ws, stream));
             HIP_CHECK(hipEventRecord(ev1, stream));
             HIP_CHECK(hipEventSynchronize(ev1));
             float ms = 0.f; HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
@@ -184,7 +210,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
         }
         if (!opts.film_on_device) HIP_CHECK(hipMemcpyAsync(film, d_film, film_floats * sizeof(float), hipMemcpyDeviceToHost, stream));
         unsigned long long h_counters[4] = { 0, 0, 0, 0 };
-        HIP_CHECK(hipMemcpyAsync(h_counters, d_counters.p, sizeof(h_counters), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(h_counters, d_counters, sizeof(h_counters), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
         if (stats) {
             memset(stats, 0, sizeof(*stats));
@@ -192,8 +218,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             stats->kernel_ms = kernel_ms; stats->kernel_launches = launches; stats->cancelled = cancelled ? 1 : 0;
             stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
-    } catch (...) { (void) hipEventDestroy(ev0); (void) hipEventDestroy(ev1); throw; }
-    (void) hipEventDestroy(ev0); (void) hipEventDestroy(ev1);
+    } catch (...) { (void) hipStreamSynchronize(stream); throw; }     // nothing of this render may still be using the cached buffers
     API_CATCH
 }
 
