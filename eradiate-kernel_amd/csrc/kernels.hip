@@ -146,7 +146,7 @@ size_t render_workspace_floats(uint32_t n_blocks, uint32_t block_size, int varia
     if (variant >= 10000) variant -= 10000;
     const uint64_t threads = (uint64_t) n_blocks * block_size * block_size;
     const uint64_t padded = (threads + variant - 1) / variant * variant;
-    return (size_t) padded * C_COUNT;
+    return (size_t) padded * (variant >= 256 && variant <= 4096 ? MTS_COLD_RECORD : C_COUNT) + 32;      // workgroup drivers: one 128-byte record per path
 }
 
 hipError_t launch_render(const DScene &sc, const DBlock *d_blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,

@@ -227,10 +227,13 @@ enum { C_POS = 0,            // 2: film position of the current sample
        C_SAMPLE = 29,        // 1: index of the sample in flight (bits of a uint32)
        C_COUNT = 30 };
 // Struct-of-arrays store addressed as base[k * stride]: LDS (stride 256, one workgroup) or HBM (stride = paths in flight)
-template <class Ptr /* float* into LDS, or MTS_GLOBAL_AS float* into HBM */>
+// or as one 128-byte record per path (AOS: the workgroup driver, whose lanes hold arbitrary paths -- a record is written by one
+// lane as whole cache lines instead of 30 scattered dwords)
+#define MTS_COLD_RECORD 32      // floats per path record (C_COUNT rounded up to a 128-byte line)
+template <class Ptr /* float* into LDS, or MTS_GLOBAL_AS float* into HBM */, bool AOS = false>
 struct ColdStoreT {
     Ptr base; uint32_t stride;
-    DEV auto &f(int k) const { return base[(size_t) k * stride]; }
+    DEV auto &f(int k) const { return AOS ? base[k] : base[(size_t) k * stride]; }
     DEV void put3(int k, F3 v) const { f(k) = v.x; f(k + 1) = v.y; f(k + 2) = v.z; }
     DEV F3 get3(int k) const { return f3(f(k), f(k + 1), f(k + 2)); }
     DEV void put_hit(const Hit &h) const {
@@ -244,7 +247,12 @@ struct ColdStoreT {
 };
 // What a path needs from its surroundings
 typedef ColdStoreT<float *> ColdStore;                       // generic pointer (the per-lane driver parks cold state in LDS)
-typedef ColdStoreT<MTS_GLOBAL_AS float *> ColdStoreHbm;      // workgroup driver: cold state in HBM, addressed with GLOBAL instructions
+#if defined(EXP_COLD_SOA)
+typedef ColdStoreT<MTS_GLOBAL_AS float *> ColdStoreHbm;
+#else
+typedef ColdStoreT<MTS_GLOBAL_AS float *, true> ColdStoreHbm;
+#endif
+// (workgroup driver: cold state in HBM, addressed with GLOBAL instructions)
 template <class Cold>
 struct PathEnvT {
     DBlock blk; uint32_t lx, ly, sample_count; MTS_GLOBAL_AS float *film; Cold cold;
@@ -769,7 +777,12 @@ DEV bool wg_env(const WgArgs &a, uint32_t wg_base, uint32_t pid, PathEnvT<ColdSt
     const uint32_t b = wg_base / ppb;                        // uniform
     const uint32_t i = (wg_base - b * ppb) + pid;
     e.sample_count = a.sample_count; e.film = as_global(a.film);
+#if defined(EXP_COLD_SOA)
     e.cold.base = as_global(a.cold_g) + wg_base + pid; e.cold.stride = a.cold_stride;
+#else
+    e.cold.base = as_global(a.cold_g) + (size_t) (wg_base + pid) * MTS_COLD_RECORD; e.cold.stride = 1;
+    __builtin_assume(((uintptr_t) e.cold.base & 127u) == 0);       // hipMalloc'ed base, 128-byte records: lets neighbouring fields share one wide access
+#endif
     e.lx = e.ly = 0;
     if (b >= a.n_blocks) return false;
     e.blk = cload(a.blocks + b);
