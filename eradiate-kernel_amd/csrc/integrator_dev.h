@@ -360,12 +360,23 @@ DEV float trilerp(float d000, float d100, float d010, float d110, float d001, fl
 // The grid lookup with its wrap modes, channel counts and filters is a real function: it is off the hot paths (the metric scene
 // reads its grids through the pair-grid fast path, constant volumes return above), and inlining its ~25 copies of the repeat /
 // mirror index arithmetic into every block was costing instruction-cache space.
-DEV_NOINLINE F3 volume_eval_grid(const DVolume v, F3 p_world);
+// It receives the 23 dwords of the volume record it reads, which travel in argument registers; the whole record (by value) would
+// be copied through scratch memory at every call.
+struct GridRef { float w2l[16]; const float *data; int32_t nx, ny, nz; uint32_t channels_affine_filter_wrap; };
+DEV_NOINLINE F3 volume_eval_grid(const GridRef g, F3 p_world);
 DEV F3 volume_eval(const DVolume &v, F3 p_world) {
     if (v.type == MTS_VOLUME_CONST) return f3(v.value);
-    return volume_eval_grid(v, p_world);
+    GridRef g;
+    for (int k = 0; k < 16; ++k) g.w2l[k] = v.w2l[k];
+    g.data = v.data; g.nx = v.nx; g.ny = v.ny; g.nz = v.nz;
+    g.channels_affine_filter_wrap = (uint32_t) v.channels | ((uint32_t) (v.affine != 0) << 8) | ((uint32_t) v.filter << 16) | ((uint32_t) v.wrap << 24);
+    return volume_eval_grid(g, p_world);
 }
-DEV_NOINLINE F3 volume_eval_grid(const DVolume v, F3 p_world) {
+DEV_NOINLINE F3 volume_eval_grid(const GridRef g, F3 p_world) {
+    struct { const float *w2l; const float *data; int nx, ny, nz, channels, affine, filter, wrap; } v;
+    v.w2l = g.w2l; v.data = g.data; v.nx = g.nx; v.ny = g.ny; v.nz = g.nz;
+    v.channels = (int) (g.channels_affine_filter_wrap & 0xffu); v.affine = (int) ((g.channels_affine_filter_wrap >> 8) & 0xffu);
+    v.filter = (int) ((g.channels_affine_filter_wrap >> 16) & 0xffu); v.wrap = (int) (g.channels_affine_filter_wrap >> 24);
     F3 p = v.affine ? mat_point_affine(v.w2l, p_world) : mat_point(v.w2l, p_world);    // x / 1 == x
     const MTS_GLOBAL_AS float *D = as_global(v.data); const int nx = v.nx, ny = v.ny, nz = v.nz, ch = v.channels;
     if (v.filter == MTS_FILTER_TRILINEAR) {
