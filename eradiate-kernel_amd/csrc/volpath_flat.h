@@ -840,14 +840,19 @@ static __device__ WG_BLOCK_ATTR int wg_block(const MTS_CONST_AS void *kernarg_, 
 // tail counts the finished paths.  One LDS atomic per push: lane c adds the number of paths this wave appends to ring c.
 template <int WG>
 DEV void wga_push(int cls, uint32_t pid, bool valid, uint16_t (*q_ids)[WG], uint32_t *q_ht, uint32_t lane) {
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    uint32_t my_count = 0, my_rank = 0;
+    // Per class: one compare (the ballot), the count into lane c with a writelane, and the class's mask kept by its own lanes;
+    // the rank is then one mbcnt pair on the lane's own mask.  (Written with the builtins: the generic popcount / select
+    // formulation compiled to about a hundred instructions, a quarter of them restoring spilled lane masks.)
+    const int ceff = valid ? cls : 15;
+    uint32_t my_count = 0, own_lo = 0, own_hi = 0;
 #pragma unroll
     for (int c = 0; c < B_COUNT; ++c) {
-        const unsigned long long m = __ballot(valid && cls == c);
-        if ((int) lane == c) my_count = (uint32_t) __popcll(m);
-        if (cls == c) my_rank = (uint32_t) __popcll(m & lt);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(ceff == c);
+        const uint32_t cnt_c = (uint32_t) __builtin_popcountll(m);
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(my_count) : "s"(cnt_c), "n"(c));
+        if (ceff == c) { own_lo = (uint32_t) m; own_hi = (uint32_t) (m >> 32); }
     }
+    const uint32_t my_rank = __builtin_amdgcn_mbcnt_hi(own_hi, __builtin_amdgcn_mbcnt_lo(own_lo, 0u));
     uint32_t base = 0;
     if (lane < (uint32_t) B_COUNT && my_count != 0u) base = atomicAdd(&q_ht[2 * lane + 1], my_count);
     const uint32_t my_base = (uint32_t) __builtin_amdgcn_ds_bpermute(cls << 2, (int) base);     // the base lane `cls` obtained
