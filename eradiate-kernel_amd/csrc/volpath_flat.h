@@ -876,7 +876,11 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
     uint32_t *const q_ht = (uint32_t *) q_ht64;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wg_base = blockIdx.x * WG;
-    for (int c = 0; c < NQ; ++c) for (uint32_t i = tid; i < (uint32_t) WG; i += NT) q_ids[c][i] = 0xFFFFu;
+#pragma unroll 1
+    for (int c = 0; c < NQ; ++c) {
+#pragma unroll 1
+        for (uint32_t i = tid; i < (uint32_t) WG; i += NT) q_ids[c][i] = 0xFFFFu;      // runs once: not worth 300 unrolled instructions
+    }
     if (tid < 2u * B_COUNT) q_ht[tid] = 0;
     __syncthreads();
 #pragma unroll 1
