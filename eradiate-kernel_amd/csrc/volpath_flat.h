@@ -933,6 +933,9 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         const uint32_t h = (uint32_t) __builtin_amdgcn_readlane((int) hd, sel);
         uint32_t won = 0;
         if (lane == 0) won = atomicCAS(&q_ht[2 * sel], h, h + n) == h ? 1u : 0u;
+#if defined(MTSAMD_BLOCKSTATS)
+        if (COUNT) { bs_loc[10] += 1ull; if (!__builtin_amdgcn_readfirstlane((int) won)) bs_loc[11] += 1ull; }      // claim attempts / lost compare-and-swaps
+#endif
         if (!__builtin_amdgcn_readfirstlane((int) won)) continue;
         uint32_t pid = 0;
         const bool mine = lane < n;

@@ -23,5 +23,6 @@ for i, n in enumerate(names):
         n, ex / waves / spp, lanes / max(ex, 1), lanes / (w * h * spp), cyc / max(ex, 1), 100.0 * cyc / max(total, 1)))
 print("claim / vote %5.1f %%   idle %5.1f %%   push %5.1f %%   total cycles/wave/sample %9.0f" % (
     100.0 * out[44] / max(total, 1), 100.0 * out[42] / max(total, 1), 100.0 * out[43] / max(total, 1), total / waves / spp))
+print("claim attempts %d, lost compare-and-swaps %d (%.1f %%)" % (out[10], out[11], 100.0 * out[11] / max(out[10], 1)))
 seg = ["lds load", "rng+free-flight sample", "grid lookup", "transmittance/decide", "top", "lds store"]
 print("MED segments (cycles / execution):", ", ".join("%s %.0f" % (n, out[36 + i] / max(out[1], 1)) for i, n in enumerate(seg)))
