@@ -685,8 +685,11 @@ DEV void volpath_pixel_flat(const DScene &sc, Pcg32 &rng, const DBlock &blk, uin
 // Every block class loads / stores only the fields it can touch (ClassFields), which keeps the blocks' register budget small.
 // depth shares a dword with the packed small fields (15 bits: a path of more than 32767 scattering events would need to
 // survive Russian roulette with probability < 0.95^32000).
-enum { H_RNG = 0, H_O = 2, H_D = 5, H_MINT = 8, H_MAXT = 9, H_SI = 10, H_MEDIUM = 18, H_THR = 19, H_RES = 22, H_ETA = 25,
-       H_PACKED = 26 /* st, mode, channel, flags, class, depth */, H_TRANS = 27, H_WA = 30, H_WB = 31, H_DRCP = 32, H_COUNT = 35 };
+// The sixteen dwords every tracking step touches come first: an LDS instruction reaches 64 KB (16 fields of 1024 paths) from its
+// address register, later fields cost an address computation each.
+enum { H_RNG = 0, H_O = 2, H_D = 5, H_DRCP = 8, H_MINT = 11, H_MAXT = 12, H_SIT = 13, H_MEDIUM = 14,
+       H_PACKED = 15 /* st, mode, channel, flags, class, depth */, H_THR = 16, H_TRANS = 19, H_WA = 22, H_WB = 23, H_ETA = 24, H_RES = 25,
+       H_SIX = 28 /* si.p, si.uv, si.shape, si.prim */, H_COUNT = 35 };
 
 enum : uint32_t { G_RNG = 1, G_O = 2, G_D = 4 /* d and 1/d */, G_MINT = 8, G_MAXT = 16, G_SIT = 32 /* si.t */, G_SIX = 64 /* rest of si */,
                   G_MED = 128, G_THR = 256, G_RES = 512, G_ETA = 1024, G_TRANS = 2048, G_WA = 4096, G_WB = 8192, G_ALL = 16383 };
@@ -735,8 +738,8 @@ struct HotStore {
         if (M & G_D) { put3(H_D, p.ray.d); put3(H_DRCP, p.ray.d_rcp); }
         if (M & G_MINT) putf(H_MINT, p.ray.mint);
         if (M & G_MAXT) putf(H_MAXT, p.ray.maxt);
-        if (M & G_SIT) putf(H_SI, p.si.t);
-        if (M & G_SIX) { put3(H_SI + 1, p.si.p); putf(H_SI + 4, p.si.uv.x); putf(H_SI + 5, p.si.uv.y); u(H_SI + 6) = (uint32_t) p.si.shape; u(H_SI + 7) = (uint32_t) p.si.prim; }
+        if (M & G_SIT) putf(H_SIT, p.si.t);
+        if (M & G_SIX) { put3(H_SIX, p.si.p); putf(H_SIX + 3, p.si.uv.x); putf(H_SIX + 4, p.si.uv.y); u(H_SIX + 5) = (uint32_t) p.si.shape; u(H_SIX + 6) = (uint32_t) p.si.prim; }
         if (M & G_MED) u(H_MEDIUM) = (uint32_t) p.medium;
         if (M & G_THR) put3(H_THR, p.thr);
         if (M & G_RES) put3(H_RES, p.res);
@@ -752,9 +755,9 @@ struct HotStore {
         p.ray.o = (M & G_O) ? get3(H_O) : f3s(0.f);
         p.ray.d = (M & G_D) ? get3(H_D) : f3s(0.f); p.ray.d_rcp = (M & G_D) ? get3(H_DRCP) : f3s(0.f);
         p.ray.mint = (M & G_MINT) ? f(H_MINT) : 0.f; p.ray.maxt = (M & G_MAXT) ? f(H_MAXT) : 0.f;
-        p.si.t = (M & G_SIT) ? f(H_SI) : pm_inf();
+        p.si.t = (M & G_SIT) ? f(H_SIT) : pm_inf();
         p.si.p = f3s(0.f); p.si.uv.x = p.si.uv.y = 0.f; p.si.shape = -1; p.si.prim = 0;
-        if (M & G_SIX) { p.si.p = get3(H_SI + 1); p.si.uv.x = f(H_SI + 4); p.si.uv.y = f(H_SI + 5); p.si.shape = (int) u(H_SI + 6); p.si.prim = (int) u(H_SI + 7); }
+        if (M & G_SIX) { p.si.p = get3(H_SIX); p.si.uv.x = f(H_SIX + 3); p.si.uv.y = f(H_SIX + 4); p.si.shape = (int) u(H_SIX + 5); p.si.prim = (int) u(H_SIX + 6); }
         p.medium = (M & G_MED) ? (int) u(H_MEDIUM) : -1;
         p.thr = (M & G_THR) ? get3(H_THR) : f3s(0.f); p.res = (M & G_RES) ? get3(H_RES) : f3s(0.f);
         p.eta = (M & G_ETA) ? f(H_ETA) : 1.f;
