@@ -13,7 +13,7 @@ import math
 import numpy as np
 
 from . import _capi as A
-from .transform import ScalarTransform4f, coordinate_system
+from .transform import ScalarTransform4f, coordinate_system, normalize32
 from .volume_io import read_volume
 from .mesh_io import load_mesh
 
@@ -474,7 +474,7 @@ class SceneBuilder:
                 if p.has("to_world"):
                     raise RuntimeError("Only one of the parameters 'direction' and 'to_world' can be specified at the same time!'")
                 direction = np.asarray(p.get("direction"), dtype=np.float32)
-                direction = (direction / np.sqrt(np.dot(direction, direction), dtype=np.float32)).astype(np.float32)
+                direction = normalize32(direction)
                 up, _ = coordinate_system(direction)                       # directional.cpp:55-60
                 e.to_world = _xf(ScalarTransform4f.look_at([0, 0, 0], direction, up))
             else:
@@ -589,10 +589,10 @@ class SceneBuilder:
                 if p.has("to_world"):
                     raise RuntimeError("Only one of the parameters 'direction' and 'to_world'can be specified at the same time!'")
                 direction = np.asarray(p.get("direction"), dtype=np.float32)
-                direction = (direction / np.sqrt(np.dot(direction, direction), dtype=np.float32)).astype(np.float32)
+                direction = normalize32(direction)
                 if p.has("orientation"):
                     up = np.cross(direction, np.asarray(p.get("orientation"), dtype=np.float32)).astype(np.float32)
-                    up = (up / np.sqrt(np.dot(up, up), dtype=np.float32)).astype(np.float32)
+                    up = normalize32(up)
                 else:
                     _, up = coordinate_system(direction)
                 s.to_world = _xf(ScalarTransform4f.look_at([0, 0, 0], direction, up))

@@ -14,6 +14,21 @@ def _m(a):
     return np.ascontiguousarray(np.asarray(a, dtype=np.float32).reshape(4, 4))
 
 
+def _fma32(a, b, c):
+    """float32 fused multiply-add (the product of two float32 is exact in float64; one rounding to float32 at the end, up to
+    the rare double rounding of the float64 sum)."""
+    return np.float32(np.float64(a) * np.float64(b) + np.float64(c))
+
+
+def normalize32(v):
+    """enoki's normalize for a float32 3-vector: v * rsqrt(squared_norm(v)), squared_norm as the fma chain of dot()
+    (the same convention as oracle/oracle_math.h and csrc/dmath.h)."""
+    v = np.asarray(v, dtype=np.float32)
+    sq = _fma32(v[2], v[2], _fma32(v[1], v[1], np.float32(v[0] * v[0])))
+    r = np.float32(1.0) / np.sqrt(sq, dtype=np.float32)
+    return (v * r).astype(np.float32)
+
+
 class ScalarTransform4f:
     __slots__ = ("matrix", "inverse_transpose")
 
@@ -99,8 +114,7 @@ class ScalarTransform4f:
         target = np.asarray(target, dtype=np.float32)
         up = np.asarray(up, dtype=np.float32)
 
-        def normalize(v):
-            return (v / np.sqrt(np.dot(v, v), dtype=np.float32)).astype(np.float32)
+        normalize = normalize32
         d = normalize(target - origin)
         d = normalize(d)
         left = normalize(np.cross(up, d).astype(np.float32))
