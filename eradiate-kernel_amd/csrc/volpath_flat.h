@@ -912,8 +912,15 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
             const unsigned long long ht = __atomic_load_n(&q_ht64[lane], __ATOMIC_RELAXED);
             hd = (uint32_t) ht; avail = (uint32_t) (ht >> 32) - hd;
         }
-        int sel = -1; uint32_t best = 0;
-        for (int c = 0; c < NQ; ++c) { const uint32_t v = (uint32_t) __builtin_amdgcn_readlane((int) avail, c); if (v > best) { best = v; sel = c; } }
+        // argmax over the NQ rings in three DPP steps: lanes 0..7 hold (avail << 4 | 15 - ring), the maximum of a row's first eight
+        // lanes ends up in lane 7 (ties go to the lower ring, as a first-maximum scan would have it); one readlane instead of eight
+        // and no scalar compare chain
+        uint32_t key = lane < (uint32_t) NQ ? ((avail << 4) | (15u - lane)) : 0u;
+        key = max(key, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) key, 0x111 /* row_shr:1 */, 0xf, 0xf, true));
+        key = max(key, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) key, 0x112 /* row_shr:2 */, 0xf, 0xf, true));
+        key = max(key, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) key, 0x114 /* row_shr:4 */, 0xf, 0xf, true));
+        const uint32_t top_key = (uint32_t) __builtin_amdgcn_readlane((int) key, 7);
+        const uint32_t best = top_key >> 4; const int sel = 15 - (int) (top_key & 15u);
         if (best == 0) {
             if ((uint32_t) __builtin_amdgcn_readlane((int) avail, B_DONE) == (uint32_t) WG) break;     // every path of the workgroup has finished
             __builtin_amdgcn_s_sleep(2);
