@@ -777,8 +777,10 @@ struct WgArgs {
 template <int WG>
 DEV bool wg_env(const WgArgs &a, uint32_t wg_base, uint32_t pid, PathEnvT<ColdStoreHbm> &e) {     // pixel owned by path `pid`; false: outside the block
     const uint32_t ppb = a.block_size * a.block_size;       // a multiple of WG (checked by the launcher): the workgroup sits in ONE block
-    const uint32_t b = wg_base / ppb;                        // uniform
-    const uint32_t i = (wg_base - b * ppb) + pid;
+    // block_size is a power of two (mts_render rounds it up, as integrator.cpp:91-97 does): shift and mask instead of the ~30
+    // instructions of a 32-bit division, on every block visit
+    const uint32_t b = wg_base >> (uint32_t) __builtin_ctz(ppb);   // uniform
+    const uint32_t i = (wg_base & (ppb - 1u)) + pid;
     e.sample_count = a.sample_count; e.film = as_global(a.film);
 #if defined(EXP_COLD_SOA)
     e.cold.base = as_global(a.cold_g) + wg_base + pid; e.cold.stride = a.cold_stride;
