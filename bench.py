@@ -138,11 +138,11 @@ def main():
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
     kv = os.environ.get("MTSAMD_KERNEL", "wga1024")
     if d["integrator"]["type"] == "path" or kv == "nested":
-        kernel_name = "render_kernel<false, false>"
+        kernel_name = "render_kernel<false, false, %d>" % {"path": 0, "volpath": 1, "volpathmis": 2}.get(d["integrator"]["type"], 0)
     elif kv == "flat":
-        kernel_name = "render_kernel<false, true>"
+        kernel_name = "render_kernel<false, true, 1>"
     else:
-        paths = int(kv[3:]); nt = int(os.environ.get("MTSAMD_WG_THREADS", "768" if paths == 1024 else str(paths)))
+        paths = int(kv[3:]); nt = int(os.environ.get("MTSAMD_WG_THREADS", str(paths)))
         kernel_name = "render_kernel_wga<false, %d, %d, %d>" % (paths, nt, {1: 4, 0.75: 3, 0.5: 2}[nt / paths])
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,

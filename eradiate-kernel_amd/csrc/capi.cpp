@@ -191,14 +191,14 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             HIP_CHECK(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(DBlock), hipMemcpyHostToDevice, stream));
             HIP_CHECK(hipEventRecord(ev0, stream));
             // kernel variant: MTSAMD_KERNEL = nested | flat | wga256 | wga512 | wga1024 (default)
-            int variant = 11024;                                   // asynchronous regrouping, 1024 paths served by 768 threads
+            int variant = 11024;                                   // asynchronous regrouping, 1024 paths served by 1024 threads
             if (const char *kv = getenv("MTSAMD_KERNEL")) {
                 if (!strcmp(kv, "nested")) variant = 0; else if (!strcmp(kv, "flat")) variant = 1;
                 else if (!strcmp(kv, "wga256")) variant = 10256; else if (!strcmp(kv, "wga512")) variant = 10512; else if (!strcmp(kv, "wga1024")) variant = 11024;
                 else throw std::runtime_error("MTSAMD_KERNEL must be one of nested, flat, wga256, wga512, wga1024");
             }
             if (variant > 1 && (block_size * block_size) % (uint32_t) (variant - 10000) != 0) variant = 1;     // small blocks: per-lane kernel
-            int wg_threads = variant == 11024 ? 768 : 0;            // MTSAMD_WG_THREADS: threads per workgroup of the wga kernels (<= paths)
+            int wg_threads = 0;                                     // MTSAMD_WG_THREADS: threads per workgroup of the wga kernels (<= paths; default = paths)
             if (const char *tv = getenv("MTSAMD_WG_THREADS")) wg_threads = atoi(tv);
             float *d_ws = (float *) rc.get(3, render_workspace_floats((uint32_t) blocks.size(), block_size, variant) * sizeof(float));
             HIP_CHECK(launch_render(hs.scene, d_blocks, (uint32_t) blocks.size(), block_size, (uint32_t) samples_per_pass, d_film, d_counters,

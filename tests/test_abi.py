@@ -75,9 +75,9 @@ def test_default_kernel_resource_budget(tmp_path):
         name = re.search(r"\.name:\s+(\S+)", block).group(1)
         kernels[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, block).group(1))
                          for k in ("private_segment_fixed_size", "vgpr_count", "vgpr_spill_count", "sgpr_spill_count")}
-    default = [v for k, v in kernels.items() if "render_kernel_wgaILb0ELi1024ELi768ELi3E" in k]
+    default = [v for k, v in kernels.items() if "render_kernel_wgaILb0ELi1024ELi1024ELi4E" in k]
     assert len(default) == 1, sorted(kernels)
     d = default[0]
-    assert d["vgpr_count"] <= 170                       # 3 waves per SIMD (launch bounds 768 threads x 3)
+    assert d["vgpr_count"] <= 128                       # 4 waves per SIMD (launch bounds 1024 threads x 4)
     assert d["private_segment_fixed_size"] <= 256 and d["vgpr_spill_count"] <= 8, d
     assert d["sgpr_spill_count"] <= 400, d
