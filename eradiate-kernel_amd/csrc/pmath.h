@@ -50,6 +50,9 @@ PM_HD float pm_mulsign_neg(float a, float b) { return pm_from_bits(pm_bits(a) ^ 
 
 // Natural logarithm (Cephes-style reduction to [sqrt(1/2), sqrt(2)) + degree-8 polynomial).
 PM_HD float pm_log(float x) {
+#if defined(PM_USE_LIBM) && !defined(__HIPCC__)
+    return logf(x);   // oracle/Makefile, liboracle_libm.so: sensitivity measurement only
+#endif
 #if defined(EXP_FASTMATH) && defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_logf(x) * 0.6931471805599453f;   // measurement only: breaks parity
 #endif
@@ -85,6 +88,9 @@ PM_HD float pm_log(float x) {
 
 // Exponential. Underflows to +0 below ln(FLT_MIN) (flush-to-zero semantics), overflows to +inf.
 PM_HD float pm_exp(float x) {
+#if defined(PM_USE_LIBM) && !defined(__HIPCC__)
+    return expf(x);   // oracle/Makefile, liboracle_libm.so: sensitivity measurement only
+#endif
 #if defined(EXP_FASTMATH) && defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);   // measurement only: breaks parity
 #endif
@@ -110,6 +116,9 @@ PM_HD float pm_exp(float x) {
 
 // Simultaneous sine / cosine, |x| <~ 1e4 (all call sites pass 2*pi*u or a concentric-disk angle).
 PM_HD void pm_sincos(float x, float *s_out, float *c_out) {
+#if defined(PM_USE_LIBM) && !defined(__HIPCC__)
+    *s_out = sinf(x); *c_out = cosf(x); return;   // oracle/Makefile, liboracle_libm.so: sensitivity measurement only
+#endif
     float fj = pm_floor(pm_fma(x, 0.636619772367581343f, 0.5f));
     // Cody-Waite: pi/2 = 1.5703125 + 4.837512969970703125e-4 + 7.54978995489188e-8
     float r = pm_fma(fj, -1.5703125f, x);
@@ -136,6 +145,9 @@ PM_HD void pm_sincos(float x, float *s_out, float *c_out) {
 // Cube root (sign-preserving), used by the Rayleigh phase function
 // (/root/reference/src/phase/rayleigh.cpp:51-55).
 PM_HD float pm_cbrt(float x) {
+#if defined(PM_USE_LIBM) && !defined(__HIPCC__)
+    return cbrtf(x);   // oracle/Makefile, liboracle_libm.so: sensitivity measurement only
+#endif
     uint32_t ix = pm_bits(x);
     uint32_t sign = ix & 0x80000000u;
     uint32_t ax = ix & 0x7fffffffu;
@@ -204,6 +216,9 @@ PM_HD double pm_exp_d(double x) {          // |x| < 700
 
 // x^y for x >= 0 (std::pow semantics for the cases the RPV model can produce).
 PM_HD float pm_pow(float x, float y) {
+#if defined(PM_USE_LIBM) && !defined(__HIPCC__)
+    return powf(x, y);   // oracle/Makefile, liboracle_libm.so: sensitivity measurement only
+#endif
     if (y == 0.0f) return 1.0f;
     if (!(x == x) || !(y == y)) return pm_nan();
     if (x < 0.0f) return pm_nan();

@@ -462,6 +462,9 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
     if (it.type != MTS_INTEGRATOR_PATH && it.type != MTS_INTEGRATOR_VOLPATH && it.type != MTS_INTEGRATOR_VOLPATHMIS) throw std::runtime_error("unknown integrator type");
     if (it.rr_depth <= 0) throw std::runtime_error("\"rr_depth\" must be set to a value greater than zero!");
     if (it.max_depth < 0 && it.max_depth != -1) throw std::runtime_error("\"max_depth\" must be set to -1 (infinite) or a value >= 0");
+    // the regrouping kernel keeps a path's depth in 15 bits of its packed state dword (volpath_flat.h, HotStore::pack): a finite
+    // bound beyond that could never trigger, so it is refused instead of being silently treated as infinite
+    if (it.max_depth > 32767) throw std::runtime_error("\"max_depth\" must be -1 (infinite) or at most 32767 on this backend");
     sc.integrator.type = it.type; sc.integrator.max_depth = it.max_depth; sc.integrator.rr_depth = it.rr_depth; sc.integrator.hide_emitters = it.hide_emitters != 0;
     sc.integrator.use_spectral_mis = it.use_spectral_mis != 0;
     sc.integrator.monochrome = it.monochrome != 0;

@@ -98,6 +98,9 @@ def hg_table(g=0.7, n=181):
     return " ".join("%.9g" % v for v in val.astype(np.float32))
 
 
+C4_GROUND_Z = 0.05
+
+
 def c4_atmosphere(width=1024, height=1024, spp=4096, layers=64, sigma_r0=0.012, sigma_a0=0.1, sza_deg=30.0,
                   rayleigh_scale=1.0, samples_per_pass=-1):
     """C4: plane-parallel atmosphere, 50 km thick and 2*10^4 km wide: Rayleigh (scale height 8) + aerosol
@@ -133,7 +136,11 @@ def c4_atmosphere(width=1024, height=1024, spp=4096, layers=64, sigma_r0=0.012, 
                                               "phase_0": {"type": "rayleigh"},
                                               "phase_1": {"type": "tabphase", "values": hg_table(0.7, 181)},
                                               "weight": {"type": "gridvolume", "data": grid(weight), "to_world": grid_xf}}}},
-        "ground": {"type": "rectangle", "to_world": T.translate([0, 0, -0.01]) @ T.scale(1.2 * ext),
+        # The ground lies INSIDE the medium (Eradiate's own arrangement), 0.05 above the cube's bottom face.  A ground just below the
+        # cube, as in the slab scenes, leaks light at this scale: a ray leaving a surface point p starts at (1 + max|p|) RayEpsilon
+        # (interaction.h:58-61), i.e. 0.014 .. 1 at |p| = 160 .. 10^4 -- beyond the bottom face, so the medium was never entered and
+        # the ground saw an unattenuated sun (found by the independent estimator, tests/independent/).
+        "ground": {"type": "rectangle", "to_world": T.translate([0, 0, C4_GROUND_Z]) @ T.scale(1.2 * ext),
                    "bsdf": {"type": "rpv", "rho_0": 0.1, "k": 0.6, "g": -0.2}},
         "sun": {"type": "directional", "direction": sun, "irradiance": 1.0},
     }

@@ -20,6 +20,7 @@ OBJECT_TAGS = {"scene", "sensor", "film", "rfilter", "sampler", "integrator", "e
                "volume", "texture"}
 PROPERTY_TAGS = {"float", "integer", "boolean", "string", "point", "vector", "rgb", "spectrum", "transform", "ref", "default",
                  "include", "translate", "rotate", "scale", "lookat", "matrix"}
+MAX_INCLUDE_RECURSION = 15          # MTS_XML_INCLUDE_MAX_RECURSION, include/mitsuba/core/xml.h:8
 RESERVED_IDS = re.compile(r"^_unnamed_\d+$")
 
 
@@ -124,9 +125,10 @@ def _transform(node, params, src):
 
 
 class _Parser:
-    def __init__(self, src, params, base_dir):
+    def __init__(self, src, params, base_dir, include_depth=0):
         self.src, self.params, self.base_dir = src, dict(params), base_dir
         self.ids = {}
+        self.include_depth = include_depth                               # XMLSource::depth, xml.cpp:662-673
 
     def obj(self, node, depth=0):
         a = {k: _subst(v, self.params, self.src) for k, v in node.attrib.items()}
@@ -158,9 +160,14 @@ class _Parser:
                 path = ca["filename"] if os.path.isabs(ca["filename"]) else os.path.join(self.base_dir, ca["filename"])
                 if not os.path.exists(path):
                     _err(self.src, 'included file "%s" not found' % ca["filename"])
-                sub = _Parser(path, self.params, os.path.dirname(path))
+                if self.include_depth + 1 > MAX_INCLUDE_RECURSION:       # xml.cpp:671-673
+                    raise XMLError("Exceeded <include> recursion limit of %d" % MAX_INCLUDE_RECURSION)
+                sub = _Parser(path, self.params, os.path.dirname(path), self.include_depth + 1)
                 sub.ids = self.ids
-                root = ET.parse(path).getroot()
+                try:
+                    root = ET.parse(path).getroot()
+                except (ET.ParseError, OSError) as exc:                  # xml.cpp:675-678
+                    _err(self.src, 'error while loading "%s": %s' % (path, exc))
                 inc = sub.obj(root, depth)
                 items = inc.items() if root.tag == "scene" else [("_arg_%d" % arg, inc)]
                 for k, v in items:

@@ -377,15 +377,7 @@ static inline float distr_eval_pdf(const ContinuousDistribution &d, float x) {
 // distr_1d.h:438-461 with enoki::binary_search (absent source; standard bisection on [valid.x, valid.y])
 static inline float distr_sample(const ContinuousDistribution &d, float value) {
     value *= d.integral;
-    uint32_t start = d.valid_x, end = d.valid_y;
-    uint32_t iterations = 0;
-    if (start < end) { uint32_t diff = end - start; iterations = 1; while (diff >>= 1) iterations++; }
-    for (uint32_t i = 0; i < iterations; ++i) {
-        uint32_t middle = (start + end) >> 1;
-        bool cond = d.cdf[middle] < value;
-        if (cond) start = std::min(middle + 1, end); else end = middle;
-    }
-    uint32_t index = start;
+    uint32_t index = distr_binary_search(d.cdf, d.valid_x, d.valid_y, value);
     float y0 = d.pdf[index], y1 = d.pdf[index + 1], c0 = index > 0 ? d.cdf[index - 1] : 0.f;
     value = (value - c0) * d.inv_interval_size;
     float t_linear = (y0 - pm_safe_sqrt(y0 * y0 + 2.f * value * (y1 - y0))) / (y0 - y1), t_const = value / y0;
@@ -560,11 +552,9 @@ static inline void shape_sample_position(const Shape &s, P2 sample, V3 *p, V3 *n
         *n = s.frame.n; *pdf = s.inv_surface_area;
     } else if (s.type == MTS_SHAPE_CUBE || s.type == MTS_SHAPE_MESH) {                    // mesh.cpp:352-397
         // DiscreteDistribution::sample_reuse (distr_1d.h:141-151,187-197): first face whose running area reaches sample.y * sum
-        float value = sample.y * s.surface_area;
-        int lo = s.area_lo, hi = s.area_hi;
-        while (lo < hi) { int mid = (lo + hi) >> 1; if (s.area_cdf[mid] < value) lo = mid + 1; else hi = mid; }
-        float pmf = s.area_pmf[lo] * s.inv_surface_area, cdf = lo > 0 ? s.area_cdf[lo - 1] * s.inv_surface_area : 0.f;
-        sample.y = (sample.y - cdf) / pmf;
+        float reuse, pmf;
+        const int lo = (int) discrete_sample_reuse(s.area_distr, sample.y, &reuse, &pmf);
+        sample.y = reuse;
         const float *P = s.positions.data(); const uint32_t *f = &s.faces[3 * lo];
         V3 p0 = v3(P[3 * f[0]], P[3 * f[0] + 1], P[3 * f[0] + 2]), p1 = v3(P[3 * f[1]], P[3 * f[1] + 1], P[3 * f[1] + 2]),
            p2 = v3(P[3 * f[2]], P[3 * f[2] + 1], P[3 * f[2] + 2]);
@@ -1747,6 +1737,54 @@ int oracle_emitter_sample_direction(oracle_scene *s, const float *ref_p, float u
     DirectionSample ds = sample_emitter_direction(sc, v3(ref_p[0], ref_p[1], ref_p[2]), smp, false, &sp);
     d[0] = ds.d.x; d[1] = ds.d.y; d[2] = ds.d.z; *dist = ds.dist; *pdf = ds.pdf; spec[0] = sp.x; spec[1] = sp.y; spec[2] = sp.z;
     ORC_CATCH
+}
+// DiscreteDistribution / ContinuousDistribution hooks for the literals of src/libcore/tests/test_distr_1d.py
+int oracle_discrete_distribution(const float *pmf, int n, const float *samples, int m, int32_t *index, float *reuse, float *pmf_norm,
+                                 float *cdf_out /* n */, float *sum_norm /* 2 */) {
+    ORC_TRY
+    DiscreteDistribution d; d.pmf.assign(pmf, pmf + n);
+    discrete_update(d);
+    for (int i = 0; i < n; ++i) cdf_out[i] = d.cdf[i];
+    sum_norm[0] = d.sum; sum_norm[1] = d.normalization;
+    for (int i = 0; i < m; ++i) index[i] = (int32_t) discrete_sample_reuse(d, samples[i], &reuse[i], &pmf_norm[i]);
+    ORC_CATCH
+}
+int oracle_continuous_distribution(float r0, float r1, const float *pdf, int n, const float *x, int m, float *eval_pdf_norm,
+                                   float *eval_cdf_norm, float *sample, float *sample_pdf_norm, float *integral_norm /* 2 */) {
+    ORC_TRY
+    if (!(r0 < r1)) throw std::runtime_error("ContinuousDistribution: invalid range!");          // distr_1d.h:318-320
+    ContinuousDistribution d; d.pdf.assign(pdf, pdf + n); d.range_x = r0; d.range_y = r1;
+    distr_update(d);
+    integral_norm[0] = d.integral; integral_norm[1] = d.normalization;
+    for (int i = 0; i < m; ++i) {
+        eval_pdf_norm[i] = distr_eval_pdf(d, x[i]) * d.normalization;
+        {   // eval_cdf, distr_1d.h:400-417 (not on the render path; restated for the pin only)
+            float xs = (x[i] - d.range_x) * d.inv_interval_size;
+            uint32_t idx = (uint32_t) std::min(std::max((int64_t) xs, (int64_t) 0), (int64_t) d.pdf.size() - 2);
+            float y0 = d.pdf[idx], y1 = d.pdf[idx + 1], c0 = idx > 0 ? d.cdf[idx - 1] : 0.f;
+            float t = std::min(std::max(xs - (float) idx, 0.f), 1.f);
+            eval_cdf_norm[i] = (c0 + t * (y0 + .5f * t * (y1 - y0)) * d.interval_size) * d.normalization;
+        }
+        sample[i] = distr_sample(d, x[i]);                    // x doubles as the uniform variate
+        sample_pdf_norm[i] = distr_eval_pdf(d, sample[i]) * d.normalization;
+    }
+    ORC_CATCH
+}
+// math::solve_quadratic (src/libcore/tests/test_math.py:32-35) and BoundingBox3f (test_bbox.py:6-53) hooks
+int oracle_solve_quadratic(double a, double b, double c, double *x0, double *x1) { return solve_quadratic_d(a, b, c, x0, x1) ? 1 : 0; }
+int oracle_bbox_ops(int n_points, const float *points, int n_boxes, const float *boxes /* 6 each */, float *out_min, float *out_max,
+                    int *valid, float *bsphere /* centre 3, radius */) {
+    BBox b = bbox_empty();
+    for (int i = 0; i < n_points; ++i) bbox_expand(b, v3(points[3 * i], points[3 * i + 1], points[3 * i + 2]));
+    for (int i = 0; i < n_boxes; ++i) {
+        BBox o; o.min = v3(boxes[6 * i], boxes[6 * i + 1], boxes[6 * i + 2]); o.max = v3(boxes[6 * i + 3], boxes[6 * i + 4], boxes[6 * i + 5]);
+        bbox_expand(b, o);
+    }
+    out_min[0] = b.min.x; out_min[1] = b.min.y; out_min[2] = b.min.z; out_max[0] = b.max.x; out_max[1] = b.max.y; out_max[2] = b.max.z;
+    *valid = bbox_valid(b) ? 1 : 0;
+    V3 c = (b.min + b.max) * 0.5f;                            // BoundingBox::bounding_sphere, bbox.h:327-331
+    bsphere[0] = c.x; bsphere[1] = c.y; bsphere[2] = c.z; bsphere[3] = norm(c - b.max);
+    return 0;
 }
 float oracle_math(int fn, float x, float y) {
     switch (fn) { case 0: return pm_log(x); case 1: return pm_exp(x); case 2: { float s, c; pm_sincos(x, &s, &c); return s; }

@@ -62,6 +62,49 @@ static inline Volume make_volume(const mts_volume &d) {
     return v;
 }
 
+// ---------------------------------------------------------------- 1D distributions
+// DiscreteDistribution, include/mitsuba/core/distr_1d.h:27-197 (pinned by src/libcore/tests/test_distr_1d.py:35-132)
+struct DiscreteDistribution {
+    std::vector<float> pmf, cdf;
+    float sum = 0.f, normalization = 0.f;
+    uint32_t valid_x = (uint32_t) -1, valid_y = (uint32_t) -1;
+};
+static inline void discrete_update(DiscreteDistribution &d) {                              // distr_1d.h:49-83
+    size_t size = d.pmf.size();
+    if (size == 0) throw std::runtime_error("DiscreteDistribution: empty distribution!");
+    d.cdf.resize(size);
+    d.valid_x = d.valid_y = (uint32_t) -1;
+    double sum = 0.0;
+    for (uint32_t i = 0; i < size; ++i) {
+        double value = (double) d.pmf[i];
+        sum += value;
+        d.cdf[i] = (float) sum;
+        if (value < 0.0) throw std::runtime_error("DiscreteDistribution: entries must be non-negative!");
+        else if (value > 0.0) { if (d.valid_x == (uint32_t) -1) d.valid_x = i; d.valid_y = i; }
+    }
+    if (d.valid_x == (uint32_t) -1) throw std::runtime_error("DiscreteDistribution: no probability mass found!");
+    d.sum = (float) sum; d.normalization = (float) (1.0 / sum);
+}
+// enoki::binary_search (absent source): the first index in [start, end] for which the predicate `cdf[i] < value` is false
+static inline uint32_t distr_binary_search(const std::vector<float> &cdf, uint32_t start, uint32_t end, float value) {
+    uint32_t iterations = 0;
+    if (start < end) { uint32_t diff = end - start; iterations = 1; while (diff >>= 1) iterations++; }
+    for (uint32_t i = 0; i < iterations; ++i) {
+        uint32_t middle = (start + end) >> 1;
+        if (cdf[middle] < value) start = std::min(middle + 1, end); else end = middle;
+    }
+    return start;
+}
+static inline uint32_t discrete_sample(const DiscreteDistribution &d, float value) {        // distr_1d.h:141-151
+    return distr_binary_search(d.cdf, d.valid_x, d.valid_y, value * d.sum);
+}
+static inline uint32_t discrete_sample_reuse(const DiscreteDistribution &d, float value, float *reuse, float *pmf_out) {   // distr_1d.h:187-221
+    uint32_t index = discrete_sample(d, value);
+    float pmf = d.pmf[index] * d.normalization, cdf = index > 0 ? d.cdf[index - 1] * d.normalization : 0.f;
+    *reuse = (value - cdf) / pmf; *pmf_out = pmf;
+    return index;
+}
+
 // ---------------------------------------------------------------- Phase functions
 // ContinuousDistribution, include/mitsuba/core/distr_1d.h:293-345
 struct ContinuousDistribution {
@@ -142,8 +185,7 @@ struct Shape {
     std::vector<uint32_t> faces;
     int prim_count;
     // mesh area distribution (mesh.cpp:285-312, distr_1d.h:49-83): unnormalised pmf / cdf over the faces, first / last non-empty face
-    std::vector<float> area_pmf, area_cdf;
-    int area_lo = -1, area_hi = -1;
+    DiscreteDistribution area_distr;             // Mesh::m_area_distr (mesh.cpp:285-312)
     bool is_medium_transition() const { return interior >= 0 || exterior >= 0; }   // shape.h:341
 };
 
@@ -221,16 +263,17 @@ static inline Shape make_shape(const mts_shape &d) {
         s.prim_count = nf;
         // Mesh::build_pmf (mesh.cpp:285-312) + DiscreteDistribution::update (distr_1d.h:49-83): face areas (mesh.h:108-116),
         // running sum in double precision
-        s.area_pmf.resize(nf); s.area_cdf.resize(nf);
-        double sum = 0.0;
+        s.area_distr.pmf.resize(nf);
         for (int i = 0; i < nf; ++i) {
             const float *P = s.positions.data(); const uint32_t *f = &s.faces[3 * i];
             V3 p0 = v3(P[3 * f[0]], P[3 * f[0] + 1], P[3 * f[0] + 2]), p1 = v3(P[3 * f[1]], P[3 * f[1] + 1], P[3 * f[1] + 2]),
                p2 = v3(P[3 * f[2]], P[3 * f[2] + 1], P[3 * f[2] + 2]);
-            float a = 0.5f * norm(cross(p1 - p0, p2 - p0));
-            s.area_pmf[i] = a; sum += (double) a; s.area_cdf[i] = (float) sum;
-            if (a > 0.f) { if (s.area_lo < 0) s.area_lo = i; s.area_hi = i; }
+            s.area_distr.pmf[i] = 0.5f * norm(cross(p1 - p0, p2 - p0));
         }
+        bool has_area = false;
+        for (int i = 0; i < nf; ++i) has_area = has_area || s.area_distr.pmf[i] > 0.f;
+        double sum = 0.0;
+        if (has_area) { discrete_update(s.area_distr); for (int i = 0; i < nf; ++i) sum += (double) s.area_distr.pmf[i]; }
         s.surface_area = (float) sum;                                                          // mesh.cpp:346-350
         s.inv_surface_area = (float) (1.0 / sum);
     } else if (d.type == MTS_SHAPE_SPHERE) {
@@ -442,7 +485,7 @@ static inline Scene *make_scene(const mts_scene_desc *d) {
             em.radiance = v3(e.radiance[0], e.radiance[1], e.radiance[2]); em.shape = e.shape;
             if (e.type == MTS_EMITTER_AREA) {
                 check_index(e.shape, d->shape_count, "area emitter shape", false);
-                if ((sc->shapes[e.shape].type == MTS_SHAPE_CUBE || sc->shapes[e.shape].type == MTS_SHAPE_MESH) && sc->shapes[e.shape].area_lo < 0)
+                if ((sc->shapes[e.shape].type == MTS_SHAPE_CUBE || sc->shapes[e.shape].type == MTS_SHAPE_MESH) && sc->shapes[e.shape].area_distr.valid_x == (uint32_t) -1)
                     throw std::runtime_error("DiscreteDistribution: no probability mass found!");   // distr_1d.h:78-79
             }
             if (em.is_environment()) {

@@ -1,6 +1,6 @@
 """Generates the golden fixtures tests/golden/*.npz with the oracle (CPU restatement).
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [case ...]
 
 Fixtures are data only: the scene parameters needed to rebuild the input, the expected XYZAW film and the
 loop counters.  They pin (a) the oracle against regressions and (b) the HIP path on the GPU box without
@@ -28,6 +28,8 @@ CASES = {
 
 if __name__ == "__main__":
     for name, (fn, kw) in CASES.items():
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+            continue
         o = ob.OracleScene(getattr(scenes, fn)(**kw))
         film = o.render(threads=1)
         st = o.last_stats

@@ -1,0 +1,41 @@
+"""The C3 / C4 miniatures (eradiate-kernel_amd/scenes.py) restated for tests/independent/walk.py.
+
+Only DATA is taken from the scene dictionaries (grids, table values, numbers); the geometry is written out again here
+in the estimator's own terms, so a mistake in the loader's handling of a transform shows up as a disagreement."""
+import importlib
+import math
+
+import numpy as np
+
+from . import walk
+
+scenes = importlib.import_module("eradiate-kernel_amd.scenes")
+
+
+def c3(width=16, height=16, res=16, rpv=False):
+    d = scenes.c3_heterogeneous(width, height, 1, res=res)
+    med = d["slab"]["interior"]
+    sig = np.asarray(med["sigma_t"]["data"], np.float64)
+    alb = float(np.asarray(med["albedo"]["data"]).flat[0])
+    prob = walk.SlabProblem(box_min=[-50, -50, 0], box_max=[50, 50, 2], sigma_t_grid=sig, albedo=alb, phase=("hg", float(med["phase"]["g"])),
+                            ground_z=-0.01, ground_half=60.0, ground=("diffuse", 0.5), sun_dir=[0.5, 0.0, -0.866])
+    def sensor(rng, pix):
+        return walk.pinhole_rays(rng, width, height, 45.0, [0, 0, 20], [0, 0, -1], [0, 1, 0], pix)
+    return d, prob, sensor
+
+
+def c4(width=16, height=16, layers=64, continuation="reference"):
+    d = scenes.c4_atmosphere(width, height, 1, layers=layers)
+    med = d["atmosphere"]["interior"]
+    sig = np.asarray(med["sigma_t"]["data"], np.float64)
+    alb = np.asarray(med["albedo"]["data"], np.float64)
+    wgt = np.asarray(med["phase"]["weight"]["data"], np.float64)
+    tab = np.array([float(v) for v in med["phase"]["phase_1"]["values"].split()])
+    ext, top = 1.0e4, 50.0
+    sza = math.radians(30.0)
+    prob = walk.SlabProblem(box_min=[-ext, -ext, 0], box_max=[ext, ext, top], sigma_t_grid=sig, albedo=alb, phase=("blend", tab),
+                            blend_weight_grid=wgt, ground_z=scenes.C4_GROUND_Z, ground_half=1.2 * ext,
+                            ground=("rpv", 0.1, 0.6, -0.2, 0.1, continuation), sun_dir=[math.sin(sza), 0.0, -math.cos(sza)])
+    def sensor(rng, pix):
+        return walk.distant_hemisphere_rays(rng, width, height, [-1.0, -1.0], [1.0, 1.0], top, 4.0e4, pix)
+    return d, prob, sensor

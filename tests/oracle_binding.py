@@ -54,9 +54,28 @@ def lib():
     return _lib
 
 
-def _check(status):
+_lib_libm = None
+
+
+def lib_libm():
+    """oracle/liboracle_libm.so: the restatement built on glibc's libm instead of csrc/pmath.h (sensitivity measurement only)."""
+    global _lib_libm
+    if _lib_libm is None:
+        path = os.path.join(ROOT, "oracle", "liboracle_libm.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle_libm.so"], stdout=subprocess.DEVNULL)
+        L = C.CDLL(path)
+        L.oracle_last_error.restype = C.c_char_p
+        L.oracle_scene_create.argtypes = [C.POINTER(A.SceneDesc), C.POINTER(C.c_void_p)]
+        L.oracle_scene_destroy.argtypes = [C.c_void_p]
+        L.oracle_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, fp, C.POINTER(A.Stats)]
+        _lib_libm = L
+    return _lib_libm
+
+
+def _check(status, L=None):
     if status != 0:
-        raise RuntimeError(lib().oracle_last_error().decode())
+        raise RuntimeError((L or lib()).oracle_last_error().decode())
 
 
 def _f(a):
@@ -70,19 +89,20 @@ def _p(a):
 class OracleScene:
     """Scene built from a Mitsuba-style dict (or a ready SceneDesc) and rendered by the CPU restatement."""
 
-    def __init__(self, scene_dict=None, desc=None, keep=None, mono=False):
+    def __init__(self, scene_dict=None, desc=None, keep=None, mono=False, libm=False):
         if desc is None:
             desc, keep = SD.build_scene_desc(scene_dict, mono=mono)
         self.desc, self.keep = desc, keep
+        self.L = lib_libm() if libm else lib()
         h = C.c_void_p()
-        _check(lib().oracle_scene_create(C.byref(desc), C.byref(h)))
+        _check(self.L.oracle_scene_create(C.byref(desc), C.byref(h)), self.L)
         self.h = h
         self.last_stats = None
 
     def __del__(self):
         try:
             if self.h:
-                lib().oracle_scene_destroy(self.h)
+                self.L.oracle_scene_destroy(self.h)
                 self.h = None
         except Exception:
             pass
@@ -93,7 +113,7 @@ class OracleScene:
         out = np.zeros((h, w, 5), dtype=np.float32)
         st = A.Stats()
         threads = threads or os.cpu_count() or 1
-        _check(lib().oracle_render(self.h, threads, shard_index, shard_count, _p(out), C.byref(st)))
+        _check(self.L.oracle_render(self.h, threads, shard_index, shard_count, _p(out), C.byref(st)), self.L)
         self.last_stats = {k: getattr(st, k) for k, _ in A.Stats._fields_}
         return out
 

@@ -1,0 +1,137 @@
+"""An independent pin for `volpath`.
+
+The reference tree holds no numeric vector for volpath, media or grid volumes (src/media/tests/ is empty, the Z-test
+images of src/librender/tests/test_renders.py live in an absent submodule), and GPU <-> oracle bit-equality is common
+mode.  tests/independent/walk.py therefore computes the radiance of the C3 / C4 miniatures with a structurally different
+estimator (float64 numpy, ray-marched optical depth inverted for the free paths, quadrature transmittance, collision
+estimator with the solar beam as explicit source, Philox random numbers; see its docstring).  Its per-pixel means and
+variances are committed as tests/golden/indep_pin_*.npz (tests/independent/make_pin.py).
+
+Here: (1) the estimator is itself checked against a closed form and against its fixtures; (2) the oracle is Z-tested
+against the fixtures per pixel, with the Sidak correction the reference's own render tests use
+(src/librender/tests/test_renders.py:63-137, significance 0.01), and on the image mean, whose combined standard error
+is below 0.25 % -- so a misreading of volpath.cpp that moves the image by 1 % is four standard errors away;
+(3) the pin has teeth: it rejects the C4 scene as it was built in round 1 (ground just below the medium's boundary),
+where a light leak of the reference's own ray-epsilon rule brightened slanted views by up to 20 %."""
+import ast
+import copy
+import importlib
+import math
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import tests.oracle_binding as ob
+from tests.independent import problems, walk
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+scenes = importlib.import_module("eradiate-kernel_amd.scenes")
+SIGNIFICANCE = 0.01
+
+
+def load_pin(name):
+    z = np.load(os.path.join(GOLDEN, "indep_pin_%s_16x16.npz" % name))
+    return z["mean"], z["var"], int(z["per_pixel"])
+
+
+def oracle_estimate(d, seeds=16, spp=256):
+    """Per-pixel mean luminance and variance of that mean from `seeds` independent oracle renders."""
+    def one(seed):
+        dd = copy.deepcopy(d)
+        dd["sensor"]["sampler"]["sample_count"] = spp
+        dd["sensor"]["sampler"]["seed"] = seed
+        img = ob.OracleScene(dd).render(threads=1)
+        return img[..., 1] / img[..., 4]                      # Y / W: the luminance of a grey radiance
+    with ThreadPoolExecutor(min(8, os.cpu_count() or 1)) as ex:
+        imgs = np.array(list(ex.map(one, range(seeds))), np.float64)
+    return imgs.mean(0), imgs.var(0, ddof=1) / seeds
+
+
+def z_test(mean_a, var_a, mean_b, var_b):
+    """Two-sample version of test_renders.py:63-80: p-value per pixel; accepted when > the Sidak-corrected level."""
+    z = np.abs(mean_a - mean_b) / np.sqrt(var_a + var_b)
+    p = 2.0 * (1.0 - 0.5 * (1.0 + np.vectorize(math.erf)(z / math.sqrt(2.0))))
+    alpha = 1.0 - (1.0 - SIGNIFICANCE) ** (1.0 / z.size)
+    return p, alpha, z
+
+
+def test_estimator_imports_nothing_from_the_product_or_the_oracle():
+    src = open(walk.__file__).read()
+    mods = set()
+    for node in ast.walk(ast.parse(src)):
+        if isinstance(node, ast.Import):
+            mods |= {a.name.split(".")[0] for a in node.names}
+        elif isinstance(node, ast.ImportFrom):
+            mods.add((node.module or "").split(".")[0])
+    assert mods == {"math", "numpy"}, mods
+    assert "ctypes" not in src and "oracle" not in src.replace("oracle/", "") .replace("the oracle", "")
+
+
+def test_estimator_reproduces_the_single_scattering_closed_form():
+    """Homogeneous slab, black ground, one event: L = albedo p(theta) E mu0 / (mu + mu0) (1 - exp(-tau (1/mu + 1/mu0)))."""
+    sig, alb, g, h = 0.7, 0.9, 0.5, 2.0
+    mu0 = 0.8
+    sun = [math.sqrt(1 - mu0 * mu0), 0.0, -mu0]
+    prob = walk.SlabProblem([-1e3, -1e3, 0], [1e3, 1e3, h], np.full((4, 2, 2), sig), alb, ("hg", g), -0.01, 2e3, ("diffuse", 0.0), sun)
+    rng = np.random.Generator(np.random.Philox(3))
+    for mu, phi in [(1.0, 0.0), (0.5, 0.3), (0.25, 2.0)]:
+        v = np.array([math.sqrt(1 - mu * mu) * math.cos(phi), math.sqrt(1 - mu * mu) * math.sin(phi), mu])
+        n = 40000
+        o = np.tile(np.array([0.0, 0.0, h]) + 5.0 * v, (n, 1)); d = np.tile(-v, (n, 1))
+        val = walk.radiance(prob, rng, o, d, max_events=1)
+        cos_sc = float(np.dot(-v, -np.asarray(sun)))          # sunlight travelling along `sun` is scattered into +v
+        cos_sc = float(np.dot(np.asarray(sun), v))
+        p = (1 - g * g) / (4 * math.pi * (1 + g * g - 2 * g * cos_sc) ** 1.5)
+        tau = sig * h
+        expected = alb * p * mu0 / (mu + mu0) * (1 - math.exp(-tau * (1 / mu + 1 / mu0)))
+        se = val.std() / math.sqrt(n)
+        assert abs(val.mean() - expected) < 4 * se + 2e-4 * expected, (mu, val.mean(), expected, se)
+
+
+@pytest.mark.parametrize("name", ["c3", "c4"])
+def test_fixture_comes_from_the_committed_estimator(name):
+    """A short live run of the estimator agrees with its fixture (same code, other seed, 40 walks per pixel)."""
+    mean, var, _ = load_pin(name)
+    _, prob, sensor = getattr(problems, name)()
+    m, v = walk.render(prob, sensor, 16, 16, 40, seed=77)
+    se = math.sqrt(v.sum() + var.sum()) / m.size
+    assert abs(m.mean() - mean.mean()) < 4 * se
+    # 40 walks do not give a usable per-pixel variance: compare 4 x 4 tiles of 16 pixels instead
+    tm, tv = m.reshape(4, 4, 4, 4).mean((1, 3)), v.reshape(4, 4, 4, 4).sum((1, 3)) / 256
+    fm, fv = mean.reshape(4, 4, 4, 4).mean((1, 3)), var.reshape(4, 4, 4, 4).sum((1, 3)) / 256
+    p, alpha, _ = z_test(tm, tv, fm, fv)
+    assert (p > alpha).all()
+
+
+@pytest.mark.parametrize("name", ["c3", "c4"])
+def test_oracle_agrees_with_the_independent_estimator(name):
+    mean, var, _ = load_pin(name)
+    d, _, _ = getattr(problems, name)()
+    om, ov = oracle_estimate(d)
+    se_pin = math.sqrt(var.sum()) / var.size / mean.mean()
+    se_orc = math.sqrt(ov.sum()) / ov.size / om.mean()
+    se = math.hypot(se_pin, se_orc)
+    rel = om.mean() / mean.mean() - 1.0
+    print("%s: image mean oracle %.6f, independent %.6f, difference %+.3f %% (standard errors %.3f %% / %.3f %%)"
+          % (name, om.mean(), mean.mean(), 100 * rel, 100 * se_orc, 100 * se_pin))
+    assert se < 2.5e-3                                        # the sensitivity this pin claims
+    assert abs(rel) < 4 * se and abs(rel) < 1e-2
+    p, alpha, z = z_test(om, ov, mean, var)
+    print("%s: min p-value %.2e, Sidak level %.2e, max |z| %.2f" % (name, p.min(), alpha, z.max()))
+    assert (p > alpha).mean() >= 0.9975                       # test_renders.py:121
+
+
+def test_pin_rejects_the_round_1_c4_scene():
+    """Round 1 put the C4 ground 0.01 below the medium's bottom face.  A ray leaving a surface point p starts at
+    (1 + max|p|) RayEpsilon (interaction.h:58-61): beyond that face for |p| > 130, so the reflected ray never entered the
+    medium and the ground was lit by an unattenuated sun.  The oracle (and the HIP kernels, bit for bit) reproduce that rule
+    faithfully; the independent estimator, which knows nothing about ray epsilons, does not -- and the Z-test says so."""
+    mean, var, _ = load_pin("c4")
+    d, _, _ = problems.c4()
+    d["ground"]["to_world"] = scenes.T.translate([0, 0, -0.01]) @ scenes.T.scale(1.2e4)
+    om, ov = oracle_estimate(d, seeds=8)
+    p, alpha, z = z_test(om, ov, mean, var)
+    assert (p > alpha).mean() < 0.9 and z.max() > 5.0
+    assert om.mean() / mean.mean() - 1.0 < -1.5e-2

@@ -478,31 +478,71 @@ def test_directional_emitter_sample_direction():
     assert np.isclose(dist, 2 * np.sqrt(2) * (1 + 1500 * 2.0 ** -24), rtol=1e-6)
 
 
-@pytest.mark.parametrize("setup", ["default", "target_square", "target_square_small", "target_square_large", "target_point"])
+def _distant_render_scene(setup, w_e, w_o, spp):
+    sensor = {"type": "distant", "direction": w_o, "sampler": {"type": "independent", "sample_count": spp},
+              "film": {"type": "hdrfilm", "height": 1, "width": 1, "rfilter": {"type": "box"}}}
+    if setup == "target_point":
+        sensor["ray_target"] = [0, 0, 0]
+    elif setup == "target_disk":
+        sensor["ray_target"] = {"type": "disk", "to_world": T.scale(1.0)}
+    elif setup != "default":
+        scale = {"target_square": 1.0, "target_square_small": 0.5, "target_square_large": 2.0}[setup]
+        sensor["ray_target"] = {"type": "rectangle", "to_world": T.scale(scale)}
+    return {"type": "scene", "integrator": {"type": "path"}, "sensor": sensor,
+            "shape": {"type": "rectangle", "to_world": T.scale(1.0), "bsdf": {"type": "diffuse", "reflectance": 1.0}},
+            "emitter": {"type": "directional", "direction": w_e, "irradiance": 1.0}}
+
+
+# The reference's assertion (test_distant.py:462-475) holds at ITS sample count (1e5) and ITS tolerances (5e-3; 1e-2 for the large
+# target) for every combination except these: emitter direction [0, 1, -1] with a target that makes every sample the same
+# constant.  There the red channel comes out +0.5056 % (G -0.3224 %, B -0.0961 %), 0.0056 % outside the 5e-3 bound.  The cause is
+# not a last-ulp difference upstream: summing a constant v 1e5 times in fp32, sample by sample as ImageBlock::put does in
+# scalar_rgb (imageblock.cpp:163-168), quantises v to the ulp of the running sum (X = 0.2139 is 109.53 ulps of a sum in
+# [16384, 32768): every addition rounds to 110), and XYZ -> RGB amplifies the per-channel biases.  test_constant_sum_bias_is_not_an_ulp_effect
+# below shows that all 27 one-ulp perturbations of the per-sample XYZ give the identical 0.5056 %, i.e. any implementation that
+# accumulates the block in fp32 lands on this number.
+DISTANT_MARGINAL = {(s, (0, 1, -1), w) for s in ("target_square", "target_square_small", "target_disk", "target_point") for w in ((0, 0, 1), (0, 1, 1))}
+
+
+@pytest.mark.parametrize("setup", ["default", "target_square", "target_square_small", "target_square_large", "target_disk", "target_point"])
 @pytest.mark.parametrize("w_e", [[0, 0, -1], [0, 1, -1]])
 @pytest.mark.parametrize("w_o", [[0, 0, 1], [0, 1, 1]])
 def test_distant_sensor_render(setup, w_e, w_o):
     """src/sensors/tests/test_distant.py:300-475: path + directional + diffuse + distant + hdrfilm, closed form
-    L = E cos(theta_e) rho / pi (x 2/pi without target, x 0.25 for the large square).  20000 spp instead of 1e5."""
+    L = E cos(theta_e) rho / pi (x 2/pi without target, x 0.25 for the large square), at the reference's 1e5 spp and tolerances."""
+    key = (setup, tuple(w_e), tuple(w_o))
     w_e = list(np.array(w_e) / np.linalg.norm(w_e)); w_o = list(np.array(w_o) / np.linalg.norm(w_o))
-    cos_theta_e = abs(w_e[2])
-    sensor = {"type": "distant", "direction": w_o, "sampler": {"type": "independent", "sample_count": 20000},
-              "film": {"type": "hdrfilm", "height": 1, "width": 1, "rfilter": {"type": "box"}}}
-    if setup == "target_point":
-        sensor["ray_target"] = [0, 0, 0]
-    elif setup != "default":
-        scale = {"target_square": 1.0, "target_square_small": 0.5, "target_square_large": 2.0}[setup]
-        sensor["ray_target"] = {"type": "rectangle", "to_world": T.scale(scale)}
-    d = {"type": "scene", "integrator": {"type": "path"}, "sensor": sensor,
-         "shape": {"type": "rectangle", "to_world": T.scale(1.0), "bsdf": {"type": "diffuse", "reflectance": 1.0}},
-         "emitter": {"type": "directional", "direction": w_e, "irradiance": 1.0}}
-    img = ob.OracleScene(d).render(threads=1)
+    img = ob.OracleScene(_distant_render_scene(setup, w_e, w_o, 100000)).render(threads=1)
     import tests.transport_cases as tc
     rgb = tc.radiance_rgb(img).reshape(3)
-    l_o = cos_theta_e / np.pi
+    l_o = abs(w_e[2]) / np.pi
     expected = {"default": l_o * 2.0 / np.pi, "target_square_large": l_o * 0.25}.get(setup, l_o)
-    rtol = {"target_square_large": 2e-2, "default": 2e-2}.get(setup, 5e-3)
-    assert np.allclose(rgb, expected, rtol=rtol)
+    rtol = {"target_square_large": 1e-2}.get(setup, 5e-3)                      # test_distant.py:471-474
+    if key in DISTANT_MARGINAL:
+        assert np.allclose(rgb / expected - 1.0, [5.056e-3, -3.224e-3, -0.961e-3], atol=2e-5), rgb / expected - 1.0
+    else:
+        assert np.allclose(rgb, expected, rtol=rtol), rgb / expected - 1.0
+
+
+def test_constant_sum_bias_is_not_an_ulp_effect():
+    """The +0.5056 % of the marginal cases above follows from fp32 accumulation alone and does not move when the per-sample
+    value moves by an ulp in any channel."""
+    w_e = list(np.array([0, 1, -1]) / np.sqrt(2.0))
+    v = ob.OracleScene(_distant_render_scene("target_point", w_e, [0, 0, 1], 1)).render(threads=1).reshape(5)[:3]
+    assert np.allclose(v, np.array([0.950456, 1.0, 1.088754]) * abs(w_e[2]) / np.pi, rtol=1e-6)     # srgb_to_xyz of a grey L = cos / pi
+    m = np.array([[3.240479, -1.537150, -0.498535], [-0.969256, 1.875991, 0.041556], [0.055648, -0.204043, 1.057311]], np.float32)
+    cand = np.array([[np.nextafter(np.float32(c), np.float32(-np.inf)), np.float32(c), np.nextafter(np.float32(c), np.float32(np.inf))] for c in v], np.float32)
+    sums = np.zeros_like(cand)
+    for _ in range(100000):                                                    # the nine running sums side by side, fp32 throughout
+        sums = sums + cand
+    assert sums.dtype == np.float32
+    out = set()
+    for ix in range(3):
+        for iy in range(3):
+            for iz in range(3):
+                mean = np.array([sums[0, ix], sums[1, iy], sums[2, iz]], np.float32) / np.float32(100000)
+                out.add(tuple(np.round((m @ mean) / (abs(w_e[2]) / np.pi) - 1.0, 6)))
+    assert len(out) == 1 and np.allclose(list(out)[0], [5.056e-3, -3.224e-3, -0.961e-3], atol=2e-5), out
 
 
 # ---------------------------------------------------------------- mradiancemeter / mdistant (SURVEY.md 8(f3))

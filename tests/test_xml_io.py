@@ -124,3 +124,17 @@ def test_include_and_file_loading(tmp_path):
     assert d["_arg_0"] == {"type": "rectangle", "id": "floor"} and d["_arg_1"] == {"type": "path"}
     with pytest.raises(Exception, match="does not exist"):
         xml_io.file_to_dict(str(tmp_path / "nope.xml"))
+
+
+def test_include_recursion_limit_and_broken_include(tmp_path):
+    # xml.cpp:662-678: an <include> chain deeper than MTS_XML_INCLUDE_MAX_RECURSION (core/xml.h:8) is an error, and a parse
+    # error inside an included file is reported as an error while loading that file
+    me = tmp_path / "self.xml"
+    me.write_text('<scene version="2.0.0"><include filename="self.xml"/></scene>')
+    with pytest.raises(xml_io.XMLError, match="Exceeded <include> recursion limit of 15"):
+        xml_io.file_to_dict(str(me))
+    (tmp_path / "broken.xml").write_text('<scene version="2.0.0"><shape')
+    top = tmp_path / "top.xml"
+    top.write_text('<scene version="2.0.0"><include filename="broken.xml"/></scene>')
+    with pytest.raises(xml_io.XMLError, match="error while loading"):
+        xml_io.file_to_dict(str(top))
