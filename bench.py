@@ -5,12 +5,16 @@ grid + HG, 512x512x1024 spp) on N MI355X of one node.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A step = one complete render of the workload with scene (grids) and film resident in HBM.  N = 1 renders
-512x512x1024 spp.  N > 1 renders 512x512x(1024 N) spp in passes of 1024 spp (the reference's own
-`samples_per_pass` mechanism, librender/integrator.cpp:58-65): the (pass, block) pairs are dealt round-robin
-over the ranks (`block_id % N`), so every GPU always does one 512x512x1024 job (weak scaling), the per-pixel
-random streams stay those of the reference, and the only exchange is one RCCL reduce of the 5 MB XYZAW film
-over xGMI per step (inside the timed region).
+A step = one complete render of the workload with scene (grids) and film resident in HBM.
+
+STRONG scaling (the headline, `"scaling": "strong"`): every N renders the SAME 512x512x1024 job.  For N > 1 the job is cut
+into N passes of 1024/N spp with the reference's own `samples_per_pass` mechanism (librender/integrator.cpp:58-65), which
+gives N x 256 (pass, block) pairs; they are dealt round-robin over the ranks (`block_id % N`), so every GPU gets 256
+workgroups (one per CU), the per-pixel random streams are those the reference draws for that `samples_per_pass`, and the
+only exchange is one RCCL reduce of the 5 MB XYZAW film over xGMI per step (inside the timed region).  Rank 0 then checks
+that the reduced film equals the film ONE rank renders of the same job (`"film_check"`).
+
+WEAK scaling (side figure, `"weak"`): 512x512x(1024 N) spp in passes of 1024 spp, one 512x512x1024 job per GPU.
 
 Rank 0 prints ONE JSON line; see DESIGN.md for how `roofline` and `cpu_baseline` are derived.
 """
@@ -26,6 +30,80 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
+CONFIG_SIZES = {"C1": (256, 256, 64), "C2": (512, 512, 256), "C3": (512, 512, 1024), "C4": (1024, 1024, 4096), "C5": (1024, 1024, 4096)}
+C5_WAVELENGTHS = 16        # BASELINE.json configs[4]: the C4 atmosphere as a 16-wavelength batch
+
+
+def c5_rayleigh_scale(k):
+    """Rayleigh optical thickness ~ lambda^-4 over 16 wavelengths from 400 to 1000 nm, relative to 550 nm."""
+    lam = 400.0 + 40.0 * k
+    return (550.0 / lam) ** 4
+
+
+def build_scene_dict(scenes, config, width, height, spp, samples_per_pass=-1, res=128, wavelength=0):
+    if config == "C1":
+        d = scenes.c1_cornell(width, height, spp)
+    elif config == "C2":
+        d = scenes.c2_homogeneous_slab(width, height, spp)
+    elif config == "C4":
+        d = scenes.c4_atmosphere(width, height, spp)
+    elif config == "C5":
+        d = scenes.c4_atmosphere(width, height, spp, rayleigh_scale=c5_rayleigh_scale(wavelength))
+    else:
+        d = scenes.c3_heterogeneous(width, height, spp, res=res)
+    d["integrator"]["samples_per_pass"] = samples_per_pass
+    return d
+
+
+class Job:
+    """One workload resident on this rank's GPU: scene(s), film, and the step() that renders this rank's share and reduces it."""
+
+    def __init__(self, pkg, scenes, args, rank, n, local_rank, backend, spp_total, samples_per_pass):
+        import torch
+        self.torch, self.rank, self.n, self.backend = torch, rank, n, backend
+        variant = "gpu_mono" if args.config == "C5" else "gpu_rgb"      # C5: monochromatic batches (scalar_mono semantics), one per wavelength
+        pkg.set_variant(variant)
+        self.dicts = [build_scene_dict(scenes, args.config, args.width, args.height, spp_total, samples_per_pass, args.res, k)
+                      for k in range(C5_WAVELENGTHS if args.config == "C5" else 1)]
+        self.scenes = [pkg.load_dict(d, device=local_rank) for d in self.dicts]       # grids uploaded to HBM here (outside the timed region)
+        self.films = [torch.zeros((args.height, args.width, 5), dtype=torch.float32, device="cuda") for _ in self.scenes]
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.samples_step = args.width * args.height * spp_total * len(self.scenes)      # all ranks, one step
+
+    def render(self, shard_index, shard_count, collect_counters=False):
+        stats = []
+        for scene, film in zip(self.scenes, self.films):
+            integ = scene.integrator()
+            integ.render(scene, scene.sensors()[0], shard_index=shard_index, shard_count=shard_count, device_film=film.data_ptr(),
+                         stream=self.stream, collect_counters=collect_counters)
+            stats.append(integ.last_stats)
+        return stats
+
+    def step(self):
+        import torch.distributed as dist
+        stats = self.render(self.rank, self.n)
+        if self.n > 1:
+            for film in self.films:
+                if self.backend == "gloo":                   # rehearsal: all ranks on one GPU, film reduce on the host
+                    host = film.cpu(); dist.reduce(host, dst=0, op=dist.ReduceOp.SUM); film.copy_(host)
+                else:
+                    dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)       # RCCL over xGMI: W*H*5 fp32
+        return stats
+
+
+def timed(job, steps, warmup, barrier, all_max):
+    for _ in range(warmup):
+        job.step()
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms, launches, samples_rank = 0.0, 0, 0
+    for _ in range(steps):
+        sts = job.step()
+        kernel_ms += sum(s["kernel_ms"] for s in sts); launches += sum(s["kernel_launches"] for s in sts)
+        samples_rank = sum(s["samples"] for s in sts)
+    barrier()
+    elapsed = all_max(time.perf_counter() - t0)
+    return elapsed, kernel_ms, launches, samples_rank
 
 
 def main():
@@ -33,13 +111,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4"],
+    ap.add_argument("--config", default="C3", choices=sorted(CONFIG_SIZES),
                     help="BASELINE.json configuration; C3 is the one the metric is quoted on, the others are side measurements")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--res", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-weak", action="store_true", help="skip the weak-scaling side measurement (N > 1)")
+    ap.add_argument("--no-film-check", action="store_true", help="skip the N-rank == 1-rank film check (N > 1)")
     ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU-baseline sample (0 = sized for ~15 s)")
     args = ap.parse_args()
 
@@ -72,91 +152,100 @@ def main():
 
     pkg = importlib.import_module("eradiate-kernel_amd")
     scenes = importlib.import_module("eradiate-kernel_amd.scenes")
-    pkg.set_variant("gpu_rgb")
 
-    cfg_w, cfg_h, cfg_spp = {"C1": (256, 256, 64), "C2": (512, 512, 256), "C3": (512, 512, 1024), "C4": (1024, 1024, 4096)}[args.config]
+    cfg_w, cfg_h, cfg_spp = CONFIG_SIZES[args.config]
     args.width, args.height, args.spp = args.width or cfg_w, args.height or cfg_h, args.spp or cfg_spp
-    spp_total = args.spp * n
-
-    def make_scene(spp, samples_per_pass=-1):
-        if args.config == "C1":
-            d_ = scenes.c1_cornell(args.width, args.height, spp)
-        elif args.config == "C2":
-            d_ = scenes.c2_homogeneous_slab(args.width, args.height, spp)
-        elif args.config == "C4":
-            d_ = scenes.c4_atmosphere(args.width, args.height, spp, samples_per_pass=samples_per_pass)
-        else:
-            return scenes.c3_heterogeneous(args.width, args.height, spp, res=args.res, samples_per_pass=samples_per_pass)
-        d_["integrator"]["samples_per_pass"] = samples_per_pass
-        return d_
-    d = make_scene(spp_total, args.spp)
-    scene = pkg.load_dict(d, device=local_rank)            # grids uploaded to HBM here (outside the timed region)
-    sensor = scene.sensors()[0]
-    integ = scene.integrator()
-    film = torch.zeros((args.height, args.width, 5), dtype=torch.float32, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def step():
-        integ.render(scene, sensor, shard_index=rank, shard_count=n, device_film=film.data_ptr(), stream=stream)
-        if n > 1 and backend == "gloo":
-            host = film.cpu(); dist.reduce(host, dst=0, op=dist.ReduceOp.SUM); film.copy_(host)
-        elif n > 1:
-            dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)   # RCCL over xGMI: W*H*5 fp32
-        return integ.last_stats
 
     def barrier():
         if n > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    kernel_ms, launches, samples_rank = 0.0, 0, 0
-    for _ in range(args.steps):
-        st = step()
-        kernel_ms += st["kernel_ms"]; launches += st["kernel_launches"]; samples_rank = st["samples"]
-    barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
+    def all_max(x):
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
+        if n > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- strong scaling: the fixed job, N passes of spp / N (the largest divisor of spp not above spp / N)
+    spp_pass = args.spp
     if n > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        spp_pass = max(1, args.spp // n)
+        while args.spp % spp_pass:
+            spp_pass -= 1
+    job = Job(pkg, scenes, args, rank, n, local_rank, backend, args.spp, spp_pass if n > 1 else -1)
+    elapsed, kernel_ms, launches, samples_rank = timed(job, args.steps, args.warmup, barrier, all_max)
+    value = job.samples_step * args.steps / elapsed / 1e6
 
-    samples_step = args.width * args.height * spp_total      # all ranks, one step
-    value = samples_step * args.steps / elapsed / 1e6
+    film_check = None
+    if n > 1 and not args.no_film_check:
+        # the reduced film of the N ranks against the film ONE rank renders of the same job with the same samples_per_pass.  Box
+        # filter: every film entry is the sum of the same per-pass values; only the order of those <= N additions differs.
+        reduced = [f.clone() for f in job.films]
+        if rank == 0:
+            job.render(0, 1)
+            worst = max(float(((a - b).abs() / b.abs().clamp_min(1e-6)).max().item()) for a, b in zip(reduced, job.films))
+            film_check = {"max_rel_diff": worst, "ok": bool(worst < 1e-5)}
+        barrier()
+        if rank == 0 and not film_check["ok"]:
+            raise SystemExit("bench.py: the %d-rank film differs from the 1-rank film (max rel %.3g)" % (n, film_check["max_rel_diff"]))
 
-    # ---- roofline of the dominant kernel (render_kernel): algorithmic bytes / measured launch duration
-    # counters come from one extra, untimed render with the counting kernel variant; they are
-    # deterministic and equal the oracle's at the same seed (tests/test_gpu_parity.py).
-    integ.render(scene, sensor, shard_index=rank, shard_count=n, device_film=film.data_ptr(), stream=stream, collect_counters=True)
-    cs = integ.last_stats
-    bytes_per_sample = (224.0 * cs["n_iter"] + 64.0 * cs["n_lookup"] + 128.0 * cs["n_nee_step"]) / cs["samples"] + 40.0
+    # ---- roofline of the dominant kernel: algorithmic bytes / measured launch duration (SURVEY.md 8(d) convention).
+    # Counters come from one extra, untimed render with the counting kernel variant; they are deterministic and equal the
+    # oracle's at the same seed (tests/test_gpu_parity.py).
+    cs = job.render(rank, n, collect_counters=True)
+    c_iter, c_look, c_nee, c_samp = (sum(s[k] for s in cs) for k in ("n_iter", "n_lookup", "n_nee_step", "samples"))
+    bytes_per_sample = (224.0 * c_iter + 64.0 * c_look + 128.0 * c_nee) / c_samp + 40.0
     avg_launch_ms = kernel_ms / max(launches, 1)
     bytes_per_launch = bytes_per_sample * samples_rank * (args.steps / max(launches, 1))
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
+    integ_type = job.dicts[0]["integrator"]["type"]
     kv = os.environ.get("MTSAMD_KERNEL", "wga1024")
-    if d["integrator"]["type"] == "path" or kv == "nested":
-        kernel_name = "render_kernel<false, false, %d>" % {"path": 0, "volpath": 1, "volpathmis": 2}.get(d["integrator"]["type"], 0)
+    if integ_type == "path" or kv == "nested":
+        kernel_name = "render_kernel<false, false, %d>" % {"path": 0, "volpath": 1, "volpathmis": 2}.get(integ_type, 0)
     elif kv == "flat":
         kernel_name = "render_kernel<false, true, 1>"
     else:
         paths = int(kv[3:]); nt = int(os.environ.get("MTSAMD_WG_THREADS", str(paths)))
         kernel_name = "render_kernel_wga<false, %d, %d, %d>" % (paths, nt, {1: 4, 0.75: 3, 0.5: 2}[nt / paths])
+    # `achieved` / `frac` follow the contract: ALGORITHMIC bytes (a wavefront formulation's state round trips) over
+    # the kernel's measured time.  This kernel keeps path state in LDS, so its real HBM traffic is several times lower and its
+    # bound is VALU issue; `traffic*` and `valu_issue_frac` (rocprofv3 --pmc, profiles/) say so whenever this run matches the
+    # profiled configuration.
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "achieved_is": "algorithmic bytes per launch / measured launch time (SURVEY.md 8(d)); not a bandwidth measurement",
                 "kernel": kernel_name, "avg_launch_ms": round(avg_launch_ms, 3),
                 "bytes_per_sample": round(bytes_per_sample, 1),
-                "n_iter_per_sample": round(cs["n_iter"] / cs["samples"], 3),
-                "n_lookup_per_sample": round(cs["n_lookup"] / cs["samples"], 3),
-                "n_nee_step_per_sample": round(cs["n_nee_step"] / cs["samples"], 3)}
-    traffic_file = os.path.join(ROOT, "profiles", "traffic_bytes_per_launch.json")
-    if os.path.exists(traffic_file) and args.config == "C3":                           # measured HBM bytes per launch from the rocprofv3 --pmc passes
+                "n_iter_per_sample": round(c_iter / c_samp, 3),
+                "n_lookup_per_sample": round(c_look / c_samp, 3),
+                "n_nee_step_per_sample": round(c_nee / c_samp, 3)}
+    this_run = {"config": args.config, "width": args.width, "height": args.height, "spp": args.spp, "res": args.res, "n_gpus": n, "kernel": kernel_name}
+    for fname in ("traffic_bytes_per_launch.json",):
+        path = os.path.join(ROOT, "profiles", fname)
         try:
-            roofline["traffic"] = json.load(open(traffic_file)).get("bytes_per_launch")
+            prof = json.load(open(path))
         except Exception:
-            pass
+            continue
+        if prof.get("run") == this_run:                          # counters describe THIS configuration and kernel only
+            roofline["traffic"] = prof.get("bytes_per_launch")
+            roofline["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration; not measured in this run)" % fname
+            roofline["traffic_gbs"] = round(prof["bytes_per_launch"] / (avg_launch_ms * 1e-3) / 1e9, 1)
+            roofline["traffic_frac_of_peak"] = round(roofline["traffic_gbs"] / HBM_PEAK_GBS, 4)
+            if "valu_issue_fraction" in prof:
+                roofline["valu_issue_frac"] = prof["valu_issue_fraction"]
+                roofline["real_bound"] = "valu issue (%.0f %% of the issue slots; HBM at %.0f %% of peak)" % (100 * prof["valu_issue_fraction"], 100 * roofline["traffic_frac_of_peak"])
+
+    # ---- weak scaling side figure (N > 1): one 512x512x1024 job per GPU
+    weak = None
+    if n > 1 and not args.no_weak:
+        del job
+        torch.cuda.empty_cache()
+        wjob = Job(pkg, scenes, args, rank, n, local_rank, backend, args.spp * n, args.spp)
+        w_elapsed, _, _, _ = timed(wjob, args.steps, args.warmup, barrier, all_max)
+        weak = {"value": round(wjob.samples_step * args.steps / w_elapsed / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(w_elapsed / args.steps * 1e3, 2),
+                "workload": "%dx%dx%d spp total, passes of %d: one %dx%dx%d job per GPU" % (args.width, args.height, args.spp * n, args.spp, args.width, args.height, args.spp)}
+        del wjob
 
     cpu_baseline = None
     if rank == 0 and n == 1 and not args.no_cpu_baseline:
@@ -164,31 +253,37 @@ def main():
         import tests.oracle_binding as ob
         cores = os.cpu_count() or 1
         def cpu_render(spp):
-            osc = ob.OracleScene(make_scene(spp))
+            osc = ob.OracleScene(build_scene_dict(scenes, args.config, args.width, args.height, spp, -1, args.res, 0), mono=args.config == "C5")
             tc0 = time.perf_counter()
             osc.render(threads=cores)
             return time.perf_counter() - tc0
         cpu_spp = args.cpu_spp
         if cpu_spp <= 0:                                         # calibrate with 2 spp, then size the sample for ~15 s
             tcal = cpu_render(2)
-            cpu_spp = int(min(1024, max(2, round(15.0 / (tcal / 2.0)))))
+            cpu_spp = int(min(args.spp, max(2, round(15.0 / (tcal / 2.0)))))
         tcpu = cpu_render(cpu_spp)
         cpu_baseline = {"value": round(args.width * args.height * cpu_spp / tcpu / 1e6, 4), "unit": "Msamples/s", "cores": cores,
-                        "kind": "port", "sample": "%dx%dx%dspp of the same scene, all pixels, seed 0 (%.1f s on %d threads)"
-                                                  % (args.width, args.height, cpu_spp, tcpu, cores)}
+                        "kind": "port", "sample": "%dx%dx%dspp of the same scene%s, all pixels, seed 0 (%.1f s on %d threads)"
+                                                  % (args.width, args.height, cpu_spp, " (first wavelength)" if args.config == "C5" else "", tcpu, cores)}
 
     if rank == 0:
         workload = {"C1": "C1 path cornell box", "C2": "C2 volpath homogeneous slab", "C4": "C4 volpath layered atmosphere, blend/tabulated phase, RPV ground",
+                    "C5": "C5 = C4 as %d monochromatic wavelength batches (Rayleigh ~ lambda^-4), gpu_mono" % C5_WAVELENGTHS,
                     "C3": "C3 volpath heterogeneous %d^3 grid + HG g=0.8" % args.res}[args.config]
         out = {"metric": "Msamples/s volpath 512x512x1024spp plane-parallel atmosphere" if args.config == "C3" else "Msamples/s %s (side measurement)" % args.config,
                "value": round(value, 2), "unit": "Msamples/s",
                "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "%s, %dx%dx%dspp per GPU (%d spp total, passes of %d)"
-                                      % (workload, args.width, args.height, args.spp, spp_total, args.spp),
-                          "integrator": d["integrator"]["type"], "sampler": "independent seed 0", "block_size": 32, "rfilter": "box",
-                          "sharding": "block_id %% %d round-robin + RCCL film reduce" % n if n > 1 else "single GPU"},
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "%s, %dx%dx%dspp%s" % (workload, args.width, args.height, args.spp,
+                                                             " in %d passes of %d spp (samples_per_pass)" % (args.spp // spp_pass, spp_pass) if n > 1 else ""),
+                          "integrator": integ_type, "sampler": "independent seed 0", "block_size": 32, "rfilter": "box",
+                          "sharding": "(pass, block) pairs: block_id %% %d round-robin, %d workgroups per GPU + RCCL film reduce" % (n, -(-args.width // 32) * -(-args.height // 32) * (args.spp // spp_pass) // n)
+                                      if n > 1 else "single GPU"},
                "roofline": roofline, "cpu_baseline": cpu_baseline}
+        if film_check is not None:
+            out["film_check"] = film_check
+        if weak is not None:
+            out["weak"] = weak
         print(json.dumps(out), flush=True)
     if n > 1:
         dist.destroy_process_group()

@@ -189,7 +189,8 @@ class Integrator:
 
     def render(self, scene, sensor, shard_index=0, shard_count=1, device_film=None, stream=None,
                collect_counters=False):
-        """Integrator.render(scene, sensor) -> bool (False iff cancelled / timed out).
+        """Integrator.render(scene, sensor) -> bool: `not m_stop` (integrator.cpp:178), i.e. False iff cancel() stopped it; a render
+        cut short by the integrator's "timeout" returns True like the reference's (last_stats["timed_out"] tells).
 
         The reference binding releases the GIL and turns SIGINT into cancel()
         (integrator_v.cpp:124-156); ctypes releases the GIL for the duration of mts_render, and the

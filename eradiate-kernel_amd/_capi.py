@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MTSAMD_LIB") or os.path.join(HERE, "libmtsamd.so")
 
-MTS_ABI_VERSION = 3
+MTS_ABI_VERSION = 4
 
 # enums (include/mtsamd.h)
 VOLUME_CONST, VOLUME_GRID = 0, 1
@@ -101,7 +101,7 @@ class SceneDesc(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("n_iter", C.c_uint64), ("n_lookup", C.c_uint64),
                 ("n_nee_step", C.c_uint64), ("kernel_ms", C.c_double), ("wall_ms", C.c_double),
-                ("kernel_launches", i32), ("cancelled", i32)]
+                ("kernel_launches", i32), ("cancelled", i32), ("timed_out", i32), ("reserved_", i32)]
 
 
 class RenderOpts(C.Structure):

@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <cmath>
 #include <mutex>
+#include <thread>
+#include <atomic>
 #include "scene_host.h"
 #include "launch.h"
 
@@ -45,7 +47,9 @@ struct RenderCache {
         if (ev1) { (void) hipEventDestroy(ev1); ev1 = nullptr; }
     }
 };
-struct mts_scene { HostScene *hs; std::mutex render_mutex; RenderCache cache; };
+// stop_word: one word of pinned, device-visible host memory per scene -- the m_stop of Integrator::cancel() (integrator.cpp:43-45)
+// as the kernels see it (stop_requested(), the stop word of the ring driver).  mts_cancel stores to it from any thread.
+struct mts_scene { HostScene *hs; std::mutex render_mutex; RenderCache cache; volatile uint32_t *stop_word = nullptr; };
 
 // librender/spiral.cpp:11-72
 namespace {
@@ -113,18 +117,26 @@ int mts_scene_create(const mts_scene_desc *desc, int device, mts_scene **out) {
     HostScene *hs = build_host_scene(desc);
     try { upload_host_scene(*hs, device); } catch (...) { free_host_scene(hs); throw; }
     mts_scene *s = new mts_scene(); s->hs = hs;
+    void *sw = nullptr;
+    if (hipHostMalloc(&sw, 64, hipHostMallocDefault) != hipSuccess) { free_host_scene(hs); delete s; throw std::runtime_error("hipHostMalloc failed (stop word)"); }
+    s->stop_word = (volatile uint32_t *) sw; *s->stop_word = 0;
     *out = s;
     API_CATCH
 }
 
 int mts_scene_destroy(mts_scene *scene) {
-    if (scene) { (void) hipSetDevice(scene->hs->device); scene->cache.release(); free_host_scene(scene->hs); delete scene; }
+    if (scene) {
+        (void) hipSetDevice(scene->hs->device); scene->cache.release();
+        if (scene->stop_word) (void) hipHostFree((void *) scene->stop_word);
+        free_host_scene(scene->hs); delete scene;
+    }
     return 0;
 }
 
 int mts_cancel(mts_scene *scene) {
     if (!scene) { g_error = "mts_cancel: scene is NULL"; return 1; }
     scene->hs->stop.store(1);
+    if (scene->stop_word) *scene->stop_word = 1;          // seen by the running kernels within a few microseconds
     return 0;
 }
 
@@ -154,11 +166,12 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
     if (block_size > 1024) throw std::runtime_error("block_size too large");
     // spiral.cpp: enumerate every (pass, block) pair in the reference's order; keep this shard's blocks
     Spiral spiral; spiral.init(se.crop_w, se.crop_h, se.crop_x, se.crop_y, (int) block_size, n_passes);
-    // Passes are independent jobs (each block id seeds its own streams) whose results add up in the film, so
-    // all (pass, block) pairs of this shard go into ONE launch; only a timeout forces pass-sized launches,
-    // because should_stop() is honoured between launches.
-    const bool per_pass_launches = hs.integrator.timeout > 0.f;
-    std::vector<std::vector<DBlock>> pass_blocks(per_pass_launches ? n_passes : 1);
+    // Passes are independent jobs (each block id seeds its own streams) whose results add up in the film, so the (pass, block)
+    // pairs of this shard are launched together, MAX_BLOCKS_PER_LAUNCH at a time: the workspace (one 128-byte record per path in
+    // flight) stays below 1 GiB however many passes samples_per_pass asks for, and thread indices stay far below 2^32.
+    // should_stop() (integrator.h:143-146) is honoured inside a launch: the kernels poll the scene's stop word.
+    const size_t MAX_BLOCKS_PER_LAUNCH = std::max<size_t>(1, ((size_t) 8 << 20) / ((size_t) block_size * block_size));
+    std::vector<std::vector<DBlock>> pass_blocks(1);
     uint64_t samples = 0;
     for (size_t pass = 0; pass < n_passes; ++pass)
         for (size_t k = 0; k < spiral.block_count; ++k) {
@@ -167,24 +180,32 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             if ((int) (id % (size_t) opts.shard_count) != opts.shard_index) continue;
             if (id >= ((uint64_t) 1 << 32)) throw std::runtime_error("block id overflow");
             b.id = (uint32_t) id;
-            pass_blocks[per_pass_launches ? pass : 0].push_back(b);
+            if (pass_blocks.back().size() >= MAX_BLOCKS_PER_LAUNCH) pass_blocks.emplace_back();
+            pass_blocks.back().push_back(b);
             samples += (uint64_t) b.sx * b.sy * samples_per_pass;
         }
     const size_t film_floats = (size_t) se.crop_w * se.crop_h * 5;
     RenderCache &rc = scene->cache;
     float *d_film = film;
     if (!opts.film_on_device) d_film = (float *) rc.get(0, film_floats * sizeof(float));
-    unsigned long long *d_counters = (unsigned long long *) rc.get(1, 4 * sizeof(unsigned long long));
+    constexpr int N_COUNTERS = 16;                                   // [0..2] loop counters, [4..9] ring-stall record (volpath_flat.h, MTS_DIAG_BASE)
+    unsigned long long *d_counters = (unsigned long long *) rc.get(1, N_COUNTERS * sizeof(unsigned long long));
     HIP_CHECK(hipMemsetAsync(d_film, 0, film_floats * sizeof(float), stream));               // hdrfilm.cpp:201-203 (storage cleared by prepare())
-    HIP_CHECK(hipMemsetAsync(d_counters, 0, 4 * sizeof(unsigned long long), stream));
+    HIP_CHECK(hipMemsetAsync(d_counters, 0, N_COUNTERS * sizeof(unsigned long long), stream));
     rc.events();
     hipEvent_t ev0 = rc.ev0, ev1 = rc.ev1;
-    double kernel_ms = 0.0; int launches = 0; bool cancelled = false;
+    double kernel_ms = 0.0; int launches = 0; bool timed_out = false;
     const float timeout = hs.integrator.timeout;
+    *scene->stop_word = 0;
+    if (hs.stop.load()) *scene->stop_word = 1;                      // cancel() raced the start of the render
+    auto should_stop = [&]() {                                      // integrator.h:143-146
+        if (hs.stop.load()) return true;
+        if (timeout > 0.f && std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count() > timeout) { timed_out = true; return true; }
+        return false;
+    };
     try {
         for (size_t pass = 0; pass < pass_blocks.size(); ++pass) {
-            // should_stop(), integrator.h:143-146 -- checked between launches
-            if (hs.stop.load() || (timeout > 0.f && std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count() > timeout)) { cancelled = true; break; }
+            if (should_stop()) break;
             const std::vector<DBlock> &blocks = pass_blocks[pass];
             if (blocks.empty()) continue;
             DBlock *d_blocks = (DBlock *) rc.get(2, blocks.size() * sizeof(DBlock));
@@ -197,25 +218,40 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
                 else if (!strcmp(kv, "wga256")) variant = 10256; else if (!strcmp(kv, "wga512")) variant = 10512; else if (!strcmp(kv, "wga1024")) variant = 11024;
                 else throw std::runtime_error("MTSAMD_KERNEL must be one of nested, flat, wga256, wga512, wga1024");
             }
-            if (variant > 1 && (block_size * block_size) % (uint32_t) (variant - 10000) != 0) variant = 1;     // small blocks: per-lane kernel
+            // a workgroup of the regrouping kernel sits in ONE spiral block: blocks smaller than its path count get the largest
+            // workgroup that divides them (16 x 16 -> 256 paths); only blocks below 256 pixels fall back to the per-lane kernel
+            while (variant > 10256 && (block_size * block_size) % (uint32_t) (variant - 10000) != 0) variant = 10000 + (variant - 10000) / 2;
+            if (variant > 1 && (block_size * block_size) % (uint32_t) (variant - 10000) != 0) variant = 1;
             int wg_threads = 0;                                     // MTSAMD_WG_THREADS: threads per workgroup of the wga kernels (<= paths; default = paths)
             if (const char *tv = getenv("MTSAMD_WG_THREADS")) wg_threads = atoi(tv);
             float *d_ws = (float *) rc.get(3, render_workspace_floats((uint32_t) blocks.size(), block_size, variant) * sizeof(float));
             HIP_CHECK(launch_render(hs.scene, d_blocks, (uint32_t) blocks.size(), block_size, (uint32_t) samples_per_pass, d_film, d_counters,
-                                    opts.collect_counters != 0, variant, wg_threads, d_ws, stream));
+                                    opts.collect_counters != 0, variant, wg_threads, d_ws, (const uint32_t *) scene->stop_word, stream));
             HIP_CHECK(hipEventRecord(ev1, stream));
-            HIP_CHECK(hipEventSynchronize(ev1));
+            // wait for the launch as a watchdog: cancel() and the timeout reach the kernel through the stop word
+            for (;;) {
+                hipError_t q = hipEventQuery(ev1);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) HIP_CHECK(q);
+                if (should_stop()) *scene->stop_word = 1;
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+            }
             float ms = 0.f; HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
             kernel_ms += ms; ++launches;
         }
         if (!opts.film_on_device) HIP_CHECK(hipMemcpyAsync(film, d_film, film_floats * sizeof(float), hipMemcpyDeviceToHost, stream));
-        unsigned long long h_counters[4] = { 0, 0, 0, 0 };
+        unsigned long long h_counters[N_COUNTERS] = {};
         HIP_CHECK(hipMemcpyAsync(h_counters, d_counters, sizeof(h_counters), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
+        if (h_counters[4] != 0)                                      // a bounded ring wait gave up (volpath_flat.h): an error, never a hang
+            throw std::runtime_error("render kernel: ring stall (" + std::string(h_counters[4] == 1 ? "consumer" : "producer") + ", ring " + std::to_string(h_counters[5]) +
+                                     ", index " + std::to_string(h_counters[6]) + ", head " + std::to_string(h_counters[7]) + ", tail " + std::to_string(h_counters[8]) +
+                                     ", workgroup " + std::to_string(h_counters[9]) + ")");
+        const bool cancelled = hs.stop.load() != 0;                  // render() returns !m_stop (integrator.cpp:178): a timeout alone is not a cancellation
         if (stats) {
             memset(stats, 0, sizeof(*stats));
             stats->samples = samples; stats->n_iter = h_counters[0]; stats->n_lookup = h_counters[1]; stats->n_nee_step = h_counters[2];
-            stats->kernel_ms = kernel_ms; stats->kernel_launches = launches; stats->cancelled = cancelled ? 1 : 0;
+            stats->kernel_ms = kernel_ms; stats->kernel_launches = launches; stats->cancelled = cancelled ? 1 : 0; stats->timed_out = timed_out ? 1 : 0;
             stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
     } catch (...) { (void) hipStreamSynchronize(stream); throw; }     // nothing of this render may still be using the cached buffers

@@ -75,6 +75,16 @@ struct Counters { uint32_t n_iter, n_lookup, n_nee_step; };
 #define MTS_SEG(c, k) do { } while (0)
 #endif
 
+// Integrator::should_stop() (include/mitsuba/render/integrator.h:143-146) on the device: one lane of the wave reads the host-visible
+// stop word (pinned host memory written by mts_cancel / the timeout watchdog), the answer is wave-uniform.
+__device__ __forceinline__ bool stop_requested(const uint32_t *stop_flag) {
+    uint32_t v = 0;
+    const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
+    if ((threadIdx.x & 63u) == (uint32_t) __builtin_ctzll(active))                     // first active lane
+        v = __hip_atomic_load(stop_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return __builtin_amdgcn_ballot_w64(v != 0u) != 0ull;
+}
+
 // What survives of a SurfaceInteraction between loop iterations: the hit distance, the hit point
 // (computed from the ray that found it), and the primitive; normals / frames / wi are rebuilt on
 // demand by complete_surface() with the same arithmetic.

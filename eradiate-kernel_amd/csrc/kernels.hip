@@ -50,7 +50,8 @@ __device__ __forceinline__ void render_sample(const DScene &sc, Pcg32 &rng, cons
 #endif
 template <bool COUNT, bool FLAT, int INTEG>
 __global__ void __launch_bounds__(256, FLAT ? 1 : (INTEG == NI_PATH ? MTS_PATH_WAVES : MTS_NESTED_WAVES)) render_kernel(DScene sc, const DBlock *__restrict__ blocks, uint32_t n_blocks, uint32_t block_size,
-                                                     uint32_t sample_count, float *__restrict__ film, unsigned long long *__restrict__ counters) {
+                                                     uint32_t sample_count, float *__restrict__ film, unsigned long long *__restrict__ counters,
+                                                     const uint32_t *__restrict__ stop_flag) {
     // LDS-staged BVH top: the breadth-first top levels of the host-built BVH (dscene.h), shared by the workgroup's traversals
     __shared__ float bvh_top[MTS_BVH_LDS_NODES * 8];
     {
@@ -76,11 +77,15 @@ __global__ void __launch_bounds__(256, FLAT ? 1 : (INTEG == NI_PATH ? MTS_PATH_W
     if (FLAT) {
         __shared__ float cold_lds[C_COUNT * 256];
         ColdStore cold; cold.base = cold_lds + threadIdx.x; cold.stride = 256;
-        volpath_pixel_flat<COUNT>(sc, rng, blk, lx, ly, sample_count, film, cold, cnt);
+        volpath_pixel_flat<COUNT>(sc, rng, blk, lx, ly, sample_count, film, cold, cnt, stop_flag);
     } else {
         float acc[5] = { 0.f, 0.f, 0.f, 0.f, 0.f };
-        for (uint32_t j = 0; j < sample_count; ++j)
+        for (uint32_t j = 0; j < sample_count; ++j) {
+            // should_stop(), integrator.h:143-146: the reference looks at its flag once per sample; here one lane of the wave reads the
+            // host-visible word every 64 samples
+            if ((j & 63u) == 63u && stop_requested(stop_flag)) break;
             render_sample<COUNT, INTEG>(sc, rng, blk, lx, ly, film, acc, cnt);
+        }
         float *dst = film + 5 * ((size_t) (blk.oy + (int) ly - sc.sensor.crop_y) * sc.sensor.crop_w + (blk.ox + (int) lx - sc.sensor.crop_x));
         for (int k = 0; k < 5; ++k) atomicAdd(dst + k, acc[k]);
     }
@@ -97,7 +102,7 @@ __global__ void __launch_bounds__(256, FLAT ? 1 : (INTEG == NI_PATH ? MTS_PATH_W
 template <bool COUNT, int WG, int NT, int WPE>
 __global__ void __launch_bounds__(NT, WPE) render_kernel_wga(DScene sc, const DBlock *blocks, uint32_t n_blocks, uint32_t block_size,
                                                            uint32_t sample_count, float *film, float *cold_g, uint32_t cold_stride,
-                                                           unsigned long long *counters) {
+                                                           unsigned long long *counters, const uint32_t *stop_flag) {
     Counters cnt = {};
     volpath_workgroup_async<COUNT, WG, NT>((const MTS_CONST_AS void *) __builtin_amdgcn_kernarg_segment_ptr(), cnt);
     if (COUNT) {
@@ -150,16 +155,18 @@ size_t render_workspace_floats(uint32_t n_blocks, uint32_t block_size, int varia
 }
 
 hipError_t launch_render(const DScene &sc, const DBlock *d_blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,
-                         float *d_film, unsigned long long *d_counters, bool count, int variant, int wg_threads, float *d_workspace, hipStream_t stream) {
+                         float *d_film, unsigned long long *d_counters, bool count, int variant, int wg_threads, float *d_workspace,
+                         const uint32_t *d_stop_flag, hipStream_t stream) {
     if (n_blocks == 0) return hipSuccess;
     const uint64_t threads = (uint64_t) n_blocks * block_size * block_size;
+    if (threads + 1024 >= ((uint64_t) 1 << 32)) return hipErrorInvalidValue;      // thread and path indices are 32 bit (mts_render launches in chunks)
     if (variant >= 10000 && sc.integrator.type == MTS_INTEGRATOR_VOLPATH) {        // asynchronous regrouping, variant = 10000 + paths per workgroup
         const uint32_t wg = (uint32_t) (variant - 10000);
         const uint32_t grid = (uint32_t) ((threads + wg - 1) / wg);
         const uint32_t stride = grid * wg;
         const int nt = wg_threads > 0 ? wg_threads : (int) wg;
-#define LAUNCH_WGA(W, T, E) do { if (count) hipLaunchKernelGGL((render_kernel_wga<true, W, T, E>), dim3(grid), dim3(T), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters); \
-                                 else hipLaunchKernelGGL((render_kernel_wga<false, W, T, E>), dim3(grid), dim3(T), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters); } while (0)
+#define LAUNCH_WGA(W, T, E) do { if (count) hipLaunchKernelGGL((render_kernel_wga<true, W, T, E>), dim3(grid), dim3(T), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag); \
+                                 else hipLaunchKernelGGL((render_kernel_wga<false, W, T, E>), dim3(grid), dim3(T), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag); } while (0)
         if (wg == 256 && nt == 256) LAUNCH_WGA(256, 256, 4);
         else if (wg == 512 && nt == 512) LAUNCH_WGA(512, 512, 4);
         else if (wg == 512 && nt == 256) LAUNCH_WGA(512, 256, 2);
@@ -173,7 +180,7 @@ hipError_t launch_render(const DScene &sc, const DBlock *d_blocks, uint32_t n_bl
     const bool flat = variant != 0;
     const uint32_t grid = (uint32_t) ((threads + 255) / 256);
     const bool use_flat = flat && sc.integrator.type == MTS_INTEGRATOR_VOLPATH;
-#define LAUNCH(C, F, I) hipLaunchKernelGGL((render_kernel<C, F, I>), dim3(grid), dim3(256), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_counters)
+#define LAUNCH(C, F, I) hipLaunchKernelGGL((render_kernel<C, F, I>), dim3(grid), dim3(256), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_counters, d_stop_flag)
 #define LAUNCH_C(F, I) do { if (count) LAUNCH(true, F, I); else LAUNCH(false, F, I); } while (0)
     if (use_flat) LAUNCH_C(true, NI_VOLPATH);
     else if (sc.integrator.type == MTS_INTEGRATOR_PATH) LAUNCH_C(false, NI_PATH);

@@ -644,7 +644,7 @@ struct VolpathMachine {
 // Driver 1: one lane = one pixel, state in registers, cold state in LDS, blocks chosen by a per-wave vote.
 template <bool COUNT>
 DEV void volpath_pixel_flat(const DScene &sc, Pcg32 &rng, const DBlock &blk, uint32_t lx, uint32_t ly, uint32_t sample_count,
-                            float *__restrict__ film, ColdStore cold, Counters &cnt) {
+                            float *__restrict__ film, ColdStore cold, Counters &cnt, const uint32_t *stop_flag) {
     VolpathMachine<COUNT> vm(sc, cnt);
     PathEnvT<ColdStore> e; e.blk = blk; e.lx = lx; e.ly = ly; e.sample_count = sample_count; e.film = as_global(film); e.cold = cold;
     PathState p; p.rng = rng;
@@ -655,7 +655,8 @@ DEV void volpath_pixel_flat(const DScene &sc, Pcg32 &rng, const DBlock &blk, uin
     long long bs_t0 = clock64(); int bs_prev_sel = 20;
     unsigned long long bs_loc[45] = {};                      // laid out like g_blockstats
 #endif
-    while (__ballot(p.st != S_DONE)) {
+    for (uint32_t iter = 0; __ballot(p.st != S_DONE); ++iter) {
+        if ((iter & 1023u) == 1023u && stop_requested(stop_flag)) break;       // should_stop(), integrator.h:143-146
 #if defined(MTSAMD_BLOCKSTATS)
         if (COUNT) { long long t = clock64(); bs_loc[24 + bs_prev_sel] += (unsigned long long) (t - bs_t0); bs_t0 = t; bs_prev_sel = 20; }
 #endif
@@ -771,7 +772,8 @@ struct HotStore {
 // kernel arguments of render_kernel_wga, re-read by the block functions through the constant address space
 struct WgArgs {
     DScene sc; const DBlock *blocks; uint32_t n_blocks, block_size, sample_count; float *film; float *cold_g; uint32_t cold_stride;
-    unsigned long long *counters;
+    unsigned long long *counters;            // [0..2] loop counters, [MTS_DIAG_BASE ..] ring-stall record
+    const uint32_t *stop_flag;               // host-visible word: non-zero = Integrator::cancel() / timeout (integrator.h:143-146)
 };
 
 template <int WG>
@@ -838,25 +840,52 @@ static __device__ WG_BLOCK_ATTR int wg_block(const MTS_CONST_AS void *kernarg_, 
 // Driver 2: asynchronous regrouping.  No workgroup barriers and no sort: one LDS ring of path ids per block class.  A wave claims up to 64 ids from the fullest ring
 // (compare-and-swap on its head), runs that block with every claimed lane active, and appends each path to
 // the ring of the class it waits for next (one LDS atomic add on the tail per lane; the value returned is the slot).  Waves never wait for
-// each other; a wave that finds every ring empty naps briefly.  A ring slot holds 0xFFFF until its producer has written the id, so a consumer that claimed
-// the slot early spins for the few cycles the write takes, and a producer whose slot still holds an unread id of the previous lap
-// waits for its consumer: a live id is never overwritten (there are WG paths and WG slots per ring, so neither wait can last).
-// q_ht[2c] / q_ht[2c + 1]: head / tail of ring c (monotonic counters, slot = counter mod WG); "ring" B_DONE has no slots, its
-// tail counts the finished paths.
+// each other; a wave that finds every ring empty naps briefly.
+//
+// Ring protocol.  q_ctl[2c] / q_ctl[2c + 1] are head / tail of ring c: two 32-bit counters that only ever grow (slot = counter mod
+// WG), each touched with 32-bit atomics only; "ring" B_DONE has no slots, its tail counts the finished paths; q_ctl[2 B_COUNT] is the
+// workgroup's stop word.  A slot holds 0xFFFF while it is empty, and every slot is touched with 16-bit atomics only.
+//   producer: release fence (state in LDS / HBM is written), tail++ -> index, wait until the slot is empty, store the id;
+//   consumer: head: h -> h + n by compare-and-swap (n <= tail - h of a snapshot: those indices are already handed out), wait until
+//             the slot holds an id, take it and store 0xFFFF AT ONCE, acquire fence.
+// A consumer can be ahead of its producer (index handed out, id not stored yet) and a producer ahead of the previous lap's consumer
+// (slot claimed, not yet emptied); with WG slots per ring and WG paths neither wait lasts.  Both waits are written as wave-uniform
+// loops whose body does the per-lane hand-over, so a lane's store never waits for another lane's spin (a divergent `while` would
+// place it after the reconvergence point), and both are BOUNDED: a wait of more than MTS_RING_SPIN_LIMIT polls writes a diagnostic
+// record (ring, index, head, tail), raises the stop word and every wave leaves -- mts_render reports an error instead of hanging.
+#define MTS_RING_SPIN_LIMIT (1u << 22)
+#define MTS_DIAG_BASE 4            // counters[MTS_DIAG_BASE + 0..5]: code (1 consumer / 2 producer), ring, index, head, tail, workgroup
+enum : uint32_t { STOP_NONE = 0, STOP_CANCEL = 1, STOP_STALL = 2 };
+
+DEV void wga_stall(uint32_t code, int ring, uint32_t index, uint32_t *q_ctl, unsigned long long *counters) {
+    if (atomicCAS(&q_ctl[2 * B_COUNT], (uint32_t) STOP_NONE, (uint32_t) STOP_STALL) == STOP_NONE) {     // first lane of the workgroup to give up
+        if (atomicCAS(counters + MTS_DIAG_BASE, 0ull, (unsigned long long) code) == 0ull) {            // first workgroup of the launch
+            counters[MTS_DIAG_BASE + 1] = (unsigned long long) ring; counters[MTS_DIAG_BASE + 2] = index;
+            counters[MTS_DIAG_BASE + 3] = __atomic_load_n(&q_ctl[2 * ring], __ATOMIC_RELAXED);
+            counters[MTS_DIAG_BASE + 4] = __atomic_load_n(&q_ctl[2 * ring + 1], __ATOMIC_RELAXED);
+            counters[MTS_DIAG_BASE + 5] = blockIdx.x;
+        }
+    }
+}
+
 template <int WG>
-DEV void wga_push(int cls, uint32_t pid, bool valid, uint16_t (*q_ids)[WG], uint32_t *q_ht, uint32_t lane) {
+DEV void wga_push(int cls, uint32_t pid, bool valid, uint16_t (*q_ids)[WG], uint32_t *q_ctl, unsigned long long *counters) {
     // One LDS atomic per lane: the tail value it returns IS the lane's slot; the LDS unit serialises the lanes that share a ring.
     // (Ranking the lanes first -- nine ballots, per-class counts, one atomic per class -- took 45 to 100 VALU instructions per push
     // and measured 1 to 3 % slower; the order of the ids inside a ring is immaterial.)
-    (void) lane;
-    if (valid) {
-        const uint32_t idx = atomicAdd(&q_ht[2 * cls + 1], 1u);
-        if (cls != B_DONE) {
-            uint16_t *slot = &q_ids[cls][idx & (uint32_t) (WG - 1)];
-            // The slot may still hold an id of the previous lap that its consumer has claimed but not read yet (the consumer resets
-            // it to 0xFFFF right after reading): wait for that, never overwrite a live id.
-            while (__atomic_load_n(slot, __ATOMIC_RELAXED) != 0xFFFFu) { }
+    uint32_t idx = 0;
+    if (valid) idx = atomicAdd(&q_ctl[2 * cls + 1], 1u);
+    bool pending = valid && cls != B_DONE;
+    uint16_t *slot = &q_ids[pending ? cls : 0][idx & (uint32_t) (WG - 1)];
+    for (uint32_t spins = 0;; ++spins) {
+        if (pending && __atomic_load_n(slot, __ATOMIC_RELAXED) == 0xFFFFu) {      // empty: hand the id over
             __atomic_store_n(slot, (uint16_t) pid, __ATOMIC_RELAXED);
+            pending = false;
+        }
+        if (!__builtin_amdgcn_ballot_w64(pending)) break;
+        if (spins > MTS_RING_SPIN_LIMIT || __atomic_load_n(&q_ctl[2 * B_COUNT], __ATOMIC_RELAXED) != STOP_NONE) {
+            if (pending && spins > MTS_RING_SPIN_LIMIT) wga_stall(2u, cls, idx, q_ctl, counters);
+            break;
         }
     }
 }
@@ -868,8 +897,7 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
     static_assert(NT % 64 == 0 && WG % 64 == 0 && NT <= WG, "whole waves");
     __shared__ uint32_t hot_lds[H_COUNT * WG];
     __shared__ uint16_t q_ids[NQ][WG];
-    __shared__ unsigned long long q_ht64[B_COUNT];           // low word: head, high word: tail
-    uint32_t *const q_ht = (uint32_t *) q_ht64;
+    __shared__ uint32_t q_ctl[2 * B_COUNT + 2];              // head / tail pairs, then the stop word
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wg_base = blockIdx.x * WG;
 #pragma unroll 1
@@ -877,7 +905,7 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
 #pragma unroll 1
         for (uint32_t i = tid; i < (uint32_t) WG; i += NT) q_ids[c][i] = 0xFFFFu;      // runs once: not worth 300 unrolled instructions
     }
-    if (tid < 2u * B_COUNT) q_ht[tid] = 0;
+    if (tid < 2u * B_COUNT + 2u) q_ctl[tid] = 0;
     __syncthreads();
 #pragma unroll 1
     for (uint32_t pid0 = tid; pid0 < (uint32_t) WG; pid0 += NT) {   // ---- initialise the paths (integrator.cpp:198) and queue them
@@ -902,17 +930,29 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         const int cls = vm.classify(p);
         hs.store(p, cls);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        wga_push<WG>(cls, pid0, true, q_ids, q_ht, lane);
+        wga_push<WG>(cls, pid0, true, q_ids, q_ctl, cload_k<WgArgs>(kernarg).counters);
     }
 #if defined(MTSAMD_BLOCKSTATS)
     long long bs_t0 = clock64(); unsigned long long bs_loc[45] = {};                      // laid out like g_blockstats
 #endif
-    for (;;) {
-        // ---- pick the fullest ring
+    const bool poller = tid < 64u;                           // wave 0 looks at the host's stop flag now and then
+#pragma unroll 1
+    for (uint32_t iter = 0;; ++iter) {
+        // ---- snapshot of the rings (lanes 0 .. B_COUNT - 1) and of the stop word (lane B_COUNT); pick the fullest ring
         uint32_t hd = 0, avail = 0;
-        if (lane < (uint32_t) B_COUNT) {
-            const unsigned long long ht = __atomic_load_n(&q_ht64[lane], __ATOMIC_RELAXED);
-            hd = (uint32_t) ht; avail = (uint32_t) (ht >> 32) - hd;
+        if (lane <= (uint32_t) B_COUNT) {
+            hd = __atomic_load_n(&q_ctl[2 * lane], __ATOMIC_RELAXED);
+            const uint32_t tl = __atomic_load_n(&q_ctl[2 * lane + 1], __ATOMIC_RELAXED);
+            // the two loads are not one atomic snapshot: a head newer than the tail gives a "negative" count, which is no count at all.
+            // Any tail that was ever read is a lower bound of the tail now, so tl - hd entries exist whenever the claim finds head == hd.
+            avail = tl - hd;
+            if (avail > (uint32_t) WG || lane == (uint32_t) B_COUNT) avail = 0;
+        }
+        if (__builtin_amdgcn_readlane((int) hd, B_COUNT) != (int) STOP_NONE) break;         // cancelled, timed out, or a ring stalled
+        if (poller && (iter & 63u) == 63u) {
+            const uint32_t *flag = cload_k<WgArgs>(kernarg).stop_flag;
+            if (lane == 0 && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
+                __atomic_store_n(&q_ctl[2 * B_COUNT], (uint32_t) STOP_CANCEL, __ATOMIC_RELAXED);
         }
         // argmax over the NQ rings in three DPP steps: lanes 0..7 hold (avail << 4 | 15 - ring), the maximum of a row's first eight
         // lanes ends up in lane 7 (ties go to the lower ring, as a first-maximum scan would have it); one readlane instead of eight
@@ -935,19 +975,28 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         const uint32_t n = best < 64u ? best : 64u;
         const uint32_t h = (uint32_t) __builtin_amdgcn_readlane((int) hd, sel);
         uint32_t won = 0;
-        if (lane == 0) won = atomicCAS(&q_ht[2 * sel], h, h + n) == h ? 1u : 0u;
+        if (lane == 0) won = atomicCAS(&q_ctl[2 * sel], h, h + n) == h ? 1u : 0u;
 #if defined(MTSAMD_BLOCKSTATS)
         if (COUNT) { bs_loc[10] += 1ull; if (!__builtin_amdgcn_readfirstlane((int) won)) bs_loc[11] += 1ull; }      // claim attempts / lost compare-and-swaps
 #endif
         if (!__builtin_amdgcn_readfirstlane((int) won)) continue;
         uint32_t pid = 0;
-        const bool mine = lane < n;
-        if (mine) {
+        bool mine = lane < n;
+        {
             uint16_t *slot = &q_ids[sel][(h + lane) & (uint32_t) (WG - 1)];     // relaxed atomics, not volatile: volatile accesses stay FLAT
-            uint32_t v;
-            do { v = __atomic_load_n(slot, __ATOMIC_RELAXED); } while (v == 0xFFFFu);
-            __atomic_store_n(slot, (uint16_t) 0xFFFFu, __ATOMIC_RELAXED);
-            pid = v;
+            bool pending = mine;
+            for (uint32_t spins = 0;; ++spins) {
+                if (pending) {
+                    const uint32_t v = __atomic_load_n(slot, __ATOMIC_RELAXED);
+                    if (v != 0xFFFFu) { __atomic_store_n(slot, (uint16_t) 0xFFFFu, __ATOMIC_RELAXED); pid = v; pending = false; }
+                }
+                if (!__builtin_amdgcn_ballot_w64(pending)) break;
+                if (spins > MTS_RING_SPIN_LIMIT || __atomic_load_n(&q_ctl[2 * B_COUNT], __ATOMIC_RELAXED) != STOP_NONE) {
+                    if (pending && spins > MTS_RING_SPIN_LIMIT) wga_stall(1u, sel, h + lane, q_ctl, cload_k<WgArgs>(kernarg).counters);
+                    mine = mine && !pending;                  // the render is over: lanes without an id drop out
+                    break;
+                }
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #if defined(MTSAMD_BLOCKSTATS)
@@ -971,7 +1020,7 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         if (COUNT) { long long t = clock64(); bs_loc[24 + sel] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
 #endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        wga_push<WG>(cls, pid, mine, q_ids, q_ht, lane);
+        wga_push<WG>(cls, pid, mine, q_ids, q_ctl, cload_k<WgArgs>(kernarg).counters);
 #if defined(MTSAMD_BLOCKSTATS)
         if (COUNT) { long long t = clock64(); bs_loc[43] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
 #endif

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MTS_ABI_VERSION 3
+#define MTS_ABI_VERSION 4
 
 /* Transform4f: row-major 4x4 matrix and its inverse transpose (transform.h:36-50). */
 typedef struct mts_transform {
@@ -213,7 +213,10 @@ typedef struct mts_stats {
     double kernel_ms;         /* device time of the render kernel(s), HIP events on the stream   */
     double wall_ms;           /* host wall time of the call                                      */
     int32_t kernel_launches;
-    int32_t cancelled;        /* 1 if the render was cancelled / timed out (render() == false)   */
+    int32_t cancelled;        /* 1 if mts_cancel stopped the render (render() == false, integrator.cpp:178) */
+    int32_t timed_out;        /* 1 if the "timeout" of the integrator stopped it (should_stop(), integrator.h:143-146;
+                                 like the reference, render() still returns true then)            */
+    int32_t reserved_;
 } mts_stats;
 
 typedef struct mts_render_opts {

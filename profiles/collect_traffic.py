@@ -1,14 +1,17 @@
 """Reduce the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE -- they do not fit one pass on gfx950)
-of `python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline` into profiles/traffic_bytes_per_launch.json.
+of `python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline [...]` into a traffic record.
 
-usage: python profiles/collect_traffic.py <fetch_pass_dir> <write_pass_dir> [out.json]
+usage: python profiles/collect_traffic.py <fetch_pass_dir> <write_pass_dir> <out.json> <bench_log_of_one_pass> [pmc_summary.json]
+
+The record carries the configuration it describes (`run`: config, size, spp, kernel -- read from the JSON line the profiled
+bench.py printed); bench.py attaches `roofline.traffic` only to runs of exactly that configuration.
 
 Units / corrections (MI355X_MICROARCH.md, section HBM): FETCH_SIZE and WRITE_SIZE are reported in KiB
 summed over the 16 TCC channels x 8 XCDs; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, so
 reads are doubled; WRITE_SIZE is exact.  The guide calibrates the doubling on 16-byte-per-lane streaming
 reads; this kernel issues 4-byte gathers, so 2 x FETCH is kept as the (conservative) figure and the raw
 value is recorded next to it."""
-import csv, glob, json, os, sys
+import csv, glob, json, os, re, sys
 
 
 kernel_name = None
@@ -28,9 +31,19 @@ def kernel_sum(d, counter):
 
 fetch_kib, nf = kernel_sum(sys.argv[1], "FETCH_SIZE")
 write_kib, nw = kernel_sum(sys.argv[2], "WRITE_SIZE")
-out = {"kernel": kernel_name, "launches": [nf, nw],
+line = json.loads([l for l in open(sys.argv[4]) if l.startswith("{")][-1])
+m = re.search(r"(\d+)x(\d+)x(\d+)spp", line["config"]["workload"])
+res = re.search(r"(\d+)\^3", line["config"]["workload"])
+cfg = re.match(r"(C\d)", line["config"]["workload"]).group(1)
+out = {"run": {"config": cfg, "width": int(m.group(1)), "height": int(m.group(2)), "spp": int(m.group(3)), "res": int(res.group(1)) if res else 128,
+               "n_gpus": line["n_gpus"], "kernel": line["roofline"]["kernel"]},
+       "kernel": kernel_name, "launches": [nf, nw],
        "fetch_bytes_raw": fetch_kib / nf * 1024.0, "fetch_bytes_corrected": 2.0 * fetch_kib / nf * 1024.0,
        "write_bytes": write_kib / nw * 1024.0}
 out["bytes_per_launch"] = out["fetch_bytes_corrected"] + out["write_bytes"]
-json.dump(out, open(sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(__file__), "traffic_bytes_per_launch.json"), "w"), indent=1)
+if len(sys.argv) > 5:
+    pmc = json.load(open(sys.argv[5]))
+    out["valu_issue_fraction"] = pmc["derived"]["valu_issue_fraction"]
+    out["valu_issue_fraction_source"] = pmc["probe"]
+json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out))

@@ -1,9 +1,35 @@
-"""Summarise rocprofv3 --pmc CSV output for the render kernels (diagnostic helper)."""
-import csv, collections, sys
-for d in sys.argv[1:]:
-    rows = list(csv.DictReader(open(d + "/p_counter_collection.csv")))
+"""Summarise rocprofv3 --pmc CSV output for the render kernels (diagnostic helper).
+
+usage: python tests/pmc_summary.py [--json out.json --probe "description"] <pass_dir> ...
+With --json the counters of all passes are merged into one record with the derived VALU issue fraction
+(SQ_INSTS_VALU x 4 cycles / (kernel time x 1024 SIMDs x clock)) and lane utilisation (SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU))."""
+import csv, collections, glob, json, os, sys
+
+args = sys.argv[1:]
+out_json = probe = None
+if args and args[0] == "--json":
+    out_json, args = args[1], args[2:]
+if args and args[0] == "--probe":
+    probe, args = args[1], args[2:]
+merged, ms = {}, 0.0
+for d in args:
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     agg = collections.defaultdict(float); t = 0
-    for r in rows:
-        if "render_kernel" in r["Kernel_Name"] and "<false" in r["Kernel_Name"]:
-            agg[r["Counter_Name"]] += float(r["Counter_Value"]); t = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if "render_kernel" in r["Kernel_Name"] and "<false" in r["Kernel_Name"]:
+                agg[r["Counter_Name"]] += float(r["Counter_Value"]); t = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
     print(d, "ms %.1f" % t, {k: "%.4g" % v for k, v in sorted(agg.items())})
+    merged.update(agg); ms = t or ms
+if out_json:
+    rec = {"probe": probe, "kernel_ms": ms}
+    rec.update({k: v for k, v in sorted(merged.items())})
+    clock_hz = 2.4e9                                   # MI355X peak engine clock (MI355X_MICROARCH.md)
+    derived = {}
+    if "SQ_INSTS_VALU" in merged and ms:
+        derived["valu_issue_fraction"] = round(merged["SQ_INSTS_VALU"] * 4.0 / (ms * 1e-3 * clock_hz * 1024), 3)
+    if "SQ_THREAD_CYCLES_VALU" in merged and "SQ_INSTS_VALU" in merged:
+        derived["lane_utilisation"] = round(merged["SQ_THREAD_CYCLES_VALU"] / (64.0 * merged["SQ_INSTS_VALU"]), 3)
+    rec["derived"] = derived
+    json.dump(rec, open(out_json, "w"), indent=1)
+    print(json.dumps(rec))

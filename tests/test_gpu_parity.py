@@ -94,6 +94,30 @@ def test_sharded_render_sums_to_full(gpu_rgb):
     assert np.all(full[..., 4] == 8)
 
 
+def test_bench_strong_scaling_rehearsal(gpu_rgb, tmp_path):
+    """bench.py's own N-rank path (strong scaling: passes of spp / N, block_id % N, film reduce, 1-rank film check, weak side
+    figure) with two ranks on this one GPU through the gloo rehearsal switch -- the code the driver runs on 8 GPUs over RCCL."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MTSAMD_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--width", "128", "--height", "96", "--spp", "64", "--res", "16"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["film_check"]["ok"]
+    assert "2 passes of 32 spp" in line["config"]["workload"] and line["weak"]["value"] > 0 and line["value"] > 0
+    # the same job through the Python surface: two shards of the 2-pass job add up to the unsharded render
+    d = scenes.c3_heterogeneous(128, 96, 64, res=16, samples_per_pass=32)
+    full, st = gpu_render(gpu_rgb, d)
+    parts = [gpu_render(gpu_rgb, d, shard_index=i, shard_count=2) for i in range(2)]
+    assert parts[0][1]["samples"] == parts[1][1]["samples"] == st["samples"] // 2      # 12 (pass, block) pairs each
+    assert np.allclose(parts[0][0] + parts[1][0], full, rtol=1e-6, atol=0)
+
+
 def test_device_film_pointer(gpu_rgb):
     import torch
     d = scenes.c3_heterogeneous(64, 32, 4, res=8)
@@ -488,11 +512,55 @@ def test_metric_scene_throughput_floor(gpu_rgb):
 
 
 def test_cancel_and_timeout(gpu_rgb):
-    d = scenes.c3_heterogeneous(64, 64, 64, res=16, samples_per_pass=1)
-    d["integrator"]["timeout"] = 1e-6
+    """Integrator::cancel / should_stop (integrator.h:143-146, integrator.cpp:43-45,178) reach the kernel INSIDE its single launch:
+    the ring driver polls the scene's stop word once per claim iteration."""
+    import threading
+    import time
+    d = scenes.c3_heterogeneous(512, 512, 8192)                   # about four seconds of kernel time
     scene = gpu_rgb.load_dict(d)
+    integ, sensor = scene.integrator(), scene.sensors()[0]
+    result = {}
+    def run():
+        t0 = time.perf_counter()
+        result["ok"] = integ.render(scene, sensor)
+        result["t"] = time.perf_counter() - t0
+    th = threading.Thread(target=run)
+    th.start()
+    time.sleep(0.3)
+    integ.cancel()
+    th.join(30)
+    assert not th.is_alive() and result["ok"] is False            # render() returns !m_stop
+    assert result["t"] < 1.5 and integ.last_stats["kernel_launches"] == 1 and integ.last_stats["cancelled"] == 1
+    # the same scene object renders normally afterwards (m_stop is reset, integrator.cpp:53)
+    d2 = scenes.c3_heterogeneous(32, 32, 16, res=16)
+    ref = ob.OracleScene(d2).render()
+    gpu, _ = gpu_render(gpu_rgb, d2)
+    assert_parity(gpu, ref)
+    # timeout: stops the render from within, and -- like the reference -- is not a cancellation
+    d["integrator"]["timeout"] = 0.25
+    scene = gpu_rgb.load_dict(d)
+    t0 = time.perf_counter()
     ok = scene.integrator().render(scene, scene.sensors()[0])
-    assert ok is False                      # render() returns False when timed out / cancelled (integrator.cpp:178)
+    st = scene.integrator().last_stats
+    assert ok is True and st["timed_out"] == 1 and st["cancelled"] == 0 and time.perf_counter() - t0 < 1.5
+    # the per-lane kernels poll the same word (path / volpathmis / MTSAMD_KERNEL=flat)
+    d = scenes.c1_cornell(512, 512, 16384)
+    d["integrator"]["timeout"] = 0.25
+    scene = gpu_rgb.load_dict(d)
+    t0 = time.perf_counter()
+    assert scene.integrator().render(scene, scene.sensors()[0]) is True
+    assert scene.integrator().last_stats["timed_out"] == 1 and time.perf_counter() - t0 < 2.0
+
+
+def test_small_blocks_keep_the_regrouping_kernel(gpu_rgb):
+    """block_size 16 (256 pixels per block) runs on the 256-path workgroups of the ring driver, not on the per-lane fallback, and
+    matches the oracle, which seeds per block like integrator.cpp:198."""
+    d = scenes.c3_heterogeneous(48, 40, 8, res=16)
+    d["integrator"]["block_size"] = 16
+    gpu, st = gpu_render(gpu_rgb, d, collect_counters=True)
+    o = ob.OracleScene(d); ref = o.render()
+    assert_parity(gpu, ref)
+    assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (o.last_stats["n_iter"], o.last_stats["n_lookup"], o.last_stats["n_nee_step"])
 
 
 def test_errors_surface_as_exceptions(gpu_rgb):
