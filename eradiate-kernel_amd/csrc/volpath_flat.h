@@ -849,23 +849,55 @@ static __device__ WG_BLOCK_ATTR int wg_block(const MTS_CONST_AS void *kernarg_, 
 //   consumer: head: h -> h + n by compare-and-swap (n <= tail - h of a snapshot: those indices are already handed out), wait until
 //             the slot holds an id, take it and store 0xFFFF AT ONCE, acquire fence.
 // A consumer can be ahead of its producer (index handed out, id not stored yet) and a producer ahead of the previous lap's consumer
-// (slot claimed, not yet emptied); with WG slots per ring and WG paths neither wait lasts.  Both waits are written as wave-uniform
-// loops whose body does the per-lane hand-over, so a lane's store never waits for another lane's spin (a divergent `while` would
-// place it after the reconvergence point), and both are BOUNDED: a wait of more than MTS_RING_SPIN_LIMIT polls writes a diagnostic
-// record (ring, index, head, tail), raises the stop word and every wave leaves -- mts_render reports an error instead of hanging.
+// (slot claimed, not yet emptied); with WG slots per ring and WG paths neither wait lasts.  The first look is inline; a lane that
+// has to wait does so in a wave-uniform loop whose body does the per-lane hand-over, so a lane's store never waits for another
+// lane's spin (a divergent `while` would place it after the reconvergence point), and the wait is BOUNDED: after
+// MTS_RING_SPIN_LIMIT polls it writes a diagnostic record (ring, index, head, tail) and stops the workgroup -- mts_render reports an
+// error instead of hanging.
+// Stopping (Integrator::cancel / timeout, or a stall) adds no exit to the claim loop (a second exit measured 4.5 % slower): the
+// first lane to raise the stop word adds 2^31 to every head, which makes every ring look empty to every wave (a count above WG is no
+// count, see the snapshot) and every pending claim fail; a wave that finds every ring empty looks at the stop word before it naps.
 #define MTS_RING_SPIN_LIMIT (1u << 22)
 #define MTS_DIAG_BASE 4            // counters[MTS_DIAG_BASE + 0..5]: code (1 consumer / 2 producer), ring, index, head, tail, workgroup
 enum : uint32_t { STOP_NONE = 0, STOP_CANCEL = 1, STOP_STALL = 2 };
 
+template <int WG>
+DEV bool wga_raise_stop(uint32_t *q_ctl, uint32_t why) {
+    if (atomicCAS(&q_ctl[2 * B_COUNT], (uint32_t) STOP_NONE, why) != STOP_NONE) return false;          // already stopping
+#pragma unroll 1
+    for (int c = 0; c < B_DONE; ++c) atomicAdd(&q_ctl[2 * c], 0x80000000u);
+    return true;
+}
+template <int WG>
 DEV void wga_stall(uint32_t code, int ring, uint32_t index, uint32_t *q_ctl, unsigned long long *counters) {
-    if (atomicCAS(&q_ctl[2 * B_COUNT], (uint32_t) STOP_NONE, (uint32_t) STOP_STALL) == STOP_NONE) {     // first lane of the workgroup to give up
+    const uint32_t hd = __atomic_load_n(&q_ctl[2 * ring], __ATOMIC_RELAXED), tl = __atomic_load_n(&q_ctl[2 * ring + 1], __ATOMIC_RELAXED);
+    if (wga_raise_stop<WG>(q_ctl, STOP_STALL)) {                                                       // first lane of the workgroup to give up
         if (atomicCAS(counters + MTS_DIAG_BASE, 0ull, (unsigned long long) code) == 0ull) {            // first workgroup of the launch
             counters[MTS_DIAG_BASE + 1] = (unsigned long long) ring; counters[MTS_DIAG_BASE + 2] = index;
-            counters[MTS_DIAG_BASE + 3] = __atomic_load_n(&q_ctl[2 * ring], __ATOMIC_RELAXED);
-            counters[MTS_DIAG_BASE + 4] = __atomic_load_n(&q_ctl[2 * ring + 1], __ATOMIC_RELAXED);
-            counters[MTS_DIAG_BASE + 5] = blockIdx.x;
+            counters[MTS_DIAG_BASE + 3] = hd; counters[MTS_DIAG_BASE + 4] = tl; counters[MTS_DIAG_BASE + 5] = blockIdx.x;
         }
     }
+}
+// Slow side of a slot hand-over, entered (wave-uniformly) when some lane's first look found its slot not ready.  TAKE: wait until
+// the slot holds an id, take it and empty the slot; otherwise wait until the slot is empty and store `id`.  Returns the id taken /
+// stored, 0xFFFF for a lane that gave up (workgroup stopping, or MTS_RING_SPIN_LIMIT polls: ring stall).
+template <int WG, bool TAKE>
+DEV uint32_t wga_slot_wait(bool pending, uint16_t *slot, uint32_t id, uint32_t *q_ctl, unsigned long long *counters, int ring, uint32_t index) {
+    uint32_t out = 0xFFFFu;
+#pragma nounroll
+    for (uint32_t spins = 0;; ++spins) {
+        if (pending) {
+            const uint32_t v = __atomic_load_n(slot, __ATOMIC_RELAXED);
+            if (TAKE ? v != 0xFFFFu : v == 0xFFFFu) {
+                __atomic_store_n(slot, (uint16_t) (TAKE ? 0xFFFFu : id), __ATOMIC_RELAXED);
+                out = TAKE ? v : id; pending = false;
+            }
+        }
+        if (!__builtin_amdgcn_ballot_w64(pending)) break;
+        if (spins > MTS_RING_SPIN_LIMIT) { if (pending) wga_stall<WG>(TAKE ? 1u : 2u, ring, index, q_ctl, counters); break; }
+        if (__atomic_load_n(&q_ctl[2 * B_COUNT], __ATOMIC_RELAXED) != STOP_NONE) break;
+    }
+    return out;
 }
 
 template <int WG>
@@ -877,17 +909,13 @@ DEV void wga_push(int cls, uint32_t pid, bool valid, uint16_t (*q_ids)[WG], uint
     if (valid) idx = atomicAdd(&q_ctl[2 * cls + 1], 1u);
     bool pending = valid && cls != B_DONE;
     uint16_t *slot = &q_ids[pending ? cls : 0][idx & (uint32_t) (WG - 1)];
-    for (uint32_t spins = 0;; ++spins) {
-        if (pending && __atomic_load_n(slot, __ATOMIC_RELAXED) == 0xFFFFu) {      // empty: hand the id over
-            __atomic_store_n(slot, (uint16_t) pid, __ATOMIC_RELAXED);
-            pending = false;
-        }
-        if (!__builtin_amdgcn_ballot_w64(pending)) break;
-        if (spins > MTS_RING_SPIN_LIMIT || __atomic_load_n(&q_ctl[2 * B_COUNT], __ATOMIC_RELAXED) != STOP_NONE) {
-            if (pending && spins > MTS_RING_SPIN_LIMIT) wga_stall(2u, cls, idx, q_ctl, counters);
-            break;
-        }
+    if (pending && __atomic_load_n(slot, __ATOMIC_RELAXED) == 0xFFFFu) {        // empty, as ever: hand the id over
+        __atomic_store_n(slot, (uint16_t) pid, __ATOMIC_RELAXED);
+        pending = false;
     }
+    // the previous lap's consumer has not emptied the slot yet (rare).  The test is wave-uniform on purpose: every ready lane has
+    // stored its id by now, whatever order the compiler gives to divergent branches.
+    if (__builtin_amdgcn_ballot_w64(pending) != 0ull) (void) wga_slot_wait<WG, false>(pending, slot, pid, q_ctl, counters, cls, idx);
 }
 
 template <bool COUNT, int WG /* paths */, int NT /* threads: fewer threads than paths keeps the rings fuller */>
@@ -897,7 +925,7 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
     static_assert(NT % 64 == 0 && WG % 64 == 0 && NT <= WG, "whole waves");
     __shared__ uint32_t hot_lds[H_COUNT * WG];
     __shared__ uint16_t q_ids[NQ][WG];
-    __shared__ uint32_t q_ctl[2 * B_COUNT + 2];              // head / tail pairs, then the stop word
+    __shared__ __attribute__((aligned(8))) uint32_t q_ctl[2 * B_COUNT + 2];      // head / tail pairs, then the stop word
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wg_base = blockIdx.x * WG;
 #pragma unroll 1
@@ -935,24 +963,19 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
 #if defined(MTSAMD_BLOCKSTATS)
     long long bs_t0 = clock64(); unsigned long long bs_loc[45] = {};                      // laid out like g_blockstats
 #endif
-    const bool poller = tid < 64u;                           // wave 0 looks at the host's stop flag now and then
+    uint32_t poll_ticks = (tid >> 6) * 2048u;                // per wave, staggered: paces the polls of the host's stop word
 #pragma unroll 1
-    for (uint32_t iter = 0;; ++iter) {
-        // ---- snapshot of the rings (lanes 0 .. B_COUNT - 1) and of the stop word (lane B_COUNT); pick the fullest ring
+    for (;;) {
+        // ---- snapshot of the rings, pick the fullest
         uint32_t hd = 0, avail = 0;
-        if (lane <= (uint32_t) B_COUNT) {
+        if (lane < (uint32_t) B_COUNT) {
             hd = __atomic_load_n(&q_ctl[2 * lane], __ATOMIC_RELAXED);
             const uint32_t tl = __atomic_load_n(&q_ctl[2 * lane + 1], __ATOMIC_RELAXED);
-            // the two loads are not one atomic snapshot: a head newer than the tail gives a "negative" count, which is no count at all.
-            // Any tail that was ever read is a lower bound of the tail now, so tl - hd entries exist whenever the claim finds head == hd.
+            // the two loads are not one atomic snapshot: a head newer than the tail gives a "negative" count, which is no count at all
+            // (so does a stopped ring, wga_raise_stop).  Any tail that was ever read is a lower bound of the tail now, so tl - hd
+            // entries exist whenever the claim finds head == hd.
             avail = tl - hd;
-            if (avail > (uint32_t) WG || lane == (uint32_t) B_COUNT) avail = 0;
-        }
-        if (__builtin_amdgcn_readlane((int) hd, B_COUNT) != (int) STOP_NONE) break;         // cancelled, timed out, or a ring stalled
-        if (poller && (iter & 63u) == 63u) {
-            const uint32_t *flag = cload_k<WgArgs>(kernarg).stop_flag;
-            if (lane == 0 && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
-                __atomic_store_n(&q_ctl[2 * B_COUNT], (uint32_t) STOP_CANCEL, __ATOMIC_RELAXED);
+            if (avail > (uint32_t) WG) avail = 0;
         }
         // argmax over the NQ rings in three DPP steps: lanes 0..7 hold (avail << 4 | 15 - ring), the maximum of a row's first eight
         // lanes ends up in lane 7 (ties go to the lower ring, as a first-maximum scan would have it); one readlane instead of eight
@@ -964,7 +987,17 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         const uint32_t top_key = (uint32_t) __builtin_amdgcn_readlane((int) key, 7);
         const uint32_t best = top_key >> 4; const int sel = 15 - (int) (top_key & 15u);
         if (best == 0) {
-            if ((uint32_t) __builtin_amdgcn_readlane((int) avail, B_DONE) == (uint32_t) WG) break;     // every path of the workgroup has finished
+            // every path of the workgroup has finished, or the workgroup was stopped (then every ring looks empty for good)
+            if ((uint32_t) __builtin_amdgcn_readlane((int) avail, B_DONE) == (uint32_t) WG || __atomic_load_n(&q_ctl[2 * B_COUNT], __ATOMIC_RELAXED) != STOP_NONE) break;
+            // Integrator::should_stop() (integrator.h:143-146): waves look at the host's stop word (pinned host memory) now and then.  Reads
+            // of host memory are a scarce resource -- the whole GPU sustains about 3 * 10^7 per second, and a poll on every nap made the
+            // render 4.7 times longer -- so a wave earns a poll with 32768 ticks: one per nap, 256 per execution of the NEW block (below).
+            // That is about 10^5 polls per second over all workgroups, and a few milliseconds until a workgroup notices.
+            if ((poll_ticks += 1u) >= 32768u) {
+                poll_ticks = 0;
+                if (lane == 0 && __hip_atomic_load(cload_k<WgArgs>(kernarg).stop_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
+                    (void) wga_raise_stop<WG>(q_ctl, STOP_CANCEL);
+            }
             __builtin_amdgcn_s_sleep(2);
 #if defined(MTSAMD_BLOCKSTATS)
             if (COUNT) { long long t = clock64(); bs_loc[42] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
@@ -980,22 +1013,19 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         if (COUNT) { bs_loc[10] += 1ull; if (!__builtin_amdgcn_readfirstlane((int) won)) bs_loc[11] += 1ull; }      // claim attempts / lost compare-and-swaps
 #endif
         if (!__builtin_amdgcn_readfirstlane((int) won)) continue;
-        uint32_t pid = 0;
+        uint32_t pid = 0xFFFFu;
         bool mine = lane < n;
         {
             uint16_t *slot = &q_ids[sel][(h + lane) & (uint32_t) (WG - 1)];     // relaxed atomics, not volatile: volatile accesses stay FLAT
-            bool pending = mine;
-            for (uint32_t spins = 0;; ++spins) {
-                if (pending) {
-                    const uint32_t v = __atomic_load_n(slot, __ATOMIC_RELAXED);
-                    if (v != 0xFFFFu) { __atomic_store_n(slot, (uint16_t) 0xFFFFu, __ATOMIC_RELAXED); pid = v; pending = false; }
-                }
-                if (!__builtin_amdgcn_ballot_w64(pending)) break;
-                if (spins > MTS_RING_SPIN_LIMIT || __atomic_load_n(&q_ctl[2 * B_COUNT], __ATOMIC_RELAXED) != STOP_NONE) {
-                    if (pending && spins > MTS_RING_SPIN_LIMIT) wga_stall(1u, sel, h + lane, q_ctl, cload_k<WgArgs>(kernarg).counters);
-                    mine = mine && !pending;                  // the render is over: lanes without an id drop out
-                    break;
-                }
+            if (mine) {
+                pid = __atomic_load_n(slot, __ATOMIC_RELAXED);
+                if (pid != 0xFFFFu) __atomic_store_n(slot, (uint16_t) 0xFFFFu, __ATOMIC_RELAXED);   // taken: empty the slot at once
+            }
+            // a lane ahead of its producer (rare); wave-uniform test, see wga_push
+            if (__builtin_amdgcn_ballot_w64(mine && pid == 0xFFFFu) != 0ull) {
+                const uint32_t got = wga_slot_wait<WG, true>(mine && pid == 0xFFFFu, slot, 0u, q_ctl, cload_k<WgArgs>(kernarg).counters, sel, h + lane);
+                if (pid == 0xFFFFu) pid = got;
+                mine = mine && pid != 0xFFFFu;                // 0xFFFF: the workgroup is stopping, the lane drops out
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1015,6 +1045,13 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
                 case B_PHASE: cls = wg_block<COUNT, WG, B_PHASE>(kernarg, hot_lds, wg_base, pid, &cnt); break;
                 default: cls = wg_block<COUNT, WG, B_NEW>(kernarg, hot_lds, wg_base, pid, &cnt); break;
             }
+        }
+        // should_stop() for a busy wave: see the nap above.  Here, in the wake of the NEW block's film atomics, the vector load is cheap; at
+        // the head of the claim loop it measured 3.5 % however seldom it ran.
+        if (sel == B_NEW && (poll_ticks += 256u) >= 32768u) {
+            poll_ticks = 0;
+            if (lane == 0 && __hip_atomic_load(cload_k<WgArgs>(kernarg).stop_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
+                (void) wga_raise_stop<WG>(q_ctl, STOP_CANCEL);
         }
 #if defined(MTSAMD_BLOCKSTATS)
         if (COUNT) { long long t = clock64(); bs_loc[24 + sel] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
