@@ -20,12 +20,14 @@ import signal
 import threading
 import types
 
+import os
 import numpy as np
 
 from . import _capi as A
 from .transform import ScalarTransform4f
 from .scene_dict import build_scene_desc
 from . import volume_io
+from .fresolver import FileResolver, file_resolver, set_file_resolver        # Thread.thread().file_resolver() of the reference
 
 __version__ = "0.1.0"
 ERADIATE_KERNEL = True          # src/python/__init__.py:191-193
@@ -305,8 +307,18 @@ def load_string(string, device=0, **kwargs):
 def load_file(path, device=0, **kwargs):
     """mitsuba.core.xml.load_file(path, variant, update_scene=False, **parameters) (xml_v.cpp:70-75)."""
     from .xml_io import file_to_dict
+    from .fresolver import FileResolver, file_resolver, set_file_resolver
     kwargs.pop("variant", None); kwargs.pop("update_scene", None)
-    return load_dict(file_to_dict(path, kwargs), device)
+    # The parser works on a copy of the FileResolver and restores the caller's afterwards (xml.cpp:1238-1240,1275); like the
+    # `mitsuba` executable (src/mitsuba/mitsuba.cpp:230-235) the copy also searches the scene file's own directory.
+    backup = file_resolver()
+    fr = FileResolver(list(backup))
+    fr.append(os.path.dirname(os.path.abspath(path)))
+    set_file_resolver(fr)
+    try:
+        return load_dict(file_to_dict(path, kwargs), device)
+    finally:
+        set_file_resolver(backup)
 
 
 # virtual modules mitsuba.core / mitsuba.core.xml / mitsuba.render (src/python/__init__.py:115-121), registered so

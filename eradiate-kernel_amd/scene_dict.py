@@ -16,6 +16,7 @@ from . import _capi as A
 from .transform import ScalarTransform4f, coordinate_system, normalize32
 from .volume_io import read_volume
 from .mesh_io import load_mesh
+from .fresolver import file_resolver
 
 
 def _key_less(a, b):
@@ -206,7 +207,7 @@ class SceneBuilder:
             else:
                 rec.type = A.VOLUME_GRID
                 if p.has("filename"):
-                    data, meta = read_volume(p.get("filename"))
+                    data, meta = read_volume(file_resolver().resolve(p.get("filename")))
                     rec.file_bbox_min[:] = meta["bbox_min"]
                     rec.file_bbox_max[:] = meta["bbox_max"]
                 elif p.has("data"):
@@ -393,7 +394,7 @@ class SceneBuilder:
             if p.type == "mesh":
                 arrays = {k: p.get(k) for k in ("vertex_positions", "faces", "vertex_normals", "vertex_texcoords") if p.has(k)}
             else:
-                arrays = load_mesh(p.type, str(p.get("filename")), p.get("to_world"), bool(p.get("face_normals", False)),
+                arrays = load_mesh(p.type, file_resolver().resolve(p.get("filename")), p.get("to_world"), bool(p.get("face_normals", False)),
                                    bool(p.get("flip_tex_coords", True)) if p.type == "obj" else True)
                 rec.to_world = _xf(None)
 

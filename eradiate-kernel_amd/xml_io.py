@@ -155,6 +155,18 @@ class _Parser:
                     _err(self.src, '"default" elements are only allowed at the root of the scene')
                 self.params.setdefault(ca["name"], ca["value"])
                 continue
+            if tag == "path":                                            # xml.cpp:633-650: a search path for the FileResolver
+                _check_attrs(child, ca, {"value"}, {"value"}, self.src)
+                if depth != 0:
+                    _err(self.src, "<path>: path can only be child of root")
+                from .fresolver import file_resolver
+                cand = ca["value"] if os.path.isabs(ca["value"]) else os.path.join(self.base_dir, ca["value"])
+                if not os.path.exists(cand):
+                    cand = file_resolver().resolve(ca["value"])
+                if not os.path.exists(cand):
+                    _err(self.src, '<path>: folder "%s" not found' % cand)
+                file_resolver().prepend(cand)
+                continue
             if tag == "include":
                 _check_attrs(child, ca, {"filename"}, {"filename"}, self.src)
                 path = ca["filename"] if os.path.isabs(ca["filename"]) else os.path.join(self.base_dir, ca["filename"])

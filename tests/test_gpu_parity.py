@@ -594,3 +594,92 @@ def test_hip_path_agrees_with_the_independent_estimator(gpu_rgb, name):
     assert se < 2.5e-3 and abs(rel) < 4 * se and abs(rel) < 1e-2, (rel, se)
     p, alpha, _ = z_test(gm, gv, mean, var)
     assert (p > alpha).mean() >= 0.9975
+
+
+INGEST_XML = """<?xml version="1.0"?>
+<scene version="2.0.0">
+    <default name="spp" value="8"/>
+    <integrator type="volpath"><integer name="max_depth" value="-1"/><integer name="rr_depth" value="5"/></integrator>
+    <medium type="heterogeneous" id="cloud">
+        <volume type="gridvolume" name="sigma_t">
+            <string name="filename" value="sigma_t.vol"/>
+            <transform name="to_world"><scale x="4" y="4" z="2"/><translate x="-2" y="-2" z="0"/></transform>
+        </volume>
+        <volume type="gridvolume" name="albedo">
+            <string name="filename" value="albedo.vol"/>
+            <transform name="to_world"><scale x="4" y="4" z="2"/><translate x="-2" y="-2" z="0"/></transform>
+        </volume>
+        <float name="scale" value="1.5"/>
+        <phase type="hg"><float name="g" value="0.6"/></phase>
+    </medium>
+    <sensor type="perspective">
+        <transform name="to_world"><lookat origin="0, -9, 5" target="0, 0, 0.5" up="0, 0, 1"/></transform>
+        <float name="fov" value="40"/>
+        <film type="hdrfilm"><integer name="width" value="$w"/><integer name="height" value="$h"/><rfilter type="box"/></film>
+        <sampler type="independent"><integer name="sample_count" value="$spp"/></sampler>
+    </sensor>
+    <shape type="cube">
+        <transform name="to_world"><scale x="2" y="2" z="1"/><translate z="1"/></transform>
+        <bsdf type="null"/>
+        <ref id="cloud" name="interior"/>
+    </shape>
+    <shape type="ply">
+        <string name="filename" value="terrain.ply"/>
+        <transform name="to_world"><translate z="-0.25"/></transform>
+        <bsdf type="diffuse"><rgb name="reflectance" value="0.6, 0.5, 0.3"/></bsdf>
+    </shape>
+    <emitter type="directional"><vector name="direction" x="0.3" y="0.2" z="-1"/><spectrum name="irradiance" value="2.0"/></emitter>
+</scene>
+"""
+
+
+def test_scene_ingestion_from_files(gpu_rgb, tmp_path):
+    """SURVEY.md 8(f4) end to end on the GPU: a scene XML (src/libcore/xml.cpp) that references a PLY mesh (src/shapes/ply.cpp) and two
+    `.vol` grids (src/textures/volume_data.h:42-102), all written by this test, is loaded with load_file and rendered by the HIP path;
+    the oracle renders the equivalent dictionary built by hand from the in-memory arrays."""
+    import struct
+    volume_io = importlib.import_module("eradiate-kernel_amd.volume_io")
+    rng = np.random.default_rng(5)
+    sigma = (0.2 + rng.random((6, 8, 10), dtype=np.float32) * 1.3).astype(np.float32)          # nz, ny, nx
+    albedo = np.stack([np.full((6, 8, 10), a, np.float32) for a in (0.9, 0.8, 0.6)], axis=-1)     # three channels
+    volume_io.write_volume(str(tmp_path / "sigma_t.vol"), sigma)
+    volume_io.write_volume(str(tmp_path / "albedo.vol"), albedo)
+    # a 5 x 5 height field as binary little-endian PLY with quads (fan-triangulated by the loader)
+    n = 5
+    xs = np.linspace(-6, 6, n, dtype=np.float32)
+    verts = np.array([[x, y, 0.3 * np.sin(0.7 * x) * np.cos(0.5 * y)] for y in xs for x in xs], np.float32)
+    quads = [[j * n + i, j * n + i + 1, (j + 1) * n + i + 1, (j + 1) * n + i] for j in range(n - 1) for i in range(n - 1)]
+    head = ["ply", "format binary_little_endian 1.0", "element vertex %d" % len(verts), "property float x", "property float y", "property float z",
+            "element face %d" % len(quads), "property list uchar int vertex_indices", "end_header"]
+    body = b"".join(struct.pack("<3f", *v) for v in verts) + b"".join(struct.pack("<B4i", 4, *q) for q in quads)
+    (tmp_path / "terrain.ply").write_bytes(("\n".join(head) + "\n").encode() + body)
+    (tmp_path / "scene.xml").write_text(INGEST_XML)
+
+    scene = gpu_rgb.load_file(str(tmp_path / "scene.xml"), w=40, h=24)
+    sensor = scene.sensors()[0]
+    assert scene.integrator().render(scene, sensor, collect_counters=True)
+    gpu, st = np.array(sensor.film().bitmap(raw=True)), scene.integrator().last_stats
+
+    grid_xf = T.translate([-2, -2, 0]) @ T.scale([4, 4, 2])
+    faces = np.array([[q[0], q[k], q[k + 1]] for q in quads for k in (1, 2)], np.uint32)
+    mesh_xf = T.translate([0, 0, -0.25])
+    pos = (verts + np.array([0, 0, -0.25], np.float32)).astype(np.float32)
+    mesh_io = importlib.import_module("eradiate-kernel_amd.mesh_io")
+    arrays = mesh_io.load_mesh("ply", str(tmp_path / "terrain.ply"), mesh_xf)
+    assert np.array_equal(arrays["faces"], faces) and np.allclose(arrays["vertex_positions"], pos, atol=1e-6)
+    d = {"type": "scene",
+         "integrator": {"type": "volpath", "max_depth": -1, "rr_depth": 5},
+         "sensor": {"type": "perspective", "to_world": T.look_at([0, -9, 5], [0, 0, 0.5], [0, 0, 1]), "fov": 40.0,
+                    "film": {"type": "hdrfilm", "width": 40, "height": 24, "rfilter": {"type": "box"}},
+                    "sampler": {"type": "independent", "sample_count": 8}},
+         "cloud_box": {"type": "cube", "to_world": T.translate([0, 0, 1]) @ T.scale([2, 2, 1]), "bsdf": {"type": "null"},
+                       "interior": {"type": "heterogeneous", "scale": 1.5, "phase": {"type": "hg", "g": 0.6},
+                                    "sigma_t": {"type": "gridvolume", "data": sigma, "to_world": grid_xf},
+                                    "albedo": {"type": "gridvolume", "data": albedo, "to_world": grid_xf}}},
+         "terrain": dict(arrays, type="mesh", bsdf={"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.6, 0.5, 0.3]}}),
+         "sun": {"type": "directional", "direction": [0.3, 0.2, -1.0], "irradiance": 2.0}}
+    o = ob.OracleScene(d)
+    ref = o.render()
+    assert_parity(gpu, ref)
+    assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (o.last_stats["n_iter"], o.last_stats["n_lookup"], o.last_stats["n_nee_step"])
+    assert ref[..., :3].max() > 0 and st["n_lookup"] > 0

@@ -138,3 +138,33 @@ def test_include_recursion_limit_and_broken_include(tmp_path):
     top.write_text('<scene version="2.0.0"><include filename="broken.xml"/></scene>')
     with pytest.raises(xml_io.XMLError, match="error while loading"):
         xml_io.file_to_dict(str(top))
+
+
+def test_file_resolver_and_path_tag(tmp_path):
+    """core/fresolver.h + the <path> tag (xml.cpp:633-650): plugins resolve relative file names through the search paths."""
+    fresolver = importlib.import_module("eradiate-kernel_amd.fresolver")
+    volume_io = importlib.import_module("eradiate-kernel_amd.volume_io")
+    (tmp_path / "data").mkdir()
+    grid = np.full((2, 2, 2), 0.7, np.float32)
+    volume_io.write_volume(str(tmp_path / "data" / "sigma.vol"), grid)
+    fr = fresolver.FileResolver([])
+    assert fr.resolve("sigma.vol") == "sigma.vol"                        # not found: unchanged
+    fr.append(str(tmp_path / "data"))
+    assert fr.resolve("sigma.vol") == str(tmp_path / "data" / "sigma.vol")
+    assert fr.resolve("/abs/x.vol") == "/abs/x.vol"
+    xml = SLAB_XML.replace('<spectrum name="sigma_t" value="1.0"/>', "").replace('<medium type="homogeneous" id="fog">',
+        '<medium type="heterogeneous" id="fog"><volume type="gridvolume" name="sigma_t"><string name="filename" value="sigma.vol"/>'
+        '<transform name="to_world"><scale x="100" y="100" z="2"/><translate x="-50" y="-50"/></transform></volume>')
+    xml = xml.replace('<default name="spp" value="4"/>', '<default name="spp" value="4"/><path value="data"/>')
+    (tmp_path / "scene.xml").write_text(xml)
+    backup = fresolver.file_resolver()
+    fresolver.set_file_resolver(fresolver.FileResolver([]))
+    try:
+        d = xml_io.file_to_dict(str(tmp_path / "scene.xml"), {"w": 16, "h": 8})
+        assert list(fresolver.file_resolver()) == [str(tmp_path / "data")]
+        img = ob.OracleScene(d).render(threads=1)
+        assert np.isfinite(img).all() and img[..., :3].max() > 0
+        with pytest.raises(xml_io.XMLError, match="<path>: folder"):
+            xml_io.xml_to_dict('<scene version="2.0.0"><path value="nowhere"/></scene>', base_dir=str(tmp_path))
+    finally:
+        fresolver.set_file_resolver(backup)
