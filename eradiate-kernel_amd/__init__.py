@@ -289,6 +289,27 @@ class Scene:
             pass
 
 
+def sample_tea(v0, v1, rounds=4, device=0):
+    """mitsuba.core.sample_tea_32 / sample_tea_64 / sample_tea_float32 (core/random.h:75-140) on the device: returns the three arrays."""
+    _require_variant()
+    a = np.ascontiguousarray(np.broadcast_arrays(np.asarray(v0, np.uint32), np.asarray(v1, np.uint32))[0].ravel())
+    b = np.ascontiguousarray(np.broadcast_arrays(np.asarray(v0, np.uint32), np.asarray(v1, np.uint32))[1].ravel())
+    n = a.size
+    o32, o64, of = np.zeros(n, np.uint32), np.zeros(n, np.uint64), np.zeros(n, np.float32)
+    u32p = C.POINTER(C.c_uint32)
+    A.check(A.lib().mts_sample_tea(device, n, a.ctypes.data_as(u32p), b.ctypes.data_as(u32p), int(rounds), o32.ctypes.data_as(u32p),
+                                   o64.ctypes.data_as(C.POINTER(C.c_uint64)), of.ctypes.data_as(A.fp)))
+    return o32, o64, of
+
+
+def wavefront_sampler(lanes, seed_value, count, device=0):
+    """The per-lane PCG32 streams of the reference's wavefront (gpu_*) variants (PCG32Sampler::seed, sampler.cpp:83-92): (lanes, count) floats."""
+    _require_variant()
+    out = np.zeros((int(lanes), int(count)), np.float32)
+    A.check(A.lib().mts_wavefront_sampler(device, int(lanes), int(seed_value), int(count), out.ctypes.data_as(A.fp)))
+    return out
+
+
 def load_dict(d, device=0):
     """mitsuba.core.xml.load_dict (src/libcore/python/xml_v.cpp:23-68,100-272)."""
     _require_variant()

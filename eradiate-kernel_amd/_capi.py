@@ -116,7 +116,7 @@ ABI_STRUCTS = {"mts_transform": Transform, "mts_volume": Volume, "mts_phase": Ph
 
 # every symbol include/mtsamd.h declares
 ABI_SYMBOLS = ["mts_abi_version", "mts_last_error", "mts_device_count", "mts_scene_create", "mts_scene_destroy",
-               "mts_render", "mts_cancel", "mts_sample", "mts_ray_intersect", "mts_abi_sizeof"]
+               "mts_render", "mts_cancel", "mts_sample", "mts_ray_intersect", "mts_abi_sizeof", "mts_sample_tea", "mts_wavefront_sampler"]
 
 _lib = None
 
@@ -144,6 +144,8 @@ def lib():
     L.mts_cancel.argtypes = [C.c_void_p]
     L.mts_sample.argtypes = [C.c_void_p, i32, C.c_uint64] + [fp] * 6 + [fp, C.POINTER(C.c_uint8)]
     L.mts_ray_intersect.argtypes = [C.c_void_p, i32, fp, fp, fp, fp, fp, C.POINTER(i32), C.POINTER(i32), fp, fp]
+    L.mts_sample_tea.argtypes = [C.c_int, i32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), i32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), fp]
+    L.mts_wavefront_sampler.argtypes = [C.c_int, i32, C.c_uint64, i32, fp]
     L.mts_abi_sizeof.argtypes = [C.c_char_p]
     L.mts_abi_sizeof.restype = C.c_int
     if L.mts_abi_version() != MTS_ABI_VERSION:

@@ -275,6 +275,30 @@ int mts_sample(mts_scene *scene, int32_t n, uint64_t seed_offset, const float *o
     API_CATCH
 }
 
+int mts_sample_tea(int device, int32_t n, const uint32_t *v0, const uint32_t *v1, int32_t rounds, uint32_t *out32, uint64_t *out64, float *out_float32) {
+    API_TRY
+    if (n < 0 || !v0 || !v1 || !out32 || !out64 || !out_float32) throw std::runtime_error("mts_sample_tea: invalid argument");
+    if (n == 0) return 0;
+    HIP_CHECK(hipSetDevice(device));
+    DeviceBuffer<uint32_t> d0(n), d1(n), o32(n); DeviceBuffer<uint64_t> o64(n); DeviceBuffer<float> of(n);
+    HIP_CHECK(hipMemcpy(d0.p, v0, (size_t) n * 4, hipMemcpyHostToDevice)); HIP_CHECK(hipMemcpy(d1.p, v1, (size_t) n * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(launch_tea(n, d0.p, d1.p, rounds, o32.p, o64.p, of.p, nullptr));
+    HIP_CHECK(hipMemcpy(out32, o32.p, (size_t) n * 4, hipMemcpyDeviceToHost)); HIP_CHECK(hipMemcpy(out64, o64.p, (size_t) n * 8, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(out_float32, of.p, (size_t) n * 4, hipMemcpyDeviceToHost));
+    API_CATCH
+}
+
+int mts_wavefront_sampler(int device, int32_t lanes, uint64_t seed_value, int32_t count, float *out) {
+    API_TRY
+    if (lanes < 0 || count < 0 || !out) throw std::runtime_error("mts_wavefront_sampler: invalid argument");
+    if (lanes == 0 || count == 0) return 0;
+    HIP_CHECK(hipSetDevice(device));
+    DeviceBuffer<float> d((size_t) lanes * count);
+    HIP_CHECK(launch_wavefront_sampler(lanes, seed_value, count, d.p, nullptr));
+    HIP_CHECK(hipMemcpy(out, d.p, (size_t) lanes * count * 4, hipMemcpyDeviceToHost));
+    API_CATCH
+}
+
 int mts_ray_intersect(mts_scene *scene, int32_t n, const float *o, const float *d, const float *mint, const float *maxt,
                       float *out_t, int32_t *out_shape, int32_t *out_prim, float *out_p, float *out_n) {
     API_TRY

@@ -136,6 +136,20 @@ struct Pcg32 {
     DM_HD F2 next_2d() { F2 p; p.x = next_1d(); p.y = next_1d(); return p; }
 };
 
+// Tiny Encryption Algorithm, core/random.h:75-85 (sample_tea_32), :106-116 (sample_tea_64), :137-140 (sample_tea_float32): the
+// reference's wavefront variants seed one PCG32 per lane with it (librender/sampler.cpp:89-92)
+DM_HD void tea_rounds(uint32_t &v0, uint32_t &v1, int rounds) {
+    uint32_t sum = 0;
+    for (int i = 0; i < rounds; ++i) {
+        sum += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+}
+DM_HD uint32_t sample_tea_32(uint32_t v0, uint32_t v1, int rounds = 4) { tea_rounds(v0, v1, rounds); return v1; }
+DM_HD uint64_t sample_tea_64(uint32_t v0, uint32_t v1, int rounds = 4) { tea_rounds(v0, v1, rounds); return (uint64_t) v0 + ((uint64_t) v1 << 32); }
+DM_HD float sample_tea_float32(uint32_t v0, uint32_t v1, int rounds = 4) { return pm_from_bits((sample_tea_32(v0, v1, rounds) >> 9) | 0x3f800000u) - 1.0f; }
+
 // enoki::morton_decode (librender/integrator.cpp:200)
 DM_HD uint32_t compact_bits(uint32_t x) {
     x &= 0x55555555u; x = (x ^ (x >> 1)) & 0x33333333u; x = (x ^ (x >> 2)) & 0x0f0f0f0fu;

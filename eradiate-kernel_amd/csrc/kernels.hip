@@ -145,7 +145,35 @@ __global__ void __launch_bounds__(256) intersect_kernel(DScene sc, int32_t n, co
     out_n[3 * i] = nn.x; out_n[3 * i + 1] = nn.y; out_n[3 * i + 2] = nn.z;
 }
 
+// sample_tea_32 / sample_tea_64 / sample_tea_float32 for n (v0, v1) pairs (core/random.h:75-140)
+__global__ void __launch_bounds__(256) tea_kernel(int32_t n, const uint32_t *__restrict__ v0, const uint32_t *__restrict__ v1, int rounds,
+                                                  uint32_t *__restrict__ out32, uint64_t *__restrict__ out64, float *__restrict__ outf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out32[i] = sample_tea_32(v0[i], v1[i], rounds); out64[i] = sample_tea_64(v0[i], v1[i], rounds); outf[i] = sample_tea_float32(v0[i], v1[i], rounds);
+}
+// PCG32Sampler::seed of the wavefront variants (librender/sampler.cpp:83-92): lane idx of a wavefront gets
+// rng.seed(tea64(seed_value, idx), tea64(idx, seed_value)); the first `count` next_1d() of every lane are written lane-major.
+__global__ void __launch_bounds__(256) wavefront_sampler_kernel(int32_t lanes, uint64_t seed_value, int32_t count, float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= lanes) return;
+    Pcg32 rng;
+    rng.seed(sample_tea_64((uint32_t) seed_value, (uint32_t) i), sample_tea_64((uint32_t) i, (uint32_t) seed_value));
+    for (int k = 0; k < count; ++k) out[(size_t) i * count + k] = rng.next_1d();
+}
+
 // ---------------------------------------------------------------- launchers
+hipError_t launch_tea(int32_t n, const uint32_t *v0, const uint32_t *v1, int rounds, uint32_t *out32, uint64_t *out64, float *outf, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(tea_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, v0, v1, rounds, out32, out64, outf);
+    return hipGetLastError();
+}
+hipError_t launch_wavefront_sampler(int32_t lanes, uint64_t seed_value, int32_t count, float *out, hipStream_t stream) {
+    if (lanes <= 0 || count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(wavefront_sampler_kernel, dim3((lanes + 255) / 256), dim3(256), 0, stream, lanes, seed_value, count, out);
+    return hipGetLastError();
+}
+
 size_t render_workspace_floats(uint32_t n_blocks, uint32_t block_size, int variant) {
     if (variant < 256) return 0;
     if (variant >= 10000) variant -= 10000;

@@ -15,4 +15,7 @@ hipError_t launch_sample(const DScene &sc, int32_t n, uint64_t seed_offset, cons
 hipError_t launch_intersect(const DScene &sc, int32_t n, const float *o, const float *d, const float *mint, const float *maxt,
                             float *t, int32_t *shape, int32_t *prim, float *p, float *nn, hipStream_t stream);
 
+hipError_t launch_tea(int32_t n, const uint32_t *v0, const uint32_t *v1, int rounds, uint32_t *out32, uint64_t *out64, float *outf, hipStream_t stream);
+hipError_t launch_wavefront_sampler(int32_t lanes, uint64_t seed_value, int32_t count, float *out, hipStream_t stream);
+
 } // namespace mtsamd

@@ -967,6 +967,9 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
 #pragma unroll 1
     for (;;) {
         // ---- snapshot of the rings, pick the fullest
+#if defined(EXP_PRIO_CLAIM)
+        __builtin_amdgcn_s_setprio(EXP_PRIO_CLAIM);
+#endif
         uint32_t hd = 0, avail = 0;
         if (lane < (uint32_t) B_COUNT) {
             hd = __atomic_load_n(&q_ctl[2 * lane], __ATOMIC_RELAXED);
@@ -1032,6 +1035,9 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
 #if defined(MTSAMD_BLOCKSTATS)
         if (COUNT) { bs_loc[sel] += 1ull; bs_loc[12 + sel] += (unsigned long long) n;
                      long long t = clock64(); bs_loc[44] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
+#endif
+#if defined(EXP_PRIO_CLAIM)
+        __builtin_amdgcn_s_setprio(EXP_PRIO_BLOCK);
 #endif
         int cls = B_DONE;
         if (mine) {

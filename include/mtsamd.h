@@ -262,6 +262,17 @@ int  mts_ray_intersect(mts_scene *scene, int32_t n,
                        float *out_t /* n, inf = miss */, int32_t *out_shape /* n */,
                        int32_t *out_prim /* n */, float *out_p /* 3*n */, float *out_n /* 3*n */);
 
+/* sample_tea_32 / sample_tea_64 / sample_tea_float32 (include/mitsuba/core/random.h:75-85,106-116,137-140) for n (v0, v1) pairs,
+ * computed on the device: the hash the reference's wavefront variants seed their per-lane PCG32 streams with. */
+int  mts_sample_tea(int device, int32_t n, const uint32_t *v0, const uint32_t *v1, int32_t rounds,
+                    uint32_t *out32 /* n */, uint64_t *out64 /* n */, float *out_float32 /* n */);
+
+/* PCG32Sampler::seed of the reference's wavefront (gpu_*) variants (src/librender/sampler.cpp:83-92): lane i is seeded with
+ * (sample_tea_64(seed_value, i), sample_tea_64(i, seed_value)); writes the first `count` next_1d() of every lane, lane-major.
+ * The render path of this backend uses the scalar seeding instead (one stream per pixel, integrator.cpp:198), which is what
+ * makes its films equal scalar_rgb's; this entry exposes the other scheme for callers that want the reference's gpu_rgb streams. */
+int  mts_wavefront_sampler(int device, int32_t lanes, uint64_t seed_value, int32_t count, float *out /* lanes * count */);
+
 #ifdef __cplusplus
 }
 #endif

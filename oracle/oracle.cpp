@@ -1648,6 +1648,13 @@ void oracle_pcg32(uint64_t initstate, uint64_t initseq, int n, uint32_t *out_u32
 void oracle_sampler_stream(uint64_t base_seed, uint64_t seed_offset, int n, float *out) {
     Sampler s; s.base_seed = base_seed; s.seed(seed_offset); for (int i = 0; i < n; ++i) out[i] = s.next_1d();
 }
+// PCG32Sampler::seed of the wavefront variants (sampler.cpp:83-92): lane idx seeded with (tea64(seed_value, idx), tea64(idx, seed_value))
+void oracle_wavefront_sampler(int lanes, uint64_t seed_value, int count, float *out) {
+    for (int i = 0; i < lanes; ++i) {
+        PCG32 rng; rng.seed(sample_tea_64((uint32_t) seed_value, (uint32_t) i), sample_tea_64((uint32_t) i, (uint32_t) seed_value));
+        for (int k = 0; k < count; ++k) out[(size_t) i * count + k] = rng.next_float32();
+    }
+}
 void oracle_warp(int kind, float u, float v, float *out) {
     P2 s = { u, v };
     if (kind == 0) { P2 p = square_to_uniform_disk_concentric(s); out[0] = p.x; out[1] = p.y; out[2] = 0.f; }

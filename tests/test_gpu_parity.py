@@ -683,3 +683,30 @@ def test_scene_ingestion_from_files(gpu_rgb, tmp_path):
     assert_parity(gpu, ref)
     assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (o.last_stats["n_iter"], o.last_stats["n_lookup"], o.last_stats["n_nee_step"])
     assert ref[..., :3].max() > 0 and st["n_lookup"] > 0
+
+
+def test_tea_and_wavefront_sampler_on_device(gpu_rgb):
+    """sample_tea_32 / 64 / float32 (core/random.h:75-140) computed on the device give the literals of
+    src/libcore/tests/test_random.py:6-29, and the per-lane PCG32 streams of the reference's wavefront seeding (sampler.cpp:83-92)
+    equal the oracle's."""
+    import ctypes as C
+    f32 = {(1, 1): 0.5424730777740479, (1, 2): 0.5079904794692993, (1, 3): 0.4171961545944214, (1, 4): 0.008385419845581055,
+           (1, 5): 0.8085528612136841, (2, 1): 0.6939879655838013, (3, 1): 0.6978365182876587, (4, 1): 0.4897364377975464}
+    f64 = {(1, 1): 0.5424730799533735, (1, 2): 0.5079905082233922, (1, 3): 0.4171962610608142, (1, 4): 0.008385529523330604,
+           (1, 5): 0.80855288317879, (2, 1): 0.6939880404156831, (3, 1): 0.6978365636630994, (4, 1): 0.48973647949223253}
+    keys = sorted(f32)
+    o32, o64, of = gpu_rgb.sample_tea([k[0] for k in keys], [k[1] for k in keys], 4)
+    assert [float(x) for x in of] == [float(np.float32(f32[k])) for k in keys]
+    as_f64 = ((o64 >> np.uint64(12)) | np.uint64(0x3ff0000000000000)).view(np.float64) - 1.0            # sample_tea_float64, random.h:159-162
+    assert [float(x) for x in as_f64] == [f64[k] for k in keys]
+    assert np.array_equal(o32, (o64 >> np.uint64(32)).astype(np.uint32))
+    rng = np.random.default_rng(11)
+    a, b = rng.integers(0, 2 ** 32, 4096, dtype=np.uint64).astype(np.uint32), rng.integers(0, 2 ** 32, 4096, dtype=np.uint64).astype(np.uint32)
+    o32, o64, of = gpu_rgb.sample_tea(a, b, 4)
+    L = ob.lib()
+    assert all(int(o64[i]) == L.oracle_tea64(int(a[i]), int(b[i]), 4) for i in range(0, 4096, 37))
+    streams = gpu_rgb.wavefront_sampler(300, 7, 16)
+    ref = np.zeros((300, 16), np.float32)
+    L.oracle_wavefront_sampler.argtypes = [C.c_int, C.c_uint64, C.c_int, ob.fp]
+    L.oracle_wavefront_sampler(300, 7, 16, ob._p(ref))
+    assert np.array_equal(streams, ref) and len(np.unique(streams[:, 0])) > 290
