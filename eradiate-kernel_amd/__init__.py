@@ -31,7 +31,9 @@ from .fresolver import FileResolver, file_resolver, set_file_resolver        # T
 
 __version__ = "0.1.0"
 ERADIATE_KERNEL = True          # src/python/__init__.py:191-193
-_VARIANTS = ["gpu_rgb", "gpu_mono"]      # gpu_mono: the semantics of scalar_mono (one channel, luminance of every colour)
+# gpu_mono: the semantics of scalar_mono (one channel, luminance of every colour); gpu_spectral: those of scalar_spectral
+# (Spectrum<Float, 4>: four wavelengths per sample, colours given as spectra; integrators path and volpath)
+_VARIANTS = ["gpu_rgb", "gpu_mono", "gpu_spectral"]
 _tls = threading.local()
 
 
@@ -313,7 +315,7 @@ def wavefront_sampler(lanes, seed_value, count, device=0):
 def load_dict(d, device=0):
     """mitsuba.core.xml.load_dict (src/libcore/python/xml_v.cpp:23-68,100-272)."""
     _require_variant()
-    desc, keep = build_scene_desc(d, mono=(variant() == "gpu_mono"))
+    desc, keep = build_scene_desc(d, mono=(variant() == "gpu_mono"), spectral=(variant() == "gpu_spectral"))
     return Scene(desc, keep, device)
 
 

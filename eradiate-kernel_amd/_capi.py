@@ -10,10 +10,11 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MTSAMD_LIB") or os.path.join(HERE, "libmtsamd.so")
 
-MTS_ABI_VERSION = 4
+MTS_ABI_VERSION = 5
 
 # enums (include/mtsamd.h)
-VOLUME_CONST, VOLUME_GRID = 0, 1
+VOLUME_CONST, VOLUME_GRID, VOLUME_GRID_SPECTRAL = 0, 1, 2
+SPECTRUM_UNIFORM, SPECTRUM_REGULAR = 0, 1
 FILTER_NEAREST, FILTER_TRILINEAR = 0, 1
 WRAP_REPEAT, WRAP_MIRROR, WRAP_CLAMP = 0, 1, 2
 PHASE_ISOTROPIC, PHASE_HG, PHASE_RAYLEIGH, PHASE_BLEND, PHASE_TABULATED = 0, 1, 2, 3, 4
@@ -35,12 +36,17 @@ class Transform(C.Structure):
     _fields_ = [("matrix", f32 * 16), ("inverse_transpose", f32 * 16)]
 
 
+class Spectrum(C.Structure):
+    _fields_ = [("type", i32), ("value", f32), ("lambda_min", f32), ("lambda_max", f32), ("values", fp), ("count", i32)]
+
+
 class Volume(C.Structure):
     _fields_ = [("type", i32), ("value", f32 * 3), ("to_world", Transform), ("data", fp),
                 ("nx", i32), ("ny", i32), ("nz", i32), ("channels", i32),
                 ("filter_type", i32), ("wrap_mode", i32), ("use_grid_bbox", i32),
                 ("file_bbox_min", f32 * 3), ("file_bbox_max", f32 * 3),
-                ("has_max_value", i32), ("max_value", f32)]
+                ("has_max_value", i32), ("max_value", f32),
+                ("value_spectrum", i32), ("lambda_min", f32), ("lambda_max", f32)]
 
 
 class Phase(C.Structure):
@@ -55,7 +61,7 @@ class Medium(C.Structure):
 
 class Bsdf(C.Structure):
     _fields_ = [("type", i32), ("reflectance", f32 * 3), ("rho_0", f32 * 3), ("k", f32 * 3),
-                ("g", f32 * 3), ("rho_c", f32 * 3), ("transmittance", f32 * 3)]
+                ("g", f32 * 3), ("rho_c", f32 * 3), ("transmittance", f32 * 3), ("spectrum", i32 * 6)]
 
 
 class Shape(C.Structure):
@@ -67,7 +73,7 @@ class Shape(C.Structure):
 
 
 class Emitter(C.Structure):
-    _fields_ = [("type", i32), ("to_world", Transform), ("radiance", f32 * 3), ("shape", i32)]
+    _fields_ = [("type", i32), ("to_world", Transform), ("radiance", f32 * 3), ("shape", i32), ("radiance_spectrum", i32)]
 
 
 class Sensor(C.Structure):
@@ -84,7 +90,8 @@ class Sensor(C.Structure):
 
 class Integrator(C.Structure):
     _fields_ = [("type", i32), ("max_depth", i32), ("rr_depth", i32), ("hide_emitters", i32),
-                ("block_size", i32), ("samples_per_pass", i32), ("timeout", f32), ("use_spectral_mis", i32), ("monochrome", i32)]
+                ("block_size", i32), ("samples_per_pass", i32), ("timeout", f32), ("use_spectral_mis", i32), ("monochrome", i32),
+                ("spectral", i32)]
 
 
 class SceneDesc(C.Structure):
@@ -95,7 +102,8 @@ class SceneDesc(C.Structure):
                 ("bsdfs", C.POINTER(Bsdf)), ("bsdf_count", i32),
                 ("shapes", C.POINTER(Shape)), ("shape_count", i32),
                 ("emitters", C.POINTER(Emitter)), ("emitter_count", i32),
-                ("sensor", Sensor), ("integrator", Integrator)]
+                ("sensor", Sensor), ("integrator", Integrator),
+                ("spectra", C.POINTER(Spectrum)), ("spectrum_count", i32)]
 
 
 class Stats(C.Structure):
@@ -109,7 +117,7 @@ class RenderOpts(C.Structure):
                 ("film_on_device", i32), ("collect_counters", i32)]
 
 
-ABI_STRUCTS = {"mts_transform": Transform, "mts_volume": Volume, "mts_phase": Phase, "mts_medium": Medium,
+ABI_STRUCTS = {"mts_spectrum": Spectrum, "mts_transform": Transform, "mts_volume": Volume, "mts_phase": Phase, "mts_medium": Medium,
                "mts_bsdf": Bsdf, "mts_shape": Shape, "mts_emitter": Emitter, "mts_sensor": Sensor,
                "mts_integrator": Integrator, "mts_scene_desc": SceneDesc, "mts_stats": Stats,
                "mts_render_opts": RenderOpts}

@@ -99,7 +99,7 @@ const char *mts_last_error(void) { return g_error.c_str(); }
 
 int mts_abi_sizeof(const char *name) {
 #define SZ(T) if (!strcmp(name, #T)) return (int) sizeof(T);
-    SZ(mts_transform) SZ(mts_volume) SZ(mts_phase) SZ(mts_medium) SZ(mts_bsdf) SZ(mts_shape) SZ(mts_emitter)
+    SZ(mts_spectrum) SZ(mts_transform) SZ(mts_volume) SZ(mts_phase) SZ(mts_medium) SZ(mts_bsdf) SZ(mts_shape) SZ(mts_emitter)
     SZ(mts_sensor) SZ(mts_integrator) SZ(mts_scene_desc) SZ(mts_stats) SZ(mts_render_opts)
 #undef SZ
     return -1;
@@ -225,8 +225,9 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             int wg_threads = 0;                                     // MTSAMD_WG_THREADS: threads per workgroup of the wga kernels (<= paths; default = paths)
             if (const char *tv = getenv("MTSAMD_WG_THREADS")) wg_threads = atoi(tv);
             float *d_ws = (float *) rc.get(3, render_workspace_floats((uint32_t) blocks.size(), block_size, variant) * sizeof(float));
-            HIP_CHECK(launch_render(hs.scene, d_blocks, (uint32_t) blocks.size(), block_size, (uint32_t) samples_per_pass, d_film, d_counters,
-                                    opts.collect_counters != 0, variant, wg_threads, d_ws, (const uint32_t *) scene->stop_word, stream));
+            HIP_CHECK((hs.integrator.spectral ? launch_render_spectral : launch_render)(
+                          hs.scene, d_blocks, (uint32_t) blocks.size(), block_size, (uint32_t) samples_per_pass, d_film, d_counters,
+                          opts.collect_counters != 0, variant, wg_threads, d_ws, (const uint32_t *) scene->stop_word, stream));
             HIP_CHECK(hipEventRecord(ev1, stream));
             // wait for the launch as a watchdog: cancel() and the timeout reach the kernel through the stop word
             for (;;) {
@@ -264,6 +265,7 @@ int mts_sample(mts_scene *scene, int32_t n, uint64_t seed_offset, const float *o
     if (!scene || n < 0) throw std::runtime_error("mts_sample: invalid argument");
     if (n == 0) return 0;
     HostScene &hs = *scene->hs;
+    if (hs.integrator.spectral) throw std::runtime_error("mts_sample: not available for scenes of the spectral variant");
     HIP_CHECK(hipSetDevice(hs.device));
     DeviceBuffer<float> d_rays((size_t) 6 * n), d_rgb((size_t) 3 * n);
     DeviceBuffer<uint8_t> d_valid((size_t) n);

@@ -45,6 +45,38 @@ DM_HD F3 vrcp(F3 a) { return f3(1.0f / a.x, 1.0f / a.y, 1.0f / a.z); }
 DM_HD float pick(F3 a, uint32_t i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 DM_HD bool any_nonzero(F3 a) { return a.x != 0.f || a.y != 0.f || a.z != 0.f; }
 
+// ---- The spectrum type of the variant this translation unit is compiled for.  rgb / mono: three channels (Color3f) -- a typedef of
+// F3, so the rgb kernels are compiled from the very same expressions as before.  Spectral (MTS_SPEC_N == 4): four wavelengths
+// (Spectrum<Float, 4>, core/spectrum.h:57-73); .x is the one the free-flight sampling follows (volpath.cpp:26-36: index_spectrum
+// returns spec[0] outside the rgb variants).  The inline namespace keeps the two builds' symbols apart inside one library.
+#ifndef MTS_SPEC_N
+#define MTS_SPEC_N 3
+#endif
+#if MTS_SPEC_N == 3
+inline namespace v_rgb {
+typedef F3 Spec;
+DM_HD Spec spec_s(float s) { return f3s(s); }
+DM_HD float spec_hmean(Spec a) { return ((a.x + a.y) + a.z) * (1.f / 3.f); }
+}
+#else
+inline namespace v_spectral {
+struct Spec { float x, y, z, w; };
+DM_HD Spec spec4(float x, float y, float z, float w) { Spec r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+DM_HD Spec spec_s(float s) { return spec4(s, s, s, s); }
+DM_HD Spec operator+(Spec a, Spec b) { return spec4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+DM_HD Spec operator-(Spec a, Spec b) { return spec4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+DM_HD Spec operator*(Spec a, float s) { return spec4(a.x * s, a.y * s, a.z * s, a.w * s); }
+DM_HD Spec operator*(float s, Spec a) { return spec4(a.x * s, a.y * s, a.z * s, a.w * s); }
+DM_HD Spec operator*(Spec a, Spec b) { return spec4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+DM_HD Spec operator/(Spec a, float s) { const float r = 1.0f / s; return spec4(a.x * r, a.y * r, a.z * r, a.w * r); }   // as for F3: reciprocal, then multiply
+DM_HD Spec operator/(Spec a, Spec b) { return spec4(a.x / b.x, a.y / b.y, a.z / b.z, a.w / b.w); }
+DM_HD float hmax(Spec a) { return pm_max(pm_max(a.x, a.y), pm_max(a.z, a.w)); }
+DM_HD float pick(Spec a, uint32_t) { return a.x; }                       // index_spectrum, volpath.cpp:26-36
+DM_HD bool any_nonzero(Spec a) { return a.x != 0.f || a.y != 0.f || a.z != 0.f || a.w != 0.f; }
+DM_HD float spec_hmean(Spec a) { return ((a.x + a.y) + (a.z + a.w)) * 0.25f; }      // enoki hmean of a 4-array: pairwise sum (enoki absent: decision)
+}
+#endif
+
 // core/math.h:13-38
 #define MTS_PI 3.14159265358979323846f
 #define MTS_INV_PI 0.31830988618379067154f

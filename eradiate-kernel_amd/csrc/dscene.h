@@ -110,6 +110,13 @@ struct DSensor {
     int32_t multi_count;
 };
 
+// Spectra (spectral variants): `uniform` (spectra/uniform.cpp:34-62: value inside [lambda_min, lambda_max], 0 outside) and `regular`
+// (spectra/regular.cpp: a ContinuousDistribution over [lambda_min, lambda_max], core/distr_1d.h:378-400 eval_pdf)
+struct DSpectrum { int32_t type; float value, lambda_min, lambda_max; const float *values; int32_t count; float inv_interval_size; };
+enum { MTS_BSDF_SP_REFLECTANCE = 0, MTS_BSDF_SP_RHO_0, MTS_BSDF_SP_K, MTS_BSDF_SP_G, MTS_BSDF_SP_RHO_C, MTS_BSDF_SP_TRANSMITTANCE, MTS_BSDF_SP_COUNT };
+// constvolume: the spectrum of its value; gridvolume_spectral (textures/gridvolume_spectral.cpp): the spectral interval its channels cover
+struct DVolumeSp { int32_t value_sp; int32_t spectral_grid; float lambda_min, lambda_max; };
+
 struct DIntegrator { int32_t type, max_depth, rr_depth, hide_emitters, use_spectral_mis, monochrome; };
 
 // One spiral block (librender/spiral.cpp:27-72) assigned to this launch
@@ -145,6 +152,13 @@ struct DScene {
     DBBox bbox;
     DSensor sensor;
     DIntegrator integrator;
+    // Spectral variants only (gpu_spectral; NULL / unused otherwise).  They sit BEHIND the records the rgb kernels load, in arrays of
+    // their own, so that the rgb records -- and the scalar loads that fetch them -- stay exactly as they are.
+    const DSpectrum *spectra;                       // every spectrum of the scene (spectra/uniform.cpp, spectra/regular.cpp; d65 expands to regular)
+    const int32_t *bsdf_sp;                         // per BSDF, MTS_BSDF_SP_COUNT indices into spectra: reflectance, rho_0, k, g, rho_c, transmittance
+    const int32_t *emitter_sp;                      // per emitter: radiance / irradiance / intensity
+    const DVolumeSp *volume_sp;                     // per volume
+    const float *cie;                               // CIE 1931 x, y, z, 95 samples each over 360 .. 830 nm (core/spectrum.h:127-133)
 };
 
 // bsdf.h:38-124

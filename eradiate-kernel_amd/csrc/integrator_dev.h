@@ -11,7 +11,13 @@
 #include "dmath.h"
 #include "../../include/mtsamd.h"
 
+#if MTS_SPEC_N == 3
+#define MTS_VARIANT_NS v_rgb
+#else
+#define MTS_VARIANT_NS v_spectral
+#endif
 namespace mtsamd {
+inline namespace MTS_VARIANT_NS {
 
 #define DEV __device__ __forceinline__
 #define DEV_NOINLINE __device__ __noinline__
@@ -350,6 +356,42 @@ DEV void complete_surface(const DScene &sc, const Hit &h, F3 d, Surf &sf) {
     WATERFALL_END
 }
 
+// ---------------------------------------------------------------- spectra
+// What a colour parameter of a plugin evaluates to for the sample at hand.  rgb / mono: the record's own three floats.  Spectral:
+// the parameter's spectrum (DScene::spectra through the per-plugin index arrays) at the sample's four wavelengths, which travel
+// in SpecCtx.  Functions take `cx` (and the plugin's index `id`) as trailing arguments with defaults, so the rgb call sites read
+// as they always did and SpecCtx is an empty struct there.
+#if MTS_SPEC_N == 3
+struct SpecCtx { };
+DEV SpecCtx make_ctx(const DScene &) { return SpecCtx(); }
+#define BSDF_COLOR(b, field, which, cx, id) f3((b).field)
+#define EMITTER_COLOR(e, cx, id) f3((e).radiance)
+#else
+struct SpecCtx { Spec wl; const DSpectrum *spectra; const int32_t *bsdf_sp, *emitter_sp; const DVolumeSp *volume_sp; };
+DEV SpecCtx make_ctx(const DScene &sc) {
+    SpecCtx cx; cx.wl = spec_s(0.f); cx.spectra = sc.spectra; cx.bsdf_sp = sc.bsdf_sp; cx.emitter_sp = sc.emitter_sp; cx.volume_sp = sc.volume_sp;
+    return cx;
+}
+// spectra/uniform.cpp:47-57 ; spectra/regular.cpp:71-78 -> ContinuousDistribution::eval_pdf (core/distr_1d.h:378-400)
+DEV float spectrum_eval_1(const DSpectrum &s, float lambda) {
+    const bool active = lambda >= s.lambda_min && lambda <= s.lambda_max;
+    if (s.type == MTS_SPECTRUM_UNIFORM) return active ? s.value : 0.f;
+    float x = (lambda - s.lambda_min) * s.inv_interval_size;
+    long long xi = (long long) x;
+    uint32_t index = (uint32_t) (xi < 0 ? 0 : (xi > (long long) s.count - 2 ? (long long) s.count - 2 : xi));
+    const MTS_GLOBAL_AS float *v = as_global(s.values);
+    float y0 = active ? v[index] : 0.f, y1 = active ? v[index + 1] : 0.f;
+    float w1 = x - (float) index, w0 = 1.f - w1;
+    return pm_fma(w0, y0, w1 * y1);
+}
+DEV Spec spectrum_eval(const DSpectrum *spectra, int idx, Spec wl) {
+    const DSpectrum s = spectra[idx];
+    return spec4(spectrum_eval_1(s, wl.x), spectrum_eval_1(s, wl.y), spectrum_eval_1(s, wl.z), spectrum_eval_1(s, wl.w));
+}
+#define BSDF_COLOR(b, field, which, cx, id) spectrum_eval((cx).spectra, (cx).bsdf_sp[(id) * MTS_BSDF_SP_COUNT + (which)], (cx).wl)
+#define EMITTER_COLOR(e, cx, id) spectrum_eval((cx).spectra, (cx).emitter_sp[id], (cx).wl)
+#endif
+
 // ---------------------------------------------------------------- volumes
 // textures/grid3d.cpp:234-250
 DEV int wrap_coord(int wrap, int value, int res) {
@@ -374,14 +416,62 @@ DEV float trilerp(float d000, float d100, float d010, float d110, float d001, fl
 // be copied through scratch memory at every call.
 struct GridRef { float w2l[16]; const float *data; int32_t nx, ny, nz; uint32_t channels_affine_filter_wrap; };
 DEV_NOINLINE F3 volume_eval_grid(const GridRef g, F3 p_world);
-DEV F3 volume_eval(const DVolume &v, F3 p_world) {
+#if MTS_SPEC_N != 3
+DEV_NOINLINE Spec volume_eval_grid_spectral(const GridRef g, F3 p_world, Spec wl, float lambda_min, float lambda_max);
+#endif
+DEV Spec volume_eval(const DVolume &v, F3 p_world, const SpecCtx &cx = SpecCtx(), int vid = 0) {
+#if MTS_SPEC_N == 3
     if (v.type == MTS_VOLUME_CONST) return f3(v.value);
+#else
+    if (v.type == MTS_VOLUME_CONST) return spectrum_eval(cx.spectra, cx.volume_sp[vid].value_sp, cx.wl);    // constant3d.cpp: m_color->eval(si)
+#endif
     GridRef g;
     for (int k = 0; k < 16; ++k) g.w2l[k] = v.w2l[k];
     g.data = v.data; g.nx = v.nx; g.ny = v.ny; g.nz = v.nz;
     g.channels_affine_filter_wrap = (uint32_t) v.channels | ((uint32_t) (v.affine != 0) << 8) | ((uint32_t) v.filter << 16) | ((uint32_t) v.wrap << 24);
+#if MTS_SPEC_N == 3
     return volume_eval_grid(g, p_world);
+#else
+    const DVolumeSp vs = cx.volume_sp[vid];
+    if (vs.spectral_grid) return volume_eval_grid_spectral(g, p_world, cx.wl, vs.lambda_min, vs.lambda_max);
+    return spec_s(volume_eval_grid(g, p_world).x);          // single-channel grid (the loader refuses 3-channel grids: they need the sRGB model)
+#endif
 }
+#if MTS_SPEC_N != 3
+// textures/gridvolume_spectral.cpp:226-388: trilinear in space (cell-centred values, wrapped indices), linear in the spectral
+// dimension (values at nodes over [lambda_min, lambda_max], clamped indices), zero outside the interval
+DEV_NOINLINE Spec volume_eval_grid_spectral(const GridRef g, F3 p_world, Spec wl, float lambda_min, float lambda_max) {
+    const int channels = (int) (g.channels_affine_filter_wrap & 0xffu), affine = (int) ((g.channels_affine_filter_wrap >> 8) & 0xffu),
+              wrap = (int) (g.channels_affine_filter_wrap >> 24);
+    F3 p = affine ? mat_point_affine(g.w2l, p_world) : mat_point(g.w2l, p_world);
+    const MTS_GLOBAL_AS float *D = as_global(g.data); const int nx = g.nx, ny = g.ny, nz = g.nz, ch = channels;
+    p = f3(pm_fma(p.x, (float) nx, -.5f), pm_fma(p.y, (float) ny, -.5f), pm_fma(p.z, (float) nz, -.5f));
+    int ix = (int) pm_floor(p.x), iy = (int) pm_floor(p.y), iz = (int) pm_floor(p.z);
+    F3 w1 = p - f3((float) ix, (float) iy, (float) iz), w0 = f3(1.f - w1.x, 1.f - w1.y, 1.f - w1.z);
+    int x0 = wrap_coord(wrap, ix, nx), x1 = wrap_coord(wrap, ix + 1, nx), y0 = wrap_coord(wrap, iy, ny), y1 = wrap_coord(wrap, iy + 1, ny),
+        z0 = wrap_coord(wrap, iz, nz), z1 = wrap_coord(wrap, iz + 1, nz);
+    int r00 = ((z0 * ny + y0) * nx), r10 = ((z0 * ny + y1) * nx), r01 = ((z1 * ny + y0) * nx), r11 = ((z1 * ny + y1) * nx);
+    const float inv_dlambda = 1.0f / (lambda_max - lambda_min), lambda_scale = (float) (ch - 1);          // array / scalar = array * (1 / scalar)
+    float out[4]; const float lam[4] = { wl.x, wl.y, wl.z, wl.w };
+    for (int k = 0; k < 4; ++k) {
+        const float wn = (lam[k] - lambda_min) * inv_dlambda;               // :232-233
+        const float ws = wn * lambda_scale;
+        const int wi = (int) pm_floor(ws);
+        const int c0 = min(max(wi, 0), ch - 1), c1 = min(max(wi + 1, 0), ch - 1);      // wrap_wavelengths: clamp (:262-265)
+        const float s1 = ws - (float) wi, s0 = 1.f - s1;
+        float d[2];
+        for (int j = 0; j < 2; ++j) {
+            const int c = j ? c1 : c0;
+            d[j] = trilerp(D[(r00 + x0) * ch + c], D[(r00 + x1) * ch + c], D[(r10 + x0) * ch + c], D[(r10 + x1) * ch + c],
+                           D[(r01 + x0) * ch + c], D[(r01 + x1) * ch + c], D[(r11 + x0) * ch + c], D[(r11 + x1) * ch + c], w0, w1);
+        }
+        const float r = pm_fma(s0, d[0], s1 * d[1]);
+        // :381-385: the mask compares the NORMALISED wavelength with lambda_min / lambda_max, exactly as the source does
+        out[k] = (wn >= lambda_min && wn <= lambda_max) ? r : 0.f;
+    }
+    return spec4(out[0], out[1], out[2], out[3]);
+}
+#endif
 DEV_NOINLINE F3 volume_eval_grid(const GridRef g, F3 p_world) {
     struct { const float *w2l; const float *data; int nx, ny, nz, channels, affine, filter, wrap; } v;
     v.w2l = g.w2l; v.data = g.data; v.nx = g.nx; v.ny = g.ny; v.nz = g.nz;
@@ -413,20 +503,25 @@ DEV_NOINLINE F3 volume_eval_grid(const GridRef g, F3 p_world) {
     return f3(D[index], D[index + 1], D[index + 2]);
 }
 // eval_1: grid3d.cpp:187-202, constant3d.cpp
-DEV float volume_eval_1(const DVolume &v, F3 p_world) {
+DEV float volume_eval_1(const DVolume &v, F3 p_world, const SpecCtx &cx = SpecCtx(), int vid = 0) {
+#if MTS_SPEC_N == 3
     F3 r = volume_eval(v, p_world);
     if (v.type == MTS_VOLUME_CONST) return (r.x + r.y + r.z) * (1.f / 3.f);
     if (v.channels == 1) return r.x;
     return r.x * 0.212671f + r.y * 0.715160f + r.z * 0.072169f;
+#else
+    if (v.type == MTS_VOLUME_CONST) return cx.spectra[cx.volume_sp[vid].value_sp].value;          // uniform.cpp:64-68 eval_1 (the loader admits uniform spectra here)
+    return volume_eval(v, p_world, cx, vid).x;                                                    // single-channel grid (grid3d.cpp:187-202)
+#endif
 }
 
 // ---------------------------------------------------------------- media
-struct MediumSample { float t, mint; F3 p, sigma_s, sigma_n, sigma_t, combined; };
+struct MediumSample { float t, mint; F3 p; Spec sigma_s, sigma_n, sigma_t, combined; };
 DEV bool ms_valid(const MediumSample &m) { return m.t != pm_inf(); }
 
 // librender/medium.cpp:34-75 ; media/homogeneous.cpp:33-54 ; media/heterogeneous.cpp:33-54
 template <bool COUNT>
-DEV MediumSample medium_sample_interaction(const DScene &sc, int medium, const DRay &ray, float sample, uint32_t channel, Counters &cnt) {
+DEV MediumSample medium_sample_interaction(const DScene &sc, int medium, const DRay &ray, float sample, uint32_t channel, Counters &cnt, const SpecCtx &cx = SpecCtx()) {
     const DMedium &m = sc.media[medium];
     MediumSample mi;
     bool active = true; float mint = 0.f, maxt = pm_inf();
@@ -437,21 +532,21 @@ DEV MediumSample medium_sample_interaction(const DScene &sc, int medium, const D
     }
     mint = pm_max(ray.mint, mint);
     maxt = pm_min(ray.maxt, maxt);
-    F3 combined = m.is_homogeneous ? volume_eval(sc.volumes[m.sigma_t], ray.o) * m.scale : f3s(m.max_density);
+    Spec combined = m.is_homogeneous ? volume_eval(sc.volumes[m.sigma_t], ray.o, cx, m.sigma_t) * m.scale : spec_s(m.max_density);
     float mext = pick(combined, channel);
     float sampled_t = mint + (-pm_log(1.f - sample) / mext);
     bool valid_mi = active && (sampled_t <= maxt);
     mi.t = valid_mi ? sampled_t : pm_inf();
     mi.p = ray_at(ray, sampled_t);
     mi.mint = mint;
-    mi.sigma_s = mi.sigma_n = mi.sigma_t = f3s(0.f);
+    mi.sigma_s = mi.sigma_n = mi.sigma_t = spec_s(0.f);
     if (m.is_homogeneous) {
-        F3 st = volume_eval(sc.volumes[m.sigma_t], mi.p) * m.scale;
-        mi.sigma_t = st; mi.sigma_s = st * volume_eval(sc.volumes[m.albedo], mi.p);
+        Spec st = volume_eval(sc.volumes[m.sigma_t], mi.p, cx, m.sigma_t) * m.scale;
+        mi.sigma_t = st; mi.sigma_s = st * volume_eval(sc.volumes[m.albedo], mi.p, cx, m.albedo);
     } else if (valid_mi) {
-        F3 st = m.scale * volume_eval(sc.volumes[m.sigma_t], mi.p);
-        mi.sigma_t = st; mi.sigma_s = st * volume_eval(sc.volumes[m.albedo], mi.p);
-        mi.sigma_n = f3s(m.max_density) - st;
+        Spec st = m.scale * volume_eval(sc.volumes[m.sigma_t], mi.p, cx, m.sigma_t);
+        mi.sigma_t = st; mi.sigma_s = st * volume_eval(sc.volumes[m.albedo], mi.p, cx, m.albedo);
+        mi.sigma_n = spec_s(m.max_density) - st;
         if (COUNT) cnt.n_lookup++;
     }
     mi.combined = combined;
@@ -507,10 +602,10 @@ DEV float phase_eval_leaf(const DPhase &ph, F3 wi, F3 wo) {
     }
 }
 template <bool U = false>
-DEV float phase_eval(const DScene &sc, int phase, F3 wi, F3 p, F3 wo) {
+DEV float phase_eval(const DScene &sc, int phase, F3 wi, F3 p, F3 wo, const SpecCtx &cx = SpecCtx()) {
     const DPhase ph = rload<U>(sc.phases, phase);
     if (ph.type != MTS_PHASE_BLEND) return phase_eval_leaf(ph, wi, wo);
-    float w = volume_eval_1(rload<U>(sc.volumes, ph.weight_volume), p);                       // blendphase.cpp:113-139
+    float w = volume_eval_1(rload<U>(sc.volumes, ph.weight_volume), p, cx, ph.weight_volume);  // blendphase.cpp:113-139
     float weight = pm_min(pm_max(w, 0.f), 1.f);
     return phase_eval_leaf(rload<U>(sc.phases, ph.child[0]), wi, wo) * (1 - weight) + phase_eval_leaf(rload<U>(sc.phases, ph.child[1]), wi, wo) * weight;
 }
@@ -535,10 +630,10 @@ DEV F3 phase_sample_leaf(const DPhase &ph, const Frame3 &frame, F2 sample2) {
 }
 // Returns wo; the pdf is never used by the integrators (volpath.cpp:171 discards it).
 template <bool U = false>
-DEV F3 phase_sample(const DScene &sc, int phase, const Frame3 &frame, F3 p, float sample1, F2 sample2) {
+DEV F3 phase_sample(const DScene &sc, int phase, const Frame3 &frame, F3 p, float sample1, F2 sample2, const SpecCtx &cx = SpecCtx()) {
     const DPhase ph = rload<U>(sc.phases, phase);
     if (ph.type != MTS_PHASE_BLEND) return phase_sample_leaf(ph, frame, sample2);
-    float w = volume_eval_1(rload<U>(sc.volumes, ph.weight_volume), p);                       // blendphase.cpp:68-111
+    float w = volume_eval_1(rload<U>(sc.volumes, ph.weight_volume), p, cx, ph.weight_volume);  // blendphase.cpp:68-111
     float weight = pm_min(pm_max(w, 0.f), 1.f);
     if (sample1 > weight) return phase_sample_leaf(rload<U>(sc.phases, ph.child[0]), frame, sample2);
     return phase_sample_leaf(rload<U>(sc.phases, ph.child[1]), frame, sample2);
@@ -591,8 +686,8 @@ DEV void frame_sincos_phi(F3 v, float &s, float &c) {                           
     s = ry; c = rx;
 }
 // bsdfs/rpv.cpp:85-131
-struct RpvParams { float rho_0[3], k[3], g[3], rho_c[3]; };     // passed by value: a reference would pin the caller's whole DBsdf copy in scratch
-DEV_NOINLINE F3 eval_rpv_p(const RpvParams b, F3 wi, F3 wo) {
+struct RpvParams { float rho_0[MTS_SPEC_N], k[MTS_SPEC_N], g[MTS_SPEC_N], rho_c[MTS_SPEC_N]; };     // passed by value: a reference would pin the caller's whole DBsdf copy in scratch
+DEV_NOINLINE Spec eval_rpv_p(const RpvParams b, F3 wi, F3 wo) {
     float sin_phi1, cos_phi1, sin_phi2, cos_phi2;
     frame_sincos_phi(wi, sin_phi1, cos_phi1); frame_sincos_phi(wo, sin_phi2, cos_phi2);
     float cos_phi1_minus_phi2 = cos_phi1 * cos_phi2 + sin_phi1 * sin_phi2;
@@ -600,38 +695,49 @@ DEV_NOINLINE F3 eval_rpv_p(const RpvParams b, F3 wi, F3 wo) {
     float sin_theta2 = frame_sin_theta(wo), cos_theta2 = wo.z, tan_theta2 = frame_tan_theta(wo);
     float G = pm_safe_sqrt(tan_theta1 * tan_theta1 + tan_theta2 * tan_theta2 - 2.f * tan_theta1 * tan_theta2 * cos_phi1_minus_phi2);
     float cos_g = cos_theta1 * cos_theta2 + sin_theta1 * sin_theta2 * cos_phi1_minus_phi2;
-    float out[3];
-    for (int c = 0; c < 3; ++c) {
+    float out[MTS_SPEC_N];
+    for (int c = 0; c < MTS_SPEC_N; ++c) {
         float g = b.g[c];
         float F = (1.f - g * g) / pm_pow((1.f + g * g + 2.f * g * cos_g), 1.5f);
         out[c] = b.rho_0[c] * (pm_pow(cos_theta1 * cos_theta2 * (cos_theta1 + cos_theta2), b.k[c] - 1.f) * F * (1.f + (1.f - b.rho_c[c]) / (1 + G))) * MTS_INV_PI;
     }
+#if MTS_SPEC_N == 3
     return f3(out[0], out[1], out[2]);
+#else
+    return spec4(out[0], out[1], out[2], out[3]);
+#endif
 }
-DEV F3 eval_rpv(const DBsdf &b, F3 wi, F3 wo) {
+DEV Spec eval_rpv(const DBsdf &b, F3 wi, F3 wo, const SpecCtx &cx = SpecCtx(), int id = 0) {
     RpvParams q;
+#if MTS_SPEC_N == 3
     for (int c = 0; c < 3; ++c) { q.rho_0[c] = b.rho_0[c]; q.k[c] = b.k[c]; q.g[c] = b.g[c]; q.rho_c[c] = b.rho_c[c]; }
+#else
+    const Spec r0 = BSDF_COLOR(b, rho_0, MTS_BSDF_SP_RHO_0, cx, id), k = BSDF_COLOR(b, k, MTS_BSDF_SP_K, cx, id),
+               g = BSDF_COLOR(b, g, MTS_BSDF_SP_G, cx, id), rc = BSDF_COLOR(b, rho_c, MTS_BSDF_SP_RHO_C, cx, id);
+    q.rho_0[0] = r0.x; q.rho_0[1] = r0.y; q.rho_0[2] = r0.z; q.rho_0[3] = r0.w; q.k[0] = k.x; q.k[1] = k.y; q.k[2] = k.z; q.k[3] = k.w;
+    q.g[0] = g.x; q.g[1] = g.y; q.g[2] = g.z; q.g[3] = g.w; q.rho_c[0] = rc.x; q.rho_c[1] = rc.y; q.rho_c[2] = rc.z; q.rho_c[3] = rc.w;
+#endif
     return eval_rpv_p(q, wi, wo);
 }
 // bsdfs/bilambertian.cpp:62-190
-DEV float bilambertian_reflection_weight(const DBsdf &b) {
-    F3 r = f3(b.reflectance), t = f3(b.transmittance);
-    F3 q = r / (r + t);
-    return ((q.x + q.y) + q.z) * (1.f / 3.f);                // hmean; NaN when r + t == 0: masked by the callers
+DEV float bilambertian_reflection_weight(const DBsdf &b, const SpecCtx &cx = SpecCtx(), int id = 0) {
+    Spec r = BSDF_COLOR(b, reflectance, MTS_BSDF_SP_REFLECTANCE, cx, id), t = BSDF_COLOR(b, transmittance, MTS_BSDF_SP_TRANSMITTANCE, cx, id);
+    Spec q = r / (r + t);
+    return spec_hmean(q);                                    // hmean; NaN when r + t == 0: masked by the callers
 }
 DEV bool same_side(float a, float b) { return (pm_bits(a) >> 31) == (pm_bits(b) >> 31); }      // eq(sign(a), sign(b))
-DEV F3 bsdf_eval(const DBsdf &b, F3 wi, F3 wo) {
-    if (b.type == MTS_BSDF_BILAMBERTIAN) return (same_side(wi.z, wo.z) ? f3(b.reflectance) : f3(b.transmittance)) * (MTS_INV_PI * pm_abs(wo.z));
+DEV Spec bsdf_eval(const DBsdf &b, F3 wi, F3 wo, const SpecCtx &cx = SpecCtx(), int id = 0) {
+    if (b.type == MTS_BSDF_BILAMBERTIAN) return (same_side(wi.z, wo.z) ? BSDF_COLOR(b, reflectance, MTS_BSDF_SP_REFLECTANCE, cx, id) : BSDF_COLOR(b, transmittance, MTS_BSDF_SP_TRANSMITTANCE, cx, id)) * (MTS_INV_PI * pm_abs(wo.z));
     bool active = wi.z > 0.f && wo.z > 0.f;
-    if (b.type == MTS_BSDF_DIFFUSE) return active ? f3(b.reflectance) * MTS_INV_PI * wo.z : f3s(0.f);     // diffuse.cpp:106-120
-    if (b.type == MTS_BSDF_RPV) return active ? eval_rpv(b, wi, wo) * pm_abs(wo.z) : f3s(0.f);             // rpv.cpp:133-142
-    return f3s(0.f);                                                                                       // null.cpp:60-63
+    if (b.type == MTS_BSDF_DIFFUSE) return active ? BSDF_COLOR(b, reflectance, MTS_BSDF_SP_REFLECTANCE, cx, id) * MTS_INV_PI * wo.z : spec_s(0.f);     // diffuse.cpp:106-120
+    if (b.type == MTS_BSDF_RPV) return active ? eval_rpv(b, wi, wo, cx, id) * pm_abs(wo.z) : spec_s(0.f);   // rpv.cpp:133-142
+    return spec_s(0.f);                                                                                    // null.cpp:60-63
 }
-DEV float bsdf_pdf(const DBsdf &b, F3 wi, F3 wo) {
+DEV float bsdf_pdf(const DBsdf &b, F3 wi, F3 wo, const SpecCtx &cx = SpecCtx(), int id = 0) {
     if (b.type == MTS_BSDF_NULL) return 0.f;                                                               // null.cpp:65-68
     if (b.type == MTS_BSDF_BILAMBERTIAN) {
         float result = MTS_INV_PI * pm_abs(wo.z);
-        float rw = bilambertian_reflection_weight(b), tw = 1.f - rw;
+        float rw = bilambertian_reflection_weight(b, cx, id), tw = 1.f - rw;
         if (rw != rw) rw = 0.f;
         if (tw != tw) tw = 0.f;
         return result * (same_side(wi.z, wo.z) ? rw : tw);
@@ -639,38 +745,38 @@ DEV float bsdf_pdf(const DBsdf &b, F3 wi, F3 wo) {
     float pdf = MTS_INV_PI * wo.z;                                                                          // warp.h:343-350
     return (wi.z > 0.f && wo.z > 0.f) ? pdf : 0.f;                                                         // diffuse.cpp:122-135, rpv.cpp:144-153
 }
-DEV F3 bsdf_sample(const DBsdf &b, F3 wi, float sample1, F2 sample2, BSDFSample &bs) {
+DEV Spec bsdf_sample(const DBsdf &b, F3 wi, float sample1, F2 sample2, BSDFSample &bs, const SpecCtx &cx = SpecCtx(), int id = 0) {
     bs.wo = f3s(0.f); bs.pdf = 0.f; bs.eta = 0.f; bs.sampled_type = 0;
     if (b.type == MTS_BSDF_BILAMBERTIAN) {                                                                 // bilambertian.cpp:62-116
         F3 wo = square_to_cosine_hemisphere(sample2);
-        float rw = bilambertian_reflection_weight(b), tw = 1.f - rw;
+        float rw = bilambertian_reflection_weight(b, cx, id), tw = 1.f - rw;
         if (rw != rw) rw = 0.f;
         if (tw != tw) tw = 0.f;
         bool selected_r = sample1 < rw;
-        F3 value = selected_r ? f3s(1.f) * (f3(b.reflectance) / rw) : f3s(1.f) * (f3(b.transmittance) / tw);
+        Spec value = selected_r ? spec_s(1.f) * (BSDF_COLOR(b, reflectance, MTS_BSDF_SP_REFLECTANCE, cx, id) / rw) : spec_s(1.f) * (BSDF_COLOR(b, transmittance, MTS_BSDF_SP_TRANSMITTANCE, cx, id) / tw);
         bs.pdf = MTS_INV_PI * wo.z;
         bs.pdf = selected_r ? bs.pdf * rw : bs.pdf * tw;
         bs.eta = 1.f;
         bs.sampled_type = selected_r ? F_DiffuseReflection : F_DiffuseTransmission;
         if (!(wi.z > 0.f)) wo.z = -wo.z;
         bs.wo = selected_r ? wo : f3(wo.x, wo.y, -wo.z);
-        return bs.pdf > 0.f ? value : f3s(0.f);
+        return bs.pdf > 0.f ? value : spec_s(0.f);
     }
     if (b.type == MTS_BSDF_NULL) {                                                                         // null.cpp:41-58
         bs.wo = -wi; bs.sampled_type = F_Null; bs.eta = 1.f; bs.pdf = 1.f;
-        return f3s(1.f);
+        return spec_s(1.f);
     }
     bool active = wi.z > 0.f;
     if (b.type == MTS_BSDF_DIFFUSE) {                                                                      // diffuse.cpp:78-104
-        if (!active) return f3s(0.f);
+        if (!active) return spec_s(0.f);
         bs.wo = square_to_cosine_hemisphere(sample2);
         bs.pdf = MTS_INV_PI * bs.wo.z; bs.eta = 1.f; bs.sampled_type = F_DiffuseReflection;
-        return (bs.pdf > 0.f) ? f3(b.reflectance) : f3s(0.f);
+        return (bs.pdf > 0.f) ? BSDF_COLOR(b, reflectance, MTS_BSDF_SP_REFLECTANCE, cx, id) : spec_s(0.f);
     }
     bs.wo = square_to_cosine_hemisphere(sample2);                                                          // rpv.cpp:85-102
     bs.pdf = MTS_INV_PI * bs.wo.z; bs.eta = 1.f; bs.sampled_type = F_GlossyReflection;
-    F3 value = eval_rpv(b, wi, bs.wo);
-    return (active && bs.pdf > 0.f) ? value : f3s(0.f);
+    Spec value = eval_rpv(b, wi, bs.wo, cx, id);
+    return (active && bs.pdf > 0.f) ? value : spec_s(0.f);
 }
 
 // ---------------------------------------------------------------- emitters
@@ -767,49 +873,49 @@ DEV float shape_pdf_direction(const DShape &s, F3 ref_p, const DirSample &ds) {
 }
 // emitters/directional.cpp:109-141, emitters/area.cpp:122-165, emitters/constant.cpp:81-111
 template <bool U = false>
-DEV DirSample emitter_sample_direction(const DScene &sc, int ei, F3 ref_p, F2 sample, F3 &spec) {
+DEV DirSample emitter_sample_direction(const DScene &sc, int ei, F3 ref_p, F2 sample, Spec &spec, const SpecCtx &cx = SpecCtx()) {
     const DEmitter e = rload<U>(sc.emitters, ei);
     DirSample ds;
     if (e.type == MTS_EMITTER_DIRECTIONAL) {
         F3 d = mat_vector(e.to_world.m, f3(0.f, 0.f, 1.f));
         float dist = 2.f * e.bsphere_radius;
         ds.p = ref_p - d * dist; ds.n = d; ds.pdf = 1.f; ds.delta = true; ds.d = -d; ds.dist = dist;
-        spec = f3(e.radiance);
+        spec = EMITTER_COLOR(e, cx, ei);
     } else if (e.type == MTS_EMITTER_CONSTANT) {
         F3 d = square_to_uniform_sphere(sample);
         float dist = 2.f * e.bsphere_radius;
         ds.p = ref_p + d * dist; ds.n = -d; ds.pdf = MTS_INV_FOUR_PI; ds.delta = false; ds.d = d; ds.dist = dist;
-        spec = f3(e.radiance) / ds.pdf;
+        spec = EMITTER_COLOR(e, cx, ei) / ds.pdf;
     } else if (e.type == MTS_EMITTER_POINT) {                                                    // point.cpp:80-107
         ds.p = f3(e.to_world.m[3], e.to_world.m[7], e.to_world.m[11]); ds.n = f3s(0.f); ds.pdf = 1.f; ds.delta = true;
         ds.d = ds.p - ref_p; ds.dist = norm(ds.d);
         float inv_dist = pm_rcp(ds.dist);
         ds.d = ds.d * inv_dist;
-        spec = f3(e.radiance) * (inv_dist * inv_dist);
+        spec = EMITTER_COLOR(e, cx, ei) * (inv_dist * inv_dist);
     } else {
         ds = shape_sample_direction(mesh_tables(sc), sc.shapes[e.shape], ref_p, sample);
         bool active = dot(ds.d, ds.n) < 0.f && ds.pdf != 0.f;
-        spec = active ? f3(e.radiance) / ds.pdf : f3s(0.f);
+        spec = active ? EMITTER_COLOR(e, cx, ei) / ds.pdf : spec_s(0.f);
     }
     ds.emitter = ei;
     return ds;
 }
 // librender/scene.cpp:168-218
-DEV DirSample sample_emitter_direction(const DScene &sc, F3 ref_p, F2 sample, bool test_visibility, F3 &spec) {
+DEV DirSample sample_emitter_direction(const DScene &sc, F3 ref_p, F2 sample, bool test_visibility, Spec &spec, const SpecCtx &cx = SpecCtx()) {
     DirSample ds; ds.pdf = 0.f; ds.dist = 0.f; ds.delta = false; ds.emitter = -1; ds.p = ds.n = ds.d = f3s(0.f);
-    if (sc.emitter_count == 0) { spec = f3s(0.f); return ds; }
-    if (sc.emitter_count == 1) ds = emitter_sample_direction<true>(sc, 0, ref_p, sample, spec);
+    if (sc.emitter_count == 0) { spec = spec_s(0.f); return ds; }
+    if (sc.emitter_count == 1) ds = emitter_sample_direction<true>(sc, 0, ref_p, sample, spec, cx);
     else {
         float n = (float) sc.emitter_count, emitter_pdf = 1.f / n;
         uint32_t index = min((uint32_t) (sample.x * n), (uint32_t) sc.emitter_count - 1);
         sample.x = (sample.x - index * emitter_pdf) * n;
-        ds = emitter_sample_direction(sc, (int) index, ref_p, sample, spec);
+        ds = emitter_sample_direction(sc, (int) index, ref_p, sample, spec, cx);
         ds.pdf *= emitter_pdf;
         spec = spec * pm_rcp(emitter_pdf);
     }
     if (test_visibility && ds.pdf != 0.f) {
         DRay ray = make_ray(ref_p, ds.d, MTS_RAY_EPSILON * (1.f + hmax_abs(ref_p)), ds.dist * (1.f - MTS_SHADOW_EPSILON));
-        if (ray_test(sc, ray)) spec = f3s(0.f);
+        if (ray_test(sc, ray)) spec = spec_s(0.f);
     }
     return ds;
 }
@@ -825,15 +931,15 @@ DEV float pdf_emitter_direction(const DScene &sc, F3 ref_p, const DirSample &ds)
 }
 // si.emitter(scene), render/scene.h:243-253 ; emitter->eval: area.cpp:63-71, constant.cpp:41-44, directional.cpp:75-78
 DEV int hit_emitter(const DScene &sc, const Hit &h) { return hit_valid(h) ? sc.shapes[h.shape].emitter : sc.environment; }
-DEV F3 emitter_eval(const DScene &sc, int ei, float wi_z) {
+DEV Spec emitter_eval(const DScene &sc, int ei, float wi_z, const SpecCtx &cx = SpecCtx()) {
     const DEmitter &e = sc.emitters[ei];
-    if (e.type == MTS_EMITTER_AREA) return wi_z > 0.f ? f3(e.radiance) : f3s(0.f);
-    if (e.type == MTS_EMITTER_CONSTANT) return f3(e.radiance);
-    return f3s(0.f);
+    if (e.type == MTS_EMITTER_AREA) return wi_z > 0.f ? EMITTER_COLOR(e, cx, ei) : spec_s(0.f);
+    if (e.type == MTS_EMITTER_CONSTANT) return EMITTER_COLOR(e, cx, ei);
+    return spec_s(0.f);
 }
 // render/interaction.h:178-200
 DEV int target_medium(const DShape &s, F3 n, F3 d) { return dot(d, n) > 0 ? s.exterior : s.interior; }
-DEV F3 null_transmission(const DScene &sc, const DShape &s) { return sc.bsdfs[s.bsdf].type == MTS_BSDF_NULL ? f3s(1.f) : f3s(0.f); }   // null.cpp:70-73, bsdf.cpp:11-14
+DEV Spec null_transmission(const DScene &sc, const DShape &s) { return sc.bsdfs[s.bsdf].type == MTS_BSDF_NULL ? spec_s(1.f) : spec_s(0.f); }   // null.cpp:70-73, bsdf.cpp:11-14
 DEV float mis_weight(float pdf_a, float pdf_b) { pdf_a *= pdf_a; pdf_b *= pdf_b; return pdf_a > 0.0f ? pdf_a / (pdf_a + pdf_b) : 0.0f; }   // volpath.cpp:479-483
 
 // Geometric normal of a hit without the full shading frame (only needed for medium transitions)
@@ -850,15 +956,19 @@ DEV F3 hit_geo_normal(const DScene &sc, const Hit &h) {
     return n;
 }
 
+#if MTS_SPEC_N == 3
 DEV F3 transmittance_exp(float t, F3 combined) { return f3(pm_exp(-t * combined.x), pm_exp(-t * combined.y), pm_exp(-t * combined.z)); }
+#else
+DEV Spec transmittance_exp(float t, Spec combined) { return spec4(pm_exp(-t * combined.x), pm_exp(-t * combined.y), pm_exp(-t * combined.z), pm_exp(-t * combined.w)); }
+#endif
 
 // ---------------------------------------------------------------- volpath
 // integrators/volpath.cpp:261-367: NEE with ratio tracking through media and null surfaces
 template <bool COUNT>
-DEV F3 volpath_sample_emitter(const DScene &sc, F3 ref_p, bool is_medium_interaction, Pcg32 &rng, int medium, uint32_t channel, DirSample &ds, Counters &cnt) {
-    F3 transmittance = f3s(1.f), emitter_val;
-    ds = sample_emitter_direction(sc, ref_p, rng.next_2d(), false, emitter_val);
-    if (ds.pdf == 0.f) return f3s(0.f);
+DEV Spec volpath_sample_emitter(const DScene &sc, F3 ref_p, bool is_medium_interaction, Pcg32 &rng, int medium, uint32_t channel, DirSample &ds, Counters &cnt, const SpecCtx &cx = SpecCtx()) {
+    Spec transmittance = spec_s(1.f), emitter_val;
+    ds = sample_emitter_direction(sc, ref_p, rng.next_2d(), false, emitter_val, cx);
+    if (ds.pdf == 0.f) return spec_s(0.f);
     bool active = true;
     DRay ray = spawn_ray(ref_p, ds.d);
     if (is_medium_interaction) ray.mint = 0.f;
@@ -874,7 +984,7 @@ DEV F3 volpath_sample_emitter(const DScene &sc, F3 ref_p, bool is_medium_interac
         bool escaped_medium = false, active_medium = medium >= 0, active_surface = !active_medium;
         if (active_medium) {
             const DMedium &m = sc.media[medium];
-            MediumSample mi = medium_sample_interaction<COUNT>(sc, medium, ray, rng.next_1d(), channel, cnt);
+            MediumSample mi = medium_sample_interaction<COUNT>(sc, medium, ray, rng.next_1d(), channel, cnt, cx);
             if (m.is_homogeneous && ms_valid(mi)) ray.maxt = pm_min(mi.t, remaining_dist);
             if (needs_intersection) si = ray_intersect(sc, ray);
             if (si.t < mi.t) mi.t = pm_inf();
@@ -882,10 +992,10 @@ DEV F3 volpath_sample_emitter(const DScene &sc, F3 ref_p, bool is_medium_interac
             bool is_spectral = m.has_spectral_extinction != 0, not_spectral = !is_spectral;
             if (is_spectral) {
                 float t = pm_min(remaining_dist, pm_min(mi.t, si.t)) - mi.mint;
-                F3 tr = transmittance_exp(t, mi.combined);
-                F3 free_flight_pdf = (si.t < mi.t || mi.t > remaining_dist) ? tr : tr * mi.combined;
+                Spec tr = transmittance_exp(t, mi.combined);
+                Spec free_flight_pdf = (si.t < mi.t || mi.t > remaining_dist) ? tr : tr * mi.combined;
                 float tr_pdf = pick(free_flight_pdf, channel);
-                transmittance = transmittance * (tr_pdf > 0.f ? tr / tr_pdf : f3s(0.f));
+                transmittance = transmittance * (tr_pdf > 0.f ? tr / tr_pdf : spec_s(0.f));
             }
             if (mi.t > remaining_dist && ms_valid(mi)) total_dist = ds.dist;
             if (mi.t > remaining_dist) mi.t = pm_inf();
@@ -919,8 +1029,8 @@ DEV F3 volpath_sample_emitter(const DScene &sc, F3 ref_p, bool is_medium_interac
 
 // integrators/volpath.cpp:370-465
 template <bool COUNT>
-DEV F3 volpath_evaluate_direct_light(const DScene &sc, F3 ref_p, Pcg32 &rng, int medium, DRay ray, Hit si, uint32_t channel, bool active, float &emitter_pdf, Counters &cnt) {
-    F3 emitter_val = f3s(0.f), transmittance = f3s(1.f);
+DEV Spec volpath_evaluate_direct_light(const DScene &sc, F3 ref_p, Pcg32 &rng, int medium, DRay ray, Hit si, uint32_t channel, bool active, float &emitter_pdf, Counters &cnt, const SpecCtx &cx = SpecCtx()) {
+    Spec emitter_val = spec_s(0.f), transmittance = spec_s(1.f);
     bool needs_intersection = false;
     emitter_pdf = 0.f;
     while (active) {
@@ -928,17 +1038,17 @@ DEV F3 volpath_evaluate_direct_light(const DScene &sc, F3 ref_p, Pcg32 &rng, int
         bool escaped_medium = false, active_medium = medium >= 0, active_surface = !active_medium;
         if (active_medium) {
             const DMedium &m = sc.media[medium];
-            MediumSample mi = medium_sample_interaction<COUNT>(sc, medium, ray, rng.next_1d(), channel, cnt);
+            MediumSample mi = medium_sample_interaction<COUNT>(sc, medium, ray, rng.next_1d(), channel, cnt, cx);
             if (m.is_homogeneous && ms_valid(mi)) ray.maxt = mi.t;
             if (needs_intersection) si = ray_intersect(sc, ray);
             if (si.t < mi.t) mi.t = pm_inf();
             bool is_spectral = m.has_spectral_extinction != 0, not_spectral = !is_spectral;
             if (is_spectral) {
                 float t = pm_min(mi.t, si.t) - mi.mint;                                       // medium.cpp:77-89
-                F3 tr = transmittance_exp(t, mi.combined);
-                F3 free_flight_pdf = si.t < mi.t ? tr : tr * mi.combined;
+                Spec tr = transmittance_exp(t, mi.combined);
+                Spec free_flight_pdf = si.t < mi.t ? tr : tr * mi.combined;
                 float tr_pdf = pick(free_flight_pdf, channel);
-                transmittance = transmittance * (tr_pdf > 0.f ? tr / tr_pdf : f3s(0.f));
+                transmittance = transmittance * (tr_pdf > 0.f ? tr / tr_pdf : spec_s(0.f));
             }
             needs_intersection = false;
             escaped_medium = !ms_valid(mi);
@@ -961,7 +1071,7 @@ DEV F3 volpath_evaluate_direct_light(const DScene &sc, F3 ref_p, Pcg32 &rng, int
             ds.p = si.p; ds.n = sf.sh.n; ds.d = si.p - ref_p; ds.dist = norm(ds.d); ds.d = ds.d / ds.dist;
             if (!hit_valid(si)) ds.d = -sf.wi;
             ds.emitter = emitter; ds.pdf = 0.f; ds.delta = false;
-            emitter_val = emitter_eval(sc, emitter, sf.wi.z);
+            emitter_val = emitter_eval(sc, emitter, sf.wi.z, cx);
             emitter_pdf = pdf_emitter_direction(sc, ref_p, ds);
             active = false; active_surface = false; active_medium = false;
         }
@@ -980,15 +1090,19 @@ DEV F3 volpath_evaluate_direct_light(const DScene &sc, F3 ref_p, Pcg32 &rng, int
 
 // integrators/volpath.cpp:38-257
 template <bool COUNT>
-DEV F3 volpath_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, bool &valid_out, Counters &cnt) {
+DEV Spec volpath_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, bool &valid_out, Counters &cnt, const SpecCtx &cx = SpecCtx()) {
     const uint32_t max_depth = (uint32_t) sc.integrator.max_depth, rr_depth = (uint32_t) sc.integrator.rr_depth;
     const bool hide_emitters = sc.integrator.hide_emitters != 0;
     bool valid_ray = !hide_emitters && sc.environment >= 0;
     float eta = 1.f;
-    F3 throughput = f3s(1.f), result = f3s(0.f);
+    Spec throughput = spec_s(1.f), result = spec_s(0.f);
     bool active = true, specular_chain = !hide_emitters;
     uint32_t depth = 0;
+#if MTS_SPEC_N == 3
     uint32_t channel = sc.integrator.monochrome ? 0u : (uint32_t) pm_min(rng.next_1d() * 3.f, 2.f);   // volpath.cpp:63-67 (rgb variants only)
+#else
+    const uint32_t channel = 0;                                                                        // volpath.cpp:63-67: no draw outside the rgb variants
+#endif
     Hit si; si.t = pm_inf(); si.shape = -1; si.prim = 0; si.p = f3s(0.f); si.uv.x = si.uv.y = 0.f;
     bool needs_intersection = true;
     for (;;) {
@@ -1007,17 +1121,17 @@ DEV F3 volpath_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, bool &
         if (active_medium) {
             const DMedium &m = sc.media[medium];
             is_spectral = m.has_spectral_extinction != 0; not_spectral = !is_spectral;
-            mi = medium_sample_interaction<COUNT>(sc, medium, ray, rng.next_1d(), channel, cnt);
+            mi = medium_sample_interaction<COUNT>(sc, medium, ray, rng.next_1d(), channel, cnt, cx);
             if (m.is_homogeneous && ms_valid(mi)) ray.maxt = mi.t;
             if (needs_intersection) si = ray_intersect(sc, ray);
             needs_intersection = false;
             if (si.t < mi.t) mi.t = pm_inf();
             if (is_spectral) {
                 float t = pm_min(mi.t, si.t) - mi.mint;                                       // medium.cpp:77-89
-                F3 tr = transmittance_exp(t, mi.combined);
-                F3 free_flight_pdf = si.t < mi.t ? tr : tr * mi.combined;
+                Spec tr = transmittance_exp(t, mi.combined);
+                Spec free_flight_pdf = si.t < mi.t ? tr : tr * mi.combined;
                 float tr_pdf = pick(free_flight_pdf, channel);
-                throughput = throughput * (tr_pdf > 0.f ? tr / tr_pdf : f3s(0.f));
+                throughput = throughput * (tr_pdf > 0.f ? tr / tr_pdf : spec_s(0.f));
             }
             escaped_medium = !ms_valid(mi);
             active_medium = ms_valid(mi);
@@ -1041,12 +1155,12 @@ DEV F3 volpath_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, bool &
             F3 wi = -ray.d;
             if (sample_emitters) {
                 DirSample ds;
-                F3 emitted = volpath_sample_emitter<COUNT>(sc, mi.p, true, rng, medium, channel, ds, cnt);
-                float phase_val = phase_eval(sc, m.phase, wi, mi.p, ds.d);
+                Spec emitted = volpath_sample_emitter<COUNT>(sc, mi.p, true, rng, medium, channel, ds, cnt, cx);
+                float phase_val = phase_eval(sc, m.phase, wi, mi.p, ds.d, cx);
                 result = result + throughput * phase_val * emitted;
             }
             float s1 = rng.next_1d(); F2 s2 = rng.next_2d();                                  // left-to-right (SURVEY.md 8(a'))
-            F3 wo = phase_sample(sc, m.phase, make_frame(ray.d), mi.p, s1, s2);              // mi.sh_frame = Frame3f(ray.d), medium.cpp:42
+            F3 wo = phase_sample(sc, m.phase, make_frame(ray.d), mi.p, s1, s2, cx);          // mi.sh_frame = Frame3f(ray.d), medium.cpp:42
             ray = spawn_ray(mi.p, wo); ray.mint = 0.0f;
             needs_intersection = true;
         }
@@ -1057,7 +1171,7 @@ DEV F3 volpath_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, bool &
         if (active_surface && hit_valid(si)) complete_surface(sc, si, ray.d, sf);
         if (active_surface) {
             int emitter = hit_emitter(sc, si);
-            if (specular_chain && emitter >= 0) result = result + throughput * emitter_eval(sc, emitter, sf.wi.z);
+            if (specular_chain && emitter >= 0) result = result + throughput * emitter_eval(sc, emitter, sf.wi.z, cx);
         }
         active_surface = active_surface && hit_valid(si);
         if (active_surface) {
@@ -1066,15 +1180,15 @@ DEV F3 volpath_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, bool &
             bool active_e = (bsdf.flags & F_Smooth) != 0 && (depth + 1 < max_depth);
             if (active_e) {
                 DirSample ds;
-                F3 emitted = volpath_sample_emitter<COUNT>(sc, si.p, false, rng, medium, channel, ds, cnt);
+                Spec emitted = volpath_sample_emitter<COUNT>(sc, si.p, false, rng, medium, channel, ds, cnt, cx);
                 F3 wo = to_local(sf.sh, ds.d);
-                F3 bsdf_val = bsdf_eval(bsdf, sf.wi, wo);
-                float bpdf = bsdf_pdf(bsdf, sf.wi, wo);
+                Spec bsdf_val = bsdf_eval(bsdf, sf.wi, wo, cx, shape.bsdf);
+                float bpdf = bsdf_pdf(bsdf, sf.wi, wo, cx, shape.bsdf);
                 result = result + throughput * bsdf_val * mis_weight(ds.pdf, ds.delta ? 0.f : bpdf) * emitted;
             }
             float s1 = rng.next_1d(); F2 s2 = rng.next_2d();
             BSDFSample bs;
-            F3 bsdf_val = bsdf_sample(bsdf, sf.wi, s1, s2, bs);
+            Spec bsdf_val = bsdf_sample(bsdf, sf.wi, s1, s2, bs, cx, shape.bsdf);
             throughput = throughput * bsdf_val;
             eta *= bs.eta;
             ray = spawn_ray(si.p, to_world(sf.sh, bs.wo));
@@ -1090,7 +1204,7 @@ DEV F3 volpath_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, bool &
             if (intersect2) si_new = ray_intersect(sc, ray);
             needs_intersection = needs_intersection && !intersect2;
             float emitter_pdf;
-            F3 emitted = volpath_evaluate_direct_light<COUNT>(sc, si.p, rng, medium, ray, si_new, channel, add_emitter, emitter_pdf, cnt);
+            Spec emitted = volpath_evaluate_direct_light<COUNT>(sc, si.p, rng, medium, ray, si_new, channel, add_emitter, emitter_pdf, cnt, cx);
             if (add_emitter && emitter_pdf != 0) result = result + mis_weight(bs.pdf, emitter_pdf) * throughput * emitted;
             if (shape.is_medium_transition) medium = target_medium(shape, sf.n, ray.d);
             if (intersect2) si = si_new;
@@ -1102,6 +1216,7 @@ DEV F3 volpath_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, bool &
 }
 
 // ---------------------------------------------------------------- volpathmis
+#if MTS_SPEC_N == 3         // the spectral build carries path and volpath (the loader refuses volpathmis there)
 // integrators/volpathmis.cpp (nested formulation, statement for statement the CPU restatement in oracle/oracle.cpp).
 // WeightMatrix: 3 rows of probability ratios with `use_spectral_mis` (default), one row without (:38-46).
 template <bool SPEC> struct MisWeights { F3 r[SPEC ? 3 : 1]; };
@@ -1385,13 +1500,14 @@ DEV F3 volpathmis_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, boo
     return result;
 }
 
+#endif // MTS_SPEC_N == 3
 // ---------------------------------------------------------------- path
 // integrators/path.cpp:100-211
 template <bool COUNT>
-DEV F3 path_sample(const DScene &sc, Pcg32 &rng, DRay ray, bool &valid_out, Counters &cnt) {
+DEV Spec path_sample(const DScene &sc, Pcg32 &rng, DRay ray, bool &valid_out, Counters &cnt, const SpecCtx &cx = SpecCtx()) {
     const int max_depth = sc.integrator.max_depth, rr_depth = sc.integrator.rr_depth;
     float eta = 1.f, emission_weight = 1.f;
-    F3 throughput = f3s(1.f), result = f3s(0.f);
+    Spec throughput = spec_s(1.f), result = spec_s(0.f);
     bool active = true;
     Hit si = ray_intersect(sc, ray);
     bool valid_ray = hit_valid(si);
@@ -1400,7 +1516,7 @@ DEV F3 path_sample(const DScene &sc, Pcg32 &rng, DRay ray, bool &valid_out, Coun
         if (COUNT) cnt.n_iter++;
         Surf sf; sf.wi = -ray.d;
         if (hit_valid(si)) complete_surface(sc, si, ray.d, sf);
-        if (emitter >= 0 && active) result = result + emission_weight * throughput * emitter_eval(sc, emitter, sf.wi.z);
+        if (emitter >= 0 && active) result = result + emission_weight * throughput * emitter_eval(sc, emitter, sf.wi.z, cx);
         active = active && hit_valid(si);
         if (depth > rr_depth) {
             float q = pm_min(hmax(throughput) * (eta * eta), .95f);
@@ -1408,21 +1524,22 @@ DEV F3 path_sample(const DScene &sc, Pcg32 &rng, DRay ray, bool &valid_out, Coun
             throughput = throughput * pm_rcp(q);
         }
         if ((uint32_t) depth >= (uint32_t) max_depth || !active) break;
-        const DBsdf &bsdf = sc.bsdfs[sc.shapes[si.shape].bsdf];
+        const int bsdf_id = sc.shapes[si.shape].bsdf;
+        const DBsdf &bsdf = sc.bsdfs[bsdf_id];
         bool active_e = (bsdf.flags & F_Smooth) != 0;
         if (active_e) {
-            F3 emitter_val;
-            DirSample ds = sample_emitter_direction(sc, si.p, rng.next_2d(), true, emitter_val);
+            Spec emitter_val;
+            DirSample ds = sample_emitter_direction(sc, si.p, rng.next_2d(), true, emitter_val, cx);
             active_e = active_e && ds.pdf != 0.f;
             F3 wo = to_local(sf.sh, ds.d);
-            F3 bsdf_val = bsdf_eval(bsdf, sf.wi, wo);
-            float bpdf = bsdf_pdf(bsdf, sf.wi, wo);
+            Spec bsdf_val = bsdf_eval(bsdf, sf.wi, wo, cx, bsdf_id);
+            float bpdf = bsdf_pdf(bsdf, sf.wi, wo, cx, bsdf_id);
             float mis = ds.delta ? 1.f : mis_weight(ds.pdf, bpdf);
             if (active_e) result = result + mis * throughput * bsdf_val * emitter_val;
         }
         float s1 = rng.next_1d(); F2 s2 = rng.next_2d();
         BSDFSample bs;
-        F3 bsdf_val = bsdf_sample(bsdf, sf.wi, s1, s2, bs);
+        Spec bsdf_val = bsdf_sample(bsdf, sf.wi, s1, s2, bs, cx, bsdf_id);
         throughput = throughput * bsdf_val;
         active = active && any_nonzero(throughput);
         if (!active) break;
@@ -1452,17 +1569,53 @@ DEV F3 path_sample(const DScene &sc, Pcg32 &rng, DRay ray, bool &valid_out, Coun
 // (NI_*: one render-kernel instantiation each, so that `path` does not carry the registers of the volumetric integrators)
 enum { NI_ANY = -1, NI_PATH = 0, NI_VOLPATH = 1, NI_VOLPATHMIS = 2, NI_VOLPATHMIS_NOSPEC = 3 };
 template <bool COUNT, int INTEG = NI_ANY>
-DEV F3 integrator_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, bool &valid, Counters &cnt) {
-    if (INTEG == NI_PATH) return path_sample<COUNT>(sc, rng, ray, valid, cnt);
-    if (INTEG == NI_VOLPATH) return volpath_sample<COUNT>(sc, rng, ray, medium, valid, cnt);
+DEV Spec integrator_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, bool &valid, Counters &cnt, const SpecCtx &cx = SpecCtx()) {
+    if (INTEG == NI_PATH) return path_sample<COUNT>(sc, rng, ray, valid, cnt, cx);
+    if (INTEG == NI_VOLPATH) return volpath_sample<COUNT>(sc, rng, ray, medium, valid, cnt, cx);
+#if MTS_SPEC_N == 3
     if (INTEG == NI_VOLPATHMIS) return volpathmis_sample<COUNT, true>(sc, rng, ray, medium, valid, cnt);
     if (INTEG == NI_VOLPATHMIS_NOSPEC) return volpathmis_sample<COUNT, false>(sc, rng, ray, medium, valid, cnt);
-    if (sc.integrator.type == MTS_INTEGRATOR_VOLPATH) return volpath_sample<COUNT>(sc, rng, ray, medium, valid, cnt);
+#endif
+    if (sc.integrator.type == MTS_INTEGRATOR_VOLPATH) return volpath_sample<COUNT>(sc, rng, ray, medium, valid, cnt, cx);
+#if MTS_SPEC_N == 3
     if (sc.integrator.type == MTS_INTEGRATOR_VOLPATHMIS)
         return sc.integrator.use_spectral_mis ? volpathmis_sample<COUNT, true>(sc, rng, ray, medium, valid, cnt)
                                               : volpathmis_sample<COUNT, false>(sc, rng, ray, medium, valid, cnt);
-    return path_sample<COUNT>(sc, rng, ray, valid, cnt);
+#endif
+    return path_sample<COUNT>(sc, rng, ray, valid, cnt, cx);
 }
+
+// ---------------------------------------------------------------- wavelengths / colour (spectral variants)
+#if MTS_SPEC_N != 3
+// math::sample_shifted (core/math.h:419-442) + sample_wavelength -> sample_rgb_spectrum -> sample_uniform_spectrum (core/spectrum.h:248-252,
+// 266-285,305-314): with MTS_WAVELENGTH_MIN / MAX = 280 / 2400 the "rgb" importance sampling falls back to the uniform one, which the
+// reference writes over the CIE range, 360 .. 830 nm; the weight (inverse pdf) is 470 for every wavelength.
+#define MTS_CIE_MIN 360.f
+#define MTS_CIE_MAX 830.f
+#define MTS_CIE_SAMPLES 95
+DEV Spec sample_wavelengths(float sample, float &weight) {
+    float v[4];
+    for (int k = 0; k < 4; ++k) { float x = sample + (float) k / 4.f; if (x > 1.f) x -= 1.f; v[k] = x * (MTS_CIE_MAX - MTS_CIE_MIN) + MTS_CIE_MIN; }
+    weight = MTS_CIE_MAX - MTS_CIE_MIN;
+    return spec4(v[0], v[1], v[2], v[3]);
+}
+// cie1931_xyz + spectrum_to_xyz (core/spectrum.h:148-178,210-217): XYZ = hmean(cmf(lambda) * value)
+DEV void spectrum_to_xyz(const float *cie, Spec value, Spec wl, float xyz[3]) {
+    const MTS_GLOBAL_AS float *T = as_global(cie);
+    const float lam[4] = { wl.x, wl.y, wl.z, wl.w }, val[4] = { value.x, value.y, value.z, value.w };
+    float cx[4], cy[4], cz[4];
+    for (int k = 0; k < 4; ++k) {
+        const float t = (lam[k] - MTS_CIE_MIN) * ((MTS_CIE_SAMPLES - 1) / (MTS_CIE_MAX - MTS_CIE_MIN));
+        const bool active = lam[k] >= MTS_CIE_MIN && lam[k] <= MTS_CIE_MAX;
+        const int i0 = min(max((int) t, 0), MTS_CIE_SAMPLES - 2), i1 = i0 + 1;
+        const float w1 = t - (float) i0, w0 = 1.f - w1;
+        cx[k] = active ? pm_fma(w0, T[i0], w1 * T[i1]) * val[k] : 0.f * val[k];
+        cy[k] = active ? pm_fma(w0, T[MTS_CIE_SAMPLES + i0], w1 * T[MTS_CIE_SAMPLES + i1]) * val[k] : 0.f * val[k];
+        cz[k] = active ? pm_fma(w0, T[2 * MTS_CIE_SAMPLES + i0], w1 * T[2 * MTS_CIE_SAMPLES + i1]) * val[k] : 0.f * val[k];
+    }
+    xyz[0] = spec_hmean(spec4(cx[0], cx[1], cx[2], cx[3])); xyz[1] = spec_hmean(spec4(cy[0], cy[1], cy[2], cy[3])); xyz[2] = spec_hmean(spec4(cz[0], cz[1], cz[2], cz[3]));
+}
+#endif
 
 // ---------------------------------------------------------------- sensors
 // Shape::ray_intersect (shape.cpp:344-352) of a stand-alone analytic shape, reduced to the hit point the distant sensors read
@@ -1559,4 +1712,5 @@ DEV DRay sensor_sample_ray(const DScene &sc, F2 position_sample, F2 aperture_sam
     return make_ray(o, d, MTS_RAY_EPSILON, pm_inf());
 }
 
+} // inline namespace
 } // namespace mtsamd

@@ -5,17 +5,72 @@
 // (librender/integrator.cpp:198) and runs all samples of its pixel; path state never leaves
 // registers, the scene is read with scalar loads, the only vector memory traffic is the volume
 // gathers and one film update per pixel.  Citations are relative to /root/reference.
+// Compiled twice into libmtsamd.so: as it is (MTS_SPEC_N = 3: the rgb / mono variants, all kernels) and through kernels_spectral.hip
+// (MTS_SPEC_N = 4: the spectral variant, per-lane kernels of `path` and `volpath`; launchers carry the suffix _spectral).
 #include <hip/hip_runtime.h>
 #include "integrator_dev.h"
+#if MTS_SPEC_N == 3
 #include "volpath_flat.h"
+#define MTS_LAUNCHER(name) name
+#else
+#define MTS_LAUNCHER(name) name##_spectral
+#endif
 #include "launch.h"
 
 namespace mtsamd {
+inline namespace MTS_VARIANT_NS {
 
 // librender/integrator.cpp:233-288 + librender/imageblock.cpp:79-172, fused: the sample is splatted
 // straight into the film.  With the default box filter a sample lands in its own pixel and is summed
 // in registers in sample order (bit-identical to the reference's block accumulation); the rare
 // sample that falls on the left/top pixel edge (u == 0) goes to the neighbour through an atomic.
+#if MTS_SPEC_N != 3
+// the per-sample tail of render_sample in the spectral variants: spectrum_to_xyz (integrator.cpp:266-269) + ImageBlock::put
+// (imageblock.cpp:79-172, box filter and wider filters alike)
+DEV void splat_xyz(const DScene &sc, const DBlock &blk, uint32_t lx, uint32_t ly, F2 position_sample, const float xyz[3], bool valid,
+                   MTS_GLOBAL_AS float *film, float *own) {
+    const DSensor &se = sc.sensor;
+    float v[5] = { xyz[0], xyz[1], xyz[2], valid ? 1.f : 0.f, 1.f };
+    bool ok = true;
+    for (int k = 0; k < 5; ++k) ok = ok && v[k] >= -1e-5f && pm_isfinite(v[k]);
+    if (!ok) return;
+    const DRFilter &rf = se.rfilter;
+    const int border = rf.border_size;
+    const int sx = blk.sx + 2 * border, sy = blk.sy + 2 * border;
+    float posx = position_sample.x - ((float) (blk.ox - border) + .5f), posy = position_sample.y - ((float) (blk.oy - border) + .5f);
+    if (rf.radius > 0.5f + MTS_RAY_EPSILON) {
+        int lox = max((int) pm_ceil(posx - rf.radius), 0), loy = max((int) pm_ceil(posy - rf.radius), 0);
+        int hix = min((int) pm_floor(posx + rf.radius), sx - 1), hiy = min((int) pm_floor(posy + rf.radius), sy - 1);
+        uint32_t n = (uint32_t) pm_ceil((rf.radius - 2.f * MTS_RAY_EPSILON) * 2.f);
+        float basex = (float) lox - posx, basey = (float) loy - posy;
+        for (uint32_t yr = 0; yr < n; ++yr) {
+            int y = loy + (int) yr;
+            if (y > hiy) break;
+            float wy = as_global(rf.values)[min((int) pm_abs((basey + (float) yr) * rf.scale_factor), 31)];
+            int fy = blk.oy - border + y - se.crop_y;
+            for (uint32_t xr = 0; xr < n; ++xr) {
+                int x = lox + (int) xr;
+                if (x > hix) break;
+                float wx = as_global(rf.values)[min((int) pm_abs((basex + (float) xr) * rf.scale_factor), 31)];
+                float weight = wy * wx;
+                int fx = blk.ox - border + x - se.crop_x;
+                if (fx >= 0 && fy >= 0 && fx < se.crop_w && fy < se.crop_h) {
+                    float *dst = (float *) (film + 5 * ((size_t) fy * se.crop_w + fx));
+                    for (int k = 0; k < 5; ++k) atomicAdd(dst + k, v[k] * weight);
+                }
+            }
+        }
+    } else {
+        int lox = (int) pm_ceil(posx - .5f), loy = (int) pm_ceil(posy - .5f);
+        if (lox == (int) lx && loy == (int) ly) { for (int k = 0; k < 5; ++k) own[k] += v[k]; }
+        else if (lox >= 0 && loy >= 0 && lox < sx && loy < sy) {
+            float *dst = (float *) (film + 5 * ((size_t) (blk.oy + loy - se.crop_y) * se.crop_w + (blk.ox + lox - se.crop_x)));
+            for (int k = 0; k < 5; ++k) atomicAdd(dst + k, v[k]);
+        }
+    }
+}
+#endif
+
 template <bool COUNT, int INTEG>
 __device__ __forceinline__ void render_sample(const DScene &sc, Pcg32 &rng, const DBlock &blk, uint32_t lx, uint32_t ly,
                                               float *__restrict__ film, float acc[5], Counters &cnt) {
@@ -26,16 +81,30 @@ __device__ __forceinline__ void render_sample(const DScene &sc, Pcg32 &rng, cons
     F2 aperture_sample; aperture_sample.x = .5f; aperture_sample.y = .5f;
     if (se.needs_aperture_sample) aperture_sample = rng.next_2d();
     if (se.shutter_open_time > 0.f) (void) rng.next_1d();        // time sample (integrator.cpp:248-250)
+#if MTS_SPEC_N == 3
     (void) rng.next_1d();                                       // wavelength sample (integrator.cpp:252), unused in rgb
+#else
+    SpecCtx cx = make_ctx(sc);
+    float wav_weight;
+    cx.wl = sample_wavelengths(rng.next_1d(), wav_weight);      // integrator.cpp:252 -> Sensor::sample_ray: perspective.cpp:169-172, distant.cpp:311-313
+#endif
     F2 adjusted;
     adjusted.x = (position_sample.x - (float) se.crop_x) / (float) se.crop_w;
     adjusted.y = (position_sample.y - (float) se.crop_y) / (float) se.crop_h;
     F3 ray_weight;
     DRay ray = sensor_sample_ray(sc, adjusted, aperture_sample, ray_weight);
     bool valid;
+#if MTS_SPEC_N == 3
     F3 L = integrator_sample<COUNT, INTEG>(sc, rng, ray, se.medium, valid, cnt);
     L = ray_weight * L;
     splat_sample_t<false>(sc, blk, lx, ly, position_sample, L, valid, as_global(film), acc);
+#else
+    Spec L = integrator_sample<COUNT, INTEG>(sc, rng, ray, se.medium, valid, cnt, cx);
+    L = (wav_weight * ray_weight.x) * L;                        // ray_weight = wav_weight (x the sensor's grey weight), integrator.cpp:265
+    float xyz[3];
+    spectrum_to_xyz(sc.cie, L, cx.wl, xyz);                     // integrator.cpp:266-269
+    splat_xyz(sc, blk, lx, ly, position_sample, xyz, valid, as_global(film), acc);
+#endif
 }
 
 // librender/integrator.cpp:181-209 (scalar branch) for every block of this launch at once.
@@ -44,6 +113,9 @@ __device__ __forceinline__ void render_sample(const DScene &sc, Pcg32 &rng, cons
 // one instantiation per integrator (INTEG = NI_*).
 #ifndef MTS_NESTED_WAVES
 #define MTS_NESTED_WAVES 1
+#endif
+#if !defined(MTS_PATH_WAVES) && MTS_SPEC_N != 3
+#define MTS_PATH_WAVES 3      // four-wide spectra: the register budget of four waves per SIMD is not met
 #endif
 #ifndef MTS_PATH_WAVES
 #define MTS_PATH_WAVES 4      // measured on the cornell box: 1 -> 1631, 3 -> 1717, 4 -> 2355, 5 -> 1870, 6 -> 1241 Msamples/s
@@ -74,11 +146,14 @@ __global__ void __launch_bounds__(256, FLAT ? 1 : (INTEG == NI_PATH ? MTS_PATH_W
     Pcg32 rng;
     rng.seed(sc.sensor.seed + (uint64_t) blk.id * ppb + i, PCG32_DEFAULT_STREAM);             // sampler.cpp:83-96, integrator.cpp:198
     Counters cnt = {};
+#if MTS_SPEC_N == 3
     if (FLAT) {
         __shared__ float cold_lds[C_COUNT * 256];
         ColdStore cold; cold.base = cold_lds + threadIdx.x; cold.stride = 256;
         volpath_pixel_flat<COUNT>(sc, rng, blk, lx, ly, sample_count, film, cold, cnt, stop_flag);
-    } else {
+    } else
+#endif
+    {
         float acc[5] = { 0.f, 0.f, 0.f, 0.f, 0.f };
         for (uint32_t j = 0; j < sample_count; ++j) {
             // should_stop(), integrator.h:143-146: the reference looks at its flag once per sample; here one lane of the wave reads the
@@ -96,6 +171,7 @@ __global__ void __launch_bounds__(256, FLAT ? 1 : (INTEG == NI_PATH ? MTS_PATH_W
     }
 }
 
+#if MTS_SPEC_N == 3
 // Asynchronous-regrouping variant of the volpath render kernel (volpath_flat.h, driver 2).  The parameter list must stay in
 // sync with WgArgs: the block functions re-read it from the kernarg segment with scalar loads.  WG paths are served by NT threads;
 // WPE = waves per SIMD the register budget is sized for (512 / WPE VGPRs).
@@ -162,7 +238,11 @@ __global__ void __launch_bounds__(256) wavefront_sampler_kernel(int32_t lanes, u
     for (int k = 0; k < count; ++k) out[(size_t) i * count + k] = rng.next_1d();
 }
 
+#endif // MTS_SPEC_N == 3
+} // inline namespace
+
 // ---------------------------------------------------------------- launchers
+#if MTS_SPEC_N == 3
 hipError_t launch_tea(int32_t n, const uint32_t *v0, const uint32_t *v1, int rounds, uint32_t *out32, uint64_t *out64, float *outf, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(tea_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, v0, v1, rounds, out32, out64, outf);
@@ -182,12 +262,15 @@ size_t render_workspace_floats(uint32_t n_blocks, uint32_t block_size, int varia
     return (size_t) padded * (variant >= 256 && variant <= 4096 ? MTS_COLD_RECORD : C_COUNT) + 32;      // workgroup drivers: one 128-byte record per path
 }
 
-hipError_t launch_render(const DScene &sc, const DBlock *d_blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,
+#endif // MTS_SPEC_N == 3
+
+hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,
                          float *d_film, unsigned long long *d_counters, bool count, int variant, int wg_threads, float *d_workspace,
                          const uint32_t *d_stop_flag, hipStream_t stream) {
     if (n_blocks == 0) return hipSuccess;
     const uint64_t threads = (uint64_t) n_blocks * block_size * block_size;
     if (threads + 1024 >= ((uint64_t) 1 << 32)) return hipErrorInvalidValue;      // thread and path indices are 32 bit (mts_render launches in chunks)
+#if MTS_SPEC_N == 3
     if (variant >= 10000 && sc.integrator.type == MTS_INTEGRATOR_VOLPATH) {        // asynchronous regrouping, variant = 10000 + paths per workgroup
         const uint32_t wg = (uint32_t) (variant - 10000);
         const uint32_t grid = (uint32_t) ((threads + wg - 1) / wg);
@@ -206,19 +289,31 @@ hipError_t launch_render(const DScene &sc, const DBlock *d_blocks, uint32_t n_bl
         return hipGetLastError();
     }
     const bool flat = variant != 0;
+#else
+    const bool flat = false; (void) variant; (void) wg_threads; (void) d_workspace;       // the spectral build has the per-lane kernels of path and volpath
+    if (sc.integrator.type == MTS_INTEGRATOR_VOLPATHMIS) return hipErrorInvalidValue;
+#endif
     const uint32_t grid = (uint32_t) ((threads + 255) / 256);
     const bool use_flat = flat && sc.integrator.type == MTS_INTEGRATOR_VOLPATH;
 #define LAUNCH(C, F, I) hipLaunchKernelGGL((render_kernel<C, F, I>), dim3(grid), dim3(256), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_counters, d_stop_flag)
 #define LAUNCH_C(F, I) do { if (count) LAUNCH(true, F, I); else LAUNCH(false, F, I); } while (0)
+#if MTS_SPEC_N == 3
     if (use_flat) LAUNCH_C(true, NI_VOLPATH);
-    else if (sc.integrator.type == MTS_INTEGRATOR_PATH) LAUNCH_C(false, NI_PATH);
+    else
+#endif
+    if (sc.integrator.type == MTS_INTEGRATOR_PATH) LAUNCH_C(false, NI_PATH);
     else if (sc.integrator.type == MTS_INTEGRATOR_VOLPATH) LAUNCH_C(false, NI_VOLPATH);
+#if MTS_SPEC_N == 3
     else if (sc.integrator.use_spectral_mis) LAUNCH_C(false, NI_VOLPATHMIS);
     else LAUNCH_C(false, NI_VOLPATHMIS_NOSPEC);
+#endif
 #undef LAUNCH_C
 #undef LAUNCH
+    (void) use_flat;
     return hipGetLastError();
 }
+
+#if MTS_SPEC_N == 3
 
 hipError_t launch_sample(const DScene &sc, int32_t n, uint64_t seed_offset, const float *d_rays, float *d_rgb, uint8_t *d_valid, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
@@ -232,10 +327,11 @@ hipError_t launch_intersect(const DScene &sc, int32_t n, const float *o, const f
     hipLaunchKernelGGL(intersect_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, sc, n, o, d, mint, maxt, t, shape, prim, p, nn);
     return hipGetLastError();
 }
+#endif // MTS_SPEC_N == 3
 
 } // namespace mtsamd
 
-#if defined(MTSAMD_BLOCKSTATS)
+#if defined(MTSAMD_BLOCKSTATS) && MTS_SPEC_N == 3
 // diagnostic build only (python eradiate-kernel_amd/build.py with MTSAMD_EXTRA_FLAGS=-DMTSAMD_BLOCKSTATS)
 extern "C" int mts_debug_blockstats(unsigned long long *out32, int reset) {
     if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(mtsamd::g_blockstats), 48 * sizeof(unsigned long long)) != hipSuccess) return 1;

@@ -11,6 +11,10 @@ size_t render_workspace_floats(uint32_t n_blocks, uint32_t block_size, int varia
 hipError_t launch_render(const DScene &sc, const DBlock *d_blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,
                          float *d_film, unsigned long long *d_counters, bool count, int variant, int wg_threads /* 0 = one thread per path */, float *d_workspace,
                          const uint32_t *d_stop_flag /* host-visible word polled by the kernels: non-zero = stop */, hipStream_t stream);
+// the same for a scene of the spectral variant (kernels_spectral.hip)
+hipError_t launch_render_spectral(const DScene &sc, const DBlock *d_blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,
+                                  float *d_film, unsigned long long *d_counters, bool count, int variant, int wg_threads, float *d_workspace,
+                                  const uint32_t *d_stop_flag, hipStream_t stream);
 hipError_t launch_sample(const DScene &sc, int32_t n, uint64_t seed_offset, const float *d_rays, float *d_rgb, uint8_t *d_valid, hipStream_t stream);
 hipError_t launch_intersect(const DScene &sc, int32_t n, const float *o, const float *d, const float *mint, const float *maxt,
                             float *t, int32_t *shape, int32_t *prim, float *p, float *nn, hipStream_t stream);

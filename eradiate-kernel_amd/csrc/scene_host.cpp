@@ -8,6 +8,7 @@
 #include <cstring>
 #include <algorithm>
 #include "scene_host.h"
+#include "cie_tables.h"
 
 namespace mtsamd {
 
@@ -191,17 +192,64 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
     std::unique_ptr<HostScene> hsp(new HostScene());
     HostScene &hs = *hsp;
     DScene &sc = hs.scene; memset(&sc, 0, sizeof(sc));
+    const bool spectral = d->integrator.spectral != 0;
+    // ---- spectra (spectral variant; uniform.cpp:34-52, regular.cpp:27-58 + distr_1d.h:318-345)
+    if (spectral) {
+        if (d->integrator.type == MTS_INTEGRATOR_VOLPATHMIS) throw std::runtime_error("volpathmis is not available in the spectral variant of this backend");
+        if (d->integrator.monochrome) throw std::runtime_error("a scene is either monochromatic or spectral");
+        for (int i = 0; i < d->spectrum_count; ++i) {
+            const mts_spectrum &sp = d->spectra[i];
+            DSpectrum ds; memset(&ds, 0, sizeof(ds));
+            ds.type = sp.type; ds.value = sp.value; ds.lambda_min = sp.lambda_min; ds.lambda_max = sp.lambda_max;
+            hs.spectrum_values.emplace_back();
+            if (sp.type == MTS_SPECTRUM_UNIFORM) {
+                ds.lambda_min = std::max(sp.lambda_min, 280.f); ds.lambda_max = std::min(sp.lambda_max, 2400.f);       // MTS_WAVELENGTH_MIN / MAX
+                if (!(ds.lambda_min < ds.lambda_max)) throw std::runtime_error("UniformSpectrum: 'lambda_min' must be less than 'lambda_max'");
+            } else if (sp.type == MTS_SPECTRUM_REGULAR) {
+                if (!(sp.lambda_min < sp.lambda_max)) throw std::runtime_error("ContinuousDistribution: invalid range!");
+                if (sp.count < 2 || !sp.values) throw std::runtime_error("ContinuousDistribution: needs at least two entries!");
+                bool mass = false;
+                for (int k = 0; k < sp.count; ++k) { if (sp.values[k] < 0.f) throw std::runtime_error("ContinuousDistribution: entries must be non-negative!"); mass = mass || sp.values[k] > 0.f; }
+                if (!mass) throw std::runtime_error("ContinuousDistribution: no probability mass found!");
+                hs.spectrum_values.back().assign(sp.values, sp.values + sp.count);
+                ds.count = sp.count;
+                const double interval_size = (double(sp.lambda_max) - double(sp.lambda_min)) / (sp.count - 1);
+                ds.inv_interval_size = (float) (1. / interval_size);
+            } else throw std::runtime_error("unknown spectrum type");
+            hs.spectra.push_back(ds);
+        }
+    }
+    auto spectrum_index = [&](int idx, const char *what) {
+        if (idx < 0 || idx >= d->spectrum_count) throw std::runtime_error(std::string("spectral variant: missing spectrum for ") + what);
+        return idx;
+    };
+    auto add_uniform_spectrum = [&](float value) {
+        DSpectrum ds; memset(&ds, 0, sizeof(ds)); ds.type = MTS_SPECTRUM_UNIFORM; ds.value = value; ds.lambda_min = 280.f; ds.lambda_max = 2400.f;
+        hs.spectra.push_back(ds); hs.spectrum_values.emplace_back();
+        return (int32_t) hs.spectra.size() - 1;
+    };
 
     // ---- volumes (texture.cpp:89-92, texture.h:262-269, grid3d.cpp:137-161, volume_data.h:24-33,86-98)
     for (int i = 0; i < d->volume_count; ++i) {
         const mts_volume &v = d->volumes[i];
         DVolume dv; memset(&dv, 0, sizeof(dv));
-        dv.type = v.type; memcpy(dv.value, v.value, 12);
+        dv.type = v.type == MTS_VOLUME_GRID_SPECTRAL ? MTS_VOLUME_GRID : v.type; memcpy(dv.value, v.value, 12);
+        DVolumeSp vsp; memset(&vsp, 0, sizeof(vsp)); vsp.value_sp = -1;
+        if (spectral && v.type == MTS_VOLUME_CONST) vsp.value_sp = spectrum_index(v.value_spectrum, "a constvolume");
+        if (v.type == MTS_VOLUME_GRID_SPECTRAL) {
+            if (!spectral) throw std::runtime_error("This volume data source can only be used with a spectral variant!");     // gridvolume_spectral.cpp:86-88
+            if (v.filter_type != MTS_FILTER_TRILINEAR) throw std::runtime_error("Invalid filter type, must be \"trilinear\"!");
+            if (v.channels < 2 || v.channels > 255) throw std::runtime_error("gridvolume_spectral: between 2 and 255 spectral nodes are supported");
+            vsp.spectral_grid = 1; vsp.lambda_min = v.lambda_min; vsp.lambda_max = v.lambda_max;
+        }
+        hs.volume_sp.push_back(vsp);
         DXf w2l = xf_inverse(xf_from_abi(v.to_world));
-        if (v.type == MTS_VOLUME_GRID) {
+        if (v.type == MTS_VOLUME_GRID || v.type == MTS_VOLUME_GRID_SPECTRAL) {
             if (!v.data) throw std::runtime_error("gridvolume: missing data");
             if ((long) v.nx * v.ny * v.nz < 8) throw std::runtime_error("Invalid grid dimensions (must have at least one value at each corner)");
-            if (v.channels != 1 && v.channels != 3) throw std::runtime_error("Unsupported channel count (expected 1 or 3)");
+            if (v.type == MTS_VOLUME_GRID && v.channels != 1 && v.channels != 3) throw std::runtime_error("Unsupported channel count (expected 1 or 3)");
+            if (spectral && v.type == MTS_VOLUME_GRID && v.channels != 1)
+                throw std::runtime_error("spectral variant: 3-channel grids need the sRGB upsampling model (ext/rgb2spec data, absent); use gridvolume_spectral");
             if ((int64_t) v.nx * v.ny * v.nz * v.channels >= (int64_t) 1 << 31) throw std::runtime_error("gridvolume: more than 2^31 values");
             dv.nx = v.nx; dv.ny = v.ny; dv.nz = v.nz; dv.channels = v.channels; dv.filter = v.filter_type; dv.wrap = v.wrap_mode;
             size_t n = (size_t) v.nx * v.ny * v.nz * v.channels;
@@ -300,6 +348,10 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
         db.type = b.type; memcpy(db.reflectance, b.reflectance, 12); memcpy(db.rho_0, b.rho_0, 12); memcpy(db.k, b.k, 12);
         memcpy(db.g, b.g, 12); memcpy(db.rho_c, b.rho_c, 12); memcpy(db.transmittance, b.transmittance, 12); db.flags = bsdf_flags(b.type);
         hs.bsdfs.push_back(db);
+        if (spectral) {                                                  // which of the six colour parameters each plugin reads
+            static const bool used[4][6] = { { 1, 0, 0, 0, 0, 0 } /* diffuse */, { 0, 0, 0, 0, 0, 0 } /* null */, { 0, 1, 1, 1, 1, 0 } /* rpv */, { 1, 0, 0, 0, 0, 1 } /* bilambertian */ };
+            for (int k = 0; k < MTS_BSDF_SP_COUNT; ++k) hs.bsdf_sp.push_back(used[b.type][k] ? spectrum_index(b.spectrum[k], "a BSDF parameter") : 0);
+        }
     }
     // default BSDFs appended after the user's (shape.cpp:74-80): diffuse 0.5, and diffuse 0 for emitters
     DBsdf def; memset(&def, 0, sizeof(def)); def.type = MTS_BSDF_DIFFUSE; def.flags = bsdf_flags(MTS_BSDF_DIFFUSE);
@@ -307,6 +359,11 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
     const int default_bsdf = (int) hs.bsdfs.size(); hs.bsdfs.push_back(def);
     def.reflectance[0] = def.reflectance[1] = def.reflectance[2] = 0.f;
     const int default_emitter_bsdf = (int) hs.bsdfs.size(); hs.bsdfs.push_back(def);
+    if (spectral) {
+        const int32_t half = add_uniform_spectrum(.5f), zero = add_uniform_spectrum(0.f);
+        for (int k = 0; k < MTS_BSDF_SP_COUNT; ++k) hs.bsdf_sp.push_back(half);
+        for (int k = 0; k < MTS_BSDF_SP_COUNT; ++k) hs.bsdf_sp.push_back(zero);
+    }
     // ---- shapes + scene bounding box (scene.cpp:31-40)
     bbox_reset(sc.bbox);
     for (int i = 0; i < d->shape_count; ++i) {
@@ -382,6 +439,7 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
         } else if (e.type != MTS_EMITTER_DIRECTIONAL && e.type != MTS_EMITTER_POINT) throw std::runtime_error("unknown emitter type");
         store3(de.bsphere_center, center); de.bsphere_radius = bsphere_radius;
         hs.emitters.push_back(de);
+        if (spectral) hs.emitter_sp.push_back(spectrum_index(e.radiance_spectrum, "an emitter"));
     }
     // ---- sensor, film, sampler
     const mts_sensor &s = d->sensor;
@@ -619,6 +677,14 @@ void upload_host_scene(HostScene &hs, int device) {
     if (sc.bvh_node_count > 0) { sc.bvh_nodes = upload(hs, hs.bvh_nodes); sc.bvh_prims = upload(hs, hs.bvh_prims); }
     sc.sensor.rfilter.values = upload(hs, hs.rfilter_values);
     sc.sensor.multi = upload(hs, hs.multi_transforms);
+    sc.spectra = nullptr; sc.bsdf_sp = nullptr; sc.emitter_sp = nullptr; sc.volume_sp = nullptr; sc.cie = nullptr;
+    if (hs.integrator.spectral) {
+        for (size_t i = 0; i < hs.spectra.size(); ++i)
+            if (hs.spectra[i].type == MTS_SPECTRUM_REGULAR) hs.spectra[i].values = upload(hs, hs.spectrum_values[i]);
+        sc.spectra = upload(hs, hs.spectra); sc.bsdf_sp = upload(hs, hs.bsdf_sp); sc.emitter_sp = upload(hs, hs.emitter_sp);
+        sc.volume_sp = upload(hs, hs.volume_sp);
+        sc.cie = upload(hs, std::vector<float>(MTS_CIE1931_XYZ, MTS_CIE1931_XYZ + 285));
+    }
     HIP_CHECK(hipDeviceSynchronize());
     hs.uploaded = true;
 }

@@ -34,6 +34,9 @@ struct HostScene {
     std::vector<std::vector<float>> grid_data, tab_pdf, tab_cdf;
     std::vector<float> multi_transforms;            // mradiancemeter / mdistant sub-sensor matrices
     std::vector<std::vector<float>> pair_data;       // per medium: interleaved {sigma_t, albedo} voxels (DMedium::pair_grid), or empty
+    // spectral variant (DScene::spectra ...)
+    std::vector<DSpectrum> spectra; std::vector<std::vector<float>> spectrum_values;
+    std::vector<int32_t> bsdf_sp, emitter_sp; std::vector<DVolumeSp> volume_sp;
     std::vector<void *> device_allocs;
     int device = 0;
     bool uploaded = false;

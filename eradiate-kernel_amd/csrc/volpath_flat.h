@@ -22,6 +22,7 @@
 #include "integrator_dev.h"
 
 namespace mtsamd {
+inline namespace MTS_VARIANT_NS {
 
 enum : uint32_t { S_TOP = 0, S_MED = 1, S_SURF = 2, S_PHASE = 3, S_BSDF = 4, S_DIRB = 5, S_NEW = 6, S_DONE = 7, S_SCATTER = 8,
                   S_ENDNEE = 9, S_ENDDIR0 = 10 };   // transient (workgroup drivers): end_nee / end_direct(0, 0) still to run on the full state
@@ -1078,4 +1079,5 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
 }
 
 
+} // inline namespace
 } // namespace mtsamd

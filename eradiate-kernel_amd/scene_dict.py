@@ -77,6 +77,75 @@ def _xf(t):
 
 
 _MONO = False      # set by build_scene_desc(mono=True): colours become their luminance (src/spectra/srgb.cpp in *_mono variants)
+_SPECTRAL = None   # set by build_scene_desc(spectral=True): the SceneBuilder that collects the scene's spectra
+
+
+WAVELENGTH_MIN, WAVELENGTH_MAX = 280.0, 2400.0       # MTS_WAVELENGTH_MIN / MAX, include/mitsuba/core/spectrum.h:15-21
+
+
+def _spectrum(v, where, default=None, emitter=False):
+    """Spectral variant: a colour parameter -> index of its spectrum record (mts_spectrum).
+    float -> `uniform` (Properties::texture, properties.h:275-296); {"type": "uniform" | "regular" | "d65"} -> the plugin of that
+    name (src/spectra/*.cpp; d65 expands to regular, d65.cpp:52-71); {"type": "spectrum", "value": c} -> uniform, or d65 scaled by c
+    inside an emitter (create_texture_from_spectrum, xml.cpp:1087-1111); a missing emitter spectrum is D65 (directional.cpp:49,
+    area.cpp:39, constant.cpp:33, point.cpp:47).  rgb colours need the sRGB upsampling model, whose data (ext/rgb2spec) is absent."""
+    b = _SPECTRAL
+    if v is None:
+        v = {"type": "d65"} if (emitter and default is None) else default
+    rec = A.Spectrum()
+    rec.lambda_min, rec.lambda_max = WAVELENGTH_MIN, WAVELENGTH_MAX
+    if isinstance(v, dict):
+        p = Props(v, where)
+        t = p.type
+        if t == "spectrum":
+            val = p.get("value", 1.0)
+            if p.has("filename") or isinstance(val, (list, tuple)):
+                raise RuntimeError("spectra given as wavelength / value pairs are not supported by this backend: %s" % where)
+            p.finish()
+            return _spectrum({"type": "d65", "scale": float(val)} if emitter else {"type": "uniform", "value": float(val)}, where)
+        if t == "uniform":
+            rec.type = A.SPECTRUM_UNIFORM
+            rec.value = float(p.get("value", 1.0))
+            if p.has("lambda_min"):
+                rec.lambda_min = max(float(p.get("lambda_min")), WAVELENGTH_MIN)
+            if p.has("lambda_max"):
+                rec.lambda_max = min(float(p.get("lambda_max")), WAVELENGTH_MAX)
+            if not rec.lambda_min < rec.lambda_max:
+                raise RuntimeError("UniformSpectrum: 'lambda_min' must be less than 'lambda_max'")
+        elif t in ("regular", "d65"):
+            rec.type = A.SPECTRUM_REGULAR
+            if t == "d65":
+                from .spectra_data import D65, D65_NORMALIZATION
+                f = np.float32
+                scale = f(f(p.get("scale", 1.0)) * f(D65_NORMALIZATION))                  # d65.cpp:56-57: m_scale *= 1.f / 10568.f
+                values = (np.asarray(D65, np.float32) * scale).astype(np.float32)         # :64-65
+                rec.lambda_min, rec.lambda_max = 360.0, 830.0
+            else:
+                if not (p.has("lambda_min") and p.has("lambda_max")):
+                    raise RuntimeError("Property \"lambda_min\" has not been specified!" if not p.has("lambda_min") else "Property \"lambda_max\" has not been specified!")
+                rec.lambda_min, rec.lambda_max = float(p.get("lambda_min")), float(p.get("lambda_max"))
+                vals = p.get("values")
+                if isinstance(vals, str):
+                    vals = [float(x) for x in vals.replace(",", " ").split()]
+                values = np.asarray(vals, np.float32).reshape(-1)
+            values = np.ascontiguousarray(values, np.float32)
+            b.keep.append(values)
+            rec.values = values.ctypes.data_as(A.fp)
+            rec.count = int(values.size)
+        elif t in ("rgb", "srgb", "srgb_d65"):
+            raise RuntimeError("rgb colours cannot be used in the spectral variant: the sRGB upsampling model needs the coefficient data of "
+                               "ext/rgb2spec, absent here; give a 'uniform' or 'regular' spectrum instead (%s)" % where)
+        else:
+            raise RuntimeError("Unsupported spectrum plugin \"%s\" in %s" % (t, where))
+        p.finish()
+    else:
+        c = np.asarray(v, dtype=np.float32).reshape(-1)
+        if c.size != 1:
+            raise RuntimeError("Cannot interpret %r as a spectrum in %s (spectral variant)" % (v, where))
+        rec.type = A.SPECTRUM_UNIFORM
+        rec.value = float(c[0])
+    b.spectra.append(rec)
+    return len(b.spectra) - 1
 
 
 def _color(v, where, default=None):
@@ -196,16 +265,32 @@ class SceneBuilder:
         rec.wrap_mode = A.WRAP_CLAMP
         if v is None:
             v = default
-        if isinstance(v, dict) and v.get("type") in ("gridvolume", "constvolume"):
+        rec.value_spectrum = -1
+        if isinstance(v, dict) and v.get("type") in ("gridvolume", "constvolume", "gridvolume_spectral"):
             p = Props(v, where)
             rec.to_world = _xf(p.get("to_world"))
             if p.type == "constvolume":
                 rec.type = A.VOLUME_CONST
                 # constant3d.cpp: "color" texture; load_dict users pass "value" (xml.cpp spectrum shorthand)
                 val = p.get("value", p.get("color", 1.0))
-                rec.value[:] = _color(val, where)
+                if _SPECTRAL is not None:
+                    rec.value_spectrum = _spectrum(val, where)
+                else:
+                    rec.value[:] = _color(val, where)
             else:
                 rec.type = A.VOLUME_GRID
+                if p.type == "gridvolume_spectral":                      # src/textures/gridvolume_spectral.cpp:84-135,186-190
+                    if _SPECTRAL is None:
+                        raise RuntimeError("This volume data source can only be used with a spectral variant!")
+                    rec.type = A.VOLUME_GRID_SPECTRAL
+                    st = str(p.get("spectrum_type", "regular"))
+                    if st != "regular":
+                        raise RuntimeError("Invalid spectrum type \"%s\", must be \"regular\"!" % st)
+                    if not p.has("lambda_min"):
+                        raise RuntimeError("Property \"lambda_min\" has not been specified!")
+                    if not p.has("lambda_max"):
+                        raise RuntimeError("Property \"lambda_max\" has not been specified!")
+                    rec.lambda_min, rec.lambda_max = float(p.get("lambda_min")), float(p.get("lambda_max"))
                 if p.has("filename"):
                     data, meta = read_volume(file_resolver().resolve(p.get("filename")))
                     rec.file_bbox_min[:] = meta["bbox_min"]
@@ -234,6 +319,8 @@ class SceneBuilder:
                 rec.data = data.ctypes.data_as(A.fp)
                 rec.nz, rec.ny, rec.nx, rec.channels = data.shape
                 ft = str(p.get("filter_type", "trilinear"))
+                if p.type == "gridvolume_spectral" and ft != "trilinear":
+                    raise RuntimeError("Invalid filter type \"%s\", must be \"trilinear\"!" % ft)
                 if ft not in ("nearest", "trilinear"):
                     raise RuntimeError("Invalid filter type \"%s\", must be one of: \"nearest\" or \"trilinear\"!" % ft)
                 rec.filter_type = A.FILTER_NEAREST if ft == "nearest" else A.FILTER_TRILINEAR
@@ -253,7 +340,10 @@ class SceneBuilder:
         else:
             # float / rgb given where a volume is expected -> constvolume (properties.h:319-366)
             rec.type = A.VOLUME_CONST
-            rec.value[:] = _color(v, where)
+            if _SPECTRAL is not None:
+                rec.value_spectrum = _spectrum(v, where)
+            else:
+                rec.value[:] = _color(v, where)
         self.volumes.append(rec)
         self._register(v, "volume", len(self.volumes) - 1)
         return len(self.volumes) - 1
@@ -345,21 +435,33 @@ class SceneBuilder:
             return r
         p = Props(d, where)
         rec = A.Bsdf()
+        rec.spectrum[:] = [-1] * 6
+        spectral = _SPECTRAL is not None
+        def colour(field, slot, key, default):                           # rgb triple, or (spectral variant) the index of the spectrum
+            if spectral:
+                rec.spectrum[slot] = _spectrum(p.get(key), where + "." + key, default=default)
+            else:
+                getattr(rec, field)[:] = _color(p.get(key), where, default=default)
         if p.type == "diffuse":
             rec.type = A.BSDF_DIFFUSE
-            rec.reflectance[:] = _color(p.get("reflectance"), where, default=0.5)
+            colour("reflectance", 0, "reflectance", 0.5)
         elif p.type == "null":
             rec.type = A.BSDF_NULL
         elif p.type == "bilambertian":                                   # src/bsdfs/bilambertian.cpp:51-60
             rec.type = A.BSDF_BILAMBERTIAN
-            rec.reflectance[:] = _color(p.get("reflectance"), where, default=0.5)
-            rec.transmittance[:] = _color(p.get("transmittance"), where, default=0.5)
+            colour("reflectance", 0, "reflectance", 0.5)
+            colour("transmittance", 5, "transmittance", 0.5)
         elif p.type == "rpv":
             rec.type = A.BSDF_RPV
-            rec.rho_0[:] = _color(p.get("rho_0"), where, default=0.1)
-            rec.g[:] = _color(p.get("g"), where, default=0.0)
-            rec.k[:] = _color(p.get("k"), where, default=0.1)
-            rec.rho_c[:] = _color(p.get("rho_c"), where) if p.has("rho_c") else tuple(rec.rho_0)
+            colour("rho_0", 1, "rho_0", 0.1)
+            colour("g", 3, "g", 0.0)
+            colour("k", 2, "k", 0.1)
+            if p.has("rho_c"):
+                colour("rho_c", 4, "rho_c", None)
+            elif spectral:
+                rec.spectrum[4] = rec.spectrum[1]                        # rpv.cpp:75-79: rho_c defaults to rho_0
+            else:
+                rec.rho_c[:] = tuple(rec.rho_0)
         else:
             raise RuntimeError("Unknown / unsupported BSDF plugin \"%s\"" % p.type)
         p.finish()
@@ -456,7 +558,7 @@ class SceneBuilder:
             e = A.Emitter()
             e.type = A.EMITTER_AREA
             e.to_world = _xf(None)
-            e.radiance[:] = _color(ep.get("radiance"), where, default=1.0)
+            self._emitter_colour(e, ep.get("radiance"), where)
             e.shape = idx
             ep.finish()
             self.emitters.append(e)
@@ -465,6 +567,14 @@ class SceneBuilder:
         return idx
 
     # ------------------------------------------------------------ emitters
+    @staticmethod
+    def _emitter_colour(e, v, where):
+        e.radiance_spectrum = -1
+        if _SPECTRAL is not None:
+            e.radiance_spectrum = _spectrum(v, where, emitter=True)
+        else:
+            e.radiance[:] = _color(v, where, default=1.0)
+
     def add_emitter(self, d, where):
         p = Props(d, where)
         e = A.Emitter()
@@ -480,11 +590,11 @@ class SceneBuilder:
                 e.to_world = _xf(ScalarTransform4f.look_at([0, 0, 0], direction, up))
             else:
                 e.to_world = _xf(p.get("to_world"))
-            e.radiance[:] = _color(p.get("irradiance"), where, default=1.0)
+            self._emitter_colour(e, p.get("irradiance"), where)
         elif p.type == "constant":
             e.type = A.EMITTER_CONSTANT
             e.to_world = _xf(None)
-            e.radiance[:] = _color(p.get("radiance"), where, default=1.0)
+            self._emitter_colour(e, p.get("radiance"), where)
         elif p.type == "point":                                             # point.cpp:45-58
             e.type = A.EMITTER_POINT
             if p.has("position"):
@@ -493,7 +603,7 @@ class SceneBuilder:
                 e.to_world = _xf(ScalarTransform4f.translate(np.asarray(p.get("position"), dtype=np.float32)))
             else:
                 e.to_world = _xf(p.get("to_world"))
-            e.radiance[:] = _color(p.get("intensity"), where, default=1.0)
+            self._emitter_colour(e, p.get("intensity"), where)
         elif p.type == "area":
             raise RuntimeError("Can't sample from an area emitter without an associated Shape.")
         else:
@@ -799,19 +909,24 @@ class SceneBuilder:
         desc.emitters, desc.emitter_count = arr(A.Emitter, self.emitters), len(self.emitters)
         desc.sensor = self.sensor
         desc.integrator = self.integrator
+        desc.spectra, desc.spectrum_count = arr(A.Spectrum, self.spectra), len(self.spectra)
         self.keep.append(desc)
         return desc
 
 
-def build_scene_desc(d, mono=False):
+def build_scene_desc(d, mono=False, spectral=False):
     """Returns (SceneDesc, keepalive). The keepalive object owns every buffer the description points to.
-    mono: build the scene with the semantics of the *_mono variants."""
-    global _MONO
+    mono: build the scene with the semantics of the *_mono variants; spectral: with those of scalar_spectral."""
+    global _MONO, _SPECTRAL
     b = SceneBuilder()
+    b.spectra = []
     _MONO = bool(mono)
+    _SPECTRAL = b if spectral else None
     try:
         desc = b.load(d)
     finally:
         _MONO = False
+        _SPECTRAL = None
     desc.integrator.monochrome = int(bool(mono))
+    desc.integrator.spectral = int(bool(spectral))
     return desc, b

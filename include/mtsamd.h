@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MTS_ABI_VERSION 4
+#define MTS_ABI_VERSION 5
 
 /* Transform4f: row-major 4x4 matrix and its inverse transpose (transform.h:36-50). */
 typedef struct mts_transform {
@@ -43,8 +43,22 @@ typedef struct mts_transform {
     float inverse_transpose[16];
 } mts_transform;
 
-/* ---- Volume (3-D texture): constvolume (src/textures/constant3d.cpp) / gridvolume (grid3d.cpp) ---- */
-enum { MTS_VOLUME_CONST = 0, MTS_VOLUME_GRID = 1 };
+/* ---- Spectra (spectral variant only: mts_integrator.spectral): src/spectra/uniform.cpp (value inside [lambda_min, lambda_max], 0
+ *      outside; the bounds default to, and are clamped to, MTS_WAVELENGTH_MIN / MAX = 280 / 2400 nm, core/spectrum.h:15-21) and
+ *      src/spectra/regular.cpp (values at regularly spaced wavelengths over [lambda_min, lambda_max], linearly interpolated, 0 outside).
+ *      `d65` (src/spectra/d65.cpp) expands to `regular` on the caller's side, as the plugin itself does. ---- */
+enum { MTS_SPECTRUM_UNIFORM = 0, MTS_SPECTRUM_REGULAR = 1 };
+typedef struct mts_spectrum {
+    int32_t type;
+    float value;              /* uniform "value" */
+    float lambda_min, lambda_max;
+    const float *values;      /* regular "values" */
+    int32_t count;
+} mts_spectrum;
+
+/* ---- Volume (3-D texture): constvolume (src/textures/constant3d.cpp) / gridvolume (grid3d.cpp) /
+ *      gridvolume_spectral (src/textures/gridvolume_spectral.cpp, spectral variant only) ---- */
+enum { MTS_VOLUME_CONST = 0, MTS_VOLUME_GRID = 1, MTS_VOLUME_GRID_SPECTRAL = 2 };
 enum { MTS_FILTER_NEAREST = 0, MTS_FILTER_TRILINEAR = 1 };            /* grid3d.cpp:43-50 */
 enum { MTS_WRAP_REPEAT = 0, MTS_WRAP_MIRROR = 1, MTS_WRAP_CLAMP = 2 }; /* grid3d.cpp:52-61 */
 typedef struct mts_volume {
@@ -60,6 +74,9 @@ typedef struct mts_volume {
     float file_bbox_min[3], file_bbox_max[3]; /* bbox stored in the .vol header                  */
     int32_t has_max_value;    /* "max_value" override (grid3d.cpp:157-160)                       */
     float max_value;
+    /* spectral variant */
+    int32_t value_spectrum;   /* constvolume: index into mts_scene_desc.spectra of its colour (-1 in rgb / mono scenes)  */
+    float lambda_min, lambda_max;   /* gridvolume_spectral: the interval its `channels` nodes cover (:186-190); any channel count >= 2 */
 } mts_volume;
 
 /* ---- Phase functions (src/phase/{isotropic,hg,rayleigh,blendphase,tabphase}.cpp) ---- */
@@ -93,6 +110,8 @@ typedef struct mts_bsdf {
     float reflectance[3];     /* diffuse "reflectance" (rgb), default 0.5                        */
     float rho_0[3], k[3], g[3], rho_c[3];  /* rpv parameters (rpv.cpp:60-70)                     */
     float transmittance[3];   /* bilambertian "transmittance" (with "reflectance"), default 0.5 (bilambertian.cpp:52-53) */
+    int32_t spectrum[6];      /* spectral variant: indices into mts_scene_desc.spectra of reflectance, rho_0, k, g, rho_c,
+                                 transmittance, in this order (-1 in rgb / mono scenes)                                   */
 } mts_bsdf;
 
 /* ---- Shapes (src/shapes/{rectangle,cube,sphere,disk}.cpp, src/librender/mesh.cpp) ---- */
@@ -123,6 +142,7 @@ typedef struct mts_emitter {
     mts_transform to_world;   /* directional: local +z is the direction of propagation           */
     float radiance[3];        /* "irradiance" (directional) / "radiance" (area, constant), rgb   */
     int32_t shape;            /* area: index of the owning shape                                 */
+    int32_t radiance_spectrum; /* spectral variant: index into mts_scene_desc.spectra (-1 in rgb / mono scenes)           */
 } mts_emitter;
 
 /* ---- Sensor + film + sampler (src/sensors/{perspective,distant}.cpp, src/films/hdrfilm.cpp,
@@ -188,6 +208,9 @@ typedef struct mts_integrator {
     int32_t monochrome;       /* 1: the semantics of the *_mono variants (is_monochromatic_v): no colour-channel draw
                                  (volpath.cpp:64-67), film X = Y = Z = L (integrator.cpp:270-271); the caller passes every
                                  colour as its luminance in all three channels.  0: *_rgb.                                */
+    int32_t spectral;         /* 1: the semantics of scalar_spectral (is_spectral_v): Spectrum<Float, 4>, four wavelengths per sample drawn
+                                 as include/mitsuba/core/spectrum.h:305-314 prescribes, colours given as spectra (mts_scene_desc.spectra),
+                                 film = spectrum_to_xyz (:210-217).  Integrators: path, volpath.                          */
 } mts_integrator;
 
 typedef struct mts_scene_desc {
@@ -200,6 +223,7 @@ typedef struct mts_scene_desc {
     const mts_emitter *emitters; int32_t emitter_count;   /* in scene declaration order */
     mts_sensor sensor;
     mts_integrator integrator;
+    const mts_spectrum *spectra; int32_t spectrum_count;  /* spectral variant only */
 } mts_scene_desc;
 
 typedef struct mts_scene mts_scene;   /* opaque */

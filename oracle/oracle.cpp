@@ -51,7 +51,7 @@ struct SurfaceInteraction {
 };
 struct MediumInteraction {
     float t; V3 p; Frame sh_frame; V3 wi;
-    V3 sigma_s, sigma_n, sigma_t, combined_extinction; float mint; int medium;
+    Spec sigma_s, sigma_n, sigma_t, combined_extinction; float mint; int medium;
     bool is_valid() const { return t != pm_inf(); }
 };
 // interaction.h:58-61
@@ -271,8 +271,57 @@ static inline int wrap_coord(const Volume &v, int value, int res) {
     return mod;
 }
 // grid3d.cpp:220-232,259-360 ; constant3d.cpp
+#if MTS_SPEC_N != 3
+// gridvolume_spectral.cpp:226-388: trilinear in space (cell-centred values, wrapped indices), linear in the spectral dimension
+// (nodes over [lambda_min, lambda_max], clamped indices), zero outside the interval
+static inline Spec volume_eval_spectral(const Volume &v, V3 p_world) {
+    V3 p = xf_point(v.world_to_local, p_world);                                           // :232
+    const float *D = v.data; const int nx = v.nx, ny = v.ny, nz = v.nz, ch = v.channels;
+    const float inv_dlambda = 1.0f / (v.lambda_max - v.lambda_min), lambda_scale = (float) (ch - 1);      // :186-190; array / scalar = array * (1 / scalar)
+    p = v3(pm_fma(p.x, (float) nx, -.5f), pm_fma(p.y, (float) ny, -.5f), pm_fma(p.z, (float) nz, -.5f));
+    int ix = (int) pm_floor(p.x), iy = (int) pm_floor(p.y), iz = (int) pm_floor(p.z);
+    V3 w1 = p - v3((float) ix, (float) iy, (float) iz), w0 = v3(1.f - w1.x, 1.f - w1.y, 1.f - w1.z);
+    int x0 = wrap_coord(v, ix, nx), x1 = wrap_coord(v, ix + 1, nx), y0 = wrap_coord(v, iy, ny), y1 = wrap_coord(v, iy + 1, ny),
+        z0 = wrap_coord(v, iz, nz), z1 = wrap_coord(v, iz + 1, nz);
+    const float lam[4] = { tls_wavelengths.x, tls_wavelengths.y, tls_wavelengths.z, tls_wavelengths.w };
+    float out[4];
+    for (int k = 0; k < 4; ++k) {
+        const float wn = (lam[k] - v.lambda_min) * inv_dlambda;                            // :233-234 wavelengths_normalized
+        const float ws = wn * lambda_scale;                                                // :302
+        const int wi = (int) pm_floor(ws);
+        const int c0 = std::min(std::max(wi, 0), ch - 1), c1 = std::min(std::max(wi + 1, 0), ch - 1);      // wrap_wavelengths :262-265
+        const float s1 = ws - (float) wi, s0 = 1.f - s1;
+        float dd[2];
+        for (int j = 0; j < 2; ++j) {
+            const int c = j ? c1 : c0;
+            #define G(X, Y, Z) D[(size_t) (((Z) * ny + (Y)) * nx + (X)) * ch + c]
+            float d000 = G(x0, y0, z0), d100 = G(x1, y0, z0), d010 = G(x0, y1, z0), d110 = G(x1, y1, z0),
+                  d001 = G(x0, y0, z1), d101 = G(x1, y0, z1), d011 = G(x0, y1, z1), d111 = G(x1, y1, z1);
+            #undef G
+            float v00 = pm_fma(w0.x, d000, w1.x * d100), v01 = pm_fma(w0.x, d001, w1.x * d101),
+                  v10 = pm_fma(w0.x, d010, w1.x * d110), v11 = pm_fma(w0.x, d011, w1.x * d111);
+            float v0 = pm_fma(w0.y, v00, w1.y * v10), v1 = pm_fma(w0.y, v01, w1.y * v11);
+            dd[j] = pm_fma(w0.z, v0, w1.z * v1);
+        }
+        const float r = pm_fma(s0, dd[0], s1 * dd[1]);                                     // :373
+        // :380-385: the mask compares the NORMALISED wavelength (the argument the function received) with lambda_min / lambda_max
+        out[k] = (wn >= v.lambda_min && wn <= v.lambda_max) ? r : 0.f;
+    }
+    return spec4(out[0], out[1], out[2], out[3]);
+}
+#endif
+#if MTS_SPEC_N == 3
 static inline V3 volume_eval(const Volume &v, V3 p_world) {
     if (v.type == MTS_VOLUME_CONST) return v.value;
+#else
+static inline V3 volume_eval_rgb(const Volume &v, V3 p_world);
+static inline Spec volume_eval(const Volume &v, V3 p_world) {
+    if (v.type == MTS_VOLUME_CONST) return color_eval(v.value);                           // constant3d.cpp: m_color->eval(si)
+    if (v.spectral_grid) return volume_eval_spectral(v, p_world);
+    return spec_s(volume_eval_rgb(v, p_world).x);                                         // single-channel grid
+}
+static inline V3 volume_eval_rgb(const Volume &v, V3 p_world) {
+#endif
     V3 p = xf_point(v.world_to_local, p_world);                                           // grid3d.cpp:227
     const float *D = v.data; const int nx = v.nx, ny = v.ny, nz = v.nz, ch = v.channels;
     if (v.filter == MTS_FILTER_TRILINEAR) {
@@ -305,26 +354,31 @@ static inline V3 volume_eval(const Volume &v, V3 p_world) {
 }
 // eval_1: grid3d.cpp:187-202 (1 channel: hmean of a 1-vector; 3 channels: luminance), constant3d.cpp (mean)
 static inline float volume_eval_1(const Volume &v, V3 p_world) {
+#if MTS_SPEC_N == 3
     V3 r = volume_eval(v, p_world);
     if (v.type == MTS_VOLUME_CONST) return (r.x + r.y + r.z) * (1.f / 3.f);
     if (v.channels == 1) return r.x;
     return r.x * 0.212671f + r.y * 0.715160f + r.z * 0.072169f;
+#else
+    if (v.type == MTS_VOLUME_CONST) return v.value.s->value;                              // uniform.cpp:64-68 eval_1
+    return volume_eval(v, p_world).x;
+#endif
 }
 
 // ---------------------------------------------------------------- media
 // homogeneous.cpp:33-54, heterogeneous.cpp:33-54
-static inline V3 medium_combined_extinction(const Scene &sc, const Medium &m, V3 p) {
+static inline Spec medium_combined_extinction(const Scene &sc, const Medium &m, V3 p) {
     if (m.is_homogeneous) return volume_eval(sc.volumes[m.sigma_t], p) * m.scale;
-    return v3(m.max_density, m.max_density, m.max_density);
+    return spec_s(m.max_density);
 }
-static inline void medium_scattering_coefficients(const Scene &sc, const Medium &m, V3 p, V3 *sigma_s, V3 *sigma_n, V3 *sigma_t, Counters *cnt) {
+static inline void medium_scattering_coefficients(const Scene &sc, const Medium &m, V3 p, Spec *sigma_s, Spec *sigma_n, Spec *sigma_t, Counters *cnt) {
     if (m.is_homogeneous) {
-        V3 st = volume_eval(sc.volumes[m.sigma_t], p) * m.scale;
-        *sigma_t = st; *sigma_s = st * volume_eval(sc.volumes[m.albedo], p); *sigma_n = v3(0.f, 0.f, 0.f);
+        Spec st = volume_eval(sc.volumes[m.sigma_t], p) * m.scale;
+        *sigma_t = st; *sigma_s = st * volume_eval(sc.volumes[m.albedo], p); *sigma_n = spec_s(0.f);
     } else {
-        V3 st = m.scale * volume_eval(sc.volumes[m.sigma_t], p);
+        Spec st = m.scale * volume_eval(sc.volumes[m.sigma_t], p);
         *sigma_t = st; *sigma_s = st * volume_eval(sc.volumes[m.albedo], p);
-        *sigma_n = v3(m.max_density, m.max_density, m.max_density) - st;
+        *sigma_n = spec_s(m.max_density) - st;
         if (cnt) cnt->n_lookup++;
     }
 }
@@ -344,7 +398,7 @@ static inline MediumInteraction medium_sample_interaction(const Scene &sc, int m
     maxt = pm_min(ray.maxt, maxt);
     // get_combined_extinction(mi): mi.p is not initialised yet in the reference; the supported
     // homogeneous media read a constvolume, which ignores the position.
-    V3 combined = medium_combined_extinction(sc, m, ray.o);
+    Spec combined = medium_combined_extinction(sc, m, ray.o);
     float mext = idx(combined, channel);
     float sampled_t = mint + (-pm_log(1.f - sample) / mext);
     bool valid_mi = active && (sampled_t <= maxt);
@@ -353,7 +407,7 @@ static inline MediumInteraction medium_sample_interaction(const Scene &sc, int m
     mi.medium = medium;
     mi.mint = mint;
     if (valid_mi) medium_scattering_coefficients(sc, m, mi.p, &mi.sigma_s, &mi.sigma_n, &mi.sigma_t, cnt);
-    else mi.sigma_s = mi.sigma_n = mi.sigma_t = v3(0.f, 0.f, 0.f);      // eval_impl: `if (none(active)) return zero` (grid3d.cpp:228-229)
+    else mi.sigma_s = mi.sigma_n = mi.sigma_t = spec_s(0.f);            // eval_impl: `if (none(active)) return zero` (grid3d.cpp:228-229)
     if (!valid_mi && m.is_homogeneous) medium_scattering_coefficients(sc, m, mi.p, &mi.sigma_s, &mi.sigma_n, &mi.sigma_t, cnt);   // constvolume ignores the mask
     mi.combined_extinction = combined;
     return mi;
@@ -452,7 +506,7 @@ static inline void frame_sincos_phi(V3 v, float *s, float *c) {
     *s = ry; *c = rx;
 }
 // rpv.cpp:85-131
-static inline V3 eval_rpv(const Bsdf &b, V3 wi, V3 wo) {
+static inline Spec eval_rpv(const Bsdf &b, V3 wi, V3 wo) {
     float sin_phi1, cos_phi1, sin_phi2, cos_phi2;
     frame_sincos_phi(wi, &sin_phi1, &cos_phi1); frame_sincos_phi(wo, &sin_phi2, &cos_phi2);
     float cos_phi1_minus_phi2 = cos_phi1 * cos_phi2 + sin_phi1 * sin_phi2;
@@ -460,31 +514,39 @@ static inline V3 eval_rpv(const Bsdf &b, V3 wi, V3 wo) {
     float sin_theta2 = frame_sin_theta(wo), cos_theta2 = wo.z, tan_theta2 = frame_tan_theta(wo);
     float G = pm_safe_sqrt(tan_theta1 * tan_theta1 + tan_theta2 * tan_theta2 - 2.f * tan_theta1 * tan_theta2 * cos_phi1_minus_phi2);
     float cos_g = cos_theta1 * cos_theta2 + sin_theta1 * sin_theta2 * cos_phi1_minus_phi2;
-    float rho_0[3] = { b.rho_0.x, b.rho_0.y, b.rho_0.z }, rho_c[3] = { b.rho_c.x, b.rho_c.y, b.rho_c.z },
-          g[3] = { b.g.x, b.g.y, b.g.z }, k[3] = { b.k.x, b.k.y, b.k.z }, out[3];
-    for (int c = 0; c < 3; ++c) {
+    const Spec r0 = color_eval(b.rho_0), rc = color_eval(b.rho_c), gg = color_eval(b.g), kk = color_eval(b.k);
+#if MTS_SPEC_N == 3
+    float rho_0[3] = { r0.x, r0.y, r0.z }, rho_c[3] = { rc.x, rc.y, rc.z }, g[3] = { gg.x, gg.y, gg.z }, k[3] = { kk.x, kk.y, kk.z }, out[3];
+#else
+    float rho_0[4] = { r0.x, r0.y, r0.z, r0.w }, rho_c[4] = { rc.x, rc.y, rc.z, rc.w }, g[4] = { gg.x, gg.y, gg.z, gg.w }, k[4] = { kk.x, kk.y, kk.z, kk.w }, out[4];
+#endif
+    for (int c = 0; c < MTS_SPEC_N; ++c) {
         float F = (1.f - g[c] * g[c]) / pm_pow((1.f + g[c] * g[c] + 2.f * g[c] * cos_g), 1.5f);
         out[c] = rho_0[c] * (pm_pow(cos_theta1 * cos_theta2 * (cos_theta1 + cos_theta2), k[c] - 1.f) * F * (1.f + (1.f - rho_c[c]) / (1 + G))) * InvPi;
     }
+#if MTS_SPEC_N == 3
     return v3(out[0], out[1], out[2]);
+#else
+    return spec4(out[0], out[1], out[2], out[3]);
+#endif
 }
 // bilambertian.cpp:62-190: reflection and transmission lobes, both Lambertian, on both sides
 static inline float bilambertian_reflection_weight(const Bsdf &b) {
-    V3 r = b.reflectance, t = b.transmittance;
-    V3 q = r / (r + t);
-    return ((q.x + q.y) + q.z) * (1.f / 3.f);                                                         // hmean; NaN when r + t == 0: masked by the callers
+    Spec r = color_eval(b.reflectance), t = color_eval(b.transmittance);
+    Spec q = r / (r + t);
+    return spec_hmean(q);                                                                             // hmean; NaN when r + t == 0: masked by the callers
 }
-static V3 bsdf_eval(const Bsdf &b, const SurfaceInteraction &si, V3 wo) {
+static Spec bsdf_eval(const Bsdf &b, const SurfaceInteraction &si, V3 wo) {
     if (b.type == MTS_BSDF_BILAMBERTIAN) {                                                            // bilambertian.cpp:118-146
         bool same = std::signbit(si.wi.z) == std::signbit(wo.z);
-        return (same ? b.reflectance : b.transmittance) * (InvPi * pm_abs(wo.z));
+        return (same ? color_eval(b.reflectance) : color_eval(b.transmittance)) * (InvPi * pm_abs(wo.z));
     }
     float cos_theta_i = si.wi.z, cos_theta_o = wo.z;
     bool active = cos_theta_i > 0.f && cos_theta_o > 0.f;
     switch (b.type) {
-        case MTS_BSDF_DIFFUSE: return active ? b.reflectance * InvPi * cos_theta_o : v3(0, 0, 0);     // diffuse.cpp:106-120
-        case MTS_BSDF_RPV: return active ? eval_rpv(b, si.wi, wo) * pm_abs(cos_theta_o) : v3(0, 0, 0);   // rpv.cpp:133-142
-        default: return v3(0, 0, 0);                                                                  // null.cpp:60-63
+        case MTS_BSDF_DIFFUSE: return active ? color_eval(b.reflectance) * InvPi * cos_theta_o : spec_s(0.f);     // diffuse.cpp:106-120
+        case MTS_BSDF_RPV: return active ? eval_rpv(b, si.wi, wo) * pm_abs(cos_theta_o) : spec_s(0.f);   // rpv.cpp:133-142
+        default: return spec_s(0.f);                                                                  // null.cpp:60-63
     }
 }
 static float bsdf_pdf(const Bsdf &b, const SurfaceInteraction &si, V3 wo) {
@@ -501,7 +563,7 @@ static float bsdf_pdf(const Bsdf &b, const SurfaceInteraction &si, V3 wo) {
     float pdf = InvPi * wo.z;                                                                          // warp.h:343-350
     return (cos_theta_i > 0.f && cos_theta_o > 0.f) ? pdf : 0.f;                                      // diffuse.cpp:122-135, rpv.cpp:144-153
 }
-static V3 bsdf_sample(const Bsdf &b, const SurfaceInteraction &si, float sample1, P2 sample2, BSDFSample *bs) {
+static Spec bsdf_sample(const Bsdf &b, const SurfaceInteraction &si, float sample1, P2 sample2, BSDFSample *bs) {
     bs->wo = v3(0, 0, 0); bs->pdf = 0.f; bs->eta = 0.f; bs->sampled_type = 0;
     if (b.type == MTS_BSDF_BILAMBERTIAN) {                                                            // bilambertian.cpp:62-116
         V3 wo = square_to_cosine_hemisphere(sample2);
@@ -509,34 +571,34 @@ static V3 bsdf_sample(const Bsdf &b, const SurfaceInteraction &si, float sample1
         if (rw != rw) rw = 0.f;
         if (tw != tw) tw = 0.f;
         bool selected_r = sample1 < rw;
-        V3 value = selected_r ? v3(1.f, 1.f, 1.f) * (b.reflectance / rw) : v3(1.f, 1.f, 1.f) * (b.transmittance / tw);
+        Spec value = selected_r ? spec_s(1.f) * (color_eval(b.reflectance) / rw) : spec_s(1.f) * (color_eval(b.transmittance) / tw);
         bs->pdf = InvPi * wo.z;
         bs->pdf = selected_r ? bs->pdf * rw : bs->pdf * tw;
         bs->eta = 1.f;
         bs->sampled_type = selected_r ? F_DiffuseReflection : F_DiffuseTransmission;
         if (!(si.wi.z > 0.f)) wo.z = -wo.z;
         bs->wo = selected_r ? wo : v3(wo.x, wo.y, -wo.z);
-        return bs->pdf > 0.f ? value : v3(0, 0, 0);
+        return bs->pdf > 0.f ? value : spec_s(0.f);
     }
     if (b.type == MTS_BSDF_NULL) {                                                                    // null.cpp:41-58
         bs->wo = -si.wi; bs->sampled_type = F_Null; bs->eta = 1.f; bs->pdf = 1.f;
-        return v3(1.f, 1.f, 1.f);
+        return spec_s(1.f);
     }
     float cos_theta_i = si.wi.z;
     bool active = cos_theta_i > 0.f;
     if (b.type == MTS_BSDF_DIFFUSE) {                                                                 // diffuse.cpp:78-104
-        if (!active) return v3(0, 0, 0);
+        if (!active) return spec_s(0.f);
         bs->wo = square_to_cosine_hemisphere(sample2);
         bs->pdf = InvPi * bs->wo.z; bs->eta = 1.f; bs->sampled_type = F_DiffuseReflection;
-        return (bs->pdf > 0.f) ? b.reflectance : v3(0, 0, 0);
+        return (bs->pdf > 0.f) ? color_eval(b.reflectance) : spec_s(0.f);
     }
     // rpv.cpp:85-102 (fields are filled even when the lane is inactive)
     bs->wo = square_to_cosine_hemisphere(sample2);
     bs->pdf = InvPi * bs->wo.z; bs->eta = 1.f; bs->sampled_type = F_GlossyReflection;
-    V3 value = eval_rpv(b, si.wi, bs->wo);
-    return (active && bs->pdf > 0.f) ? value : v3(0, 0, 0);
+    Spec value = eval_rpv(b, si.wi, bs->wo);
+    return (active && bs->pdf > 0.f) ? value : spec_s(0.f);
 }
-static inline V3 bsdf_eval_null_transmission(const Bsdf &b) { return b.type == MTS_BSDF_NULL ? v3(1, 1, 1) : v3(0, 0, 0); }   // null.cpp:70-73, bsdf.cpp:11-14
+static inline Spec bsdf_eval_null_transmission(const Bsdf &b) { return b.type == MTS_BSDF_NULL ? spec_s(1.f) : spec_s(0.f); }   // null.cpp:70-73, bsdf.cpp:11-14
 
 // ---------------------------------------------------------------- emitters
 struct DirectionSample { V3 p, n, d; float pdf, dist; bool delta; int emitter; };
@@ -628,37 +690,37 @@ static inline float shape_pdf_direction(const Shape &s, V3 ref_p, const Directio
 }
 
 // directional.cpp:109-141, area.cpp:122-165, constant.cpp:81-111
-static inline DirectionSample emitter_sample_direction(const Scene &sc, int ei, V3 ref_p, P2 sample, V3 *spec) {
+static inline DirectionSample emitter_sample_direction(const Scene &sc, int ei, V3 ref_p, P2 sample, Spec *spec) {
     const Emitter &e = sc.emitters[ei];
     DirectionSample ds; memset(&ds, 0, sizeof(ds));
     if (e.type == MTS_EMITTER_DIRECTIONAL) {
         V3 d = xf_vector(e.to_world, v3(0.f, 0.f, 1.f));
         float dist = 2.f * e.bsphere_radius;
         ds.p = ref_p - d * dist; ds.n = d; ds.pdf = 1.f; ds.delta = true; ds.d = -d; ds.dist = dist;
-        *spec = e.radiance;
+        *spec = color_eval(e.radiance);
     } else if (e.type == MTS_EMITTER_CONSTANT) {
         V3 d = square_to_uniform_sphere(sample);
         float dist = 2.f * e.bsphere_radius;
         ds.p = ref_p + d * dist; ds.n = -d; ds.pdf = InvFourPi; ds.delta = false; ds.d = d; ds.dist = dist;
-        *spec = e.radiance / ds.pdf;
+        *spec = color_eval(e.radiance) / ds.pdf;
     } else if (e.type == MTS_EMITTER_POINT) {                                                // point.cpp:80-107
         ds.p = xf_translation(e.to_world); ds.n = v3(0, 0, 0); ds.pdf = 1.f; ds.delta = true;
         ds.d = ds.p - ref_p; ds.dist = norm(ds.d);
         float inv_dist = pm_rcp(ds.dist);
         ds.d = ds.d * inv_dist;
-        *spec = e.radiance * (inv_dist * inv_dist);
+        *spec = color_eval(e.radiance) * (inv_dist * inv_dist);
     } else {
         ds = shape_sample_direction(sc.shapes[e.shape], ref_p, sample);
         bool active = dot(ds.d, ds.n) < 0.f && ds.pdf != 0.f;
-        *spec = active ? e.radiance / ds.pdf : v3(0, 0, 0);
+        *spec = active ? color_eval(e.radiance) / ds.pdf : spec_s(0.f);
     }
     ds.emitter = ei;
     return ds;
 }
 // scene.cpp:168-218
-static inline DirectionSample sample_emitter_direction(const Scene &sc, V3 ref_p, P2 sample, bool test_visibility, V3 *spec) {
+static inline DirectionSample sample_emitter_direction(const Scene &sc, V3 ref_p, P2 sample, bool test_visibility, Spec *spec) {
     DirectionSample ds; memset(&ds, 0, sizeof(ds)); ds.emitter = -1;
-    if (sc.emitters.empty()) { *spec = v3(0, 0, 0); return ds; }
+    if (sc.emitters.empty()) { *spec = spec_s(0.f); return ds; }
     bool active = true;
     if (sc.emitters.size() == 1) ds = emitter_sample_direction(sc, 0, ref_p, sample, spec);
     else {
@@ -672,7 +734,7 @@ static inline DirectionSample sample_emitter_direction(const Scene &sc, V3 ref_p
     active = active && ds.pdf != 0.f;
     if (test_visibility && active) {
         Ray ray = make_ray(ref_p, ds.d, RayEpsilon * (1.f + hmax_abs(ref_p)), ds.dist * (1.f - ShadowEpsilon));
-        if (ray_test(sc, ray)) *spec = v3(0, 0, 0);
+        if (ray_test(sc, ray)) *spec = spec_s(0.f);
     }
     return ds;
 }
@@ -688,11 +750,11 @@ static inline float pdf_emitter_direction(const Scene &sc, V3 ref_p, const Direc
 }
 // area.cpp:63-71, constant.cpp:41-44, directional.cpp:75-78 ; si.emitter(scene), scene.h:243-253
 static inline int si_emitter(const Scene &sc, const SurfaceInteraction &si) { return si.is_valid() ? sc.shapes[si.shape].emitter : sc.environment; }
-static inline V3 emitter_eval(const Scene &sc, int ei, const SurfaceInteraction &si) {
+static inline Spec emitter_eval(const Scene &sc, int ei, const SurfaceInteraction &si) {
     const Emitter &e = sc.emitters[ei];
-    if (e.type == MTS_EMITTER_AREA) return si.wi.z > 0.f ? e.radiance : v3(0, 0, 0);
-    if (e.type == MTS_EMITTER_CONSTANT) return e.radiance;
-    return v3(0, 0, 0);
+    if (e.type == MTS_EMITTER_AREA) return si.wi.z > 0.f ? color_eval(e.radiance) : spec_s(0.f);
+    if (e.type == MTS_EMITTER_CONSTANT) return color_eval(e.radiance);
+    return spec_s(0.f);
 }
 // interaction.h:178-200
 static inline int target_medium(const Scene &sc, const SurfaceInteraction &si, V3 d) {
@@ -703,12 +765,18 @@ static inline int target_medium(const Scene &sc, const SurfaceInteraction &si, V
 // ---------------------------------------------------------------- integrators
 static inline float mis_weight(float pdf_a, float pdf_b) { pdf_a *= pdf_a; pdf_b *= pdf_b; return pdf_a > 0.0f ? pdf_a / (pdf_a + pdf_b) : 0.0f; }   // volpath.cpp:479-483
 
+// exp(-t * sigma) per channel (medium.cpp:84)
+#if MTS_SPEC_N == 3
+static inline Spec transmittance_exp(float t, Spec c) { return v3(pm_exp(-t * c.x), pm_exp(-t * c.y), pm_exp(-t * c.z)); }
+#else
+static inline Spec transmittance_exp(float t, Spec c) { return spec4(pm_exp(-t * c.x), pm_exp(-t * c.y), pm_exp(-t * c.z), pm_exp(-t * c.w)); }
+#endif
 // volpath.cpp:261-367
-static V3 volpath_sample_emitter(const Scene &sc, V3 ref_p, bool is_medium_interaction, Sampler &sampler, int medium, uint32_t channel, DirectionSample *ds_out, Counters *cnt) {
-    V3 transmittance = v3(1.f, 1.f, 1.f), emitter_val;
+static Spec volpath_sample_emitter(const Scene &sc, V3 ref_p, bool is_medium_interaction, Sampler &sampler, int medium, uint32_t channel, DirectionSample *ds_out, Counters *cnt) {
+    Spec transmittance = spec_s(1.f), emitter_val;
     DirectionSample ds = sample_emitter_direction(sc, ref_p, sampler.next_2d(), false, &emitter_val);
     *ds_out = ds;
-    if (ds.pdf == 0.f) return v3(0.f, 0.f, 0.f);
+    if (ds.pdf == 0.f) return spec_s(0.f);
     bool active = true;
     Ray ray = spawn_ray(ref_p, ds.d);
     if (is_medium_interaction) ray.mint = 0.f;
@@ -732,10 +800,10 @@ static V3 volpath_sample_emitter(const Scene &sc, V3 ref_p, bool is_medium_inter
             bool is_spectral = m.has_spectral_extinction, not_spectral = !is_spectral;
             if (is_spectral) {
                 float t = pm_min(remaining_dist, pm_min(mi.t, si.t)) - mi.mint;
-                V3 tr = v3(pm_exp(-t * mi.combined_extinction.x), pm_exp(-t * mi.combined_extinction.y), pm_exp(-t * mi.combined_extinction.z));
-                V3 free_flight_pdf = (si.t < mi.t || mi.t > remaining_dist) ? tr : tr * mi.combined_extinction;
+                Spec tr = transmittance_exp(t, mi.combined_extinction);
+                Spec free_flight_pdf = (si.t < mi.t || mi.t > remaining_dist) ? tr : tr * mi.combined_extinction;
                 float tr_pdf = idx(free_flight_pdf, channel);
-                transmittance = transmittance * (tr_pdf > 0.f ? tr / tr_pdf : v3(0.f, 0.f, 0.f));
+                transmittance = transmittance * (tr_pdf > 0.f ? tr / tr_pdf : spec_s(0.f));
             }
             if (mi.t > remaining_dist && mi.is_valid()) total_dist = ds.dist;
             if (mi.t > remaining_dist) mi.t = pm_inf();
@@ -766,9 +834,9 @@ static V3 volpath_sample_emitter(const Scene &sc, V3 ref_p, bool is_medium_inter
 }
 
 // volpath.cpp:370-465
-static V3 volpath_evaluate_direct_light(const Scene &sc, V3 ref_p, Sampler &sampler, int medium, Ray ray, const SurfaceInteraction &si_ray,
+static Spec volpath_evaluate_direct_light(const Scene &sc, V3 ref_p, Sampler &sampler, int medium, Ray ray, const SurfaceInteraction &si_ray,
                                         uint32_t channel, bool active, float *emitter_pdf_out, Counters *cnt) {
-    V3 emitter_val = v3(0.f, 0.f, 0.f), transmittance = v3(1.f, 1.f, 1.f);
+    Spec emitter_val = spec_s(0.f), transmittance = spec_s(1.f);
     bool needs_intersection = false;
     float emitter_pdf = 0.f;
     SurfaceInteraction si = si_ray;
@@ -784,10 +852,10 @@ static V3 volpath_evaluate_direct_light(const Scene &sc, V3 ref_p, Sampler &samp
             bool is_spectral = m.has_spectral_extinction, not_spectral = !is_spectral;
             if (is_spectral) {
                 float t = pm_min(mi.t, si.t) - mi.mint;                                       // medium.cpp:77-89
-                V3 tr = v3(pm_exp(-t * mi.combined_extinction.x), pm_exp(-t * mi.combined_extinction.y), pm_exp(-t * mi.combined_extinction.z));
-                V3 free_flight_pdf = si.t < mi.t ? tr : tr * mi.combined_extinction;
+                Spec tr = transmittance_exp(t, mi.combined_extinction);
+                Spec free_flight_pdf = si.t < mi.t ? tr : tr * mi.combined_extinction;
                 float tr_pdf = idx(free_flight_pdf, channel);
-                transmittance = transmittance * (tr_pdf > 0.f ? tr / tr_pdf : v3(0.f, 0.f, 0.f));
+                transmittance = transmittance * (tr_pdf > 0.f ? tr / tr_pdf : spec_s(0.f));
             }
             needs_intersection = false;
             escaped_medium = !mi.is_valid();
@@ -825,16 +893,20 @@ static V3 volpath_evaluate_direct_light(const Scene &sc, V3 ref_p, Sampler &samp
 }
 
 // volpath.cpp:38-257
-static V3 volpath_sample(const Scene &sc, Sampler &sampler, Ray ray, int medium, bool *valid_out, Counters *cnt) {
+static Spec volpath_sample(const Scene &sc, Sampler &sampler, Ray ray, int medium, bool *valid_out, Counters *cnt) {
     const uint32_t max_depth = (uint32_t) sc.integrator.max_depth, rr_depth = (uint32_t) sc.integrator.rr_depth;
     const bool hide_emitters = sc.integrator.hide_emitters != 0;
     bool valid_ray = !hide_emitters && sc.environment >= 0;
     float eta = 1.f;
-    V3 throughput = v3(1.f, 1.f, 1.f), result = v3(0.f, 0.f, 0.f);
+    Spec throughput = spec_s(1.f), result = spec_s(0.f);
     MediumInteraction mi; memset(&mi, 0, sizeof(mi)); mi.t = pm_inf();
     bool active = true, specular_chain = !hide_emitters;
     uint32_t depth = 0;
+#if MTS_SPEC_N == 3
     uint32_t channel = sc.integrator.monochrome ? 0u : (uint32_t) pm_min(sampler.next_1d() * 3.f, 2.f);   // volpath.cpp:63-67 (rgb variants only)
+#else
+    const uint32_t channel = 0;                                                                            // no draw outside the rgb variants
+#endif
     SurfaceInteraction si; memset(&si, 0, sizeof(si)); si.t = pm_inf(); si.shape = -1;
     bool needs_intersection = true;
     for (;;) {
@@ -859,10 +931,10 @@ static V3 volpath_sample(const Scene &sc, Sampler &sampler, Ray ray, int medium,
             if (si.t < mi.t) mi.t = pm_inf();
             if (is_spectral) {
                 float t = pm_min(mi.t, si.t) - mi.mint;                                       // medium.cpp:77-89
-                V3 tr = v3(pm_exp(-t * mi.combined_extinction.x), pm_exp(-t * mi.combined_extinction.y), pm_exp(-t * mi.combined_extinction.z));
-                V3 free_flight_pdf = si.t < mi.t ? tr : tr * mi.combined_extinction;
+                Spec tr = transmittance_exp(t, mi.combined_extinction);
+                Spec free_flight_pdf = si.t < mi.t ? tr : tr * mi.combined_extinction;
                 float tr_pdf = idx(free_flight_pdf, channel);
-                throughput = throughput * (tr_pdf > 0.f ? tr / tr_pdf : v3(0.f, 0.f, 0.f));
+                throughput = throughput * (tr_pdf > 0.f ? tr / tr_pdf : spec_s(0.f));
             }
             escaped_medium = !mi.is_valid();
             active_medium = mi.is_valid();
@@ -885,7 +957,7 @@ static V3 volpath_sample(const Scene &sc, Sampler &sampler, Ray ray, int medium,
             specular_chain = !sample_emitters;
             if (sample_emitters) {
                 DirectionSample ds;
-                V3 emitted = volpath_sample_emitter(sc, mi.p, true, sampler, medium, channel, &ds, cnt);
+                Spec emitted = volpath_sample_emitter(sc, mi.p, true, sampler, medium, channel, &ds, cnt);
                 float phase_val = phase_eval(sc, m.phase, mi, ds.d);
                 result = result + throughput * phase_val * emitted;
             }
@@ -909,15 +981,15 @@ static V3 volpath_sample(const Scene &sc, Sampler &sampler, Ray ray, int medium,
             bool active_e = (bsdf.flags & F_Smooth) != 0 && (depth + 1 < max_depth);
             if (active_e) {
                 DirectionSample ds;
-                V3 emitted = volpath_sample_emitter(sc, si.p, false, sampler, medium, channel, &ds, cnt);
+                Spec emitted = volpath_sample_emitter(sc, si.p, false, sampler, medium, channel, &ds, cnt);
                 V3 wo = si.to_local(ds.d);
-                V3 bsdf_val = bsdf_eval(bsdf, si, wo);
+                Spec bsdf_val = bsdf_eval(bsdf, si, wo);
                 float bpdf = bsdf_pdf(bsdf, si, wo);
                 result = result + throughput * bsdf_val * mis_weight(ds.pdf, ds.delta ? 0.f : bpdf) * emitted;
             }
             float s1 = sampler.next_1d(); P2 s2 = sampler.next_2d();
             BSDFSample bs;
-            V3 bsdf_val = bsdf_sample(bsdf, si, s1, s2, &bs);
+            Spec bsdf_val = bsdf_sample(bsdf, si, s1, s2, &bs);
             throughput = throughput * bsdf_val;
             eta *= bs.eta;
             ray = spawn_ray(si.p, si.to_world(bs.wo));
@@ -934,7 +1006,7 @@ static V3 volpath_sample(const Scene &sc, Sampler &sampler, Ray ray, int medium,
             if (intersect2) si_new = ray_intersect(sc, ray);
             needs_intersection = needs_intersection && !intersect2;
             float emitter_pdf;
-            V3 emitted = volpath_evaluate_direct_light(sc, si.p, sampler, medium, ray, si_new, channel, add_emitter, &emitter_pdf, cnt);
+            Spec emitted = volpath_evaluate_direct_light(sc, si.p, sampler, medium, ray, si_new, channel, add_emitter, &emitter_pdf, cnt);
             if (add_emitter && emitter_pdf != 0) result = result + mis_weight(bs.pdf, emitter_pdf) * throughput * emitted;
             if (shape.is_medium_transition()) medium = target_medium(sc, si, ray.d);
             if (intersect2) si = si_new;
@@ -945,6 +1017,7 @@ static V3 volpath_sample(const Scene &sc, Sampler &sampler, Ray ray, int medium,
     return result;
 }
 
+#if MTS_SPEC_N == 3         // volpathmis is restated for the rgb / mono variants only
 // ---------------------------------------------------------------- volpathmis
 // src/integrators/volpathmis.cpp: the volumetric path tracer with spectral multiple importance sampling.  WeightMatrix is a
 // 3 x 3 matrix (one row of probability ratios per colour channel) with `use_spectral_mis` (the default, :29,38-46), a single
@@ -1231,11 +1304,12 @@ static V3 volpathmis_sample(const Scene &sc, Sampler &sampler, Ray ray, int medi
     return result;
 }
 
+#endif // MTS_SPEC_N == 3
 // path.cpp:100-211
-static V3 path_sample(const Scene &sc, Sampler &sampler, Ray ray, bool *valid_out, Counters *cnt) {
+static Spec path_sample(const Scene &sc, Sampler &sampler, Ray ray, bool *valid_out, Counters *cnt) {
     const int max_depth = sc.integrator.max_depth, rr_depth = sc.integrator.rr_depth;
     float eta = 1.f, emission_weight = 1.f;
-    V3 throughput = v3(1.f, 1.f, 1.f), result = v3(0.f, 0.f, 0.f);
+    Spec throughput = spec_s(1.f), result = spec_s(0.f);
     bool active = true;
     SurfaceInteraction si = ray_intersect(sc, ray);
     bool valid_ray = si.is_valid();
@@ -1253,18 +1327,18 @@ static V3 path_sample(const Scene &sc, Sampler &sampler, Ray ray, bool *valid_ou
         const Bsdf &bsdf = sc.bsdf_of(sc.shapes[si.shape]);
         bool active_e = active && (bsdf.flags & F_Smooth);
         if (active_e) {
-            V3 emitter_val;
+            Spec emitter_val;
             DirectionSample ds = sample_emitter_direction(sc, si.p, sampler.next_2d(), true, &emitter_val);
             active_e = active_e && ds.pdf != 0.f;
             V3 wo = si.to_local(ds.d);
-            V3 bsdf_val = bsdf_eval(bsdf, si, wo);
+            Spec bsdf_val = bsdf_eval(bsdf, si, wo);
             float bpdf = bsdf_pdf(bsdf, si, wo);
             float mis = ds.delta ? 1.f : mis_weight(ds.pdf, bpdf);
             if (active_e) result = result + mis * throughput * bsdf_val * emitter_val;
         }
         float s1 = sampler.next_1d(); P2 s2 = sampler.next_2d();
         BSDFSample bs;
-        V3 bsdf_val = bsdf_sample(bsdf, si, s1, s2, &bs);
+        Spec bsdf_val = bsdf_sample(bsdf, si, s1, s2, &bs);
         throughput = throughput * bsdf_val;
         active = active && any_nonzero(throughput);
         if (!active) break;
@@ -1286,11 +1360,13 @@ static V3 path_sample(const Scene &sc, Sampler &sampler, Ray ray, bool *valid_ou
     return result;
 }
 
-static V3 integrator_sample(const Scene &sc, Sampler &sampler, Ray ray, int medium, bool *valid, Counters *cnt) {
+static Spec integrator_sample(const Scene &sc, Sampler &sampler, Ray ray, int medium, bool *valid, Counters *cnt) {
     switch (sc.integrator.type) {
         case MTS_INTEGRATOR_VOLPATH: return volpath_sample(sc, sampler, ray, medium, valid, cnt);
+#if MTS_SPEC_N == 3
         case MTS_INTEGRATOR_VOLPATHMIS: return sc.integrator.use_spectral_mis ? volpathmis_sample<true>(sc, sampler, ray, medium, valid, cnt)
                                                                              : volpathmis_sample<false>(sc, sampler, ray, medium, valid, cnt);
+#endif
         default: return path_sample(sc, sampler, ray, valid, cnt);
     }
 }
@@ -1479,6 +1555,27 @@ struct Spiral {
     }
 };
 
+#if MTS_SPEC_N != 3
+// cie1931_xyz + spectrum_to_xyz (core/spectrum.h:148-178,210-217): XYZ = hmean(cmf(lambda) * value); the 95-sample tables of
+// libcore/spectrum.cpp:110-189 (the published CIE 1931 standard observer, shared as data with the product: csrc/cie_tables.h)
+#include "../eradiate-kernel_amd/csrc/cie_tables.h"
+static inline void spectrum_to_xyz(Spec value, Spec wl, float xyz[3]) {
+    const float lam[4] = { wl.x, wl.y, wl.z, wl.w }, val[4] = { value.x, value.y, value.z, value.w };
+    float c[3][4];
+    for (int k = 0; k < 4; ++k) {
+        const float t = (lam[k] - 360.f) * ((95 - 1) / (830.f - 360.f));
+        const bool active = lam[k] >= 360.f && lam[k] <= 830.f;
+        const int i0 = std::min(std::max((int) t, 0), 95 - 2), i1 = i0 + 1;
+        const float w1 = t - (float) i0, w0 = 1.f - w1;
+        for (int a = 0; a < 3; ++a) {
+            const float cmf = active ? pm_fma(w0, MTS_CIE1931_XYZ[95 * a + i0], w1 * MTS_CIE1931_XYZ[95 * a + i1]) : 0.f;
+            c[a][k] = cmf * val[k];
+        }
+    }
+    for (int a = 0; a < 3; ++a) xyz[a] = spec_hmean(spec4(c[a][0], c[a][1], c[a][2], c[a][3]));
+}
+#endif
+
 // ---------------------------------------------------------------- render driver
 // integrator.cpp:233-288
 static void render_sample(const Scene &sc, Sampler &sampler, ImageBlock &block, float px, float py, Counters *cnt) {
@@ -1489,19 +1586,36 @@ static void render_sample(const Scene &sc, Sampler &sampler, ImageBlock &block, 
     if (se.needs_aperture_sample) aperture_sample = sampler.next_2d();
     if (se.shutter_open_time > 0.f) (void) sampler.next_1d();      // integrator.cpp:248-250: the time sample (nothing is animated)
     float wavelength_sample = sampler.next_1d(); (void) wavelength_sample;
+#if MTS_SPEC_N != 3
+    // Sensor::sample_ray -> sample_wavelength<Float, Spectrum> (perspective.cpp:169-172, distant.cpp:311-313; core/spectrum.h:305-314):
+    // math::sample_shifted (core/math.h:419-442), then sample_rgb_spectrum, which for MTS_WAVELENGTH_MIN / MAX = 280 / 2400 falls back
+    // to sample_uniform_spectrum -- written over the CIE range: lambda = s (830 - 360) + 360, weight 830 - 360 (:248-252,266-285)
+    float wav_weight = 830.f - 360.f;
+    {
+        float v[4];
+        for (int k = 0; k < 4; ++k) { float x = wavelength_sample + (float) k / 4.f; if (x > 1.f) x -= 1.f; v[k] = x * (830.f - 360.f) + 360.f; }
+        tls_wavelengths = spec4(v[0], v[1], v[2], v[3]);
+    }
+#endif
     P2 adjusted = { (position_sample.x - (float) se.crop_x) / (float) se.crop_w, (position_sample.y - (float) se.crop_y) / (float) se.crop_h };
     V3 ray_weight;
     Ray ray = sensor_sample_ray(sc, adjusted, aperture_sample, &ray_weight);
     bool valid;
+    float aovs[5];
+#if MTS_SPEC_N == 3
     V3 L = integrator_sample(sc, sampler, ray, se.medium, &valid, cnt);
     L = ray_weight * L;
     // srgb_to_xyz, spectrum.h:221-227 (matrix * vector = fmadd chain over columns)
-    float aovs[5];
     aovs[0] = pm_fma(0.180423f, L.z, pm_fma(0.357580f, L.y, 0.412453f * L.x));
     aovs[1] = pm_fma(0.072169f, L.z, pm_fma(0.715160f, L.y, 0.212671f * L.x));
     aovs[2] = pm_fma(0.950227f, L.z, pm_fma(0.119193f, L.y, 0.019334f * L.x));
     if (sc.integrator.monochrome)                              // integrator.cpp:270-271: xyz = spec_u.x()
         aovs[0] = aovs[1] = aovs[2] = L.x;
+#else
+    Spec L = integrator_sample(sc, sampler, ray, se.medium, &valid, cnt);
+    L = (wav_weight * ray_weight.x) * L;                       // ray_weight = wav_weight (x the sensor's grey weight), integrator.cpp:265
+    spectrum_to_xyz(L, tls_wavelengths, aovs);                 // integrator.cpp:266-269
+#endif
     aovs[3] = valid ? 1.f : 0.f;
     aovs[4] = 1.f;
     block.put(position_sample, aovs);
@@ -1616,7 +1730,7 @@ int oracle_sample(oracle_scene *s, int32_t n, uint64_t seed_offset, const float 
         Sampler sampler; sampler.base_seed = sc.sensor.seed; sampler.seed(seed_offset + (uint64_t) i);
         Ray ray = make_ray(v3(ox[i], oy[i], oz[i]), v3(dx[i], dy[i], dz[i]), RayEpsilon, pm_inf());
         bool valid;
-        V3 L = integrator_sample(sc, sampler, ray, sc.sensor.medium, &valid, nullptr);
+        Spec L = integrator_sample(sc, sampler, ray, sc.sensor.medium, &valid, nullptr);      // spectral build: at the wavelengths of oracle_set_wavelengths, first three entries
         out_rgb[3 * i] = L.x; out_rgb[3 * i + 1] = L.y; out_rgb[3 * i + 2] = L.z; out_valid[i] = valid;
     }
     _mm_setcsr(csr);
@@ -1706,7 +1820,7 @@ int oracle_bsdf_eval(oracle_scene *s, int bsdf, const float *wi, const float *wo
     ORC_TRY
     const Scene &sc = *((OracleScene *) s)->scene;
     SurfaceInteraction si; memset(&si, 0, sizeof(si)); si.wi = v3(wi[0], wi[1], wi[2]);
-    V3 v = bsdf_eval(sc.bsdfs[bsdf], si, v3(wo[0], wo[1], wo[2]));
+    Spec v = bsdf_eval(sc.bsdfs[bsdf], si, v3(wo[0], wo[1], wo[2]));
     value[0] = v.x; value[1] = v.y; value[2] = v.z; *pdf = bsdf_pdf(sc.bsdfs[bsdf], si, v3(wo[0], wo[1], wo[2]));
     ORC_CATCH
 }
@@ -1715,14 +1829,14 @@ int oracle_bsdf_sample(oracle_scene *s, int bsdf, const float *wi, float s1, flo
     const Scene &sc = *((OracleScene *) s)->scene;
     SurfaceInteraction si; memset(&si, 0, sizeof(si)); si.wi = v3(wi[0], wi[1], wi[2]);
     BSDFSample bs; P2 s2 = { s2x, s2y };
-    V3 w = bsdf_sample(sc.bsdfs[bsdf], si, s1, s2, &bs);
+    Spec w = bsdf_sample(sc.bsdfs[bsdf], si, s1, s2, &bs);
     wo[0] = bs.wo.x; wo[1] = bs.wo.y; wo[2] = bs.wo.z; *pdf = bs.pdf; weight[0] = w.x; weight[1] = w.y; weight[2] = w.z; *sampled_type = bs.sampled_type;
     ORC_CATCH
 }
 int oracle_volume_eval(oracle_scene *s, int volume, int n, const float *p, float *out) {
     ORC_TRY
     const Scene &sc = *((OracleScene *) s)->scene;
-    for (int i = 0; i < n; ++i) { V3 r = volume_eval(sc.volumes[volume], v3(p[3 * i], p[3 * i + 1], p[3 * i + 2])); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; }
+    for (int i = 0; i < n; ++i) { Spec r = volume_eval(sc.volumes[volume], v3(p[3 * i], p[3 * i + 1], p[3 * i + 2])); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; }
     ORC_CATCH
 }
 // sensor rays for given film positions (normalised film coordinates) and aperture samples
@@ -1740,11 +1854,38 @@ int oracle_sensor_sample_ray(oracle_scene *s, int n, const float *film_sample, c
 int oracle_emitter_sample_direction(oracle_scene *s, const float *ref_p, float u, float v, float *d, float *dist, float *pdf, float *spec) {
     ORC_TRY
     const Scene &sc = *((OracleScene *) s)->scene;
-    P2 smp = { u, v }; V3 sp;
+    P2 smp = { u, v }; Spec sp;
     DirectionSample ds = sample_emitter_direction(sc, v3(ref_p[0], ref_p[1], ref_p[2]), smp, false, &sp);
     d[0] = ds.d.x; d[1] = ds.d.y; d[2] = ds.d.z; *dist = ds.dist; *pdf = ds.pdf; spec[0] = sp.x; spec[1] = sp.y; spec[2] = sp.z;
     ORC_CATCH
 }
+// Spectral build: the wavelengths the hooks above evaluate at, and four-wide evaluations for the reference's spectral unit tests
+// (src/spectra/tests/test_uniform.py, test_regular.py, test_d65.py; src/textures/tests/test_gridvolume_spectral.py)
+int oracle_spec_n(void) { return MTS_SPEC_N; }
+#if MTS_SPEC_N != 3
+int oracle_set_wavelengths(const float *w) { tls_wavelengths = spec4(w[0], w[1], w[2], w[3]); return 0; }
+int oracle_spectrum_eval(oracle_scene *s, int spectrum, const float *w, float *out) {
+    ORC_TRY
+    const Scene &sc = *((OracleScene *) s)->scene;
+    if (spectrum < 0 || spectrum >= (int) sc.spectra.size()) throw std::runtime_error("spectrum index out of range");
+    tls_wavelengths = spec4(w[0], w[1], w[2], w[3]);
+    Spec r = color_eval(Color{ &sc.spectra[(size_t) spectrum] });
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+    ORC_CATCH
+}
+int oracle_volume_eval_spectral(oracle_scene *s, int volume, const float *p, const float *w, float *out) {
+    ORC_TRY
+    const Scene &sc = *((OracleScene *) s)->scene;
+    tls_wavelengths = spec4(w[0], w[1], w[2], w[3]);
+    Spec r = volume_eval(sc.volumes[volume], v3(p[0], p[1], p[2]));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+    ORC_CATCH
+}
+int oracle_spectrum_to_xyz(const float *value, const float *w, float *xyz) {
+    spectrum_to_xyz(spec4(value[0], value[1], value[2], value[3]), spec4(w[0], w[1], w[2], w[3]), xyz);
+    return 0;
+}
+#endif
 // DiscreteDistribution / ContinuousDistribution hooks for the literals of src/libcore/tests/test_distr_1d.py
 int oracle_discrete_distribution(const float *pmf, int n, const float *samples, int m, int32_t *index, float *reuse, float *pmf_norm,
                                  float *cdf_out /* n */, float *sum_norm /* 2 */) {

@@ -50,6 +50,36 @@ static inline V3 vrcp(V3 a) { return v3(1.0f / a.x, 1.0f / a.y, 1.0f / a.z); }
 static inline float idx(V3 a, uint32_t i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 static inline bool any_nonzero(V3 a) { return a.x != 0.f || a.y != 0.f || a.z != 0.f; }
 
+// ---- The spectrum type of the variant this library is compiled for (oracle/Makefile): liboracle.so = rgb / mono, three channels
+// (Color3f; Spec is V3 itself), liboracle_spectral.so (-DMTS_SPEC_N=4) = the semantics of scalar_spectral, Spectrum<Float, 4>
+// (core/spectrum.h:57-73): four wavelengths, .x the one index_spectrum follows outside the rgb variants (volpath.cpp:26-36).
+// The wavelengths of the sample in flight (ray.wavelengths / si.wavelengths in the reference) live in a thread-local: every
+// oracle thread renders one sample at a time, and it spares each texture evaluation an argument.
+#ifndef MTS_SPEC_N
+#define MTS_SPEC_N 3
+#endif
+#if MTS_SPEC_N == 3
+typedef V3 Spec;
+static inline Spec spec_s(float v) { return v3(v, v, v); }
+static inline float spec_hmean(Spec a) { return ((a.x + a.y) + a.z) * (1.f / 3.f); }
+#else
+struct Spec { float x, y, z, w; };
+static inline Spec spec4(float x, float y, float z, float w) { Spec r = { x, y, z, w }; return r; }
+static inline Spec spec_s(float v) { return spec4(v, v, v, v); }
+static inline Spec operator+(Spec a, Spec b) { return spec4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+static inline Spec operator-(Spec a, Spec b) { return spec4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+static inline Spec operator*(Spec a, float s) { return spec4(a.x * s, a.y * s, a.z * s, a.w * s); }
+static inline Spec operator*(float s, Spec a) { return spec4(a.x * s, a.y * s, a.z * s, a.w * s); }
+static inline Spec operator*(Spec a, Spec b) { return spec4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+static inline Spec operator/(Spec a, float s) { float r = 1.0f / s; return spec4(a.x * r, a.y * r, a.z * r, a.w * r); }   // as for V3: reciprocal, then multiply
+static inline Spec operator/(Spec a, Spec b) { return spec4(a.x / b.x, a.y / b.y, a.z / b.z, a.w / b.w); }
+static inline float hmax(Spec a) { return pm_max(pm_max(a.x, a.y), pm_max(a.z, a.w)); }
+static inline float idx(Spec a, uint32_t) { return a.x; }
+static inline bool any_nonzero(Spec a) { return a.x != 0.f || a.y != 0.f || a.z != 0.f || a.w != 0.f; }
+static inline float spec_hmean(Spec a) { return ((a.x + a.y) + (a.z + a.w)) * 0.25f; }    // enoki hmean of a 4-array: pairwise sum (enoki absent: decision)
+static thread_local Spec tls_wavelengths = { 0.f, 0.f, 0.f, 0.f };
+#endif
+
 // math constants, include/mitsuba/core/math.h:13-38
 static const float Pi = 3.14159265358979323846f;
 static const float InvPi = 0.31830988618379067154f;

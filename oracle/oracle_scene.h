@@ -5,6 +5,7 @@
 // plugins hold after construction.  Citations are relative to /root/reference.
 #pragma once
 #include <vector>
+#include <deque>
 #include <string>
 #include <stdexcept>
 #include <algorithm>
@@ -15,12 +16,38 @@ namespace orc {
 
 static inline Xf xf_from_abi(const mts_transform &t) { Xf x; memcpy(x.m, t.matrix, 64); memcpy(x.it, t.inverse_transpose, 64); return x; }
 
+// ---------------------------------------------------------------- colour parameters of plugins
+// rgb / mono: the colour itself.  Spectral: the plugin's spectrum texture (spectra/uniform.cpp, spectra/regular.cpp; d65 arrives
+// expanded to regular), evaluated at the wavelengths of the sample in flight.
+#if MTS_SPEC_N == 3
+typedef V3 Color;
+static inline Spec color_eval(const Color &c) { return c; }
+#else
+struct SpectrumRec { int type; float value, lambda_min, lambda_max; std::vector<float> values; float inv_interval_size; };
+struct Color { const SpectrumRec *s; };
+// uniform.cpp:47-57 ; regular.cpp:71-78 -> ContinuousDistribution::eval_pdf (distr_1d.h:378-400)
+static inline float spectrum_eval_1(const SpectrumRec &s, float lambda) {
+    const bool active = lambda >= s.lambda_min && lambda <= s.lambda_max;
+    if (s.type == MTS_SPECTRUM_UNIFORM) return active ? s.value : 0.f;
+    float x = (lambda - s.lambda_min) * s.inv_interval_size;
+    uint32_t index = (uint32_t) std::min(std::max((int64_t) x, (int64_t) 0), (int64_t) s.values.size() - 2);
+    float y0 = active ? s.values[index] : 0.f, y1 = active ? s.values[index + 1] : 0.f;
+    float w1 = x - (float) index, w0 = 1.f - w1;
+    return pm_fma(w0, y0, w1 * y1);
+}
+static inline Spec color_eval(const Color &c) {
+    const Spec wl = tls_wavelengths;
+    return spec4(spectrum_eval_1(*c.s, wl.x), spectrum_eval_1(*c.s, wl.y), spectrum_eval_1(*c.s, wl.z), spectrum_eval_1(*c.s, wl.w));
+}
+#endif
+
 // ---------------------------------------------------------------- Volume
 // include/mitsuba/render/texture.h:210-279, src/librender/texture.cpp:89-92,
 // src/textures/constant3d.cpp, src/textures/grid3d.cpp:131-161,362
 struct Volume {
     int type;
-    V3 value;
+    Color value;
+    bool spectral_grid = false; float lambda_min = 0.f, lambda_max = 0.f;      // gridvolume_spectral.cpp:186-190
     Xf world_to_local;
     BBox bbox;
     const float *data;
@@ -32,15 +59,28 @@ struct Volume {
 static inline Volume make_volume(const mts_volume &d) {
     Volume v = {};
     v.type = d.type;
+#if MTS_SPEC_N == 3
     v.value = v3(d.value[0], d.value[1], d.value[2]);
+    if (d.type == MTS_VOLUME_GRID_SPECTRAL) throw std::runtime_error("This volume data source can only be used with a spectral variant!");   // gridvolume_spectral.cpp:86-88
+#else
+    v.value.s = nullptr;                                                 // set by make_scene (needs the scene's spectra)
+    if (d.type == MTS_VOLUME_GRID_SPECTRAL) {
+        if (d.filter_type != MTS_FILTER_TRILINEAR) throw std::runtime_error("Invalid filter type, must be \"trilinear\"!");
+        v.type = MTS_VOLUME_GRID; v.spectral_grid = true; v.lambda_min = d.lambda_min; v.lambda_max = d.lambda_max;
+    }
+#endif
     v.world_to_local = xf_inverse(xf_from_abi(d.to_world));           // texture.cpp:90
     v.has_max = false;
-    if (d.type == MTS_VOLUME_GRID) {
+    if (v.type == MTS_VOLUME_GRID) {
         if (!d.data) throw std::runtime_error("gridvolume: missing data");
         if ((long) d.nx * d.ny * d.nz < 8)                                // volume_data.h:70-73
             throw std::runtime_error("Invalid grid dimensions (must have at least one value at each corner)");
-        if (d.channels != 1 && d.channels != 3)                           // grid3d.cpp:115-116
+        if (!v.spectral_grid && d.channels != 1 && d.channels != 3)       // grid3d.cpp:115-116
             throw std::runtime_error("Unsupported channel count (expected 1 or 3)");
+#if MTS_SPEC_N != 3
+        if (!v.spectral_grid && d.channels != 1)
+            throw std::runtime_error("spectral variant: 3-channel grids need the sRGB upsampling model (ext/rgb2spec data, absent); use gridvolume_spectral");
+#endif
         v.data = d.data; v.nx = d.nx; v.ny = d.ny; v.nz = d.nz; v.channels = d.channels;
         v.filter = d.filter_type; v.wrap = d.wrap_mode;
         float mx = -pm_inf();                                             // volume_data.h:86-98
@@ -161,7 +201,7 @@ struct Medium {
 };
 
 // ---------------------------------------------------------------- BSDF
-struct Bsdf { int type; V3 reflectance, rho_0, k, g, rho_c; uint32_t flags; V3 transmittance; };
+struct Bsdf { int type; Color reflectance, rho_0, k, g, rho_c; uint32_t flags; Color transmittance; };
 // bsdf.h:38-124
 enum : uint32_t { F_Null = 0x1, F_DiffuseReflection = 0x2, F_DiffuseTransmission = 0x4, F_GlossyReflection = 0x8,
                   F_GlossyTransmission = 0x10, F_DeltaReflection = 0x20, F_DeltaTransmission = 0x40,
@@ -314,7 +354,7 @@ static inline Shape make_shape(const mts_shape &d) {
 
 // ---------------------------------------------------------------- Emitter
 struct Emitter {
-    int type; Xf to_world; V3 radiance; int shape;
+    int type; Xf to_world; Color radiance; int shape;
     V3 bsphere_center; float bsphere_radius;    // directional.cpp:68-73, constant.cpp:35-39
     bool is_environment() const { return type == MTS_EMITTER_CONSTANT; }
 };
@@ -403,6 +443,9 @@ struct Scene {
     mts_integrator integrator;
     BBox bbox;
     std::vector<Prim> prims;
+#if MTS_SPEC_N != 3
+    std::deque<SpectrumRec> spectra;                                   // stable addresses: the colour parameters point at them
+#endif
     Bsdf default_bsdf, default_emitter_bsdf;
     const Bsdf &bsdf_of(const Shape &s) const {
         if (s.bsdf >= 0) return bsdfs[s.bsdf];
@@ -426,7 +469,47 @@ static inline Scene *make_scene(const mts_scene_desc *d) {
     if (!d || d->abi_version != MTS_ABI_VERSION) throw std::runtime_error("scene description: ABI version mismatch");
     Scene *sc = new Scene();
     try {
-        for (int i = 0; i < d->volume_count; ++i) sc->volumes.push_back(make_volume(d->volumes[i]));
+#if MTS_SPEC_N == 3
+        if (d->integrator.spectral) throw std::runtime_error("liboracle.so is the rgb / mono build; spectral scenes need liboracle_spectral.so");
+#else
+        if (!d->integrator.spectral) throw std::runtime_error("liboracle_spectral.so renders scenes of the spectral variant only");
+        if (d->integrator.type == MTS_INTEGRATOR_VOLPATHMIS) throw std::runtime_error("volpathmis is not restated for the spectral variant");
+        for (int i = 0; i < d->spectrum_count; ++i) {                      // uniform.cpp:34-52, regular.cpp:27-58 + distr_1d.h:318-345
+            const mts_spectrum &sp = d->spectra[i];
+            SpectrumRec r; r.type = sp.type; r.value = sp.value; r.lambda_min = sp.lambda_min; r.lambda_max = sp.lambda_max; r.inv_interval_size = 0.f;
+            if (sp.type == MTS_SPECTRUM_UNIFORM) {
+                r.lambda_min = std::max(sp.lambda_min, 280.f); r.lambda_max = std::min(sp.lambda_max, 2400.f);      // MTS_WAVELENGTH_MIN / MAX
+                if (!(r.lambda_min < r.lambda_max)) throw std::runtime_error("UniformSpectrum: 'lambda_min' must be less than 'lambda_max'");
+            } else if (sp.type == MTS_SPECTRUM_REGULAR) {
+                if (!(sp.lambda_min < sp.lambda_max)) throw std::runtime_error("ContinuousDistribution: invalid range!");
+                if (sp.count < 2 || !sp.values) throw std::runtime_error("ContinuousDistribution: needs at least two entries!");
+                bool mass = false;
+                for (int k = 0; k < sp.count; ++k) { if (sp.values[k] < 0.f) throw std::runtime_error("ContinuousDistribution: entries must be non-negative!"); mass = mass || sp.values[k] > 0.f; }
+                if (!mass) throw std::runtime_error("ContinuousDistribution: no probability mass found!");
+                r.values.assign(sp.values, sp.values + sp.count);
+                r.inv_interval_size = (float) (1. / ((double(sp.lambda_max) - double(sp.lambda_min)) / (sp.count - 1)));
+            } else throw std::runtime_error("unknown spectrum type");
+            sc->spectra.push_back(r);
+        }
+        sc->spectra.push_back(SpectrumRec{ MTS_SPECTRUM_UNIFORM, .5f, 280.f, 2400.f, {}, 0.f });      // default BSDF reflectance (shape.cpp:74-80)
+        sc->spectra.push_back(SpectrumRec{ MTS_SPECTRUM_UNIFORM, 0.f, 280.f, 2400.f, {}, 0.f });
+#endif
+        auto color3 = [&](const float *rgb, int sp, bool used) -> Color {
+#if MTS_SPEC_N == 3
+            (void) sp; (void) used; return v3(rgb[0], rgb[1], rgb[2]);
+#else
+            (void) rgb;
+            if (!used) return Color{ &sc->spectra.back() };
+            if (sp < 0 || sp >= d->spectrum_count) throw std::runtime_error("spectral variant: missing spectrum for a colour parameter");
+            return Color{ &sc->spectra[(size_t) sp] };
+#endif
+        };
+        for (int i = 0; i < d->volume_count; ++i) {
+            sc->volumes.push_back(make_volume(d->volumes[i]));
+#if MTS_SPEC_N != 3
+            if (d->volumes[i].type == MTS_VOLUME_CONST) sc->volumes.back().value = color3(nullptr, d->volumes[i].value_spectrum, true);
+#endif
+        }
         for (int i = 0; i < d->phase_count; ++i) {
             sc->phases.push_back(make_phase(d->phases[i]));
             if (d->phases[i].type == MTS_PHASE_BLEND) {
@@ -457,15 +540,25 @@ static inline Scene *make_scene(const mts_scene_desc *d) {
             const mts_bsdf &b = d->bsdfs[i];
             Bsdf bs = {};
             bs.type = b.type;
-            bs.reflectance = v3(b.reflectance[0], b.reflectance[1], b.reflectance[2]);
-            bs.rho_0 = v3(b.rho_0[0], b.rho_0[1], b.rho_0[2]); bs.k = v3(b.k[0], b.k[1], b.k[2]);
-            bs.g = v3(b.g[0], b.g[1], b.g[2]); bs.rho_c = v3(b.rho_c[0], b.rho_c[1], b.rho_c[2]);
+            static const bool used[4][6] = { { 1, 0, 0, 0, 0, 0 } /* diffuse */, { 0, 0, 0, 0, 0, 0 } /* null */, { 0, 1, 1, 1, 1, 0 } /* rpv */, { 1, 0, 0, 0, 0, 1 } /* bilambertian */ };
+            if (b.type < MTS_BSDF_DIFFUSE || b.type > MTS_BSDF_BILAMBERTIAN) throw std::runtime_error("unknown BSDF type");
+            bs.reflectance = color3(b.reflectance, b.spectrum[0], used[b.type][0]);
+            bs.rho_0 = color3(b.rho_0, b.spectrum[1], used[b.type][1]); bs.k = color3(b.k, b.spectrum[2], used[b.type][2]);
+            bs.g = color3(b.g, b.spectrum[3], used[b.type][3]); bs.rho_c = color3(b.rho_c, b.spectrum[4], used[b.type][4]);
             bs.flags = bsdf_flags(b.type);
-            bs.transmittance = v3(b.transmittance[0], b.transmittance[1], b.transmittance[2]);
+            bs.transmittance = color3(b.transmittance, b.spectrum[5], used[b.type][5]);
             sc->bsdfs.push_back(bs);
         }
+#if MTS_SPEC_N == 3
         sc->default_bsdf = Bsdf{ MTS_BSDF_DIFFUSE, v3(.5f, .5f, .5f), {}, {}, {}, {}, bsdf_flags(MTS_BSDF_DIFFUSE) };
         sc->default_emitter_bsdf = Bsdf{ MTS_BSDF_DIFFUSE, v3(0.f, 0.f, 0.f), {}, {}, {}, {}, bsdf_flags(MTS_BSDF_DIFFUSE) };
+#else
+        {
+            const SpectrumRec *half = &sc->spectra[sc->spectra.size() - 2], *zero = &sc->spectra[sc->spectra.size() - 1];
+            sc->default_bsdf = Bsdf{ MTS_BSDF_DIFFUSE, Color{ half }, Color{ half }, Color{ half }, Color{ half }, Color{ half }, bsdf_flags(MTS_BSDF_DIFFUSE), Color{ half } };
+            sc->default_emitter_bsdf = Bsdf{ MTS_BSDF_DIFFUSE, Color{ zero }, Color{ zero }, Color{ zero }, Color{ zero }, Color{ zero }, bsdf_flags(MTS_BSDF_DIFFUSE), Color{ zero } };
+        }
+#endif
         sc->bbox = bbox_empty();
         for (int i = 0; i < d->shape_count; ++i) {
             const mts_shape &s = d->shapes[i];
@@ -482,7 +575,7 @@ static inline Scene *make_scene(const mts_scene_desc *d) {
             const mts_emitter &e = d->emitters[i];
             Emitter em = {};
             em.type = e.type; em.to_world = xf_from_abi(e.to_world);
-            em.radiance = v3(e.radiance[0], e.radiance[1], e.radiance[2]); em.shape = e.shape;
+            em.radiance = color3(e.radiance, e.radiance_spectrum, true); em.shape = e.shape;
             if (e.type == MTS_EMITTER_AREA) {
                 check_index(e.shape, d->shape_count, "area emitter shape", false);
                 if ((sc->shapes[e.shape].type == MTS_SHAPE_CUBE || sc->shapes[e.shape].type == MTS_SHAPE_MESH) && sc->shapes[e.shape].area_distr.valid_x == (uint32_t) -1)

@@ -73,6 +73,31 @@ def lib_libm():
     return _lib_libm
 
 
+_lib_spectral = None
+
+
+def lib_spectral():
+    """oracle/liboracle_spectral.so: the restatement compiled for the spectral variant (Spectrum<Float, 4>, scalar_spectral semantics)."""
+    global _lib_spectral
+    if _lib_spectral is None:
+        path = os.path.join(ROOT, "oracle", "liboracle_spectral.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle_spectral.so"], stdout=subprocess.DEVNULL)
+        L = C.CDLL(path)
+        L.oracle_last_error.restype = C.c_char_p
+        L.oracle_scene_create.argtypes = [C.POINTER(A.SceneDesc), C.POINTER(C.c_void_p)]
+        L.oracle_scene_destroy.argtypes = [C.c_void_p]
+        L.oracle_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, fp, C.POINTER(A.Stats)]
+        L.oracle_spectrum_eval.argtypes = [C.c_void_p, C.c_int, fp, fp]
+        L.oracle_volume_eval_spectral.argtypes = [C.c_void_p, C.c_int, fp, fp, fp]
+        L.oracle_spectrum_to_xyz.argtypes = [fp, fp, fp]
+        L.oracle_set_wavelengths.argtypes = [fp]
+        L.oracle_bsdf_eval.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, fp]
+        assert L.oracle_spec_n() == 4
+        _lib_spectral = L
+    return _lib_spectral
+
+
 def _check(status, L=None):
     if status != 0:
         raise RuntimeError((L or lib()).oracle_last_error().decode())
@@ -89,11 +114,11 @@ def _p(a):
 class OracleScene:
     """Scene built from a Mitsuba-style dict (or a ready SceneDesc) and rendered by the CPU restatement."""
 
-    def __init__(self, scene_dict=None, desc=None, keep=None, mono=False, libm=False):
+    def __init__(self, scene_dict=None, desc=None, keep=None, mono=False, libm=False, spectral=False):
         if desc is None:
-            desc, keep = SD.build_scene_desc(scene_dict, mono=mono)
+            desc, keep = SD.build_scene_desc(scene_dict, mono=mono, spectral=spectral)
         self.desc, self.keep = desc, keep
-        self.L = lib_libm() if libm else lib()
+        self.L = lib_spectral() if spectral else (lib_libm() if libm else lib())
         h = C.c_void_p()
         _check(self.L.oracle_scene_create(C.byref(desc), C.byref(h)), self.L)
         self.h = h
@@ -115,6 +140,17 @@ class OracleScene:
         threads = threads or os.cpu_count() or 1
         _check(self.L.oracle_render(self.h, threads, shard_index, shard_count, _p(out), C.byref(st)), self.L)
         self.last_stats = {k: getattr(st, k) for k, _ in A.Stats._fields_}
+        return out
+
+    # ---- spectral build only
+    def spectrum_eval(self, spectrum, wavelengths):
+        w = _f(wavelengths); out = np.zeros(4, np.float32)
+        _check(self.L.oracle_spectrum_eval(self.h, spectrum, _p(w), _p(out)), self.L)
+        return out
+
+    def volume_eval_spectral(self, volume, p, wavelengths):
+        w = _f(wavelengths); q = _f(p); out = np.zeros(4, np.float32)
+        _check(self.L.oracle_volume_eval_spectral(self.h, volume, _p(q), _p(w), _p(out)), self.L)
         return out
 
     def sample(self, origins, directions, seed_offset=0):

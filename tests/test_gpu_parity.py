@@ -710,3 +710,62 @@ def test_tea_and_wavefront_sampler_on_device(gpu_rgb):
     L.oracle_wavefront_sampler.argtypes = [C.c_int, C.c_uint64, C.c_int, ob.fp]
     L.oracle_wavefront_sampler(300, 7, 16, ob._p(ref))
     assert np.array_equal(streams, ref) and len(np.unique(streams[:, 0])) > 290
+
+
+# ---------------------------------------------------------------- spectral variant
+@pytest.fixture(scope="module")
+def gpu_spectral(pkg):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    pkg.set_variant("gpu_spectral")
+    yield pkg
+    pkg.set_variant("gpu_rgb")
+
+
+def _spectral_cases():
+    rng = np.random.default_rng(3)
+    def slab(spp=8, **kw):
+        d = scenes.c2_homogeneous_slab(40, 24, spp, **kw)
+        d["sun"]["irradiance"] = {"type": "uniform", "value": 1.5, "lambda_min": 380., "lambda_max": 780.}
+        d["ground"]["bsdf"]["reflectance"] = {"type": "regular", "lambda_min": 400., "lambda_max": 800., "values": "0.2, 0.9, 0.4"}
+        return d
+    cases = {"slab_regular_reflectance": slab()}
+    d = slab(phase={"type": "hg", "g": 0.6})
+    d["slab"]["interior"]["sigma_t"] = {"type": "regular", "lambda_min": 300., "lambda_max": 900., "values": [2.0, 1.0, 0.5, 0.25]}    # chromatic extinction
+    d["slab"]["interior"]["albedo"] = {"type": "uniform", "value": 0.9}
+    cases["slab_chromatic_medium"] = d
+    d = scenes.c3_heterogeneous(32, 24, 8, res=8)
+    grid = (0.2 + rng.random((6, 5, 4, 7), dtype=np.float32)).astype(np.float32)            # nz, ny, nx, 7 spectral nodes
+    xf = T.translate([-50, -50, 0]) @ T.scale([100, 100, 2])
+    # lambda_min = 0: see tests/test_spectral.py::test_gridvolume_spectral_eval for the mask the plugin applies
+    d["slab"]["interior"]["sigma_t"] = {"type": "gridvolume_spectral", "data": grid, "lambda_min": 0., "lambda_max": 1000., "to_world": xf}
+    d["slab"]["interior"]["albedo"] = {"type": "gridvolume", "data": np.full((4, 4, 4), 0.85, np.float32), "to_world": xf}
+    d["sun"]["irradiance"] = None
+    del d["sun"]["irradiance"]                                                                # default: D65
+    d["ground"]["bsdf"] = {"type": "rpv", "rho_0": {"type": "uniform", "value": 0.2}, "k": 0.7, "g": -0.1}
+    cases["grid_spectral_d65_rpv"] = d
+    d = scenes.c1_cornell(32, 32, 8)
+    for k, v in d.items():
+        if isinstance(v, dict) and "bsdf" in v:
+            rgb = v["bsdf"]["reflectance"]["value"]
+            v["bsdf"]["reflectance"] = {"type": "regular", "lambda_min": 400., "lambda_max": 700., "values": [rgb[2], rgb[1], rgb[0]]}
+    d["light"]["emitter"]["radiance"] = {"type": "d65", "scale": 3.0}
+    cases["cornell_path"] = d
+    d = scenes.c4_atmosphere(16, 16, 8, layers=8)
+    d["sun"]["irradiance"] = {"type": "uniform", "value": 1.0}
+    cases["c4_atmosphere"] = d
+    return cases
+
+
+@pytest.mark.parametrize("name", ["slab_regular_reflectance", "slab_chromatic_medium", "grid_spectral_d65_rpv", "cornell_path", "c4_atmosphere"])
+def test_spectral_variant_against_oracle(gpu_spectral, name):
+    """gpu_spectral (kernels_spectral.hip: Spectrum<Float, 4>, sample_wavelength, spectrum_to_xyz) against liboracle_spectral.so on the
+    same seeded inputs: the films and the loop counters are identical."""
+    d = _spectral_cases()[name]
+    gpu, st = gpu_render(gpu_spectral, d, collect_counters=True)
+    o = ob.OracleScene(d, spectral=True)
+    ref = o.render()
+    assert ref[..., :3].max() > 0
+    assert_parity(gpu, ref)
+    assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (o.last_stats["n_iter"], o.last_stats["n_lookup"], o.last_stats["n_nee_step"])

@@ -115,7 +115,7 @@ def test_volume_file_roundtrip(tmp_path):
 
 
 def test_variant_handling():
-    assert pkg.variants() == ["gpu_rgb", "gpu_mono"]
+    assert pkg.variants() == ["gpu_rgb", "gpu_mono", "gpu_spectral"]
     with pytest.raises(ImportError):
         pkg.set_variant("scalar_rgb")          # only the HIP backend exists; no CPU path in the product
 
