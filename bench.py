@@ -30,7 +30,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
-CONFIG_SIZES = {"C1": (256, 256, 64), "C2": (512, 512, 256), "C3": (512, 512, 1024), "C4": (1024, 1024, 4096), "C5": (1024, 1024, 4096)}
+CONFIG_SIZES = {"C1": (256, 256, 64), "C2": (512, 512, 256), "C3": (512, 512, 1024), "C4": (1024, 1024, 4096), "C5": (1024, 1024, 4096),
+                "C5S": (1024, 1024, 256)}     # C5S: the same atmosphere in the spectral variant (gpu_spectral, per-lane kernel), 256 spp
 C5_WAVELENGTHS = 16        # BASELINE.json configs[4]: the C4 atmosphere as a 16-wavelength batch
 
 
@@ -49,6 +50,8 @@ def build_scene_dict(scenes, config, width, height, spp, samples_per_pass=-1, re
         d = scenes.c4_atmosphere(width, height, spp)
     elif config == "C5":
         d = scenes.c4_atmosphere(width, height, spp, rayleigh_scale=c5_rayleigh_scale(wavelength))
+    elif config == "C5S":
+        d = scenes.c5_atmosphere_spectral(width, height, spp)
     else:
         d = scenes.c3_heterogeneous(width, height, spp, res=res)
     d["integrator"]["samples_per_pass"] = samples_per_pass
@@ -61,7 +64,8 @@ class Job:
     def __init__(self, pkg, scenes, args, rank, n, local_rank, backend, spp_total, samples_per_pass):
         import torch
         self.torch, self.rank, self.n, self.backend = torch, rank, n, backend
-        variant = "gpu_mono" if args.config == "C5" else "gpu_rgb"      # C5: monochromatic batches (scalar_mono semantics), one per wavelength
+        # C5: monochromatic batches (scalar_mono semantics), one per wavelength; C5S: the spectral variant
+        variant = {"C5": "gpu_mono", "C5S": "gpu_spectral"}.get(args.config, "gpu_rgb")
         pkg.set_variant(variant)
         self.dicts = [build_scene_dict(scenes, args.config, args.width, args.height, spp_total, samples_per_pass, args.res, k)
                       for k in range(C5_WAVELENGTHS if args.config == "C5" else 1)]
@@ -201,7 +205,7 @@ def main():
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
     integ_type = job.dicts[0]["integrator"]["type"]
     kv = os.environ.get("MTSAMD_KERNEL", "wga1024")
-    if integ_type == "path" or kv == "nested":
+    if integ_type == "path" or kv == "nested" or args.config == "C5S":
         kernel_name = "render_kernel<false, false, %d>" % {"path": 0, "volpath": 1, "volpathmis": 2}.get(integ_type, 0)
     elif kv == "flat":
         kernel_name = "render_kernel<false, true, 1>"
@@ -253,7 +257,8 @@ def main():
         import tests.oracle_binding as ob
         cores = os.cpu_count() or 1
         def cpu_render(spp):
-            osc = ob.OracleScene(build_scene_dict(scenes, args.config, args.width, args.height, spp, -1, args.res, 0), mono=args.config == "C5")
+            osc = ob.OracleScene(build_scene_dict(scenes, args.config, args.width, args.height, spp, -1, args.res, 0), mono=args.config == "C5",
+                                 spectral=args.config == "C5S")
             tc0 = time.perf_counter()
             osc.render(threads=cores)
             return time.perf_counter() - tc0
@@ -269,6 +274,7 @@ def main():
     if rank == 0:
         workload = {"C1": "C1 path cornell box", "C2": "C2 volpath homogeneous slab", "C4": "C4 volpath layered atmosphere, blend/tabulated phase, RPV ground",
                     "C5": "C5 = C4 as %d monochromatic wavelength batches (Rayleigh ~ lambda^-4), gpu_mono" % C5_WAVELENGTHS,
+                    "C5S": "C5S = the C4 atmosphere in the spectral variant (gpu_spectral: 4 wavelengths per sample, gridvolume_spectral), per-lane kernel",
                     "C3": "C3 volpath heterogeneous %d^3 grid + HG g=0.8" % args.res}[args.config]
         out = {"metric": "Msamples/s volpath 512x512x1024spp plane-parallel atmosphere" if args.config == "C3" else "Msamples/s %s (side measurement)" % args.config,
                "value": round(value, 2), "unit": "Msamples/s",

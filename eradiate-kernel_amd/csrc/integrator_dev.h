@@ -1585,6 +1585,57 @@ DEV Spec integrator_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, b
     return path_sample<COUNT>(sc, rng, ray, valid, cnt, cx);
 }
 
+// ---------------------------------------------------------------- film
+#if MTS_SPEC_N != 3         // rgb: splat_sample_t (volpath_flat.h)
+// ImageBlock::put of the five film values X, Y, Z, alpha, weight of one finished sample (librender/imageblock.cpp:79-172).
+// `own` receives the samples that land in the lane's own pixel: either register accumulators (per-lane kernels) or the pixel's film
+// entry itself, updated with float atomics in sample order.
+template <bool OWN_ATOMIC>
+DEV void splat_values_t(const DScene &sc, const DBlock &blk, uint32_t lx, uint32_t ly, F2 position_sample, const float v[5],
+                        MTS_GLOBAL_AS float *film, float *own) {
+    const DSensor &se = sc.sensor;
+    bool ok = true;                                             // imageblock.cpp:85-109: invalid samples are dropped
+    for (int k = 0; k < 5; ++k) ok = ok && v[k] >= -1e-5f && pm_isfinite(v[k]);
+    if (!ok) return;
+    const DRFilter &rf = se.rfilter;
+    const int border = rf.border_size;
+    const int sx = blk.sx + 2 * border, sy = blk.sy + 2 * border;
+    float posx = position_sample.x - ((float) (blk.ox - border) + .5f), posy = position_sample.y - ((float) (blk.oy - border) + .5f);
+    if (rf.radius > 0.5f + MTS_RAY_EPSILON) {
+        int lox = max((int) pm_ceil(posx - rf.radius), 0), loy = max((int) pm_ceil(posy - rf.radius), 0);
+        int hix = min((int) pm_floor(posx + rf.radius), sx - 1), hiy = min((int) pm_floor(posy + rf.radius), sy - 1);
+        uint32_t n = (uint32_t) pm_ceil((rf.radius - 2.f * MTS_RAY_EPSILON) * 2.f);
+        float basex = (float) lox - posx, basey = (float) loy - posy;
+        for (uint32_t yr = 0; yr < n; ++yr) {
+            int y = loy + (int) yr;
+            if (y > hiy) break;
+            float wy = as_global(rf.values)[min((int) pm_abs((basey + (float) yr) * rf.scale_factor), 31)];     // eval_discretized, core/rfilter.h:62-65
+            int fy = blk.oy - border + y - se.crop_y;
+            for (uint32_t xr = 0; xr < n; ++xr) {
+                int x = lox + (int) xr;
+                if (x > hix) break;
+                float wx = as_global(rf.values)[min((int) pm_abs((basex + (float) xr) * rf.scale_factor), 31)];
+                float weight = wy * wx;
+                int fx = blk.ox - border + x - se.crop_x;
+                if (fx >= 0 && fy >= 0 && fx < se.crop_w && fy < se.crop_h) {                         // film clipping, imageblock.cpp:49-77
+                    float *dst = (float *) (film + 5 * ((size_t) fy * se.crop_w + fx));
+                    for (int k = 0; k < 5; ++k) atomicAdd(dst + k, v[k] * weight);
+                }
+            }
+        }
+    } else {
+        int lox = (int) pm_ceil(posx - .5f), loy = (int) pm_ceil(posy - .5f);
+        if (lox == (int) lx && loy == (int) ly) {
+            if (OWN_ATOMIC) { for (int k = 0; k < 5; ++k) atomicAdd(own + k, v[k]); }
+            else { for (int k = 0; k < 5; ++k) own[k] += v[k]; }
+        } else if (lox >= 0 && loy >= 0 && lox < sx && loy < sy) {
+            float *dst = (float *) (film + 5 * ((size_t) (blk.oy + loy - se.crop_y) * se.crop_w + (blk.ox + lox - se.crop_x)));
+            for (int k = 0; k < 5; ++k) atomicAdd(dst + k, v[k]);
+        }
+    }
+}
+
+#endif
 // ---------------------------------------------------------------- wavelengths / colour (spectral variants)
 #if MTS_SPEC_N != 3
 // math::sample_shifted (core/math.h:419-442) + sample_wavelength -> sample_rgb_spectrum -> sample_uniform_spectrum (core/spectrum.h:248-252,

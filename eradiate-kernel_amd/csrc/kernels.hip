@@ -24,53 +24,6 @@ inline namespace MTS_VARIANT_NS {
 // straight into the film.  With the default box filter a sample lands in its own pixel and is summed
 // in registers in sample order (bit-identical to the reference's block accumulation); the rare
 // sample that falls on the left/top pixel edge (u == 0) goes to the neighbour through an atomic.
-#if MTS_SPEC_N != 3
-// the per-sample tail of render_sample in the spectral variants: spectrum_to_xyz (integrator.cpp:266-269) + ImageBlock::put
-// (imageblock.cpp:79-172, box filter and wider filters alike)
-DEV void splat_xyz(const DScene &sc, const DBlock &blk, uint32_t lx, uint32_t ly, F2 position_sample, const float xyz[3], bool valid,
-                   MTS_GLOBAL_AS float *film, float *own) {
-    const DSensor &se = sc.sensor;
-    float v[5] = { xyz[0], xyz[1], xyz[2], valid ? 1.f : 0.f, 1.f };
-    bool ok = true;
-    for (int k = 0; k < 5; ++k) ok = ok && v[k] >= -1e-5f && pm_isfinite(v[k]);
-    if (!ok) return;
-    const DRFilter &rf = se.rfilter;
-    const int border = rf.border_size;
-    const int sx = blk.sx + 2 * border, sy = blk.sy + 2 * border;
-    float posx = position_sample.x - ((float) (blk.ox - border) + .5f), posy = position_sample.y - ((float) (blk.oy - border) + .5f);
-    if (rf.radius > 0.5f + MTS_RAY_EPSILON) {
-        int lox = max((int) pm_ceil(posx - rf.radius), 0), loy = max((int) pm_ceil(posy - rf.radius), 0);
-        int hix = min((int) pm_floor(posx + rf.radius), sx - 1), hiy = min((int) pm_floor(posy + rf.radius), sy - 1);
-        uint32_t n = (uint32_t) pm_ceil((rf.radius - 2.f * MTS_RAY_EPSILON) * 2.f);
-        float basex = (float) lox - posx, basey = (float) loy - posy;
-        for (uint32_t yr = 0; yr < n; ++yr) {
-            int y = loy + (int) yr;
-            if (y > hiy) break;
-            float wy = as_global(rf.values)[min((int) pm_abs((basey + (float) yr) * rf.scale_factor), 31)];
-            int fy = blk.oy - border + y - se.crop_y;
-            for (uint32_t xr = 0; xr < n; ++xr) {
-                int x = lox + (int) xr;
-                if (x > hix) break;
-                float wx = as_global(rf.values)[min((int) pm_abs((basex + (float) xr) * rf.scale_factor), 31)];
-                float weight = wy * wx;
-                int fx = blk.ox - border + x - se.crop_x;
-                if (fx >= 0 && fy >= 0 && fx < se.crop_w && fy < se.crop_h) {
-                    float *dst = (float *) (film + 5 * ((size_t) fy * se.crop_w + fx));
-                    for (int k = 0; k < 5; ++k) atomicAdd(dst + k, v[k] * weight);
-                }
-            }
-        }
-    } else {
-        int lox = (int) pm_ceil(posx - .5f), loy = (int) pm_ceil(posy - .5f);
-        if (lox == (int) lx && loy == (int) ly) { for (int k = 0; k < 5; ++k) own[k] += v[k]; }
-        else if (lox >= 0 && loy >= 0 && lox < sx && loy < sy) {
-            float *dst = (float *) (film + 5 * ((size_t) (blk.oy + loy - se.crop_y) * se.crop_w + (blk.ox + lox - se.crop_x)));
-            for (int k = 0; k < 5; ++k) atomicAdd(dst + k, v[k]);
-        }
-    }
-}
-#endif
-
 template <bool COUNT, int INTEG>
 __device__ __forceinline__ void render_sample(const DScene &sc, Pcg32 &rng, const DBlock &blk, uint32_t lx, uint32_t ly,
                                               float *__restrict__ film, float acc[5], Counters &cnt) {
@@ -103,7 +56,8 @@ __device__ __forceinline__ void render_sample(const DScene &sc, Pcg32 &rng, cons
     L = (wav_weight * ray_weight.x) * L;                        // ray_weight = wav_weight (x the sensor's grey weight), integrator.cpp:265
     float xyz[3];
     spectrum_to_xyz(sc.cie, L, cx.wl, xyz);                     // integrator.cpp:266-269
-    splat_xyz(sc, blk, lx, ly, position_sample, xyz, valid, as_global(film), acc);
+    const float v[5] = { xyz[0], xyz[1], xyz[2], valid ? 1.f : 0.f, 1.f };
+    splat_values_t<false>(sc, blk, lx, ly, position_sample, v, as_global(film), acc);
 #endif
 }
 

@@ -149,6 +149,8 @@ DEV F3 transmittance_exp_g(float t, F3 combined, bool grey) {
 }
 
 // Film splat of one finished sample: librender/integrator.cpp:265-285 + librender/imageblock.cpp:79-172
+// (The spectral build's splat_values_t in integrator_dev.h is this function's second half; sharing it changed the register allocation of
+// the regrouping kernel -- 170 -> 197 SGPR spills -- so the rgb kernels keep their own copy.)
 // `own` receives the samples that land in the lane's own pixel: either register accumulators (nested
 // formulation) or the pixel's film entry itself, updated with float atomics in sample order.
 template <bool OWN_ATOMIC>

@@ -146,6 +146,30 @@ def c4_atmosphere(width=1024, height=1024, spp=4096, layers=64, sigma_r0=0.012, 
     }
 
 
+def c5_atmosphere_spectral(width=1024, height=1024, spp=4096, layers=64, nodes=17, samples_per_pass=-1):
+    """C5 in the spectral variant (gpu_spectral): the C4 atmosphere with extinction and albedo as `gridvolume_spectral` grids whose
+    `nodes` spectral nodes cover 0 .. 1600 nm (Rayleigh ~ lambda^-4 relative to 550 nm, aerosol grey), a D65 sun and an RPV ground with
+    a sloped rho_0.  lambda_min = 0 because of the mask gridvolume_spectral applies (tests/test_spectral.py::test_gridvolume_spectral_eval).
+    The blend weight stays a plain grid (gridvolume_spectral has no eval_1, gridvolume_spectral.cpp:204-214): its 550 nm value."""
+    d = c4_atmosphere(width, height, spp, layers=layers, samples_per_pass=samples_per_pass)
+    top = 50.0
+    z = (np.arange(layers, dtype=np.float64) + 0.5) * (top / layers)
+    lam = np.linspace(0.0, 1600.0, nodes)
+    ray = 0.012 * np.exp(-z / 8.0)[:, None] * (550.0 / np.maximum(lam, 350.0)[None, :]) ** 4       # flat below 350 nm (never sampled: 360 .. 830)
+    aer = (0.1 * np.exp(-z / 2.0))[:, None] * np.ones_like(lam)[None, :]
+    sigma_t = ray + aer
+    albedo = (ray * 1.0 + aer * 0.92) / sigma_t
+    def grid(v):
+        return np.ascontiguousarray(np.broadcast_to(v[:, None, None, :], (layers, 2, 2, nodes)), dtype=np.float32)
+    med = d["atmosphere"]["interior"]
+    xf = med["sigma_t"]["to_world"]
+    med["sigma_t"] = {"type": "gridvolume_spectral", "data": grid(sigma_t), "lambda_min": 0.0, "lambda_max": 1600.0, "to_world": xf}
+    med["albedo"] = {"type": "gridvolume_spectral", "data": grid(albedo), "lambda_min": 0.0, "lambda_max": 1600.0, "to_world": xf}
+    del d["sun"]["irradiance"]                                                                  # D65 (directional.cpp:49)
+    d["ground"]["bsdf"]["rho_0"] = {"type": "regular", "lambda_min": 300.0, "lambda_max": 900.0, "values": [0.05, 0.1, 0.3]}
+    return d
+
+
 CONFIGS = {
     "C1": ("Cornell box, path, 256x256x64spp", c1_cornell),
     "C2": ("volpath homogeneous slab, 512x512x256spp", c2_homogeneous_slab),
