@@ -31,7 +31,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
 CONFIG_SIZES = {"C1": (256, 256, 64), "C2": (512, 512, 256), "C3": (512, 512, 1024), "C4": (1024, 1024, 4096), "C5": (1024, 1024, 4096),
-                "C5S": (1024, 1024, 256)}     # C5S: the same atmosphere in the spectral variant (gpu_spectral, per-lane kernel), 256 spp
+                "C5S": (1024, 1024, 32)}      # C5S: the same atmosphere in the spectral variant (gpu_spectral, per-lane kernel: slow), 32 spp
 C5_WAVELENGTHS = 16        # BASELINE.json configs[4]: the C4 atmosphere as a 16-wavelength batch
 
 
