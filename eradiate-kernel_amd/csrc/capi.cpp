@@ -218,6 +218,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
                 else if (!strcmp(kv, "wga256")) variant = 10256; else if (!strcmp(kv, "wga512")) variant = 10512; else if (!strcmp(kv, "wga1024")) variant = 11024;
                 else throw std::runtime_error("MTSAMD_KERNEL must be one of nested, flat, wga256, wga512, wga1024");
             }
+            if (hs.integrator.type == MTS_INTEGRATOR_VOLPATHMIS && variant > 10512) variant = 10512;     // four weight matrices per path: 512 paths fill the LDS
             // a workgroup of the regrouping kernel sits in ONE spiral block: blocks smaller than its path count get the largest
             // workgroup that divides them (16 x 16 -> 256 paths); only blocks below 256 pixels fall back to the per-lane kernel
             while (variant > 10256 && (block_size * block_size) % (uint32_t) (variant - 10000) != 0) variant = 10000 + (variant - 10000) / 2;

@@ -11,6 +11,7 @@
 #include "integrator_dev.h"
 #if MTS_SPEC_N == 3
 #include "volpath_flat.h"
+#include "volpathmis_flat.h"
 #define MTS_LAUNCHER(name) name
 #else
 #define MTS_LAUNCHER(name) name##_spectral
@@ -143,6 +144,20 @@ __global__ void __launch_bounds__(NT, WPE) render_kernel_wga(DScene sc, const DB
 }
 static_assert(sizeof(WgArgs) % 4 == 0, "WgArgs mirrors the kernel parameters");
 
+// The same driver for volpathmis (volpathmis_flat.h): four weight matrices per path, 512 paths per workgroup, two waves per SIMD.
+template <bool COUNT, bool SPEC, int WG, int NT>
+__global__ void __launch_bounds__(NT, 2) render_kernel_wga_mis(DScene sc, const DBlock *blocks, uint32_t n_blocks, uint32_t block_size,
+                                                               uint32_t sample_count, float *film, float *cold_g, uint32_t cold_stride,
+                                                               unsigned long long *counters, const uint32_t *stop_flag) {
+    Counters cnt = {};
+    volpathmis_workgroup_async<COUNT, SPEC, WG, NT>((const MTS_CONST_AS void *) __builtin_amdgcn_kernarg_segment_ptr(), cnt);
+    if (COUNT) {
+        atomicAdd(counters + 0, (unsigned long long) cnt.n_iter);
+        atomicAdd(counters + 1, (unsigned long long) cnt.n_lookup);
+        atomicAdd(counters + 2, (unsigned long long) cnt.n_nee_step);
+    }
+}
+
 // SamplingIntegrator::sample for caller-supplied rays (librender/python/integrator_v.cpp:62-78)
 __global__ void __launch_bounds__(256) sample_kernel(DScene sc, int32_t n, uint64_t seed_offset, const float *__restrict__ rays /* 6 SoA rows */,
                                                      float *__restrict__ out_rgb, uint8_t *__restrict__ out_valid) {
@@ -240,6 +255,21 @@ hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks,
         else if (wg == 1024 && nt == 512) LAUNCH_WGA(1024, 512, 2);
         else return hipErrorInvalidConfiguration;
 #undef LAUNCH_WGA
+        return hipGetLastError();
+    }
+    if (variant >= 10000 && sc.integrator.type == MTS_INTEGRATOR_VOLPATHMIS) {     // the same machinery, variant = 10000 + paths per workgroup (<= 512)
+        const uint32_t wg = (uint32_t) (variant - 10000);
+        const uint32_t grid = (uint32_t) ((threads + wg - 1) / wg);
+        const uint32_t stride = grid * wg;
+        const bool spec = sc.integrator.use_spectral_mis != 0;
+#define LAUNCH_MIS(C, S, W) hipLaunchKernelGGL((render_kernel_wga_mis<C, S, W, W>), dim3(grid), dim3(W), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag)
+#define LAUNCH_MIS_W(W) do { if (count) { if (spec) LAUNCH_MIS(true, true, W); else LAUNCH_MIS(true, false, W); } \
+                             else { if (spec) LAUNCH_MIS(false, true, W); else LAUNCH_MIS(false, false, W); } } while (0)
+        if (wg == 512) LAUNCH_MIS_W(512);
+        else if (wg == 256) LAUNCH_MIS_W(256);
+        else return hipErrorInvalidConfiguration;
+#undef LAUNCH_MIS_W
+#undef LAUNCH_MIS
         return hipGetLastError();
     }
     const bool flat = variant != 0;

@@ -1,0 +1,541 @@
+// volpathmis_flat.h -- volpathmis (integrators/volpathmis.cpp:86-445) on the regrouping machinery of volpath_flat.h.
+//
+// The spectral-MIS volumetric path tracer carries probability-ratio matrices instead of a throughput: p_over_f / p_over_f_nee along
+// the path (volpathmis.cpp:117-118), and two more, started from p_over_f, along every emitter-sampling walk (sample_emitter,
+// :330-445).  As in volpath_flat.h the three nested loops become one state machine -- a path is (mode, state) and advances one block
+// at a time: INTERSECT, MEDIUM step of the path, MEDIUM step of a walk, SCATTER (emitter sampling at a medium interaction), walk
+// SURFACE, path SURFACE + BSDF, PHASE, NEW sample -- and the workgroup regroups its paths by the block they wait for through the LDS
+// rings of volpath_flat.h (same protocol: wga_push, wga_slot_wait, wga_raise_stop).  The hot state is 67 dwords per path with the
+// four 3 x 3 matrices (43 with `use_spectral_mis = false`), so a workgroup holds 512 paths (137 KB of LDS) served by 512 threads.
+// The draws happen in the order of the nested formulation (integrator_dev.h, volpathmis_sample) -- results are bit-identical to it
+// and to the CPU restatement.  Citations are relative to /root/reference.
+#pragma once
+#include "volpath_flat.h"
+
+namespace mtsamd {
+inline namespace MTS_VARIANT_NS {
+
+enum { C_PDFV = 30 };          // cold record: (delta ? 0 : phase / bsdf pdf) of the pending emitter sample; C_CW holds the phase / bsdf value
+
+template <bool SPEC>
+struct MisPathState {
+    Pcg32 rng;
+    DRay ray; Hit si; int medium;
+    MisWeights<SPEC> pf, pn;       // path: p_over_f, p_over_f_nee (volpathmis.cpp:117-118)
+    MisWeights<SPEC> wn, wu;       // walk: p_over_f_nee / p_over_f_uni of sample_emitter (:345-346)
+    F3 res, lsp;                   // result; last_scatter_event.p (:131-132: only the position is read)
+    float eta, wa, wb;             // walk: wa = total_dist, wb = ds.dist
+    uint32_t depth, channel, st, mode, flags;
+};
+
+template <bool COUNT, bool SPEC>
+struct VolpathMisMachine {
+    typedef MisPathState<SPEC> P;
+    typedef MisWeights<SPEC> W;
+    const DScene &sc;
+    Counters &cnt;
+    DEV VolpathMisMachine(const DScene &sc_, Counters &cnt_) : sc(sc_), cnt(cnt_) {}
+
+    DEV void queue_intersection(P &p) const {                  // as VolpathMachine::queue_intersection
+        float bmint, bmaxt;
+        bbox_ray_intersect(sc.bbox, p.ray, bmint, bmaxt);
+        p.si.t = pm_inf();
+        if (pm_max(p.ray.mint, bmint) <= bmaxt) p.flags |= FL_NEEDS_INT; else p.flags &= ~FL_NEEDS_INT;
+    }
+    DEV bool walk_goes_on(const P &p) const {                  // volpathmis.cpp:438-441
+        if (SPEC) return any_nonzero(mis_weight_w(p.wu));
+        return any_nonzero(p.wu.r[0]) || any_nonzero(p.wn.r[0]);
+    }
+    template <class E> DEV void begin_sample(P &p, const E &e) const {      // integrator.cpp:242-264, volpathmis.cpp:98-132
+        const DSensor &se = sc.sensor;
+        const float px = (float) (e.lx + (uint32_t) e.blk.ox), py = (float) (e.ly + (uint32_t) e.blk.oy);
+        F2 u = p.rng.next_2d();
+        F2 position_sample; position_sample.x = px + u.x; position_sample.y = py + u.y;
+        F2 aperture_sample; aperture_sample.x = .5f; aperture_sample.y = .5f;
+        if (se.needs_aperture_sample) aperture_sample = p.rng.next_2d();
+        if (se.shutter_open_time > 0.f) (void) p.rng.next_1d();
+        (void) p.rng.next_1d();                                // wavelength sample, unused in rgb
+        F2 adjusted;
+        adjusted.x = (position_sample.x - (float) se.crop_x) / (float) se.crop_w;
+        adjusted.y = (position_sample.y - (float) se.crop_y) / (float) se.crop_h;
+        F3 rw;
+        p.ray = sensor_sample_ray(sc, adjusted, aperture_sample, rw);
+        e.cold.f(C_POS) = position_sample.x; e.cold.f(C_POS + 1) = position_sample.y; e.cold.f(C_RAYW) = rw.x;
+        p.medium = se.medium;
+        p.res = f3s(0.f); p.lsp = f3s(0.f); p.eta = 1.f; p.depth = 0;
+        p.pf = mw_full<SPEC>(1.f); p.pn = mw_full<SPEC>(1.f); p.wn = mw_full<SPEC>(1.f); p.wu = mw_full<SPEC>(1.f);
+        p.channel = sc.integrator.monochrome ? 0u : (uint32_t) pm_min(p.rng.next_1d() * 3.f, 2.f);     // volpathmis.cpp:120-124
+        p.si.p = f3s(0.f); p.si.uv.x = p.si.uv.y = 0.f; p.si.prim = 0; p.si.shape = -1;
+        const bool hide_emitters = sc.integrator.hide_emitters != 0;
+        p.flags = FL_ALIVE | ((!hide_emitters && sc.environment >= 0) ? FL_VALID_RAY : 0u) | (!hide_emitters ? FL_SPEC_CHAIN : 0u);
+        p.wa = p.wb = 0.f;
+        queue_intersection(p);
+        p.mode = M_MAIN; p.st = S_TOP;
+    }
+    // emitter-sampling walk finished (volpathmis.cpp:443-444 + :233-236 / :297-299): MIS-weighted contribution, resume the path
+    template <class E> DEV void end_nee(P &p, const E &e) const {
+        const F3 fval = e.cold.get3(C_CW), emitted = e.cold.get3(C_EMIT);
+        const float pdfv = e.cold.f(C_PDFV);
+        update_weights(p.wn, 1.0f, fval, p.channel, true);
+        update_weights(p.wu, pdfv, fval, p.channel, true);
+        p.res = p.res + mis_weight_w(p.wn, p.wu) * emitted;
+        p.mode = M_MAIN; p.medium = __float_as_int(e.cold.f(C_SMED));
+        F3 d = e.cold.get3(C_SD);
+        p.ray.d = d; p.ray.d_rcp = vrcp(d);
+        if (p.flags & FL_FROM_MEDIUM) { p.ray.o = e.cold.get3(C_SO); p.st = S_PHASE; }
+        else { p.si = e.cold.get_hit(); p.st = S_BSDF; }
+    }
+    // loop heads: volpathmis.cpp:134-151 (path), :358-362 (walk)
+    template <class E> DEV void top(P &p, const E &e) const {
+        if (p.st != S_TOP) return;
+        const uint32_t max_depth = (uint32_t) sc.integrator.max_depth, rr_depth = (uint32_t) sc.integrator.rr_depth;
+        if (p.mode == M_MAIN) {
+            bool active = (p.flags & FL_ALIVE) != 0;
+            F3 mis_throughput = mis_weight_w(p.pf);
+            float q = pm_min(hmax(mis_throughput) * (p.eta * p.eta), .95f);
+            bool perform_rr = active && (p.depth > rr_depth);                          // last_event_was_null is never set (:146)
+            active = active && !(p.rng.next_1d() >= q && perform_rr);
+            update_weights(p.pf, q, 1.0f, p.channel, perform_rr);
+            active = active && !(p.depth >= max_depth);
+            active = active && any_nonzero(mis_weight_w(p.pf));
+            if (!active) p.st = S_NEW;
+            else { if (COUNT) cnt.n_iter++; p.st = p.medium >= 0 ? S_MED : S_SURF; }
+        } else {
+            float remaining_dist = p.wb * (1.f - MTS_SHADOW_EPSILON) - p.wa;
+            p.ray.maxt = remaining_dist;
+            if (!(remaining_dist > 0.f)) end_nee(p, e);
+            else { if (COUNT) cnt.n_nee_step++; p.st = p.medium >= 0 ? S_MED : S_SURF; }
+        }
+    }
+    DEV static bool wants_int(const P &p) { return (p.st == S_MED || p.st == S_SURF) && (p.flags & FL_NEEDS_INT); }
+    DEV static int classify(const P &p) {
+        if (p.st == S_DONE) return B_DONE;
+        if (wants_int(p)) return B_INT;
+        if (p.st == S_MED) return p.mode == M_MAIN ? B_MED : B_MEDW;
+        if (p.st == S_SCATTER) return B_SCATTER;
+        if (p.st == S_SURF) return p.mode == M_MAIN ? B_SURF : B_WSURF;
+        if (p.st == S_BSDF) return B_SURF;
+        if (p.st == S_PHASE) return B_PHASE;
+        return B_NEW;
+    }
+
+    // ================================================================= NEW (integrator.cpp:265-288)
+    template <class E> DEV void blk_new(P &p, const E &e) const {
+        if (p.st != S_NEW) return;
+        const DSensor &se = sc.sensor;
+        F2 position_sample; position_sample.x = e.cold.f(C_POS); position_sample.y = e.cold.f(C_POS + 1);
+        float acc[5];
+        for (int k = 0; k < 5; ++k) acc[k] = e.cold.f(C_ACC + k);
+        splat_sample_t<false>(sc, e.blk, e.lx, e.ly, position_sample, f3s(e.cold.f(C_RAYW)) * p.res, (p.flags & FL_VALID_RAY) != 0, e.film, acc);
+        const uint32_t sample_idx = __float_as_uint(e.cold.f(C_SAMPLE)) + 1u;
+        if (sample_idx == e.sample_count) {
+            float *own = (float *) (e.film + 5 * ((size_t) (e.blk.oy + (int) e.ly - se.crop_y) * se.crop_w + (e.blk.ox + (int) e.lx - se.crop_x)));
+            for (int k = 0; k < 5; ++k) atomicAdd(own + k, acc[k]);
+            p.st = S_DONE;
+        } else {
+            for (int k = 0; k < 5; ++k) e.cold.f(C_ACC + k) = acc[k];
+            e.cold.f(C_SAMPLE) = __uint_as_float(sample_idx);
+            begin_sample(p, e);
+        }
+    }
+    // ================================================================= INTERSECT
+    template <class E> DEV void blk_int(P &p, const E &) const {
+        if (!wants_int(p)) return;
+        p.si = ray_intersect(sc, p.ray);
+        p.flags &= ~FL_NEEDS_INT;
+    }
+    // ================================================================= MEDIUM step of the path (volpathmis.cpp:165-245)
+    template <class E> DEV void blk_med(P &p, const E &) const {
+        if (p.st != S_MED || p.mode != M_MAIN || (p.flags & FL_NEEDS_INT)) return;
+        const uint32_t max_depth = (uint32_t) sc.integrator.max_depth, channel = p.channel;
+        const float u = p.rng.next_1d();
+        MedStep mi;
+        WATERFALL_BEGIN(p.medium, mu)
+            mi = medium_step<COUNT>(sc, cload(sc.media + mu), p.ray, u, channel, true, cnt);
+        WATERFALL_END
+        if (p.si.t < mi.t) mi.t = pm_inf();
+        const bool spectral = (mi.info & MI_SPECTRAL) != 0, homogeneous = (mi.info & MI_HOMOGENEOUS) != 0;
+        const F3 sigma_n = homogeneous ? f3s(0.f) : mi.combined - mi.sigma_t;
+        if (spectral) {
+            float t = pm_min(mi.t, p.si.t) - mi.mint;                                  // medium.cpp:77-89
+            F3 tr = transmittance_exp(t, mi.combined);
+            F3 free_flight_pdf = p.si.t < mi.t ? tr : tr * mi.combined;
+            update_weights(p.pf, free_flight_pdf, tr, channel, true);
+            update_weights(p.pn, free_flight_pdf, tr, channel, true);
+        }
+        if (mi.t == pm_inf()) { p.st = S_SURF; return; }                               // escaped_medium: the surface part of this iteration
+        const bool null_scatter = p.rng.next_1d() >= pick(mi.sigma_t, channel) / pick(mi.combined, channel);
+        if (null_scatter) {
+            if (spectral) {
+                update_weights(p.pf, sigma_n / mi.combined, sigma_n, channel, true);
+                update_weights(p.pn, 1.0f, sigma_n, channel, true);
+            } else {
+                update_weights(p.pf, sigma_n, sigma_n, channel, true);
+                update_weights(p.pn, 1.0f, sigma_n / mi.combined, channel, true);
+            }
+            p.ray.o = mi.p; p.ray.mint = 0.f; p.si.t = p.si.t - mi.t;
+            p.st = S_TOP;
+            return;
+        }
+        p.depth += 1; p.lsp = mi.p;
+        const bool sample_emitters = (mi.info & MI_SAMPLE_EMITTERS) != 0;
+        if (!(p.depth < max_depth)) { p.flags &= ~FL_ALIVE; p.st = S_TOP; return; }    // :197-198: the path ends at the next loop head
+        if (sample_emitters) p.flags &= ~FL_SPEC_CHAIN;                                // :199
+        if (spectral) update_weights(p.pf, mi.sigma_t / mi.combined, mi.sigma_s, channel, true);
+        else update_weights(p.pf, mi.sigma_t, mi.sigma_s, channel, true);
+        p.flags |= FL_VALID_RAY;
+        p.ray.o = mi.p;                                                                // scattering position; ray.d stays the incident direction
+        p.st = sample_emitters ? S_SCATTER : S_PHASE;
+    }
+    // ================================================================= SCATTER: emitter sampling at a medium interaction (:228-237 -> :330-356)
+    template <class E> DEV void start_walk(P &p, const E &e, F3 ref_p, const DirSample &ds, F3 emitter_sample_weight, F3 fval, float pdfv, bool from_medium) const {
+        p.wn = p.pf; p.wu = p.pf;
+        F3 emitter_val = emitter_sample_weight * ds.pdf;
+        if (ds.pdf == 0.f) emitter_val = f3s(0.f);
+        const bool active = ds.pdf != 0.f;
+        update_weights(p.wn, ds.pdf, 1.0f, p.channel, active);
+        e.cold.put3(C_CW, fval); e.cold.put3(C_EMIT, emitter_val); e.cold.f(C_PDFV) = pdfv;
+        e.cold.put3(C_SD, p.ray.d); e.cold.f(C_SMED) = __int_as_float(p.medium);
+        if (from_medium) { e.cold.put3(C_SO, p.ray.o); p.flags |= FL_FROM_MEDIUM; }
+        else { e.cold.put_hit(p.si); p.flags &= ~FL_FROM_MEDIUM; }
+        p.mode = M_NEE;
+        if (!active) { end_nee(p, e); return; }
+        p.wa = 0.f; p.wb = ds.dist;
+        p.ray = spawn_ray(ref_p, ds.d);
+        if (from_medium) p.ray.mint = 0.f;
+        queue_intersection(p);
+        p.st = S_TOP;
+    }
+    template <class E> DEV void blk_scatter(P &p, const E &e) const {
+        if (p.st != S_SCATTER) return;
+        F3 esw;
+        DirSample ds = sample_emitter_direction(sc, p.ray.o, p.rng.next_2d(), false, esw);
+        float phase_val = 0.f;
+        WATERFALL_BEGIN(p.medium, mu)
+            phase_val = phase_eval<true>(sc, cload(sc.media + mu).phase, -p.ray.d, p.ray.o, ds.d);
+        WATERFALL_END
+        start_walk(p, e, p.ray.o, ds, esw, f3s(phase_val), ds.delta ? 0.f : phase_val, true);
+    }
+    // ================================================================= MEDIUM step of a walk (volpathmis.cpp:364-411)
+    template <class E> DEV void blk_medw(P &p, const E &e) const {
+        if (p.st != S_MED || p.mode == M_MAIN || (p.flags & FL_NEEDS_INT)) return;
+        const uint32_t channel = p.channel;
+        const float u = p.rng.next_1d();
+        MedStep mi;
+        WATERFALL_BEGIN(p.medium, mu)
+            mi = medium_step<COUNT>(sc, cload(sc.media + mu), p.ray, u, channel, false, cnt);
+        WATERFALL_END
+        if (p.si.t < mi.t) mi.t = pm_inf();
+        const bool spectral = (mi.info & MI_SPECTRAL) != 0, homogeneous = (mi.info & MI_HOMOGENEOUS) != 0;
+        const F3 sigma_n = homogeneous ? f3s(0.f) : mi.combined - mi.sigma_t;
+        const float remaining_dist = p.ray.maxt;
+        if (spectral) {
+            float t = pm_min(remaining_dist, pm_min(mi.t, p.si.t)) - mi.mint;
+            F3 tr = transmittance_exp(t, mi.combined);
+            F3 free_flight_pdf = (p.si.t < mi.t || mi.t > remaining_dist) ? tr : tr * mi.combined;
+            update_weights(p.wn, free_flight_pdf, tr, channel, true);
+            update_weights(p.wu, free_flight_pdf, tr, channel, true);
+        }
+        if (mi.t > remaining_dist && mi.t != pm_inf()) p.wa = p.wb;
+        if (mi.t > remaining_dist) mi.t = pm_inf();
+        if (mi.t == pm_inf()) { p.st = S_SURF; return; }                               // escaped_medium
+        p.wa += mi.t;
+        p.ray.o = mi.p; p.ray.mint = 0.f; p.si.t = p.si.t - mi.t;
+        if (spectral) {
+            update_weights(p.wn, 1.f, sigma_n, channel, true);
+            update_weights(p.wu, sigma_n / mi.combined, sigma_n, channel, true);
+        } else {
+            update_weights(p.wn, 1.f, sigma_n / mi.combined, channel, true);
+            update_weights(p.wu, sigma_n, sigma_n, channel, true);
+        }
+        if (walk_goes_on(p)) p.st = S_TOP; else end_nee(p, e);
+    }
+    // ================================================================= SURFACE step of a walk (volpathmis.cpp:413-441)
+    template <class E> DEV void blk_wsurf(P &p, const E &e) const {
+        if (p.st != S_SURF || p.mode == M_MAIN || (p.flags & FL_NEEDS_INT)) return;
+        const bool hit = hit_valid(p.si);
+        p.wa += p.si.t;
+        if (!hit) { end_nee(p, e); return; }
+        F3 nt = f3s(0.f), n = f3s(0.f); int is_tr = 0, ext = -1, inte = -1;
+        WATERFALL_BEGIN(p.si.shape, su)
+            const DShape s = cload(sc.shapes + su);
+            nt = s.bsdf_type == MTS_BSDF_NULL ? f3s(1.f) : f3s(0.f);
+            is_tr = s.is_medium_transition; ext = s.exterior; inte = s.interior;
+            if (is_tr) n = hit_geo_normal(sc, s, p.si);
+        WATERFALL_END
+        update_weights(p.wn, 1.0f, nt, p.channel, true);
+        update_weights(p.wu, 1.0f, nt, p.channel, true);
+        p.ray = spawn_ray(p.si.p, p.ray.d);
+        queue_intersection(p);
+        const bool go_on = walk_goes_on(p);
+        if (is_tr) p.medium = dot(p.ray.d, n) > 0 ? ext : inte;
+        if (go_on) p.st = S_TOP; else end_nee(p, e);
+    }
+    // ================================================================= SURFACE interaction of the path (volpathmis.cpp:253-300)
+    template <class E> DEV void blk_surf(P &p, const E &e) const {
+        if (p.st != S_SURF || p.mode != M_MAIN || (p.flags & FL_NEEDS_INT)) return;
+        const uint32_t max_depth = (uint32_t) sc.integrator.max_depth;
+        const bool hide_emitters = sc.integrator.hide_emitters != 0;
+        const bool hit = hit_valid(p.si);
+        Surf sf; sf.wi = -p.ray.d; sf.n = f3s(0.f); sf.sh.s = sf.sh.t = sf.sh.n = f3s(0.f);
+        int emitter = sc.environment, bsdf_id = 0;
+        if (hit) {
+            WATERFALL_BEGIN(p.si.shape, su)
+                const DShape s = cload(sc.shapes + su);
+                emitter = s.emitter; bsdf_id = s.bsdf;
+                complete_surface(sc, s, p.si, p.ray.d, sf);
+            WATERFALL_END
+        }
+        const bool count_direct = p.depth == 0 || (p.flags & FL_SPEC_CHAIN);
+        if (emitter >= 0 && !(p.depth == 0 && hide_emitters)) {
+            if (!count_direct) {
+                DirSample ds;                                                          // records.h:168-174
+                ds.p = p.si.p; ds.n = sf.sh.n; ds.d = p.si.p - p.lsp; ds.dist = norm(ds.d); ds.d = ds.d / ds.dist;
+                if (!hit) ds.d = -sf.wi;
+                ds.emitter = emitter; ds.pdf = 0.f; ds.delta = false;
+                float emitter_pdf = pdf_emitter_direction(sc, p.lsp, ds);
+                update_weights(p.pn, emitter_pdf, 1.f, p.channel, true);
+            }
+            F3 emitted = emitter_eval(sc, emitter, sf.wi.z);
+            p.res = p.res + (count_direct ? mis_weight_w(p.pf) * emitted : mis_weight_w(p.pf, p.pn) * emitted);
+        }
+        if (!hit) { p.flags &= ~FL_ALIVE; p.st = S_TOP; return; }
+        p.st = S_BSDF;
+        bool active_e = false;
+        WATERFALL_BEGIN(bsdf_id, bu)
+            active_e = (cload(sc.bsdfs + bu).flags & F_Smooth) != 0 && (p.depth + 1 < max_depth);
+        WATERFALL_END
+        if (!active_e) return;
+        F3 esw;
+        DirSample ds = sample_emitter_direction(sc, p.si.p, p.rng.next_2d(), false, esw);
+        F3 wo = to_local(sf.sh, ds.d);
+        F3 bsdf_val; float bpdf;
+        WATERFALL_BEGIN(bsdf_id, bu)
+            const DBsdf bsdf = cload(sc.bsdfs + bu);
+            bsdf_val = bsdf_eval(bsdf, sf.wi, wo);
+            bpdf = bsdf_pdf(bsdf, sf.wi, wo);
+        WATERFALL_END
+        start_walk(p, e, p.si.p, ds, esw, bsdf_val, ds.delta ? 0.f : bpdf, false);
+    }
+    // ================================================================= BSDF sampling (volpathmis.cpp:302-328)
+    template <class E> DEV void blk_bsdf(P &p, const E &) const {
+        if (p.st != S_BSDF) return;
+        Surf sf; int bsdf_id = 0, is_tr = 0, ext = -1, inte = -1;
+        WATERFALL_BEGIN(p.si.shape, su)
+            const DShape s = cload(sc.shapes + su);
+            complete_surface(sc, s, p.si, p.ray.d, sf);
+            bsdf_id = s.bsdf; is_tr = s.is_medium_transition; ext = s.exterior; inte = s.interior;
+        WATERFALL_END
+        const float s1 = p.rng.next_1d(); const F2 s2 = p.rng.next_2d();
+        BSDFSample bs; F3 bsdf_weight;
+        WATERFALL_BEGIN(bsdf_id, bu)
+            const DBsdf bsdf = cload(sc.bsdfs + bu);
+            bsdf_weight = bsdf_sample(bsdf, sf.wi, s1, s2, bs);
+        WATERFALL_END
+        const bool invalid_bsdf_sample = bs.pdf == 0.f;
+        const bool active_surface = bs.pdf > 0.f;
+        if (active_surface) p.eta *= bs.eta;
+        if (active_surface) { p.ray = spawn_ray(p.si.p, to_world(sf.sh, bs.wo)); queue_intersection(p); }
+        const bool non_null_bsdf = active_surface && !(bs.sampled_type & F_Null);
+        if (non_null_bsdf || invalid_bsdf_sample) p.flags |= FL_VALID_RAY;
+        if (non_null_bsdf && (bs.sampled_type & F_Delta)) p.flags |= FL_SPEC_CHAIN;
+        if (active_surface && (bs.sampled_type & F_Smooth)) p.flags &= ~FL_SPEC_CHAIN;
+        if (non_null_bsdf) { p.depth += 1; p.lsp = p.si.p; p.pn = p.pf; }
+        update_weights(p.pf, bs.pdf, bsdf_weight * bs.pdf, p.channel, active_surface);
+        update_weights(p.pn, 1.f, bsdf_weight * bs.pdf, p.channel, non_null_bsdf);
+        if (active_surface && is_tr) p.medium = dot(p.ray.d, sf.n) > 0 ? ext : inte;
+        if (!active_surface) p.flags &= ~FL_ALIVE;                                     // :327: active &= (active_surface | active_medium)
+        p.st = S_TOP;
+    }
+    // ================================================================= PHASE sampling (volpathmis.cpp:239-251)
+    template <class E> DEV void blk_phase(P &p, const E &) const {
+        if (p.st != S_PHASE) return;
+        p.pn = p.pf;                                                                   // :240: a real interaction resets p_over_f_nee
+        const float s1 = p.rng.next_1d(); const F2 s2 = p.rng.next_2d();
+        F3 wo; float phase_pdf = 0.f;
+        WATERFALL_BEGIN(p.medium, mu)
+            wo = phase_sample_pdf(sc, cload(sc.media + mu).phase, make_frame(p.ray.d), p.ray.o, s1, s2, phase_pdf);
+        WATERFALL_END
+        p.ray = spawn_ray(p.ray.o, wo); p.ray.mint = 0.0f;
+        queue_intersection(p);
+        update_weights(p.pf, phase_pdf, phase_pdf, p.channel, true);
+        update_weights(p.pn, 1.f, phase_pdf, p.channel, true);
+        p.st = S_TOP;
+    }
+    template <class E> DEV void run(P &p, const E &e, int sel) const {
+        switch (sel) {
+            case B_NEW: blk_new(p, e); break;
+            case B_INT: blk_int(p, e); break;
+            case B_MED: blk_med(p, e); break;
+            case B_MEDW: blk_medw(p, e); break;
+            case B_SCATTER: blk_scatter(p, e); break;
+            case B_WSURF: blk_wsurf(p, e); break;
+            case B_SURF: blk_surf(p, e); blk_bsdf(p, e); break;
+            case B_PHASE: blk_phase(p, e); break;
+            default: break;
+        }
+    }
+};
+
+// Hot state in LDS, struct of arrays over the workgroup's paths (as HotStore of volpath_flat.h; every block loads / stores all of it:
+// at two waves per SIMD the register budget of 256 VGPRs holds the whole state)
+template <int WG, bool SPEC>
+struct MisHotStore {
+    static constexpr int NW = SPEC ? 9 : 3;                     // floats per weight matrix
+    enum { M_RNG = 0, M_O = 2, M_D = 5, M_DRCP = 8, M_MINT = 11, M_MAXT = 12, M_SIT = 13, M_MEDIUM = 14, M_PACKED = 15, M_WA = 16, M_WB = 17,
+           M_ETA = 18, M_RES = 19, M_LSP = 22, M_SIX = 25, M_W = 32, M_COUNT = 32 + 4 * NW };
+    uint32_t *base;
+    DEV uint32_t &u(int k) const { return base[k * WG]; }
+    DEV float f(int k) const { return __uint_as_float(base[k * WG]); }
+    DEV void putf(int k, float v) const { base[k * WG] = __float_as_uint(v); }
+    DEV void put3(int k, F3 v) const { putf(k, v.x); putf(k + 1, v.y); putf(k + 2, v.z); }
+    DEV F3 get3(int k) const { return f3(f(k), f(k + 1), f(k + 2)); }
+    DEV void putw(int k, const MisWeights<SPEC> &w) const { for (int i = 0; i < NW / 3; ++i) put3(k + 3 * i, w.r[i]); }
+    DEV MisWeights<SPEC> getw(int k) const { MisWeights<SPEC> w; for (int i = 0; i < NW / 3; ++i) w.r[i] = get3(k + 3 * i); return w; }
+    DEV void store(const MisPathState<SPEC> &p, int cls) const {
+        u(M_RNG) = (uint32_t) p.rng.state; u(M_RNG + 1) = (uint32_t) (p.rng.state >> 32);
+        put3(M_O, p.ray.o); put3(M_D, p.ray.d); put3(M_DRCP, p.ray.d_rcp); putf(M_MINT, p.ray.mint); putf(M_MAXT, p.ray.maxt);
+        putf(M_SIT, p.si.t); u(M_MEDIUM) = (uint32_t) p.medium;
+        u(M_PACKED) = p.st | (p.mode << 4) | (p.channel << 6) | (p.flags << 8) | ((uint32_t) cls << 13) | ((p.depth < 32767u ? p.depth : 32767u) << 17);
+        putf(M_WA, p.wa); putf(M_WB, p.wb); putf(M_ETA, p.eta); put3(M_RES, p.res); put3(M_LSP, p.lsp);
+        put3(M_SIX, p.si.p); putf(M_SIX + 3, p.si.uv.x); putf(M_SIX + 4, p.si.uv.y); u(M_SIX + 5) = (uint32_t) p.si.shape; u(M_SIX + 6) = (uint32_t) p.si.prim;
+        putw(M_W, p.pf); putw(M_W + NW, p.pn); putw(M_W + 2 * NW, p.wn); putw(M_W + 3 * NW, p.wu);
+    }
+    DEV void load(MisPathState<SPEC> &p) const {
+        p.rng.state = (uint64_t) u(M_RNG) | ((uint64_t) u(M_RNG + 1) << 32); p.rng.inc = (PCG32_DEFAULT_STREAM << 1u) | 1u;
+        p.ray.o = get3(M_O); p.ray.d = get3(M_D); p.ray.d_rcp = get3(M_DRCP); p.ray.mint = f(M_MINT); p.ray.maxt = f(M_MAXT);
+        p.si.t = f(M_SIT); p.medium = (int) u(M_MEDIUM);
+        const uint32_t pk = u(M_PACKED);
+        p.st = pk & 15u; p.mode = (pk >> 4) & 3u; p.channel = (pk >> 6) & 3u; p.flags = (pk >> 8) & 31u; p.depth = pk >> 17;
+        p.wa = f(M_WA); p.wb = f(M_WB); p.eta = f(M_ETA); p.res = get3(M_RES); p.lsp = get3(M_LSP);
+        p.si.p = get3(M_SIX); p.si.uv.x = f(M_SIX + 3); p.si.uv.y = f(M_SIX + 4); p.si.shape = (int) u(M_SIX + 5); p.si.prim = (int) u(M_SIX + 6);
+        p.pf = getw(M_W); p.pn = getw(M_W + NW); p.wn = getw(M_W + 2 * NW); p.wu = getw(M_W + 3 * NW);
+    }
+};
+
+// One block of class `sel` for the path `pid` (the class is wave-uniform, the blocks are inlined as in volpath_flat.h)
+template <bool COUNT, bool SPEC, int WG>
+static __device__ __forceinline__ int mis_block(const MTS_CONST_AS void *kernarg_, uint32_t *hot_lds, uint32_t wg_base_, uint32_t pid, int sel, Counters *cnt) {
+    const uint64_t ka = (uint64_t) (uintptr_t) kernarg_;
+    uint32_t ka_lo = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) ka), ka_hi = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (ka >> 32));
+    asm volatile("" : "+s"(ka_lo), "+s"(ka_hi));             // opaque: scene loads stay inside this block
+    const MTS_CONST_AS void *kernarg = (const MTS_CONST_AS void *) (uintptr_t) ((uint64_t) ka_lo | ((uint64_t) ka_hi << 32));
+    const uint32_t wg_base = (uint32_t) __builtin_amdgcn_readfirstlane((int) wg_base_);
+    const WgArgs a = cload_k<WgArgs>(kernarg);
+    VolpathMisMachine<COUNT, SPEC> vm(a.sc, *cnt);
+    PathEnvT<ColdStoreHbm> e; wg_env<WG>(a, wg_base, pid, e);
+    MisHotStore<WG, SPEC> hs; hs.base = hot_lds + pid;
+    MisPathState<SPEC> p;
+    hs.load(p);
+    vm.run(p, e, sel);
+    vm.top(p, e);
+    const int cls = vm.classify(p);
+    hs.store(p, cls);
+    return cls;
+}
+
+// The asynchronous-regrouping driver of volpath_flat.h (volpath_workgroup_async) for the MIS machine: same rings, same claim, same
+// hand-over and stop protocol; it is a second copy rather than a shared template so that the tuned volpath kernel keeps its code.
+template <bool COUNT, bool SPEC, int WG /* paths */, int NT /* threads */>
+DEV void volpathmis_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt) {
+    constexpr int NQ = B_DONE;
+    typedef MisHotStore<WG, SPEC> Hot;
+    static_assert((WG & (WG - 1)) == 0 && NT % 64 == 0 && WG % 64 == 0 && NT <= WG, "whole waves, power-of-two rings");
+    __shared__ uint32_t hot_lds[Hot::M_COUNT * WG];
+    __shared__ uint16_t q_ids[NQ][WG];
+    __shared__ __attribute__((aligned(8))) uint32_t q_ctl[2 * B_COUNT + 2];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wg_base = blockIdx.x * WG;
+#pragma unroll 1
+    for (int c = 0; c < NQ; ++c) {
+#pragma unroll 1
+        for (uint32_t i = tid; i < (uint32_t) WG; i += NT) q_ids[c][i] = 0xFFFFu;
+    }
+    if (tid < 2u * B_COUNT + 2u) q_ctl[tid] = 0;
+    __syncthreads();
+#pragma unroll 1
+    for (uint32_t pid0 = tid; pid0 < (uint32_t) WG; pid0 += NT) {   // ---- initialise the paths (integrator.cpp:198) and queue them
+        const WgArgs a = cload_k<WgArgs>(kernarg);
+        VolpathMisMachine<COUNT, SPEC> vm(a.sc, cnt);
+        PathEnvT<ColdStoreHbm> e; MisPathState<SPEC> p;
+        Hot hs; hs.base = hot_lds + pid0;
+        const bool ok = wg_env<WG>(a, wg_base, pid0, e);
+        p.rng.state = 0; p.rng.inc = 0;
+        p.ray = make_ray(f3s(0.f), f3(0.f, 0.f, 1.f), 0.f, 0.f); p.si.t = pm_inf(); p.si.p = f3s(0.f); p.si.uv.x = p.si.uv.y = 0.f; p.si.shape = -1; p.si.prim = 0;
+        p.medium = -1; p.res = p.lsp = f3s(0.f); p.eta = 1.f; p.depth = 0; p.channel = 0; p.mode = M_MAIN; p.flags = 0; p.wa = p.wb = 0.f;
+        p.pf = p.pn = p.wn = p.wu = mw_full<SPEC>(1.f);
+        p.st = S_DONE;
+        if (ok) {
+            const uint32_t ppb = a.block_size * a.block_size;
+            const uint32_t i = (wg_base % ppb) + pid0;
+            p.rng.seed(a.sc.sensor.seed + (uint64_t) e.blk.id * ppb + i, PCG32_DEFAULT_STREAM);
+            for (int k = 0; k < 5; ++k) e.cold.f(C_ACC + k) = 0.f;
+            e.cold.f(C_SAMPLE) = __uint_as_float(0u);
+            vm.begin_sample(p, e);
+            vm.top(p, e);
+        }
+        const int cls = vm.classify(p);
+        hs.store(p, cls);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        wga_push<WG>(cls, pid0, true, q_ids, q_ctl, cload_k<WgArgs>(kernarg).counters);
+    }
+    uint32_t poll_ticks = (tid >> 6) * 2048u;
+#pragma unroll 1
+    for (;;) {
+        uint32_t hd = 0, avail = 0;
+        if (lane < (uint32_t) B_COUNT) {
+            hd = __atomic_load_n(&q_ctl[2 * lane], __ATOMIC_RELAXED);
+            const uint32_t tl = __atomic_load_n(&q_ctl[2 * lane + 1], __ATOMIC_RELAXED);
+            avail = tl - hd;
+            if (avail > (uint32_t) WG) avail = 0;
+        }
+        uint32_t key = lane < (uint32_t) NQ ? ((avail << 4) | (15u - lane)) : 0u;
+        key = max(key, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) key, 0x111 /* row_shr:1 */, 0xf, 0xf, true));
+        key = max(key, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) key, 0x112 /* row_shr:2 */, 0xf, 0xf, true));
+        key = max(key, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) key, 0x114 /* row_shr:4 */, 0xf, 0xf, true));
+        const uint32_t top_key = (uint32_t) __builtin_amdgcn_readlane((int) key, 7);
+        const uint32_t best = top_key >> 4; const int sel = 15 - (int) (top_key & 15u);
+        if (best == 0) {
+            if ((uint32_t) __builtin_amdgcn_readlane((int) avail, B_DONE) == (uint32_t) WG || __atomic_load_n(&q_ctl[2 * B_COUNT], __ATOMIC_RELAXED) != STOP_NONE) break;
+            if ((poll_ticks += 1u) >= 32768u) {
+                poll_ticks = 0;
+                if (lane == 0 && __hip_atomic_load(cload_k<WgArgs>(kernarg).stop_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
+                    (void) wga_raise_stop<WG>(q_ctl, STOP_CANCEL);
+            }
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        const uint32_t n = best < 64u ? best : 64u;
+        const uint32_t h = (uint32_t) __builtin_amdgcn_readlane((int) hd, sel);
+        uint32_t won = 0;
+        if (lane == 0) won = atomicCAS(&q_ctl[2 * sel], h, h + n) == h ? 1u : 0u;
+        if (!__builtin_amdgcn_readfirstlane((int) won)) continue;
+        uint32_t pid = 0xFFFFu;
+        bool mine = lane < n;
+        {
+            uint16_t *slot = &q_ids[sel][(h + lane) & (uint32_t) (WG - 1)];
+            if (mine) {
+                pid = __atomic_load_n(slot, __ATOMIC_RELAXED);
+                if (pid != 0xFFFFu) __atomic_store_n(slot, (uint16_t) 0xFFFFu, __ATOMIC_RELAXED);
+            }
+            if (__builtin_amdgcn_ballot_w64(mine && pid == 0xFFFFu) != 0ull) {
+                const uint32_t got = wga_slot_wait<WG, true>(mine && pid == 0xFFFFu, slot, 0u, q_ctl, cload_k<WgArgs>(kernarg).counters, sel, h + lane);
+                if (pid == 0xFFFFu) pid = got;
+                mine = mine && pid != 0xFFFFu;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        int cls = B_DONE;
+        if (mine) cls = mis_block<COUNT, SPEC, WG>(kernarg, hot_lds, wg_base, pid, sel, &cnt);
+        if (sel == B_NEW && (poll_ticks += 256u) >= 32768u) {
+            poll_ticks = 0;
+            if (lane == 0 && __hip_atomic_load(cload_k<WgArgs>(kernarg).stop_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
+                (void) wga_raise_stop<WG>(q_ctl, STOP_CANCEL);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        wga_push<WG>(cls, pid, mine, q_ids, q_ctl, cload_k<WgArgs>(kernarg).counters);
+    }
+}
+
+} // inline namespace
+} // namespace mtsamd

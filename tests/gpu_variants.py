@@ -6,13 +6,18 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     pkg = importlib.import_module("eradiate-kernel_amd"); scenes = importlib.import_module("eradiate-kernel_amd.scenes")
     import tests.oracle_binding as ob
     pkg.set_variant("gpu_rgb")
-    d = scenes.c3_heterogeneous(96, 64, 8, res=16)
+    integ = os.environ.get("MTSAMD_AB_INTEGRATOR")            # e.g. volpathmis: the same scenes under another integrator
+    def with_integrator(d):
+        if integ:
+            d = dict(d); d["integrator"] = dict(d["integrator"], type=integ)
+        return d
+    d = with_integrator(scenes.c3_heterogeneous(96, 64, 8, res=16))
     scene = pkg.load_dict(d); sensor = scene.sensors()[0]
     scene.integrator().render(scene, sensor, collect_counters=True); st = scene.integrator().last_stats
     gpu = np.array(sensor.film().bitmap(raw=True)); o = ob.OracleScene(d); ref = o.render(); so = o.last_stats
     ok = np.array_equal(gpu, ref) and (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
     w, h, spp = [int(x) for x in sys.argv[2:5]]
-    scene = pkg.load_dict(scenes.c3_heterogeneous(w, h, spp)); sensor = scene.sensors()[0]
+    scene = pkg.load_dict(with_integrator(scenes.c3_heterogeneous(w, h, spp))); sensor = scene.sensors()[0]
     for rep in range(2):
         scene.integrator().render(scene, sensor); st = scene.integrator().last_stats
     print("%-7s parity %s   C3 %dx%dx%d: kernel %.1f ms -> %.1f Msamples/s" % (os.environ.get("MTSAMD_KERNEL", "default"), "EXACT" if ok else "MISMATCH max rel %.3g" % float(np.max(np.abs(gpu - ref) / np.maximum(np.abs(ref), 1e-6))), w, h, spp, st["kernel_ms"], st["samples"] / st["kernel_ms"] / 1e3), flush=True)
