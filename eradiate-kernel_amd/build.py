@@ -17,7 +17,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.environ.get("MTSAMD_LIB_OUT") or os.path.join(HERE, "libmtsamd.so")   # MTSAMD_LIB_OUT: A/B builds next to the product
 SOURCES = ["kernels.hip", "kernels_spectral.hip", "scene_host.cpp", "capi.cpp"]
-HEADERS = ["pmath.h", "dmath.h", "dscene.h", "integrator_dev.h", "volpath_flat.h", "launch.h", "scene_host.h", "cie_tables.h"]
+HEADERS = ["pmath.h", "dmath.h", "dscene.h", "integrator_dev.h", "volpath_flat.h", "volpathmis_flat.h", "launch.h", "scene_host.h", "cie_tables.h"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fgpu-flush-denormals-to-zero",

@@ -85,8 +85,11 @@ struct VolpathMisMachine {
         if (p.flags & FL_FROM_MEDIUM) { p.ray.o = e.cold.get3(C_SO); p.st = S_PHASE; }
         else { p.si = e.cold.get_hit(); p.st = S_BSDF; }
     }
+    // A block that runs on a partial state (MisClassFields) leaves the end of a walk to finish(), which runs on the full state
+    template <bool DEFER, class E> DEV void nee_done(P &p, const E &e) const { if (DEFER) p.st = S_ENDNEE; else end_nee(p, e); }
+    template <class E> DEV void finish(P &p, const E &e) const { if (p.st == S_ENDNEE) end_nee(p, e); }
     // loop heads: volpathmis.cpp:134-151 (path), :358-362 (walk)
-    template <class E> DEV void top(P &p, const E &e) const {
+    template <bool DEFER = false, class E> DEV void top(P &p, const E &e) const {
         if (p.st != S_TOP) return;
         const uint32_t max_depth = (uint32_t) sc.integrator.max_depth, rr_depth = (uint32_t) sc.integrator.rr_depth;
         if (p.mode == M_MAIN) {
@@ -103,7 +106,7 @@ struct VolpathMisMachine {
         } else {
             float remaining_dist = p.wb * (1.f - MTS_SHADOW_EPSILON) - p.wa;
             p.ray.maxt = remaining_dist;
-            if (!(remaining_dist > 0.f)) end_nee(p, e);
+            if (!(remaining_dist > 0.f)) nee_done<DEFER>(p, e);
             else { if (COUNT) cnt.n_nee_step++; p.st = p.medium >= 0 ? S_MED : S_SURF; }
         }
     }
@@ -188,7 +191,7 @@ struct VolpathMisMachine {
         p.st = sample_emitters ? S_SCATTER : S_PHASE;
     }
     // ================================================================= SCATTER: emitter sampling at a medium interaction (:228-237 -> :330-356)
-    template <class E> DEV void start_walk(P &p, const E &e, F3 ref_p, const DirSample &ds, F3 emitter_sample_weight, F3 fval, float pdfv, bool from_medium) const {
+    template <bool DEFER, class E> DEV void start_walk(P &p, const E &e, F3 ref_p, const DirSample &ds, F3 emitter_sample_weight, F3 fval, float pdfv, bool from_medium) const {
         p.wn = p.pf; p.wu = p.pf;
         F3 emitter_val = emitter_sample_weight * ds.pdf;
         if (ds.pdf == 0.f) emitter_val = f3s(0.f);
@@ -199,14 +202,14 @@ struct VolpathMisMachine {
         if (from_medium) { e.cold.put3(C_SO, p.ray.o); p.flags |= FL_FROM_MEDIUM; }
         else { e.cold.put_hit(p.si); p.flags &= ~FL_FROM_MEDIUM; }
         p.mode = M_NEE;
-        if (!active) { end_nee(p, e); return; }
+        if (!active) { nee_done<DEFER>(p, e); return; }
         p.wa = 0.f; p.wb = ds.dist;
         p.ray = spawn_ray(ref_p, ds.d);
         if (from_medium) p.ray.mint = 0.f;
         queue_intersection(p);
         p.st = S_TOP;
     }
-    template <class E> DEV void blk_scatter(P &p, const E &e) const {
+    template <bool DEFER = false, class E> DEV void blk_scatter(P &p, const E &e) const {
         if (p.st != S_SCATTER) return;
         F3 esw;
         DirSample ds = sample_emitter_direction(sc, p.ray.o, p.rng.next_2d(), false, esw);
@@ -214,10 +217,10 @@ struct VolpathMisMachine {
         WATERFALL_BEGIN(p.medium, mu)
             phase_val = phase_eval<true>(sc, cload(sc.media + mu).phase, -p.ray.d, p.ray.o, ds.d);
         WATERFALL_END
-        start_walk(p, e, p.ray.o, ds, esw, f3s(phase_val), ds.delta ? 0.f : phase_val, true);
+        start_walk<DEFER>(p, e, p.ray.o, ds, esw, f3s(phase_val), ds.delta ? 0.f : phase_val, true);
     }
     // ================================================================= MEDIUM step of a walk (volpathmis.cpp:364-411)
-    template <class E> DEV void blk_medw(P &p, const E &e) const {
+    template <bool DEFER = false, class E> DEV void blk_medw(P &p, const E &e) const {
         if (p.st != S_MED || p.mode == M_MAIN || (p.flags & FL_NEEDS_INT)) return;
         const uint32_t channel = p.channel;
         const float u = p.rng.next_1d();
@@ -248,7 +251,7 @@ struct VolpathMisMachine {
             update_weights(p.wn, 1.f, sigma_n / mi.combined, channel, true);
             update_weights(p.wu, sigma_n, sigma_n, channel, true);
         }
-        if (walk_goes_on(p)) p.st = S_TOP; else end_nee(p, e);
+        if (walk_goes_on(p)) p.st = S_TOP; else nee_done<DEFER>(p, e);
     }
     // ================================================================= SURFACE step of a walk (volpathmis.cpp:413-441)
     template <class E> DEV void blk_wsurf(P &p, const E &e) const {
@@ -315,7 +318,7 @@ struct VolpathMisMachine {
             bsdf_val = bsdf_eval(bsdf, sf.wi, wo);
             bpdf = bsdf_pdf(bsdf, sf.wi, wo);
         WATERFALL_END
-        start_walk(p, e, p.si.p, ds, esw, bsdf_val, ds.delta ? 0.f : bpdf, false);
+        start_walk<false>(p, e, p.si.p, ds, esw, bsdf_val, ds.delta ? 0.f : bpdf, false);
     }
     // ================================================================= BSDF sampling (volpathmis.cpp:302-328)
     template <class E> DEV void blk_bsdf(P &p, const E &) const {
@@ -362,13 +365,13 @@ struct VolpathMisMachine {
         update_weights(p.pn, 1.f, phase_pdf, p.channel, true);
         p.st = S_TOP;
     }
-    template <class E> DEV void run(P &p, const E &e, int sel) const {
+    template <bool DEFER, class E> DEV void run(P &p, const E &e, int sel) const {
         switch (sel) {
             case B_NEW: blk_new(p, e); break;
             case B_INT: blk_int(p, e); break;
             case B_MED: blk_med(p, e); break;
-            case B_MEDW: blk_medw(p, e); break;
-            case B_SCATTER: blk_scatter(p, e); break;
+            case B_MEDW: blk_medw<DEFER>(p, e); break;
+            case B_SCATTER: blk_scatter<DEFER>(p, e); break;
             case B_WSURF: blk_wsurf(p, e); break;
             case B_SURF: blk_surf(p, e); blk_bsdf(p, e); break;
             case B_PHASE: blk_phase(p, e); break;
@@ -377,8 +380,33 @@ struct VolpathMisMachine {
     }
 };
 
-// Hot state in LDS, struct of arrays over the workgroup's paths (as HotStore of volpath_flat.h; every block loads / stores all of it:
-// at two waves per SIMD the register budget of 256 VGPRs holds the whole state)
+// Hot state in LDS, struct of arrays over the workgroup's paths (as HotStore of volpath_flat.h).  A block loads / stores only the field
+// groups its class can read / write (MisClassFields); at two waves per SIMD the register budget of 256 VGPRs holds the whole state.
+enum : uint32_t { K_RNG = 1, K_O = 2, K_D = 4 /* d and 1/d */, K_MINT = 8, K_MAXT = 16, K_SIT = 32, K_SIX = 64 /* rest of si */, K_MED = 128,
+                  K_PF = 256, K_PN = 512, K_WN = 1024, K_WU = 2048, K_RES = 4096, K_LSP = 8192, K_ETA = 16384, K_WA = 32768, K_WB = 65536,
+                  K_ALL = 131071 };
+// What block class C (followed by top()) may read (`load`, a superset of `store`) and write (`store`); `defer`: the end of a walk,
+// which touches almost everything, runs afterwards on the full state (VolpathMisMachine::finish).
+template <int C> struct MisClassFields { static constexpr uint32_t load = K_ALL, store = K_ALL; static constexpr bool defer = false; };
+template <> struct MisClassFields<B_INT> {
+    static constexpr uint32_t load = K_O | K_D | K_MINT | K_MAXT, store = K_SIT | K_SIX; static constexpr bool defer = true; };
+template <> struct MisClassFields<B_MED> {       // the path: p_over_f, p_over_f_nee; the loop head reads eta
+    static constexpr uint32_t load = K_RNG | K_O | K_D | K_MINT | K_MAXT | K_SIT | K_MED | K_PF | K_PN | K_ETA | K_LSP,
+                              store = K_RNG | K_O | K_MINT | K_SIT | K_PF | K_PN | K_LSP;
+    static constexpr bool defer = true; };
+template <> struct MisClassFields<B_MEDW> {      // a walk: its two matrices and its distance budget
+    static constexpr uint32_t load = K_RNG | K_O | K_D | K_MINT | K_MAXT | K_SIT | K_MED | K_WN | K_WU | K_WA | K_WB,
+                              store = K_RNG | K_O | K_MINT | K_MAXT | K_SIT | K_WN | K_WU | K_WA;
+    static constexpr bool defer = true; };
+template <> struct MisClassFields<B_SCATTER> {
+    static constexpr uint32_t load = K_RNG | K_O | K_D | K_MINT | K_MAXT | K_SIT | K_MED | K_PF | K_WA | K_WB,
+                              store = K_RNG | K_O | K_D | K_MINT | K_MAXT | K_SIT | K_WN | K_WU | K_WA | K_WB;
+    static constexpr bool defer = true; };
+template <> struct MisClassFields<B_PHASE> {
+    static constexpr uint32_t load = K_RNG | K_O | K_D | K_MINT | K_MAXT | K_SIT | K_MED | K_PF | K_ETA,
+                              store = K_RNG | K_O | K_D | K_MINT | K_MAXT | K_SIT | K_PF | K_PN;
+    static constexpr bool defer = true; };
+
 template <int WG, bool SPEC>
 struct MisHotStore {
     static constexpr int NW = SPEC ? 9 : 3;                     // floats per weight matrix
@@ -392,30 +420,50 @@ struct MisHotStore {
     DEV F3 get3(int k) const { return f3(f(k), f(k + 1), f(k + 2)); }
     DEV void putw(int k, const MisWeights<SPEC> &w) const { for (int i = 0; i < NW / 3; ++i) put3(k + 3 * i, w.r[i]); }
     DEV MisWeights<SPEC> getw(int k) const { MisWeights<SPEC> w; for (int i = 0; i < NW / 3; ++i) w.r[i] = get3(k + 3 * i); return w; }
-    DEV void store(const MisPathState<SPEC> &p, int cls) const {
-        u(M_RNG) = (uint32_t) p.rng.state; u(M_RNG + 1) = (uint32_t) (p.rng.state >> 32);
-        put3(M_O, p.ray.o); put3(M_D, p.ray.d); put3(M_DRCP, p.ray.d_rcp); putf(M_MINT, p.ray.mint); putf(M_MAXT, p.ray.maxt);
-        putf(M_SIT, p.si.t); u(M_MEDIUM) = (uint32_t) p.medium;
+    template <uint32_t M> DEV void store_m(const MisPathState<SPEC> &p, int cls) const {
+        if (M & K_RNG) { u(M_RNG) = (uint32_t) p.rng.state; u(M_RNG + 1) = (uint32_t) (p.rng.state >> 32); }
+        if (M & K_O) put3(M_O, p.ray.o);
+        if (M & K_D) { put3(M_D, p.ray.d); put3(M_DRCP, p.ray.d_rcp); }
+        if (M & K_MINT) putf(M_MINT, p.ray.mint);
+        if (M & K_MAXT) putf(M_MAXT, p.ray.maxt);
+        if (M & K_SIT) putf(M_SIT, p.si.t);
+        if (M & K_SIX) { put3(M_SIX, p.si.p); putf(M_SIX + 3, p.si.uv.x); putf(M_SIX + 4, p.si.uv.y); u(M_SIX + 5) = (uint32_t) p.si.shape; u(M_SIX + 6) = (uint32_t) p.si.prim; }
+        if (M & K_MED) u(M_MEDIUM) = (uint32_t) p.medium;
         u(M_PACKED) = p.st | (p.mode << 4) | (p.channel << 6) | (p.flags << 8) | ((uint32_t) cls << 13) | ((p.depth < 32767u ? p.depth : 32767u) << 17);
-        putf(M_WA, p.wa); putf(M_WB, p.wb); putf(M_ETA, p.eta); put3(M_RES, p.res); put3(M_LSP, p.lsp);
-        put3(M_SIX, p.si.p); putf(M_SIX + 3, p.si.uv.x); putf(M_SIX + 4, p.si.uv.y); u(M_SIX + 5) = (uint32_t) p.si.shape; u(M_SIX + 6) = (uint32_t) p.si.prim;
-        putw(M_W, p.pf); putw(M_W + NW, p.pn); putw(M_W + 2 * NW, p.wn); putw(M_W + 3 * NW, p.wu);
+        if (M & K_WA) putf(M_WA, p.wa);
+        if (M & K_WB) putf(M_WB, p.wb);
+        if (M & K_ETA) putf(M_ETA, p.eta);
+        if (M & K_RES) put3(M_RES, p.res);
+        if (M & K_LSP) put3(M_LSP, p.lsp);
+        if (M & K_PF) putw(M_W, p.pf);
+        if (M & K_PN) putw(M_W + NW, p.pn);
+        if (M & K_WN) putw(M_W + 2 * NW, p.wn);
+        if (M & K_WU) putw(M_W + 3 * NW, p.wu);
     }
-    DEV void load(MisPathState<SPEC> &p) const {
-        p.rng.state = (uint64_t) u(M_RNG) | ((uint64_t) u(M_RNG + 1) << 32); p.rng.inc = (PCG32_DEFAULT_STREAM << 1u) | 1u;
-        p.ray.o = get3(M_O); p.ray.d = get3(M_D); p.ray.d_rcp = get3(M_DRCP); p.ray.mint = f(M_MINT); p.ray.maxt = f(M_MAXT);
-        p.si.t = f(M_SIT); p.medium = (int) u(M_MEDIUM);
+    template <uint32_t M> DEV void load_m(MisPathState<SPEC> &p) const {
+        p.rng.state = 0; p.rng.inc = (PCG32_DEFAULT_STREAM << 1u) | 1u;
+        if (M & K_RNG) p.rng.state = (uint64_t) u(M_RNG) | ((uint64_t) u(M_RNG + 1) << 32);
+        p.ray.o = (M & K_O) ? get3(M_O) : f3s(0.f);
+        p.ray.d = (M & K_D) ? get3(M_D) : f3s(0.f); p.ray.d_rcp = (M & K_D) ? get3(M_DRCP) : f3s(0.f);
+        p.ray.mint = (M & K_MINT) ? f(M_MINT) : 0.f; p.ray.maxt = (M & K_MAXT) ? f(M_MAXT) : 0.f;
+        p.si.t = (M & K_SIT) ? f(M_SIT) : pm_inf();
+        p.si.p = f3s(0.f); p.si.uv.x = p.si.uv.y = 0.f; p.si.shape = -1; p.si.prim = 0;
+        if (M & K_SIX) { p.si.p = get3(M_SIX); p.si.uv.x = f(M_SIX + 3); p.si.uv.y = f(M_SIX + 4); p.si.shape = (int) u(M_SIX + 5); p.si.prim = (int) u(M_SIX + 6); }
+        p.medium = (M & K_MED) ? (int) u(M_MEDIUM) : -1;
         const uint32_t pk = u(M_PACKED);
         p.st = pk & 15u; p.mode = (pk >> 4) & 3u; p.channel = (pk >> 6) & 3u; p.flags = (pk >> 8) & 31u; p.depth = pk >> 17;
-        p.wa = f(M_WA); p.wb = f(M_WB); p.eta = f(M_ETA); p.res = get3(M_RES); p.lsp = get3(M_LSP);
-        p.si.p = get3(M_SIX); p.si.uv.x = f(M_SIX + 3); p.si.uv.y = f(M_SIX + 4); p.si.shape = (int) u(M_SIX + 5); p.si.prim = (int) u(M_SIX + 6);
-        p.pf = getw(M_W); p.pn = getw(M_W + NW); p.wn = getw(M_W + 2 * NW); p.wu = getw(M_W + 3 * NW);
+        p.wa = (M & K_WA) ? f(M_WA) : 0.f; p.wb = (M & K_WB) ? f(M_WB) : 0.f; p.eta = (M & K_ETA) ? f(M_ETA) : 1.f;
+        p.res = (M & K_RES) ? get3(M_RES) : f3s(0.f); p.lsp = (M & K_LSP) ? get3(M_LSP) : f3s(0.f);
+        p.pf = (M & K_PF) ? getw(M_W) : mw_full<SPEC>(1.f); p.pn = (M & K_PN) ? getw(M_W + NW) : mw_full<SPEC>(1.f);
+        p.wn = (M & K_WN) ? getw(M_W + 2 * NW) : mw_full<SPEC>(1.f); p.wu = (M & K_WU) ? getw(M_W + 3 * NW) : mw_full<SPEC>(1.f);
     }
+    DEV void store(const MisPathState<SPEC> &p, int cls) const { store_m<K_ALL>(p, cls); }
+    DEV void load(MisPathState<SPEC> &p) const { load_m<K_ALL>(p); }
 };
 
-// One block of class `sel` for the path `pid` (the class is wave-uniform, the blocks are inlined as in volpath_flat.h)
-template <bool COUNT, bool SPEC, int WG>
-static __device__ __forceinline__ int mis_block(const MTS_CONST_AS void *kernarg_, uint32_t *hot_lds, uint32_t wg_base_, uint32_t pid, int sel, Counters *cnt) {
+// One block of class C for the path `pid` (the class is wave-uniform, the blocks are inlined as in volpath_flat.h)
+template <bool COUNT, bool SPEC, int WG, int C>
+static __device__ __forceinline__ int mis_block(const MTS_CONST_AS void *kernarg_, uint32_t *hot_lds, uint32_t wg_base_, uint32_t pid, Counters *cnt) {
     const uint64_t ka = (uint64_t) (uintptr_t) kernarg_;
     uint32_t ka_lo = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) ka), ka_hi = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (ka >> 32));
     asm volatile("" : "+s"(ka_lo), "+s"(ka_hi));             // opaque: scene loads stay inside this block
@@ -425,12 +473,21 @@ static __device__ __forceinline__ int mis_block(const MTS_CONST_AS void *kernarg
     VolpathMisMachine<COUNT, SPEC> vm(a.sc, *cnt);
     PathEnvT<ColdStoreHbm> e; wg_env<WG>(a, wg_base, pid, e);
     MisHotStore<WG, SPEC> hs; hs.base = hot_lds + pid;
+    typedef MisClassFields<C> CF;
     MisPathState<SPEC> p;
-    hs.load(p);
-    vm.run(p, e, sel);
-    vm.top(p, e);
-    const int cls = vm.classify(p);
-    hs.store(p, cls);
+    hs.template load_m<CF::load>(p);
+    vm.template run<CF::defer>(p, e, C);
+    vm.template top<CF::defer>(p, e);
+    int cls = vm.classify(p);
+    hs.template store_m<CF::store>(p, cls);
+    if (CF::defer && p.st == S_ENDNEE) {                        // the end of a walk, on the full state
+        MisPathState<SPEC> q;
+        hs.template load_m<K_ALL>(q);
+        vm.finish(q, e);
+        vm.top(q, e);
+        cls = vm.classify(q);
+        hs.template store_m<K_ALL>(q, cls);
+    }
     return cls;
 }
 
@@ -526,7 +583,18 @@ DEV void volpathmis_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         int cls = B_DONE;
-        if (mine) cls = mis_block<COUNT, SPEC, WG>(kernarg, hot_lds, wg_base, pid, sel, &cnt);
+        if (mine) {
+            switch (sel) {                                      // wave-uniform
+                case B_INT: cls = mis_block<COUNT, SPEC, WG, B_INT>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                case B_MED: cls = mis_block<COUNT, SPEC, WG, B_MED>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                case B_MEDW: cls = mis_block<COUNT, SPEC, WG, B_MEDW>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                case B_SCATTER: cls = mis_block<COUNT, SPEC, WG, B_SCATTER>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                case B_WSURF: cls = mis_block<COUNT, SPEC, WG, B_WSURF>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                case B_SURF: cls = mis_block<COUNT, SPEC, WG, B_SURF>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                case B_PHASE: cls = mis_block<COUNT, SPEC, WG, B_PHASE>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                default: cls = mis_block<COUNT, SPEC, WG, B_NEW>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+            }
+        }
         if (sel == B_NEW && (poll_ticks += 256u) >= 32768u) {
             poll_ticks = 0;
             if (lane == 0 && __hip_atomic_load(cload_k<WgArgs>(kernarg).stop_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
