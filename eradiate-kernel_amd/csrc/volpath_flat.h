@@ -969,10 +969,12 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
     uint32_t poll_ticks = (tid >> 6) * 2048u;                // per wave, staggered: paces the polls of the host's stop word
 #pragma unroll 1
     for (;;) {
+      uint32_t n = 0, h = 0; int sel = 0; bool finished = false;
+      // ---- the claim: an inner loop of its own (snapshot, vote, compare-and-swap), left with a claim or when the workgroup is done.
+      // (As `continue`s of the outer loop the retries dragged eighteen register copies of dead path state through every round.)
+#pragma unroll 1
+      for (;;) {
         // ---- snapshot of the rings, pick the fullest
-#if defined(EXP_PRIO_CLAIM)
-        __builtin_amdgcn_s_setprio(EXP_PRIO_CLAIM);
-#endif
         uint32_t hd = 0, avail = 0;
         if (lane < (uint32_t) B_COUNT) {
             hd = __atomic_load_n(&q_ctl[2 * lane], __ATOMIC_RELAXED);
@@ -991,10 +993,10 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         key = max(key, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) key, 0x112 /* row_shr:2 */, 0xf, 0xf, true));
         key = max(key, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) key, 0x114 /* row_shr:4 */, 0xf, 0xf, true));
         const uint32_t top_key = (uint32_t) __builtin_amdgcn_readlane((int) key, 7);
-        const uint32_t best = top_key >> 4; const int sel = 15 - (int) (top_key & 15u);
+        const uint32_t best = top_key >> 4; sel = 15 - (int) (top_key & 15u);
         if (best == 0) {
             // every path of the workgroup has finished, or the workgroup was stopped (then every ring looks empty for good)
-            if ((uint32_t) __builtin_amdgcn_readlane((int) avail, B_DONE) == (uint32_t) WG || __atomic_load_n(&q_ctl[2 * B_COUNT], __ATOMIC_RELAXED) != STOP_NONE) break;
+            if ((uint32_t) __builtin_amdgcn_readlane((int) avail, B_DONE) == (uint32_t) WG || __atomic_load_n(&q_ctl[2 * B_COUNT], __ATOMIC_RELAXED) != STOP_NONE) { finished = true; break; }
             // Integrator::should_stop() (integrator.h:143-146): waves look at the host's stop word (pinned host memory) now and then.  Reads
             // of host memory are a scarce resource -- the whole GPU sustains about 3 * 10^7 per second, and a poll on every nap made the
             // render 4.7 times longer -- so a wave earns a poll with 32768 ticks: one per nap, 256 per execution of the NEW block (below).
@@ -1011,14 +1013,16 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
             continue;
         }
         // ---- claim up to 64 ids
-        const uint32_t n = best < 64u ? best : 64u;
-        const uint32_t h = (uint32_t) __builtin_amdgcn_readlane((int) hd, sel);
+        n = best < 64u ? best : 64u;
+        h = (uint32_t) __builtin_amdgcn_readlane((int) hd, sel);
         uint32_t won = 0;
         if (lane == 0) won = atomicCAS(&q_ctl[2 * sel], h, h + n) == h ? 1u : 0u;
 #if defined(MTSAMD_BLOCKSTATS)
         if (COUNT) { bs_loc[10] += 1ull; if (!__builtin_amdgcn_readfirstlane((int) won)) bs_loc[11] += 1ull; }      // claim attempts / lost compare-and-swaps
 #endif
-        if (!__builtin_amdgcn_readfirstlane((int) won)) continue;
+        if (__builtin_amdgcn_readfirstlane((int) won)) break;
+      }
+      if (finished) break;
         uint32_t pid = 0xFFFFu;
         bool mine = lane < n;
         {
@@ -1038,9 +1042,6 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
 #if defined(MTSAMD_BLOCKSTATS)
         if (COUNT) { bs_loc[sel] += 1ull; bs_loc[12 + sel] += (unsigned long long) n;
                      long long t = clock64(); bs_loc[44] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
-#endif
-#if defined(EXP_PRIO_CLAIM)
-        __builtin_amdgcn_s_setprio(EXP_PRIO_BLOCK);
 #endif
         int cls = B_DONE;
         if (mine) {

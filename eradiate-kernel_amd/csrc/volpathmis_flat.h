@@ -539,6 +539,9 @@ DEV void volpathmis_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &
     uint32_t poll_ticks = (tid >> 6) * 2048u;
 #pragma unroll 1
     for (;;) {
+      uint32_t n = 0, h = 0; int sel = 0; bool finished = false;
+#pragma unroll 1
+      for (;;) {                                                // the claim: snapshot, vote, compare-and-swap (see volpath_flat.h)
         uint32_t hd = 0, avail = 0;
         if (lane < (uint32_t) B_COUNT) {
             hd = __atomic_load_n(&q_ctl[2 * lane], __ATOMIC_RELAXED);
@@ -551,9 +554,9 @@ DEV void volpathmis_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &
         key = max(key, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) key, 0x112 /* row_shr:2 */, 0xf, 0xf, true));
         key = max(key, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) key, 0x114 /* row_shr:4 */, 0xf, 0xf, true));
         const uint32_t top_key = (uint32_t) __builtin_amdgcn_readlane((int) key, 7);
-        const uint32_t best = top_key >> 4; const int sel = 15 - (int) (top_key & 15u);
+        const uint32_t best = top_key >> 4; sel = 15 - (int) (top_key & 15u);
         if (best == 0) {
-            if ((uint32_t) __builtin_amdgcn_readlane((int) avail, B_DONE) == (uint32_t) WG || __atomic_load_n(&q_ctl[2 * B_COUNT], __ATOMIC_RELAXED) != STOP_NONE) break;
+            if ((uint32_t) __builtin_amdgcn_readlane((int) avail, B_DONE) == (uint32_t) WG || __atomic_load_n(&q_ctl[2 * B_COUNT], __ATOMIC_RELAXED) != STOP_NONE) { finished = true; break; }
             if ((poll_ticks += 1u) >= 32768u) {
                 poll_ticks = 0;
                 if (lane == 0 && __hip_atomic_load(cload_k<WgArgs>(kernarg).stop_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
@@ -562,11 +565,13 @@ DEV void volpathmis_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &
             __builtin_amdgcn_s_sleep(2);
             continue;
         }
-        const uint32_t n = best < 64u ? best : 64u;
-        const uint32_t h = (uint32_t) __builtin_amdgcn_readlane((int) hd, sel);
+        n = best < 64u ? best : 64u;
+        h = (uint32_t) __builtin_amdgcn_readlane((int) hd, sel);
         uint32_t won = 0;
         if (lane == 0) won = atomicCAS(&q_ctl[2 * sel], h, h + n) == h ? 1u : 0u;
-        if (!__builtin_amdgcn_readfirstlane((int) won)) continue;
+        if (__builtin_amdgcn_readfirstlane((int) won)) break;
+      }
+      if (finished) break;
         uint32_t pid = 0xFFFFu;
         bool mine = lane < n;
         {

@@ -17,10 +17,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     gpu = np.array(sensor.film().bitmap(raw=True)); o = ob.OracleScene(d); ref = o.render(); so = o.last_stats
     ok = np.array_equal(gpu, ref) and (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
     w, h, spp = [int(x) for x in sys.argv[2:5]]
-    scene = pkg.load_dict(with_integrator(scenes.c3_heterogeneous(w, h, spp))); sensor = scene.sensors()[0]
+    big = {"C3": scenes.c3_heterogeneous, "C4": scenes.c4_atmosphere, "C2": scenes.c2_homogeneous_slab}[os.environ.get("MTSAMD_AB_SCENE", "C3")]
+    scene = pkg.load_dict(with_integrator(big(w, h, spp))); sensor = scene.sensors()[0]
     for rep in range(2):
         scene.integrator().render(scene, sensor); st = scene.integrator().last_stats
-    print("%-7s parity %s   C3 %dx%dx%d: kernel %.1f ms -> %.1f Msamples/s" % (os.environ.get("MTSAMD_KERNEL", "default"), "EXACT" if ok else "MISMATCH max rel %.3g" % float(np.max(np.abs(gpu - ref) / np.maximum(np.abs(ref), 1e-6))), w, h, spp, st["kernel_ms"], st["samples"] / st["kernel_ms"] / 1e3), flush=True)
+    print("%-7s parity %s   %s %dx%dx%d: kernel %.1f ms -> %.1f Msamples/s" % (os.environ.get("MTSAMD_KERNEL", "default"), "EXACT" if ok else "MISMATCH max rel %.3g" % float(np.max(np.abs(gpu - ref) / np.maximum(np.abs(ref), 1e-6))), os.environ.get("MTSAMD_AB_SCENE", "C3"), w, h, spp, st["kernel_ms"], st["samples"] / st["kernel_ms"] / 1e3), flush=True)
 else:
     for v in sys.argv[4:]:
         env = dict(os.environ, MTSAMD_KERNEL=v)

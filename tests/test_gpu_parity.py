@@ -511,6 +511,33 @@ def test_metric_scene_throughput_floor(gpu_rgb):
     assert best > 200.0, best
 
 
+@pytest.mark.parametrize("kernel", [None, "nested"])
+def test_volpathmis_machine_and_nested_kernel_agree(gpu_rgb, monkeypatch, kernel):
+    """volpathmis runs on the regrouping machine (volpathmis_flat.h) by default and in the nested per-lane formulation with
+    MTSAMD_KERNEL=nested: both bit-identical to the oracle on a film of partial blocks, with and without spectral MIS; the machine
+    at about 280 Msamples/s on the metric scene (the per-lane kernel: 27) -- floor 120."""
+    if kernel:
+        monkeypatch.setenv("MTSAMD_KERNEL", kernel)
+    for spectral_mis in (True, False):
+        d = scenes.c3_heterogeneous(72, 40, 6, res=16)
+        d["integrator"] = dict(d["integrator"], type="volpathmis", use_spectral_mis=spectral_mis, max_depth=24, rr_depth=3)
+        gpu, st = gpu_render(gpu_rgb, d, collect_counters=True)
+        o = ob.OracleScene(d); ref = o.render(); so = o.last_stats
+        assert np.array_equal(gpu, ref) and gpu[..., :3].max() > 0
+        assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
+    if kernel is None:
+        d = scenes.c3_heterogeneous(512, 512, 64)
+        d["integrator"] = dict(d["integrator"], type="volpathmis")
+        scene = gpu_rgb.load_dict(d)
+        sensor = scene.sensors()[0]
+        best = 0.0
+        for _ in range(3):
+            assert scene.integrator().render(scene, sensor)
+            st = scene.integrator().last_stats
+            best = max(best, st["samples"] / (st["kernel_ms"] * 1e-3) / 1e6)
+        assert best > 120.0, best
+
+
 def test_cancel_and_timeout(gpu_rgb):
     """Integrator::cancel / should_stop (integrator.h:143-146, integrator.cpp:43-45,178) reach the kernel INSIDE its single launch:
     the ring driver polls the scene's stop word once per claim iteration."""
@@ -543,7 +570,14 @@ def test_cancel_and_timeout(gpu_rgb):
     ok = scene.integrator().render(scene, scene.sensors()[0])
     st = scene.integrator().last_stats
     assert ok is True and st["timed_out"] == 1 and st["cancelled"] == 0 and time.perf_counter() - t0 < 1.5
-    # the per-lane kernels poll the same word (path / volpathmis / MTSAMD_KERNEL=flat)
+    # the regrouping kernel of volpathmis (volpathmis_flat.h) shares the ring and stop protocol
+    d["integrator"]["type"] = "volpathmis"
+    scene = gpu_rgb.load_dict(d)
+    t0 = time.perf_counter()
+    ok = scene.integrator().render(scene, scene.sensors()[0])
+    st = scene.integrator().last_stats
+    assert ok is True and st["timed_out"] == 1 and st["kernel_launches"] == 1 and time.perf_counter() - t0 < 1.5
+    # the per-lane kernels poll the same word (path / MTSAMD_KERNEL=nested | flat)
     d = scenes.c1_cornell(512, 512, 16384)
     d["integrator"]["timeout"] = 0.25
     scene = gpu_rgb.load_dict(d)
@@ -552,11 +586,13 @@ def test_cancel_and_timeout(gpu_rgb):
     assert scene.integrator().last_stats["timed_out"] == 1 and time.perf_counter() - t0 < 2.0
 
 
-def test_small_blocks_keep_the_regrouping_kernel(gpu_rgb):
+@pytest.mark.parametrize("integrator", ["volpath", "volpathmis"])
+def test_small_blocks_keep_the_regrouping_kernel(gpu_rgb, integrator):
     """block_size 16 (256 pixels per block) runs on the 256-path workgroups of the ring driver, not on the per-lane fallback, and
     matches the oracle, which seeds per block like integrator.cpp:198."""
     d = scenes.c3_heterogeneous(48, 40, 8, res=16)
     d["integrator"]["block_size"] = 16
+    d["integrator"]["type"] = integrator
     gpu, st = gpu_render(gpu_rgb, d, collect_counters=True)
     o = ob.OracleScene(d); ref = o.render()
     assert_parity(gpu, ref)
