@@ -31,7 +31,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
 CONFIG_SIZES = {"C1": (256, 256, 64), "C2": (512, 512, 256), "C3": (512, 512, 1024), "C4": (1024, 1024, 4096), "C5": (1024, 1024, 4096),
-                "C5S": (1024, 1024, 32), "C3M": (512, 512, 1024)}      # C5S: the same atmosphere in the spectral variant (gpu_spectral, per-lane kernel: slow), 32 spp
+                "C5S": (1024, 1024, 32), "C3M": (512, 512, 1024), "C1L": (512, 512, 256)}      # C5S: the same atmosphere in the spectral variant (gpu_spectral, per-lane kernel: slow), 32 spp
 C5_WAVELENGTHS = 16        # BASELINE.json configs[4]: the C4 atmosphere as a 16-wavelength batch
 
 
@@ -42,7 +42,7 @@ def c5_rayleigh_scale(k):
 
 
 def build_scene_dict(scenes, config, width, height, spp, samples_per_pass=-1, res=128, wavelength=0):
-    if config == "C1":
+    if config in ("C1", "C1L"):                                     # C1L: the same cornell box at a size that fills the chip
         d = scenes.c1_cornell(width, height, spp)
     elif config == "C2":
         d = scenes.c2_homogeneous_slab(width, height, spp)
@@ -218,8 +218,8 @@ def main():
         kernel_name = "render_kernel_wga<false, %d, %d, %d>" % (paths, nt, {1: 4, 0.75: 3, 0.5: 2}[nt / paths])
     # `achieved` / `frac` follow the contract: ALGORITHMIC bytes (a wavefront formulation's state round trips) over
     # the kernel's measured time.  This kernel keeps path state in LDS, so its real HBM traffic is several times lower and its
-    # bound is VALU issue; `traffic*` and `valu_issue_frac` (rocprofv3 --pmc, profiles/) say so whenever this run matches the
-    # profiled configuration.
+    # bound is latency at 4 waves per SIMD; `traffic*` and `valu_pipe_busy` (rocprofv3 --pmc, profiles/) say so whenever this run
+    # matches the profiled configuration.
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "achieved_is": "algorithmic bytes per launch / measured launch time (SURVEY.md 8(d)); not a bandwidth measurement",
@@ -240,9 +240,11 @@ def main():
             roofline["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration; not measured in this run)" % fname
             roofline["traffic_gbs"] = round(prof["bytes_per_launch"] / (avg_launch_ms * 1e-3) / 1e9, 1)
             roofline["traffic_frac_of_peak"] = round(roofline["traffic_gbs"] / HBM_PEAK_GBS, 4)
-            if "valu_issue_fraction" in prof:
-                roofline["valu_issue_frac"] = prof["valu_issue_fraction"]
-                roofline["real_bound"] = "valu issue (%.0f %% of the issue slots; HBM at %.0f %% of peak)" % (100 * prof["valu_issue_fraction"], 100 * roofline["traffic_frac_of_peak"])
+            dv = prof.get("derived") or {}
+            if "valu_pipe_busy" in dv:
+                roofline["valu_pipe_busy"] = dv["valu_pipe_busy"]
+                roofline["real_bound"] = ("latency at 4 waves per SIMD: vector pipes %.0f %% busy, a wave waits %.0f %% of its time in s_waitcnt, "
+                                          "HBM at %.0f %% of peak" % (100 * dv["valu_pipe_busy"], 100 * dv.get("wave_wait_share", 0.0), 100 * roofline["traffic_frac_of_peak"]))
 
     # ---- weak scaling side figure (N > 1): one 512x512x1024 job per GPU
     weak = None
@@ -276,7 +278,7 @@ def main():
                                                   % (args.width, args.height, cpu_spp, " (first wavelength)" if args.config == "C5" else "", tcpu, cores)}
 
     if rank == 0:
-        workload = {"C1": "C1 path cornell box", "C2": "C2 volpath homogeneous slab", "C4": "C4 volpath layered atmosphere, blend/tabulated phase, RPV ground",
+        workload = {"C1": "C1 path cornell box", "C1L": "C1L = the C1 cornell box at 512x512x256 (262144 pixel streams: one per lane of the chip)", "C2": "C2 volpath homogeneous slab", "C4": "C4 volpath layered atmosphere, blend/tabulated phase, RPV ground",
                     "C5": "C5 = C4 as %d monochromatic wavelength batches (Rayleigh ~ lambda^-4), gpu_mono" % C5_WAVELENGTHS,
                     "C5S": "C5S = the C4 atmosphere in the spectral variant (gpu_spectral: 4 wavelengths per sample, gridvolume_spectral), per-lane kernel",
                     "C3M": "C3M = the C3 scene under volpathmis (spectral MIS), regrouping kernel of volpathmis_flat.h",

@@ -29,7 +29,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLE
 done
 cd $R
 python3 tests/pmc_summary.py --json $O/pmc_summary_c4.json --probe "bench.py --config C4 --spp 256 --steps 1 (1024x1024x256)" $O/c4_FETCH_SIZE $O/c4_WRITE_SIZE $O/c4_SQ_INSTS_VALU $O/c4_SQ_THREAD_CYCLES_VALU
-for c in C1 C2 C3M C5S; do python bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_$c.log 2>&1; tail -1 $O/bench_$c.log; done
+for c in C1 C1L C2 C3M C5S; do python bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_$c.log 2>&1; tail -1 $O/bench_$c.log; done
 # C5 = 16 wavelength batches of the C4 atmosphere: 256 spp per batch here (the full 4096 spp take ~5 minutes per step)
 python bench.py --config C5 --spp 256 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_C5.log 2>&1; tail -1 $O/bench_C5.log
 find $O -name "*kernel_stats*" | head

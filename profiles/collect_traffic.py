@@ -43,7 +43,7 @@ out = {"run": {"config": cfg, "width": int(m.group(1)), "height": int(m.group(2)
 out["bytes_per_launch"] = out["fetch_bytes_corrected"] + out["write_bytes"]
 if len(sys.argv) > 5:
     pmc = json.load(open(sys.argv[5]))
-    out["valu_issue_fraction"] = pmc["derived"]["valu_issue_fraction"]
-    out["valu_issue_fraction_source"] = pmc["probe"]
+    out["derived"] = pmc["derived"]                     # tests/pmc_summary.py: valu_pipe_busy, wave_wait_share, lane_utilisation ...
+    out["derived_source"] = pmc["probe"]
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out))
