@@ -31,7 +31,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
 CONFIG_SIZES = {"C1": (256, 256, 64), "C2": (512, 512, 256), "C3": (512, 512, 1024), "C4": (1024, 1024, 4096), "C5": (1024, 1024, 4096),
-                "C5S": (1024, 1024, 32), "C3M": (512, 512, 1024), "C1L": (512, 512, 256)}      # C5S: the same atmosphere in the spectral variant (gpu_spectral, per-lane kernel: slow), 32 spp
+                "C5S": (1024, 1024, 256), "C3M": (512, 512, 1024), "C1L": (512, 512, 256)}      # C5S: the same atmosphere in the spectral variant (gpu_spectral), 256 spp
 C5_WAVELENGTHS = 16        # BASELINE.json configs[4]: the C4 atmosphere as a 16-wavelength batch
 
 
@@ -207,12 +207,14 @@ def main():
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
     integ_type = job.dicts[0]["integrator"]["type"]
     kv = os.environ.get("MTSAMD_KERNEL", "wga1024")
-    if integ_type == "path" or kv == "nested" or args.config == "C5S":
+    if integ_type == "path" or kv == "nested":
         kernel_name = "render_kernel<false, false, %d>" % {"path": 0, "volpath": 1, "volpathmis": 2}.get(integ_type, 0)
     elif kv == "flat" and integ_type == "volpath":
         kernel_name = "render_kernel<false, true, 1>"
     elif integ_type == "volpathmis":
         kernel_name = "render_kernel_wga_mis<false, true, 512, 512>"
+    elif args.config == "C5S":
+        kernel_name = "v_spectral::render_kernel_wga<false, 256, 256, 2>"
     else:
         paths = int(kv[3:]); nt = int(os.environ.get("MTSAMD_WG_THREADS", str(paths)))
         kernel_name = "render_kernel_wga<false, %d, %d, %d>" % (paths, nt, {1: 4, 0.75: 3, 0.5: 2}[nt / paths])
@@ -280,7 +282,7 @@ def main():
     if rank == 0:
         workload = {"C1": "C1 path cornell box", "C1L": "C1L = the C1 cornell box at 512x512x256 (262144 pixel streams: one per lane of the chip)", "C2": "C2 volpath homogeneous slab", "C4": "C4 volpath layered atmosphere, blend/tabulated phase, RPV ground",
                     "C5": "C5 = C4 as %d monochromatic wavelength batches (Rayleigh ~ lambda^-4), gpu_mono" % C5_WAVELENGTHS,
-                    "C5S": "C5S = the C4 atmosphere in the spectral variant (gpu_spectral: 4 wavelengths per sample, gridvolume_spectral), per-lane kernel",
+                    "C5S": "C5S = the C4 atmosphere in the spectral variant (gpu_spectral: 4 wavelengths per sample, gridvolume_spectral grids, global majorant)",
                     "C3M": "C3M = the C3 scene under volpathmis (spectral MIS), regrouping kernel of volpathmis_flat.h",
                     "C3": "C3 volpath heterogeneous %d^3 grid + HG g=0.8" % args.res}[args.config]
         out = {"metric": "Msamples/s volpath 512x512x1024spp plane-parallel atmosphere" if args.config == "C3" else "Msamples/s %s (side measurement)" % args.config,

@@ -219,6 +219,8 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
                 else throw std::runtime_error("MTSAMD_KERNEL must be one of nested, flat, wga256, wga512, wga1024");
             }
             if (hs.integrator.type == MTS_INTEGRATOR_VOLPATHMIS && variant > 10512) variant = 10512;     // four weight matrices per path: 512 paths fill the LDS
+            if (hs.integrator.spectral && variant > 10256) variant = 10256;                               // four-wide spectra: 42 hot dwords per path; three 256-path workgroups per CU (12 waves) beat one of 512 (8 waves) by 10 %
+            if (hs.integrator.spectral && variant == 1) variant = 0;                                      // no per-lane flat kernel in the spectral build
             // a workgroup of the regrouping kernel sits in ONE spiral block: blocks smaller than its path count get the largest
             // workgroup that divides them (16 x 16 -> 256 paths); only blocks below 256 pixels fall back to the per-lane kernel
             while (variant > 10256 && (block_size * block_size) % (uint32_t) (variant - 10000) != 0) variant = 10000 + (variant - 10000) / 2;

@@ -6,11 +6,12 @@
 // registers, the scene is read with scalar loads, the only vector memory traffic is the volume
 // gathers and one film update per pixel.  Citations are relative to /root/reference.
 // Compiled twice into libmtsamd.so: as it is (MTS_SPEC_N = 3: the rgb / mono variants, all kernels) and through kernels_spectral.hip
-// (MTS_SPEC_N = 4: the spectral variant, per-lane kernels of `path` and `volpath`; launchers carry the suffix _spectral).
+// (MTS_SPEC_N = 4: the spectral variant: `volpath` on the regrouping machine with 512-path workgroups, `path` per lane; launchers carry
+// the suffix _spectral).
 #include <hip/hip_runtime.h>
 #include "integrator_dev.h"
-#if MTS_SPEC_N == 3
 #include "volpath_flat.h"
+#if MTS_SPEC_N == 3
 #include "volpathmis_flat.h"
 #define MTS_LAUNCHER(name) name
 #else
@@ -126,7 +127,6 @@ __global__ void __launch_bounds__(256, FLAT ? 1 : (INTEG == NI_PATH ? MTS_PATH_W
     }
 }
 
-#if MTS_SPEC_N == 3
 // Asynchronous-regrouping variant of the volpath render kernel (volpath_flat.h, driver 2).  The parameter list must stay in
 // sync with WgArgs: the block functions re-read it from the kernarg segment with scalar loads.  WG paths are served by NT threads;
 // WPE = waves per SIMD the register budget is sized for (512 / WPE VGPRs).
@@ -144,6 +144,7 @@ __global__ void __launch_bounds__(NT, WPE) render_kernel_wga(DScene sc, const DB
 }
 static_assert(sizeof(WgArgs) % 4 == 0, "WgArgs mirrors the kernel parameters");
 
+#if MTS_SPEC_N == 3
 // The same driver for volpathmis (volpathmis_flat.h): four weight matrices per path, 512 paths per workgroup, two waves per SIMD.
 template <bool COUNT, bool SPEC, int WG, int NT>
 __global__ void __launch_bounds__(NT, 2) render_kernel_wga_mis(DScene sc, const DBlock *blocks, uint32_t n_blocks, uint32_t block_size,
@@ -274,8 +275,20 @@ hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks,
     }
     const bool flat = variant != 0;
 #else
-    const bool flat = false; (void) variant; (void) wg_threads; (void) d_workspace;       // the spectral build has the per-lane kernels of path and volpath
     if (sc.integrator.type == MTS_INTEGRATOR_VOLPATHMIS) return hipErrorInvalidValue;
+    if (variant >= 10000 && sc.integrator.type == MTS_INTEGRATOR_VOLPATH) {        // four-wide state: 42 hot dwords per path, 512 paths fill the LDS
+        const uint32_t wg = (uint32_t) (variant - 10000);
+        const uint32_t grid = (uint32_t) ((threads + wg - 1) / wg);
+        const uint32_t stride = grid * wg;
+#define LAUNCH_WGA(W) do { if (count) hipLaunchKernelGGL((render_kernel_wga<true, W, W, 2>), dim3(grid), dim3(W), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag); \
+                           else hipLaunchKernelGGL((render_kernel_wga<false, W, W, 2>), dim3(grid), dim3(W), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag); } while (0)
+        if (wg == 512) LAUNCH_WGA(512);
+        else if (wg == 256) LAUNCH_WGA(256);
+        else return hipErrorInvalidConfiguration;
+#undef LAUNCH_WGA
+        return hipGetLastError();
+    }
+    const bool flat = false; (void) wg_threads; (void) d_workspace;               // path: the per-lane kernel
 #endif
     const uint32_t grid = (uint32_t) ((threads + 255) / 256);
     const bool use_flat = flat && sc.integrator.type == MTS_INTEGRATOR_VOLPATH;

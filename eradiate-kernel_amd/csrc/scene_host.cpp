@@ -327,7 +327,7 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
             dm.shared_grid = (a.type == MTS_VOLUME_GRID && b.type == MTS_VOLUME_GRID && a.nx == b.nx && a.ny == b.ny && a.nz == b.nz &&
                               a.filter == b.filter && a.wrap == b.wrap && memcmp(a.w2l, b.w2l, 64) == 0) ? 1 : 0;
             auto grey = [](const DVolume &v) { return v.type == MTS_VOLUME_GRID ? v.channels == 1 : (v.value[0] == v.value[1] && v.value[1] == v.value[2]); };
-            dm.grey = (grey(a) && grey(b)) ? 1 : 0;
+            dm.grey = (grey(a) && grey(b) && !spectral) ? 1 : 0;       // spectral variant: values depend on the wavelength
             std::vector<float> pair;
             if (dm.shared_grid && a.channels == 1 && b.channels == 1 && a.filter == MTS_FILTER_TRILINEAR && a.wrap == MTS_WRAP_CLAMP && a.nx >= 2) {
                 const std::vector<float> &ga = hs.grid_data[m.sigma_t_volume], &gb = hs.grid_data[m.albedo_volume];

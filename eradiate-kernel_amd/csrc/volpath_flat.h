@@ -24,6 +24,18 @@
 namespace mtsamd {
 inline namespace MTS_VARIANT_NS {
 
+// The machine is written once for both builds (MTS_SPEC_N = 3: rgb / mono, 4: spectral).  In the rgb build `Spec` is F3, the
+// wavelength context is an empty struct and the macros below vanish, so its kernels are compiled from the same expressions as ever.
+#if MTS_SPEC_N == 3
+#define MTS_CX
+#define MTS_CXI(id)
+#define MTS_SPEC_DW 3
+#else
+#define MTS_CX , cx
+#define MTS_CXI(id) , cx, (id)
+#define MTS_SPEC_DW 4
+#endif
+
 enum : uint32_t { S_TOP = 0, S_MED = 1, S_SURF = 2, S_PHASE = 3, S_BSDF = 4, S_DIRB = 5, S_NEW = 6, S_DONE = 7, S_SCATTER = 8,
                   S_ENDNEE = 9, S_ENDDIR0 = 10 };   // transient (workgroup drivers): end_nee / end_direct(0, 0) still to run on the full state
 enum : uint32_t { M_MAIN = 0, M_NEE = 1, M_DIR = 2 };
@@ -31,7 +43,7 @@ enum : uint32_t { FL_ALIVE = 1, FL_VALID_RAY = 2, FL_SPEC_CHAIN = 4, FL_NEEDS_IN
 
 // Result of one free-flight sample (librender/medium.cpp:34-75); sigma_n is derived by the caller
 // (heterogeneous.cpp:46: combined - sigma_t, homogeneous.cpp:44: 0).
-struct MedStep { float t, mint; F3 p, sigma_t, sigma_s, combined; uint32_t info; };
+struct MedStep { float t, mint; F3 p; Spec sigma_t, sigma_s, combined; uint32_t info; };
 enum : uint32_t { MI_HOMOGENEOUS = 1, MI_SPECTRAL = 2, MI_SAMPLE_EMITTERS = 4, MI_GREY = 8, MI_PHASE_SHIFT = 8 + 8 };
 
 #if defined(MTSAMD_BLOCKSTATS)
@@ -88,7 +100,8 @@ DEV void grid_fetch_pair(const MTS_GLOBAL_AS float *__restrict__ P, const GridCe
 }
 
 template <bool COUNT>
-DEV MedStep medium_step(const DScene &sc, const DMedium m, const DRay &ray, float sample, uint32_t channel, bool want_albedo, Counters &cnt) {
+DEV MedStep medium_step(const DScene &sc, const DMedium m, const DRay &ray, float sample, uint32_t channel, bool want_albedo, Counters &cnt,
+                        const SpecCtx &cx = SpecCtx()) {
     MedStep mi;
     bool active = true; float mint = 0.f, maxt = pm_inf();
     if (!m.is_homogeneous) {
@@ -98,18 +111,18 @@ DEV MedStep medium_step(const DScene &sc, const DMedium m, const DRay &ray, floa
     }
     mint = pm_max(ray.mint, mint);
     maxt = pm_min(ray.maxt, maxt);
-    F3 combined = m.is_homogeneous ? volume_eval(cload(sc.volumes + m.sigma_t), ray.o) * m.scale : f3s(m.max_density);
+    Spec combined = m.is_homogeneous ? volume_eval(cload(sc.volumes + m.sigma_t), ray.o MTS_CXI(m.sigma_t)) * m.scale : spec_s(m.max_density);
     float mext = pick(combined, channel);
     float sampled_t = mint + (-pm_log(1.f - sample) / mext);
     bool valid_mi = active && (sampled_t <= maxt);
     mi.t = valid_mi ? sampled_t : pm_inf();
     mi.p = ray_at(ray, sampled_t);
     mi.mint = mint;
-    mi.sigma_t = mi.sigma_s = f3s(0.f);
+    mi.sigma_t = mi.sigma_s = spec_s(0.f);
     if (m.is_homogeneous) {
-        F3 st = volume_eval(cload(sc.volumes + m.sigma_t), mi.p) * m.scale;
+        Spec st = volume_eval(cload(sc.volumes + m.sigma_t), mi.p MTS_CXI(m.sigma_t)) * m.scale;
         mi.sigma_t = st;
-        if (want_albedo) mi.sigma_s = st * volume_eval(cload(sc.volumes + m.albedo), mi.p);
+        if (want_albedo) mi.sigma_s = st * volume_eval(cload(sc.volumes + m.albedo), mi.p MTS_CXI(m.albedo));
     } else if (valid_mi) {
         if (COUNT) MTS_SEG(cnt, 1);
         if (m.pair_grid != nullptr) {                          // everything comes from the medium record and the interleaved grid
@@ -117,20 +130,20 @@ DEV MedStep medium_step(const DScene &sc, const DMedium m, const DRay &ray, floa
             float st_raw, al_raw;
             grid_fetch_pair(as_global(m.pair_grid), c, m.pair_nx, st_raw, al_raw);
             float st = m.scale * st_raw;
-            mi.sigma_t = f3s(st);
-            if (want_albedo) mi.sigma_s = f3s(st * al_raw);
+            mi.sigma_t = spec_s(st);
+            if (want_albedo) mi.sigma_s = spec_s(st * al_raw);
         } else {
             const DVolume vs = cload(sc.volumes + m.sigma_t), va = cload(sc.volumes + m.albedo);
             if (m.shared_grid && m.grey && vs.filter == MTS_FILTER_TRILINEAR) {
                 // both grids share one cell / one set of weights; single channel: one value serves the three channels
                 GridCell c = grid_cell(vs, mi.p);
                 float st = m.scale * grid_fetch1(as_global(vs.data), c);
-                mi.sigma_t = f3s(st);
-                if (want_albedo) mi.sigma_s = f3s(st * grid_fetch1(as_global(va.data), c));       // the tracking walks never read sigma_s
+                mi.sigma_t = spec_s(st);
+                if (want_albedo) mi.sigma_s = spec_s(st * grid_fetch1(as_global(va.data), c));    // the tracking walks never read sigma_s
             } else {
-                F3 st = m.scale * volume_eval(vs, mi.p);
+                Spec st = m.scale * volume_eval(vs, mi.p MTS_CXI(m.sigma_t));
                 mi.sigma_t = st;
-                if (want_albedo) mi.sigma_s = st * volume_eval(va, mi.p);
+                if (want_albedo) mi.sigma_s = st * volume_eval(va, mi.p MTS_CXI(m.albedo));
             }
         }
         if (COUNT) cnt.n_lookup++;
@@ -143,11 +156,12 @@ DEV MedStep medium_step(const DScene &sc, const DMedium m, const DRay &ray, floa
 }
 
 // exp(-t * combined) per channel (medium.cpp:84); grey media evaluate it once
-DEV F3 transmittance_exp_g(float t, F3 combined, bool grey) {
-    if (grey) return f3s(pm_exp(-t * combined.x));
+DEV Spec transmittance_exp_g(float t, Spec combined, bool grey) {
+    if (grey) return spec_s(pm_exp(-t * combined.x));
     return transmittance_exp(t, combined);
 }
 
+#if MTS_SPEC_N == 3
 // Film splat of one finished sample: librender/integrator.cpp:265-285 + librender/imageblock.cpp:79-172
 // (The spectral build's splat_values_t in integrator_dev.h is this function's second half; sharing it changed the register allocation of
 // the regrouping kernel -- 170 -> 197 SGPR spills -- so the rgb kernels keep their own copy.)
@@ -206,6 +220,8 @@ DEV void splat_sample_t(const DScene &sc, const DBlock &blk, uint32_t lx, uint32
     }
 }
 
+#endif // MTS_SPEC_N == 3 (the spectral build splats through splat_values_t, integrator_dev.h)
+
 // ---------------------------------------------------------------------------------------------------------
 // Per-path state.  "Hot" fields are touched by every tracking step; "cold" fields (ColdStore) only once per
 // sample or per NEE / direct-light walk.
@@ -214,8 +230,11 @@ struct PathState {
     DRay ray;                       // the ray being tracked now (main path, or the NEE / direct-light walk)
     Hit si;                         // cached closest hit of `ray`
     int medium;                     // medium containing ray.o
-    F3 thr, res; float eta; uint32_t depth, channel;         // main path (volpath.cpp:54-67)
-    F3 trans; float wa, wb;         // walk: transmittance; NEE: wa = total_dist, wb = ds.dist; direct: wb = bs.pdf
+    Spec thr, res; float eta; uint32_t depth, channel;       // main path (volpath.cpp:54-67)
+    Spec trans; float wa, wb;       // walk: transmittance; NEE: wa = total_dist, wb = ds.dist; direct: wb = bs.pdf
+#if MTS_SPEC_N != 3
+    Spec wl;                        // the sample's wavelengths (integrator.cpp:252)
+#endif
     uint32_t st, mode, flags;
 };
 // cold field offsets (floats)
@@ -224,11 +243,12 @@ enum { C_POS = 0,            // 2: film position of the current sample
        C_SO = 3, C_SD = 6,   // 3 + 3: parked main-path origin / direction
        C_SHIT = 9,           // 8: parked main-path hit (t, p, uv, shape, prim)
        C_SMED = 17,          // 1: parked medium id
-       C_CW = 18,            // 3: pending NEE weight
-       C_EMIT = 21,          // 3: emitter value of the NEE sample
-       C_ACC = 24,           // 5: this path's film accumulators X, Y, Z, A, W (the reference's per-block ImageBlock entry)
-       C_SAMPLE = 29,        // 1: index of the sample in flight (bits of a uint32)
-       C_COUNT = 30 };
+       C_CW = 18,                           // 3 (spectral: 4): pending NEE weight
+       C_EMIT = C_CW + MTS_SPEC_DW,         // 3 (4): emitter value of the NEE sample
+       C_ACC = C_EMIT + MTS_SPEC_DW,        // 5: this path's film accumulators X, Y, Z, A, W (the reference's per-block ImageBlock entry)
+       C_SAMPLE = C_ACC + 5,                // 1: index of the sample in flight (bits of a uint32)
+       C_COUNT = C_SAMPLE + 1 };            // 30 (32)
+static_assert(C_COUNT <= 32, "the cold record is one 128-byte line");
 // Struct-of-arrays store addressed as base[k * stride]: LDS (stride 256, one workgroup) or HBM (stride = paths in flight)
 // or as one 128-byte record per path (AOS: the workgroup driver, whose lanes hold arbitrary paths -- a record is written by one
 // lane as whole cache lines instead of 30 scattered dwords)
@@ -239,6 +259,13 @@ struct ColdStoreT {
     DEV auto &f(int k) const { return AOS ? base[k] : base[(size_t) k * stride]; }
     DEV void put3(int k, F3 v) const { f(k) = v.x; f(k + 1) = v.y; f(k + 2) = v.z; }
     DEV F3 get3(int k) const { return f3(f(k), f(k + 1), f(k + 2)); }
+#if MTS_SPEC_N == 3
+    DEV void put_spec(int k, Spec v) const { put3(k, v); }
+    DEV Spec get_spec(int k) const { return get3(k); }
+#else
+    DEV void put_spec(int k, Spec v) const { f(k) = v.x; f(k + 1) = v.y; f(k + 2) = v.z; f(k + 3) = v.w; }
+    DEV Spec get_spec(int k) const { return spec4(f(k), f(k + 1), f(k + 2), f(k + 3)); }
+#endif
     DEV void put_hit(const Hit &h) const {
         f(C_SHIT) = h.t; put3(C_SHIT + 1, h.p); f(C_SHIT + 4) = h.uv.x; f(C_SHIT + 5) = h.uv.y;
         f(C_SHIT + 6) = __int_as_float(h.shape); f(C_SHIT + 7) = __int_as_float(h.prim);
@@ -269,6 +296,12 @@ struct VolpathMachine {
     const DScene &sc;
     Counters &cnt;
     DEV VolpathMachine(const DScene &sc_, Counters &cnt_) : sc(sc_), cnt(cnt_) {}
+    // wavelength context of a path (empty in the rgb build)
+#if MTS_SPEC_N == 3
+    DEV SpecCtx ctx(const PathState &) const { return SpecCtx(); }
+#else
+    DEV SpecCtx ctx(const PathState &p) const { SpecCtx cx = make_ctx(sc); cx.wl = p.wl; return cx; }
+#endif
 
     // A freshly spawned ray that cannot reach the scene's bounding box is resolved on the spot (the first
     // test of ShapeKDTree::ray_intersect_scalar, kdtree.h:2095-2098); everything else queues for INTERSECT.
@@ -286,7 +319,12 @@ struct VolpathMachine {
         F2 aperture_sample; aperture_sample.x = .5f; aperture_sample.y = .5f;
         if (se.needs_aperture_sample) aperture_sample = p.rng.next_2d();
         if (se.shutter_open_time > 0.f) (void) p.rng.next_1d();   // time sample (integrator.cpp:248-250)
+#if MTS_SPEC_N == 3
         (void) p.rng.next_1d();                                // wavelength sample, unused in rgb
+#else
+        float wav_weight;                                      // constant (sample_uniform_spectrum); blk_new recomputes it
+        p.wl = sample_wavelengths(p.rng.next_1d(), wav_weight); // integrator.cpp:252 -> perspective.cpp:169-172, distant.cpp:311-313
+#endif
         F2 adjusted;
         adjusted.x = (position_sample.x - (float) se.crop_x) / (float) se.crop_w;
         adjusted.y = (position_sample.y - (float) se.crop_y) / (float) se.crop_h;
@@ -294,19 +332,23 @@ struct VolpathMachine {
         p.ray = sensor_sample_ray(sc, adjusted, aperture_sample, rw);
         e.cold.f(C_POS) = position_sample.x; e.cold.f(C_POS + 1) = position_sample.y; e.cold.f(C_RAYW) = rw.x;   // grey weight
         p.medium = se.medium;
-        p.thr = f3s(1.f); p.res = f3s(0.f); p.eta = 1.f; p.depth = 0;
+        p.thr = spec_s(1.f); p.res = spec_s(0.f); p.eta = 1.f; p.depth = 0;
+#if MTS_SPEC_N == 3
         p.channel = sc.integrator.monochrome ? 0u : (uint32_t) pm_min(p.rng.next_1d() * 3.f, 2.f);     // volpath.cpp:64-67: rgb variants only
+#else
+        p.channel = 0u;                                        // volpath.cpp:63-67: no draw outside the rgb variants
+#endif
         p.si.p = f3s(0.f); p.si.uv.x = p.si.uv.y = 0.f; p.si.prim = 0;
         const bool hide_emitters = sc.integrator.hide_emitters != 0;
         p.flags = FL_ALIVE | ((!hide_emitters && sc.environment >= 0) ? FL_VALID_RAY : 0u) | (!hide_emitters ? FL_SPEC_CHAIN : 0u);
-        p.trans = f3s(1.f); p.wa = p.wb = 0.f;
+        p.trans = spec_s(1.f); p.wa = p.wb = 0.f;
         queue_intersection(p);
         p.mode = M_MAIN; p.st = S_TOP;
     }
     // NEE walk finished (volpath.cpp:366 + :165-166 / :211): add the contribution, resume the main path
     template <class E> DEV void end_nee(PathState &p, const E &e) const {
-        F3 emitted = p.trans * e.cold.get3(C_EMIT);
-        p.res = p.res + e.cold.get3(C_CW) * emitted;
+        Spec emitted = p.trans * e.cold.get_spec(C_EMIT);
+        p.res = p.res + e.cold.get_spec(C_CW) * emitted;
         p.mode = M_MAIN; p.medium = __float_as_int(e.cold.f(C_SMED));
         F3 d = e.cold.get3(C_SD);
         p.ray.d = d; p.ray.d_rcp = vrcp(d);
@@ -314,8 +356,8 @@ struct VolpathMachine {
         else { p.si = e.cold.get_hit(); p.st = S_BSDF; }
     }
     // direct-light walk finished (volpath.cpp:464 + :246-252): MIS-weighted emitter hit, resume the main path
-    template <class E> DEV void end_direct(PathState &p, const E &e, F3 emitter_val, float emitter_pdf) const {
-        F3 emitted = p.trans * emitter_val;
+    template <class E> DEV void end_direct(PathState &p, const E &e, Spec emitter_val, float emitter_pdf) const {
+        Spec emitted = p.trans * emitter_val;
         if (emitter_pdf != 0.f) p.res = p.res + mis_weight(p.wb, emitter_pdf) * p.thr * emitted;
         p.ray = spawn_ray(e.cold.get3(C_SO), e.cold.get3(C_SD));
         p.si = e.cold.get_hit(); p.medium = __float_as_int(e.cold.f(C_SMED));
@@ -365,7 +407,18 @@ struct VolpathMachine {
         F2 position_sample; position_sample.x = e.cold.f(C_POS); position_sample.y = e.cold.f(C_POS + 1);
         float acc[5];                                          // summed in sample order like the block entry (imageblock.cpp:163-168)
         for (int k = 0; k < 5; ++k) acc[k] = e.cold.f(C_ACC + k);
+#if MTS_SPEC_N == 3
         splat_sample_t<false>(sc, e.blk, e.lx, e.ly, position_sample, f3s(e.cold.f(C_RAYW)) * p.res, (p.flags & FL_VALID_RAY) != 0, e.film, acc);
+#else
+        {
+            float wav_weight; (void) sample_wavelengths(0.f, wav_weight);
+            const Spec L = (wav_weight * e.cold.f(C_RAYW)) * p.res;     // ray_weight = wav_weight (x the sensor's grey weight), integrator.cpp:265
+            float xyz[3];
+            spectrum_to_xyz(sc.cie, L, p.wl, xyz);                      // integrator.cpp:266-269
+            const float v[5] = { xyz[0], xyz[1], xyz[2], (p.flags & FL_VALID_RAY) != 0 ? 1.f : 0.f, 1.f };
+            splat_values_t<false>(sc, e.blk, e.lx, e.ly, position_sample, v, e.film, acc);
+        }
+#endif
         const uint32_t sample_idx = __float_as_uint(e.cold.f(C_SAMPLE)) + 1u;
         if (sample_idx == e.sample_count) {                    // block -> film (hdrfilm.cpp:207-211)
             float *own = (float *) (e.film + 5 * ((size_t) (e.blk.oy + (int) e.ly - se.crop_y) * se.crop_w + (e.blk.ox + (int) e.lx - se.crop_x)));
@@ -387,7 +440,7 @@ struct VolpathMachine {
     template <class E> DEV void start_direct(PathState &p, const E &e) const {      // volpath.cpp:239-245: the direct-light walk runs on a copy
         if (p.st != S_DIRB || (p.flags & FL_NEEDS_INT)) return;
         e.cold.put3(C_SO, p.ray.o); e.cold.put3(C_SD, p.ray.d); e.cold.put_hit(p.si);
-        p.trans = f3s(1.f);
+        p.trans = spec_s(1.f);
         p.mode = M_DIR; p.st = S_TOP;
     }
     // ================================================================= MEDIUM: one free-flight step of any of the three loops
@@ -399,18 +452,19 @@ struct VolpathMachine {
         const uint32_t max_depth = (uint32_t) sc.integrator.max_depth;
         const float u = p.rng.next_1d();                       // volpath.cpp:105 / :294 / :391
         MedStep mi;
+        const SpecCtx cx = ctx(p); (void) cx;
         WATERFALL_BEGIN(p.medium, mu)
-            mi = medium_step<COUNT>(sc, cload(sc.media + mu), p.ray, u, p.channel, MODEK == 0 ? true : (MODEK == 1 ? false : p.mode == M_MAIN), cnt);
+            mi = medium_step<COUNT>(sc, cload(sc.media + mu), p.ray, u, p.channel, MODEK == 0 ? true : (MODEK == 1 ? false : p.mode == M_MAIN), cnt MTS_CX);
         WATERFALL_END
         if (p.si.t < mi.t) mi.t = pm_inf();                    // volpath.cpp:112 / :300 / :397
         const bool spectral = (mi.info & MI_SPECTRAL) != 0, homogeneous = (mi.info & MI_HOMOGENEOUS) != 0, grey = (mi.info & MI_GREY) != 0;
-        const F3 sigma_n = homogeneous ? f3s(0.f) : mi.combined - mi.sigma_t;
+        const Spec sigma_n = homogeneous ? spec_s(0.f) : mi.combined - mi.sigma_t;
         const uint32_t channel = p.channel;
         const bool is_main = MODEK == 0 ? true : (MODEK == 1 ? false : p.mode == M_MAIN), is_nee = MODEK == 0 ? false : p.mode == M_NEE;
         // transmittance / free-flight pdf of this step, one formula for the three loops:
         // medium.cpp:77-89 (volpath.cpp:113-117, :401-405) and the NEE variant bounded by remaining_dist (:305-311)
         const float remaining_dist = is_nee ? p.ray.maxt : pm_inf();
-        F3 weight = is_main ? p.thr : p.trans;
+        Spec weight = is_main ? p.thr : p.trans;
         if (spectral) {
             float t = pm_min(mi.t, p.si.t);
             if (is_nee) t = pm_min(remaining_dist, t);
@@ -421,10 +475,10 @@ struct VolpathMachine {
                 float tr_pdf = surface_first ? tr : tr * mi.combined.x;
                 weight = weight * (tr_pdf > 0.f ? tr * (1.0f / tr_pdf) : 0.f);     // spectrum / scalar = spectrum * (1 / scalar), dmath.h
             } else {
-                F3 tr = transmittance_exp(t, mi.combined);
-                F3 free_flight_pdf = surface_first ? tr : tr * mi.combined;
+                Spec tr = transmittance_exp(t, mi.combined);
+                Spec free_flight_pdf = surface_first ? tr : tr * mi.combined;
                 float tr_pdf = pick(free_flight_pdf, channel);
-                weight = weight * (tr_pdf > 0.f ? tr / tr_pdf : f3s(0.f));
+                weight = weight * (tr_pdf > 0.f ? tr / tr_pdf : spec_s(0.f));
             }
         }
         float u2 = 0.f;
@@ -457,7 +511,7 @@ struct VolpathMachine {
                 p.trans = weight;
                 if (!any_nonzero(weight)) {                        // volpath.cpp:358 / :456
                     if (DEFER) p.st = is_nee ? S_ENDNEE : S_ENDDIR0;
-                    else if (is_nee) end_nee(p, e); else end_direct(p, e, f3s(0.f), 0.f);
+                    else if (is_nee) end_nee(p, e); else end_direct(p, e, spec_s(0.f), 0.f);
                 }
             }
             return;
@@ -484,16 +538,17 @@ struct VolpathMachine {
     template <class E> DEV void blk_scatter(PathState &p, const E &e) const {
         if (p.st != S_SCATTER) return;
         p.st = S_PHASE;
-        F3 emitter_val;
-        DirSample ds = sample_emitter_direction(sc, p.ray.o, p.rng.next_2d(), false, emitter_val);
+        Spec emitter_val;
+        const SpecCtx cx = ctx(p); (void) cx;
+        DirSample ds = sample_emitter_direction(sc, p.ray.o, p.rng.next_2d(), false, emitter_val MTS_CX);
         if (ds.pdf == 0.f) return;
         float phase_val = 0.f;
         WATERFALL_BEGIN(p.medium, mu)
-            phase_val = phase_eval<true>(sc, cload(sc.media + mu).phase, -p.ray.d, p.ray.o, ds.d);
+            phase_val = phase_eval<true>(sc, cload(sc.media + mu).phase, -p.ray.d, p.ray.o, ds.d MTS_CX);
         WATERFALL_END
-        e.cold.put3(C_CW, p.thr * phase_val); e.cold.put3(C_EMIT, emitter_val);
+        e.cold.put_spec(C_CW, p.thr * phase_val); e.cold.put_spec(C_EMIT, emitter_val);
         e.cold.put3(C_SO, p.ray.o); e.cold.put3(C_SD, p.ray.d); e.cold.f(C_SMED) = __int_as_float(p.medium);
-        p.trans = f3s(1.f); p.wa = 0.f; p.wb = ds.dist;
+        p.trans = spec_s(1.f); p.wa = 0.f; p.wb = ds.dist;
         p.ray = spawn_ray(p.ray.o, ds.d); p.ray.mint = 0.f;
         queue_intersection(p);
         p.flags |= FL_FROM_MEDIUM;
@@ -507,12 +562,12 @@ struct VolpathMachine {
         if (is_nee) p.wa += p.si.t;
         int emitter = is_nee ? -1 : sc.environment;
         Surf sf; sf.wi = -p.ray.d; sf.sh.n = f3s(0.f); sf.n = f3s(0.f);
-        F3 nt = f3s(0.f); int is_tr = 0, ext = -1, inte = -1;
+        Spec nt = spec_s(0.f); int is_tr = 0, ext = -1, inte = -1;
         if (hit) {
             WATERFALL_BEGIN(p.si.shape, su)
                 const DShape s = cload(sc.shapes + su);
                 if (!is_nee) emitter = s.emitter;
-                nt = s.bsdf_type == MTS_BSDF_NULL ? f3s(1.f) : f3s(0.f);                      // null.cpp:70-73, bsdf.cpp:11-14
+                nt = s.bsdf_type == MTS_BSDF_NULL ? spec_s(1.f) : spec_s(0.f);                // null.cpp:70-73, bsdf.cpp:11-14
                 is_tr = s.is_medium_transition; ext = s.exterior; inte = s.interior;
                 if (emitter >= 0) complete_surface(sc, s, p.si, p.ray.d, sf);
                 else if (is_tr) sf.n = hit_geo_normal(sc, s, p.si);
@@ -524,7 +579,8 @@ struct VolpathMachine {
             ds.p = p.si.p; ds.n = sf.sh.n; ds.d = p.si.p - ref_p; ds.dist = norm(ds.d); ds.d = ds.d / ds.dist;
             if (!hit) ds.d = -sf.wi;
             ds.emitter = emitter; ds.pdf = 0.f; ds.delta = false;
-            end_direct(p, e, emitter_eval(sc, emitter, sf.wi.z), pdf_emitter_direction(sc, ref_p, ds));
+            const SpecCtx cx = ctx(p); (void) cx;
+            end_direct(p, e, emitter_eval(sc, emitter, sf.wi.z MTS_CX), pdf_emitter_direction(sc, ref_p, ds));
             return;
         }
         if (hit) {
@@ -535,7 +591,7 @@ struct VolpathMachine {
         }
         if (hit && any_nonzero(p.trans)) p.st = S_TOP;
         else if (is_nee) end_nee(p, e);
-        else end_direct(p, e, f3s(0.f), 0.f);
+        else end_direct(p, e, spec_s(0.f), 0.f);
     }
     // ================================================================= SURFACE interaction of the main path (volpath.cpp:184-212)
     template <class E> DEV void blk_surf(PathState &p, const E &e) const {
@@ -552,7 +608,8 @@ struct VolpathMachine {
                 if (s.emitter >= 0 || (s.bsdf_flags & F_Smooth) != 0) complete_surface(sc, s, p.si, p.ray.d, sf);
             WATERFALL_END
         }
-        if ((p.flags & FL_SPEC_CHAIN) && emitter >= 0) p.res = p.res + p.thr * emitter_eval(sc, emitter, sf.wi.z);
+        const SpecCtx cx = ctx(p); (void) cx;
+        if ((p.flags & FL_SPEC_CHAIN) && emitter >= 0) p.res = p.res + p.thr * emitter_eval(sc, emitter, sf.wi.z MTS_CX);
         if (!hit) { p.flags &= ~FL_ALIVE; p.st = S_TOP; return; }
         p.st = S_BSDF;
         bool active_e = false;
@@ -560,19 +617,19 @@ struct VolpathMachine {
             active_e = (cload(sc.bsdfs + bu).flags & F_Smooth) != 0 && (p.depth + 1 < max_depth);
         WATERFALL_END
         if (!active_e) return;
-        F3 emitter_val;                                        // volpath.cpp:200-212 -> sample_emitter :261-281
-        DirSample ds = sample_emitter_direction(sc, p.si.p, p.rng.next_2d(), false, emitter_val);
+        Spec emitter_val;                                      // volpath.cpp:200-212 -> sample_emitter :261-281
+        DirSample ds = sample_emitter_direction(sc, p.si.p, p.rng.next_2d(), false, emitter_val MTS_CX);
         if (ds.pdf == 0.f) return;
         F3 wo = to_local(sf.sh, ds.d);
-        F3 bsdf_val; float bpdf;
+        Spec bsdf_val; float bpdf;
         WATERFALL_BEGIN(bsdf_id, bu)
             const DBsdf bsdf = cload(sc.bsdfs + bu);
-            bsdf_val = bsdf_eval(bsdf, sf.wi, wo);
-            bpdf = bsdf_pdf(bsdf, sf.wi, wo);
+            bsdf_val = bsdf_eval(bsdf, sf.wi, wo MTS_CXI(bu));
+            bpdf = bsdf_pdf(bsdf, sf.wi, wo MTS_CXI(bu));
         WATERFALL_END
-        e.cold.put3(C_CW, p.thr * bsdf_val * mis_weight(ds.pdf, ds.delta ? 0.f : bpdf)); e.cold.put3(C_EMIT, emitter_val);
+        e.cold.put_spec(C_CW, p.thr * bsdf_val * mis_weight(ds.pdf, ds.delta ? 0.f : bpdf)); e.cold.put_spec(C_EMIT, emitter_val);
         e.cold.put_hit(p.si); e.cold.put3(C_SD, p.ray.d); e.cold.f(C_SMED) = __int_as_float(p.medium);
-        p.trans = f3s(1.f); p.wa = 0.f; p.wb = ds.dist;
+        p.trans = spec_s(1.f); p.wa = 0.f; p.wb = ds.dist;
         p.ray = spawn_ray(p.si.p, ds.d);
         queue_intersection(p);
         p.flags &= ~FL_FROM_MEDIUM;
@@ -589,10 +646,11 @@ struct VolpathMachine {
             bsdf_id = s.bsdf; is_tr = s.is_medium_transition; ext = s.exterior; inte = s.interior;
         WATERFALL_END
         const float s1 = p.rng.next_1d(); const F2 s2 = p.rng.next_2d();
-        BSDFSample bs; F3 bsdf_val;
+        BSDFSample bs; Spec bsdf_val;
+        const SpecCtx cx = ctx(p); (void) cx;
         WATERFALL_BEGIN(bsdf_id, bu)
             const DBsdf bsdf = cload(sc.bsdfs + bu);
-            bsdf_val = bsdf_sample(bsdf, sf.wi, s1, s2, bs);
+            bsdf_val = bsdf_sample(bsdf, sf.wi, s1, s2, bs MTS_CXI(bu));
         WATERFALL_END
         p.thr = p.thr * bsdf_val;
         p.eta *= bs.eta;
@@ -613,8 +671,9 @@ struct VolpathMachine {
         if (p.st != S_PHASE) return;
         const float s1 = p.rng.next_1d(); const F2 s2 = p.rng.next_2d();      // left-to-right (SURVEY.md 8(a'))
         F3 wo;
+        const SpecCtx cx = ctx(p); (void) cx;
         WATERFALL_BEGIN(p.medium, mu)
-            wo = phase_sample<true>(sc, cload(sc.media + mu).phase, make_frame(p.ray.d), p.ray.o, s1, s2);   // mi.sh_frame = Frame3f(ray.d), medium.cpp:42
+            wo = phase_sample<true>(sc, cload(sc.media + mu).phase, make_frame(p.ray.d), p.ray.o, s1, s2 MTS_CX);   // mi.sh_frame = Frame3f(ray.d), medium.cpp:42
         WATERFALL_END
         p.ray = spawn_ray(p.ray.o, wo); p.ray.mint = 0.0f;
         queue_intersection(p);
@@ -626,7 +685,7 @@ struct VolpathMachine {
     // the deferred tail of a block that ran with DEFER (p holds the full state here)
     template <class E> DEV void finish(PathState &p, const E &e) const {
         if (p.st == S_ENDNEE) end_nee(p, e);
-        else if (p.st == S_ENDDIR0) end_direct(p, e, f3s(0.f), 0.f);
+        else if (p.st == S_ENDDIR0) end_direct(p, e, spec_s(0.f), 0.f);
     }
     template <bool DEFER = false, bool SPLIT = false, class E> DEV void run(PathState &p, const E &e, int sel) const {
         switch (sel) {
@@ -643,6 +702,7 @@ struct VolpathMachine {
     }
 };
 
+#if MTS_SPEC_N == 3
 // ---------------------------------------------------------------------------------------------------------
 // Driver 1: one lane = one pixel, state in registers, cold state in LDS, blocks chosen by a per-wave vote.
 template <bool COUNT>
@@ -684,6 +744,8 @@ DEV void volpath_pixel_flat(const DScene &sc, Pcg32 &rng, const DBlock &blk, uin
 #endif
 }
 
+#endif // MTS_SPEC_N == 3
+
 // ---------------------------------------------------------------------------------------------------------
 // Hot path state of the workgroup driver: WG paths (pixels) per workgroup, struct-of-arrays in LDS; cold state lives in HBM.
 // Every block class loads / stores only the fields it can touch (ClassFields), which keeps the blocks' register budget small.
@@ -692,31 +754,41 @@ DEV void volpath_pixel_flat(const DScene &sc, Pcg32 &rng, const DBlock &blk, uin
 // The sixteen dwords every tracking step touches come first: an LDS instruction reaches 64 KB (16 fields of 1024 paths) from its
 // address register, later fields cost an address computation each.
 enum { H_RNG = 0, H_O = 2, H_D = 5, H_DRCP = 8, H_MINT = 11, H_MAXT = 12, H_SIT = 13, H_MEDIUM = 14,
-       H_PACKED = 15 /* st, mode, channel, flags, class, depth */, H_THR = 16, H_TRANS = 19, H_WA = 22, H_WB = 23, H_ETA = 24, H_RES = 25,
-       H_SIX = 28 /* si.p, si.uv, si.shape, si.prim */, H_COUNT = 35 };
+       H_PACKED = 15 /* st, mode, channel, flags, class, depth */, H_THR = 16, H_TRANS = H_THR + MTS_SPEC_DW, H_WA = H_TRANS + MTS_SPEC_DW,
+       H_WB = H_WA + 1, H_ETA = H_WB + 1, H_RES = H_ETA + 1, H_SIX = H_RES + MTS_SPEC_DW /* si.p, si.uv, si.shape, si.prim */,
+#if MTS_SPEC_N == 3
+       H_COUNT = H_SIX + 7 };                                   // 35
+#else
+       H_WL = H_SIX + 7 /* the sample's four wavelengths */, H_COUNT = H_WL + 4 };      // 42
+#endif
 
 enum : uint32_t { G_RNG = 1, G_O = 2, G_D = 4 /* d and 1/d */, G_MINT = 8, G_MAXT = 16, G_SIT = 32 /* si.t */, G_SIX = 64 /* rest of si */,
-                  G_MED = 128, G_THR = 256, G_RES = 512, G_ETA = 1024, G_TRANS = 2048, G_WA = 4096, G_WB = 8192, G_ALL = 16383 };
+                  G_MED = 128, G_THR = 256, G_RES = 512, G_ETA = 1024, G_TRANS = 2048, G_WA = 4096, G_WB = 8192,
+#if MTS_SPEC_N == 3
+                  G_WL = 0, G_ALL = 16383 };
+#else
+                  G_WL = 16384 /* read by every block that evaluates a spectrum, written by NEW */, G_ALL = 32767 };
+#endif
 // What block class C (followed by top()) may read (`load`, a superset of `store`) and write (`store`).  end_nee / end_direct touch
 // almost everything; the classes with partial sets run them deferred (VolpathMachine::finish on the full state).
 template <int C> struct ClassFields { static constexpr uint32_t load = G_ALL, store = G_ALL; static constexpr bool defer = false; };
 template <> struct ClassFields<B_MED> {          // main path: tracks thr
-    static constexpr uint32_t load = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_MED | G_THR | G_ETA,
+    static constexpr uint32_t load = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_MED | G_THR | G_ETA | G_WL,
                               store = G_RNG | G_O | G_MINT | G_SIT | G_THR;
     static constexpr bool defer = true; };
 template <> struct ClassFields<B_MEDW> {         // NEE / direct-light walk: tracks trans, the NEE walk also its distance budget
-    static constexpr uint32_t load = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_MED | G_TRANS | G_WA | G_WB,
+    static constexpr uint32_t load = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_MED | G_TRANS | G_WA | G_WB | G_WL,
                               store = G_RNG | G_O | G_MINT | G_MAXT | G_SIT | G_TRANS | G_WA;
     static constexpr bool defer = true; };
 template <> struct ClassFields<B_INT> {          // every lane of the class wants the intersection: si is written, never read
     static constexpr uint32_t load = G_O | G_D | G_MINT | G_MAXT | G_MED | G_TRANS, store = G_SIT | G_SIX | G_TRANS;
     static constexpr bool defer = true; };
 template <> struct ClassFields<B_SCATTER> {
-    static constexpr uint32_t load = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_MED | G_THR | G_TRANS | G_WA | G_WB,
+    static constexpr uint32_t load = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_MED | G_THR | G_TRANS | G_WA | G_WB | G_WL,
                               store = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_TRANS | G_WA | G_WB;
     static constexpr bool defer = true; };
 template <> struct ClassFields<B_PHASE> {
-    static constexpr uint32_t load = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_MED | G_THR | G_ETA,
+    static constexpr uint32_t load = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_MED | G_THR | G_ETA | G_WL,
                               store = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_THR;
     static constexpr bool defer = true; };
 
@@ -728,6 +800,13 @@ struct HotStore {
     DEV void putf(int k, float v) const { base[k * WG] = __float_as_uint(v); }
     DEV void put3(int k, F3 v) const { putf(k, v.x); putf(k + 1, v.y); putf(k + 2, v.z); }
     DEV F3 get3(int k) const { return f3(f(k), f(k + 1), f(k + 2)); }
+#if MTS_SPEC_N == 3
+    DEV void put_spec(int k, Spec v) const { put3(k, v); }
+    DEV Spec get_spec(int k) const { return get3(k); }
+#else
+    DEV void put_spec(int k, Spec v) const { putf(k, v.x); putf(k + 1, v.y); putf(k + 2, v.z); putf(k + 3, v.w); }
+    DEV Spec get_spec(int k) const { return spec4(f(k), f(k + 1), f(k + 2), f(k + 3)); }
+#endif
     DEV static uint32_t pack(const PathState &p, int cls) {
         return p.st | (p.mode << 4) | (p.channel << 6) | (p.flags << 8) | ((uint32_t) cls << 13) | ((p.depth < 32767u ? p.depth : 32767u) << 17);
     }
@@ -745,10 +824,13 @@ struct HotStore {
         if (M & G_SIT) putf(H_SIT, p.si.t);
         if (M & G_SIX) { put3(H_SIX, p.si.p); putf(H_SIX + 3, p.si.uv.x); putf(H_SIX + 4, p.si.uv.y); u(H_SIX + 5) = (uint32_t) p.si.shape; u(H_SIX + 6) = (uint32_t) p.si.prim; }
         if (M & G_MED) u(H_MEDIUM) = (uint32_t) p.medium;
-        if (M & G_THR) put3(H_THR, p.thr);
-        if (M & G_RES) put3(H_RES, p.res);
+        if (M & G_THR) put_spec(H_THR, p.thr);
+        if (M & G_RES) put_spec(H_RES, p.res);
         if (M & G_ETA) putf(H_ETA, p.eta);
-        if (M & G_TRANS) put3(H_TRANS, p.trans);
+        if (M & G_TRANS) put_spec(H_TRANS, p.trans);
+#if MTS_SPEC_N != 3
+        if (M & G_WL) put_spec(H_WL, p.wl);
+#endif
         if (M & G_WA) putf(H_WA, p.wa);
         if (M & G_WB) putf(H_WB, p.wb);
         u(H_PACKED) = pack(p, cls);
@@ -763,9 +845,12 @@ struct HotStore {
         p.si.p = f3s(0.f); p.si.uv.x = p.si.uv.y = 0.f; p.si.shape = -1; p.si.prim = 0;
         if (M & G_SIX) { p.si.p = get3(H_SIX); p.si.uv.x = f(H_SIX + 3); p.si.uv.y = f(H_SIX + 4); p.si.shape = (int) u(H_SIX + 5); p.si.prim = (int) u(H_SIX + 6); }
         p.medium = (M & G_MED) ? (int) u(H_MEDIUM) : -1;
-        p.thr = (M & G_THR) ? get3(H_THR) : f3s(0.f); p.res = (M & G_RES) ? get3(H_RES) : f3s(0.f);
+        p.thr = (M & G_THR) ? get_spec(H_THR) : spec_s(0.f); p.res = (M & G_RES) ? get_spec(H_RES) : spec_s(0.f);
         p.eta = (M & G_ETA) ? f(H_ETA) : 1.f;
-        p.trans = (M & G_TRANS) ? get3(H_TRANS) : f3s(0.f); p.wa = (M & G_WA) ? f(H_WA) : 0.f; p.wb = (M & G_WB) ? f(H_WB) : 0.f;
+        p.trans = (M & G_TRANS) ? get_spec(H_TRANS) : spec_s(0.f); p.wa = (M & G_WA) ? f(H_WA) : 0.f; p.wb = (M & G_WB) ? f(H_WB) : 0.f;
+#if MTS_SPEC_N != 3
+        p.wl = (M & G_WL) ? get_spec(H_WL) : spec_s(0.f);
+#endif
         unpack(u(H_PACKED), p);
     }
     DEV void store(const PathState &p, int cls) const { store_m<G_ALL>(p, cls); }
@@ -947,7 +1032,10 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         const bool ok = wg_env<WG>(a, wg_base, pid0, e);
         p.rng.state = 0; p.rng.inc = 0;
         p.ray = make_ray(f3s(0.f), f3(0.f, 0.f, 1.f), 0.f, 0.f); p.si.t = pm_inf(); p.si.p = f3s(0.f); p.si.uv.x = p.si.uv.y = 0.f; p.si.shape = -1; p.si.prim = 0;
-        p.medium = -1; p.thr = p.res = p.trans = f3s(0.f); p.eta = 1.f; p.depth = 0; p.channel = 0; p.mode = M_MAIN; p.flags = 0; p.wa = p.wb = 0.f;
+        p.medium = -1; p.thr = p.res = p.trans = spec_s(0.f); p.eta = 1.f; p.depth = 0; p.channel = 0; p.mode = M_MAIN; p.flags = 0; p.wa = p.wb = 0.f;
+#if MTS_SPEC_N != 3
+        p.wl = spec_s(0.f);
+#endif
         p.st = S_DONE;
         if (ok) {
             const uint32_t ppb = a.block_size * a.block_size;

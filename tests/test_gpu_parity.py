@@ -791,13 +791,19 @@ def _spectral_cases():
     d = scenes.c4_atmosphere(16, 16, 8, layers=8)
     d["sun"]["irradiance"] = {"type": "uniform", "value": 1.0}
     cases["c4_atmosphere"] = d
+    cases["c5s_atmosphere"] = scenes.c5_atmosphere_spectral(40, 32, 4, layers=8, nodes=5)       # bench.py --config C5S in small
     return cases
 
 
-@pytest.mark.parametrize("name", ["slab_regular_reflectance", "slab_chromatic_medium", "grid_spectral_d65_rpv", "cornell_path", "c4_atmosphere"])
-def test_spectral_variant_against_oracle(gpu_spectral, name):
+@pytest.mark.parametrize("kernel", [None, "nested"])
+@pytest.mark.parametrize("name", ["slab_regular_reflectance", "slab_chromatic_medium", "grid_spectral_d65_rpv", "cornell_path", "c4_atmosphere",
+                                  "c5s_atmosphere"])
+def test_spectral_variant_against_oracle(gpu_spectral, monkeypatch, name, kernel):
     """gpu_spectral (kernels_spectral.hip: Spectrum<Float, 4>, sample_wavelength, spectrum_to_xyz) against liboracle_spectral.so on the
-    same seeded inputs: the films and the loop counters are identical."""
+    same seeded inputs: the films and the loop counters are identical -- `volpath` on the regrouping machine (four-wide state, 256-path
+    workgroups; the default) and in the nested per-lane formulation (MTSAMD_KERNEL=nested), `path` per lane."""
+    if kernel:
+        monkeypatch.setenv("MTSAMD_KERNEL", kernel)
     d = _spectral_cases()[name]
     gpu, st = gpu_render(gpu_spectral, d, collect_counters=True)
     o = ob.OracleScene(d, spectral=True)
