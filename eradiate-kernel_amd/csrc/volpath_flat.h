@@ -36,6 +36,8 @@ inline namespace MTS_VARIANT_NS {
 #define MTS_SPEC_DW 4
 #endif
 
+#define MTS_REPEAT_MIN 32          // lanes that must stay in a MEDIUM class for the block to run again in place (wg_block)
+
 enum : uint32_t { S_TOP = 0, S_MED = 1, S_SURF = 2, S_PHASE = 3, S_BSDF = 4, S_DIRB = 5, S_NEW = 6, S_DONE = 7, S_SCATTER = 8,
                   S_ENDNEE = 9, S_ENDDIR0 = 10 };   // transient (workgroup drivers): end_nee / end_direct(0, 0) still to run on the full state
 enum : uint32_t { M_MAIN = 0, M_NEE = 1, M_DIR = 2 };
@@ -906,11 +908,21 @@ static __device__ WG_BLOCK_ATTR int wg_block(const MTS_CONST_AS void *kernarg_, 
     if (COUNT && C == B_MED) MTS_SEG_BEGIN(*cnt);
     hs.template load_m<CF::load>(p);
     if (COUNT && C == B_MED) MTS_SEG(*cnt, 0);
-    vm.template run<CF::defer, true>(p, e, C);
-    if (COUNT && C == B_MED) MTS_SEG(*cnt, 3);
-    vm.template top<CF::defer>(p, e);
-    if (COUNT && C == B_MED) MTS_SEG(*cnt, 4);
-    int cls = vm.classify(p);
+    int cls;
+    // A tracking step is most often followed by another one (null collisions): while at least half of the wave's lanes stay in this
+    // class the block runs again on the registers it holds -- no LDS round trip, no ring push, no claim for those paths; lanes that
+    // leave wait at the store below.  Measured (C3 / C4, Msamples/s): never 535 / 224, from 32 lanes 548 / 259, from 44 lanes
+    // 546 / 255, from 16 lanes 526 / 255, always 397 / 239.
+#pragma nounroll
+    for (int rounds = 0;; ++rounds) {
+        vm.template run<CF::defer, true>(p, e, C);
+        if (COUNT && C == B_MED) MTS_SEG(*cnt, 3);
+        vm.template top<CF::defer>(p, e);
+        if (COUNT && C == B_MED) MTS_SEG(*cnt, 4);
+        cls = vm.classify(p);
+        if (!(C == B_MED || C == B_MEDW) || cls != C || rounds >= 16) break;
+        if (__popcll(__ballot(true)) < MTS_REPEAT_MIN) break;
+    }
     hs.template store_m<CF::store>(p, cls);
     if (COUNT && C == B_MED) MTS_SEG(*cnt, 5);
     if (CF::defer && (p.st == S_ENDNEE || p.st == S_ENDDIR0)) {     // rare tail on the full state

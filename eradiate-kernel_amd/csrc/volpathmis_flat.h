@@ -476,9 +476,15 @@ static __device__ __forceinline__ int mis_block(const MTS_CONST_AS void *kernarg
     typedef MisClassFields<C> CF;
     MisPathState<SPEC> p;
     hs.template load_m<CF::load>(p);
-    vm.template run<CF::defer>(p, e, C);
-    vm.template top<CF::defer>(p, e);
-    int cls = vm.classify(p);
+    int cls;
+#pragma nounroll
+    for (int rounds = 0;; ++rounds) {                           // tracking steps repeat in place while half the wave stays (volpath_flat.h, wg_block)
+        vm.template run<CF::defer>(p, e, C);
+        vm.template top<CF::defer>(p, e);
+        cls = vm.classify(p);
+        if (!(C == B_MED || C == B_MEDW) || cls != C || rounds >= 16) break;
+        if (__popcll(__ballot(true)) < MTS_REPEAT_MIN) break;
+    }
     hs.template store_m<CF::store>(p, cls);
     if (CF::defer && p.st == S_ENDNEE) {                        // the end of a walk, on the full state
         MisPathState<SPEC> q;
