@@ -459,12 +459,20 @@ DEV_NOINLINE Spec volume_eval_grid_spectral(const GridRef g, F3 p_world, Spec wl
         const int wi = (int) pm_floor(ws);
         const int c0 = min(max(wi, 0), ch - 1), c1 = min(max(wi + 1, 0), ch - 1);      // wrap_wavelengths: clamp (:262-265)
         const float s1 = ws - (float) wi, s0 = 1.f - s1;
+        // the two spectral nodes of a corner are neighbours in memory (or one and the same at the ends): one 8-byte gather per corner
+        // from the pair that starts at cb, then pick (same values, same arithmetic as two dword gathers)
+        const int cb = min(c0, ch - 2);
+        const bool h0 = c0 != cb, h1 = c1 != cb;
+        typedef float mts_float2 __attribute__((ext_vector_type(2)));
+        typedef mts_float2 __attribute__((aligned(4))) mts_float2_a4;
+        mts_float2 q[8];
+        const int corner[8] = { r00 + x0, r00 + x1, r10 + x0, r10 + x1, r01 + x0, r01 + x1, r11 + x0, r11 + x1 };
+        for (int j = 0; j < 8; ++j) q[j] = *(const MTS_GLOBAL_AS mts_float2_a4 *) (D + corner[j] * ch + cb);
         float d[2];
-        for (int j = 0; j < 2; ++j) {
-            const int c = j ? c1 : c0;
-            d[j] = trilerp(D[(r00 + x0) * ch + c], D[(r00 + x1) * ch + c], D[(r10 + x0) * ch + c], D[(r10 + x1) * ch + c],
-                           D[(r01 + x0) * ch + c], D[(r01 + x1) * ch + c], D[(r11 + x0) * ch + c], D[(r11 + x1) * ch + c], w0, w1);
-        }
+        d[0] = trilerp(h0 ? q[0].y : q[0].x, h0 ? q[1].y : q[1].x, h0 ? q[2].y : q[2].x, h0 ? q[3].y : q[3].x,
+                       h0 ? q[4].y : q[4].x, h0 ? q[5].y : q[5].x, h0 ? q[6].y : q[6].x, h0 ? q[7].y : q[7].x, w0, w1);
+        d[1] = trilerp(h1 ? q[0].y : q[0].x, h1 ? q[1].y : q[1].x, h1 ? q[2].y : q[2].x, h1 ? q[3].y : q[3].x,
+                       h1 ? q[4].y : q[4].x, h1 ? q[5].y : q[5].x, h1 ? q[6].y : q[6].x, h1 ? q[7].y : q[7].x, w0, w1);
         const float r = pm_fma(s0, d[0], s1 * d[1]);
         // :381-385: the mask compares the NORMALISED wavelength with lambda_min / lambda_max, exactly as the source does
         out[k] = (wn >= lambda_min && wn <= lambda_max) ? r : 0.f;
