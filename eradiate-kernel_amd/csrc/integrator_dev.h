@@ -440,11 +440,14 @@ DEV Spec volume_eval(const DVolume &v, F3 p_world, const SpecCtx &cx = SpecCtx()
 #if MTS_SPEC_N != 3
 // textures/gridvolume_spectral.cpp:226-388: trilinear in space (cell-centred values, wrapped indices), linear in the spectral
 // dimension (values at nodes over [lambda_min, lambda_max], clamped indices), zero outside the interval
-DEV_NOINLINE Spec volume_eval_grid_spectral(const GridRef g, F3 p_world, Spec wl, float lambda_min, float lambda_max) {
+// NG grids of identical geometry and spectral interval (a medium's sigma_t and albedo) share the cell, the weights and the spectral nodes
+struct SpecPair { Spec a, b; };
+template <int NG>
+DEV void volume_eval_grid_spectral_n(const GridRef &g, const float *data_b, F3 p_world, Spec wl, float lambda_min, float lambda_max, Spec out_s[NG]) {
     const int channels = (int) (g.channels_affine_filter_wrap & 0xffu), affine = (int) ((g.channels_affine_filter_wrap >> 8) & 0xffu),
               wrap = (int) (g.channels_affine_filter_wrap >> 24);
     F3 p = affine ? mat_point_affine(g.w2l, p_world) : mat_point(g.w2l, p_world);
-    const MTS_GLOBAL_AS float *D = as_global(g.data); const int nx = g.nx, ny = g.ny, nz = g.nz, ch = channels;
+    const MTS_GLOBAL_AS float *DD[2] = { as_global(g.data), as_global(data_b) }; const int nx = g.nx, ny = g.ny, nz = g.nz, ch = channels;
     p = f3(pm_fma(p.x, (float) nx, -.5f), pm_fma(p.y, (float) ny, -.5f), pm_fma(p.z, (float) nz, -.5f));
     int ix = (int) pm_floor(p.x), iy = (int) pm_floor(p.y), iz = (int) pm_floor(p.z);
     F3 w1 = p - f3((float) ix, (float) iy, (float) iz), w0 = f3(1.f - w1.x, 1.f - w1.y, 1.f - w1.z);
@@ -452,7 +455,8 @@ DEV_NOINLINE Spec volume_eval_grid_spectral(const GridRef g, F3 p_world, Spec wl
         z0 = wrap_coord(wrap, iz, nz), z1 = wrap_coord(wrap, iz + 1, nz);
     int r00 = ((z0 * ny + y0) * nx), r10 = ((z0 * ny + y1) * nx), r01 = ((z1 * ny + y0) * nx), r11 = ((z1 * ny + y1) * nx);
     const float inv_dlambda = 1.0f / (lambda_max - lambda_min), lambda_scale = (float) (ch - 1);          // array / scalar = array * (1 / scalar)
-    float out[4]; const float lam[4] = { wl.x, wl.y, wl.z, wl.w };
+    float out[NG][4]; const float lam[4] = { wl.x, wl.y, wl.z, wl.w };
+    const int corner[8] = { (r00 + x0) * ch, (r00 + x1) * ch, (r10 + x0) * ch, (r10 + x1) * ch, (r01 + x0) * ch, (r01 + x1) * ch, (r11 + x0) * ch, (r11 + x1) * ch };
     for (int k = 0; k < 4; ++k) {
         const float wn = (lam[k] - lambda_min) * inv_dlambda;               // :232-233
         const float ws = wn * lambda_scale;
@@ -465,19 +469,31 @@ DEV_NOINLINE Spec volume_eval_grid_spectral(const GridRef g, F3 p_world, Spec wl
         const bool h0 = c0 != cb, h1 = c1 != cb;
         typedef float mts_float2 __attribute__((ext_vector_type(2)));
         typedef mts_float2 __attribute__((aligned(4))) mts_float2_a4;
-        mts_float2 q[8];
-        const int corner[8] = { r00 + x0, r00 + x1, r10 + x0, r10 + x1, r01 + x0, r01 + x1, r11 + x0, r11 + x1 };
-        for (int j = 0; j < 8; ++j) q[j] = *(const MTS_GLOBAL_AS mts_float2_a4 *) (D + corner[j] * ch + cb);
-        float d[2];
-        d[0] = trilerp(h0 ? q[0].y : q[0].x, h0 ? q[1].y : q[1].x, h0 ? q[2].y : q[2].x, h0 ? q[3].y : q[3].x,
-                       h0 ? q[4].y : q[4].x, h0 ? q[5].y : q[5].x, h0 ? q[6].y : q[6].x, h0 ? q[7].y : q[7].x, w0, w1);
-        d[1] = trilerp(h1 ? q[0].y : q[0].x, h1 ? q[1].y : q[1].x, h1 ? q[2].y : q[2].x, h1 ? q[3].y : q[3].x,
-                       h1 ? q[4].y : q[4].x, h1 ? q[5].y : q[5].x, h1 ? q[6].y : q[6].x, h1 ? q[7].y : q[7].x, w0, w1);
-        const float r = pm_fma(s0, d[0], s1 * d[1]);
-        // :381-385: the mask compares the NORMALISED wavelength with lambda_min / lambda_max, exactly as the source does
-        out[k] = (wn >= lambda_min && wn <= lambda_max) ? r : 0.f;
+        for (int gi = 0; gi < NG; ++gi) {
+            mts_float2 q[8];
+            for (int j = 0; j < 8; ++j) q[j] = *(const MTS_GLOBAL_AS mts_float2_a4 *) (DD[gi] + corner[j] + cb);
+            float d[2];
+            d[0] = trilerp(h0 ? q[0].y : q[0].x, h0 ? q[1].y : q[1].x, h0 ? q[2].y : q[2].x, h0 ? q[3].y : q[3].x,
+                           h0 ? q[4].y : q[4].x, h0 ? q[5].y : q[5].x, h0 ? q[6].y : q[6].x, h0 ? q[7].y : q[7].x, w0, w1);
+            d[1] = trilerp(h1 ? q[0].y : q[0].x, h1 ? q[1].y : q[1].x, h1 ? q[2].y : q[2].x, h1 ? q[3].y : q[3].x,
+                           h1 ? q[4].y : q[4].x, h1 ? q[5].y : q[5].x, h1 ? q[6].y : q[6].x, h1 ? q[7].y : q[7].x, w0, w1);
+            const float r = pm_fma(s0, d[0], s1 * d[1]);
+            // :381-385: the mask compares the NORMALISED wavelength with lambda_min / lambda_max, exactly as the source does
+            out[gi][k] = (wn >= lambda_min && wn <= lambda_max) ? r : 0.f;
+        }
     }
-    return spec4(out[0], out[1], out[2], out[3]);
+    for (int gi = 0; gi < NG; ++gi) out_s[gi] = spec4(out[gi][0], out[gi][1], out[gi][2], out[gi][3]);
+}
+DEV_NOINLINE Spec volume_eval_grid_spectral(const GridRef g, F3 p_world, Spec wl, float lambda_min, float lambda_max) {
+    Spec o[1];
+    volume_eval_grid_spectral_n<1>(g, nullptr, p_world, wl, lambda_min, lambda_max, o);
+    return o[0];
+}
+DEV_NOINLINE SpecPair volume_eval_grid_spectral_pair(const GridRef g, const float *data_b, F3 p_world, Spec wl, float lambda_min, float lambda_max) {
+    Spec o[2];
+    volume_eval_grid_spectral_n<2>(g, data_b, p_world, wl, lambda_min, lambda_max, o);
+    SpecPair r; r.a = o[0]; r.b = o[1];
+    return r;
 }
 #endif
 DEV_NOINLINE F3 volume_eval_grid(const GridRef g, F3 p_world) {

@@ -328,6 +328,11 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
                               a.filter == b.filter && a.wrap == b.wrap && memcmp(a.w2l, b.w2l, 64) == 0) ? 1 : 0;
             auto grey = [](const DVolume &v) { return v.type == MTS_VOLUME_GRID ? v.channels == 1 : (v.value[0] == v.value[1] && v.value[1] == v.value[2]); };
             dm.grey = (grey(a) && grey(b) && !spectral) ? 1 : 0;       // spectral variant: values depend on the wavelength
+            if (spectral && dm.shared_grid) {                          // two gridvolume_spectral grids over one spectral interval: 2
+                const DVolumeSp &sa = hs.volume_sp[m.sigma_t_volume], &sb = hs.volume_sp[m.albedo_volume];
+                if (sa.spectral_grid && sb.spectral_grid && a.channels == b.channels && sa.lambda_min == sb.lambda_min && sa.lambda_max == sb.lambda_max)
+                    dm.shared_grid = 2;
+            }
             std::vector<float> pair;
             if (dm.shared_grid && a.channels == 1 && b.channels == 1 && a.filter == MTS_FILTER_TRILINEAR && a.wrap == MTS_WRAP_CLAMP && a.nx >= 2) {
                 const std::vector<float> &ga = hs.grid_data[m.sigma_t_volume], &gb = hs.grid_data[m.albedo_volume];

@@ -142,6 +142,21 @@ DEV MedStep medium_step(const DScene &sc, const DMedium m, const DRay &ray, floa
                 float st = m.scale * grid_fetch1(as_global(vs.data), c);
                 mi.sigma_t = spec_s(st);
                 if (want_albedo) mi.sigma_s = spec_s(st * grid_fetch1(as_global(va.data), c));    // the tracking walks never read sigma_s
+#if MTS_SPEC_N != 3
+            } else if (m.shared_grid == 2) {
+                // gridvolume_spectral for both, same geometry and spectral interval: one cell, one set of weights and spectral nodes
+                GridRef g;
+                for (int k = 0; k < 16; ++k) g.w2l[k] = vs.w2l[k];
+                g.data = vs.data; g.nx = vs.nx; g.ny = vs.ny; g.nz = vs.nz;
+                g.channels_affine_filter_wrap = (uint32_t) vs.channels | ((uint32_t) (vs.affine != 0) << 8) | ((uint32_t) vs.filter << 16) | ((uint32_t) vs.wrap << 24);
+                const DVolumeSp sp = cload(cx.volume_sp + m.sigma_t);
+                if (want_albedo) {
+                    const SpecPair r = volume_eval_grid_spectral_pair(g, va.data, mi.p, cx.wl, sp.lambda_min, sp.lambda_max);
+                    const Spec st = m.scale * r.a;
+                    mi.sigma_t = st; mi.sigma_s = st * r.b;
+                } else
+                    mi.sigma_t = m.scale * volume_eval_grid_spectral(g, mi.p, cx.wl, sp.lambda_min, sp.lambda_max);
+#endif
             } else {
                 Spec st = m.scale * volume_eval(vs, mi.p MTS_CXI(m.sigma_t));
                 mi.sigma_t = st;
