@@ -65,19 +65,36 @@ def test_default_kernel_resource_budget(tmp_path):
     if not all(os.path.exists(t) for t in tools):
         pytest.skip("ROCm LLVM tools not found")
     lib = os.environ.get("MTSAMD_LIB") or os.path.join(ROOT, "eradiate-kernel_amd", "libmtsamd.so")
-    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
+    fat = str(tmp_path / "fat.bin")
     subprocess.run([tools[0], "-O", "binary", "--only-section=.hip_fatbin", lib, fat], check=True)
-    subprocess.run([tools[1], "--unbundle", "--type=o", "--input=" + fat, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co],
-                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    notes = subprocess.run([tools[2], "--notes", co], check=True, capture_output=True, text=True).stdout
+    # the section holds one offload bundle per translation unit (kernels.hip: rgb / mono, kernels_spectral.hip: spectral)
+    blob, magic = open(fat, "rb").read(), b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+    assert len(starts) == 2, starts
     kernels = {}
-    for block in notes.split("- .agpr_count")[1:]:
-        name = re.search(r"\.name:\s+(\S+)", block).group(1)
-        kernels[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, block).group(1))
-                         for k in ("private_segment_fixed_size", "vgpr_count", "vgpr_spill_count", "sgpr_spill_count")}
-    default = [v for k, v in kernels.items() if "render_kernel_wgaILb0ELi1024ELi1024ELi4E" in k]
-    assert len(default) == 1, sorted(kernels)
-    d = default[0]
+    for k, o in enumerate(starts):
+        part, co = str(tmp_path / ("b%d.bin" % k)), str(tmp_path / ("b%d.co" % k))
+        open(part, "wb").write(blob[o:starts[k + 1] if k + 1 < len(starts) else len(blob)])
+        subprocess.run([tools[1], "--unbundle", "--type=o", "--input=" + part, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co],
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        notes = subprocess.run([tools[2], "--notes", co], check=True, capture_output=True, text=True).stdout
+        for block in notes.split("- .agpr_count")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", block).group(1)
+            kernels[name] = {f: int(re.search(r"\.%s:\s+(\d+)" % f, block).group(1))
+                             for f in ("private_segment_fixed_size", "group_segment_fixed_size", "vgpr_count", "vgpr_spill_count", "sgpr_spill_count")}
+
+    def one(pattern):
+        found = [v for k, v in kernels.items() if pattern in k]
+        assert len(found) == 1, (pattern, sorted(kernels))
+        return found[0]
+    d = one("5v_rgb17render_kernel_wgaILb0ELi1024ELi1024ELi4E")
     assert d["vgpr_count"] <= 128                       # 4 waves per SIMD (launch bounds 1024 threads x 4)
     assert d["private_segment_fixed_size"] <= 256 and d["vgpr_spill_count"] <= 8, d
     assert d["sgpr_spill_count"] <= 400, d
+    assert d["group_segment_fixed_size"] <= 160 * 1024, d
+    # volpathmis on the rings: 512 paths x 68 state dwords, two waves per SIMD
+    m = one("5v_rgb21render_kernel_wga_misILb0ELb1ELi512ELi512E")
+    assert m["vgpr_count"] <= 256 and m["vgpr_spill_count"] == 0 and m["group_segment_fixed_size"] <= 160 * 1024, m
+    # the spectral variant's volpath: 256 paths x 42 state dwords, three workgroups per CU
+    sp = one("10v_spectral17render_kernel_wgaILb0ELi256ELi256ELi2E")
+    assert sp["vgpr_count"] <= 168 and sp["vgpr_spill_count"] == 0 and 3 * sp["group_segment_fixed_size"] <= 160 * 1024, sp
