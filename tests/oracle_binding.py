@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = importlib.import_module("eradiate-kernel_amd")
 A = importlib.import_module("eradiate-kernel_amd._capi")
 SD = importlib.import_module("eradiate-kernel_amd.scene_dict")
-LIB_PATH = os.path.join(ROOT, "oracle", "liboracle.so")
+SUFFIX = os.environ.get("MTSAMD_ORACLE_SUFFIX", "")          # "_asan": the sanitizer builds (tests/test_oracle_sanitizers.py)
+LIB_PATH = os.path.join(ROOT, "oracle", "liboracle%s.so" % SUFFIX)
 _lib = None
 fp = A.fp
 
@@ -23,7 +24,7 @@ def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
-            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), os.path.basename(LIB_PATH)], stdout=subprocess.DEVNULL)
         L = C.CDLL(LIB_PATH)
         L.oracle_last_error.restype = C.c_char_p
         L.oracle_scene_create.argtypes = [C.POINTER(A.SceneDesc), C.POINTER(C.c_void_p)]
@@ -80,9 +81,9 @@ def lib_spectral():
     """oracle/liboracle_spectral.so: the restatement compiled for the spectral variant (Spectrum<Float, 4>, scalar_spectral semantics)."""
     global _lib_spectral
     if _lib_spectral is None:
-        path = os.path.join(ROOT, "oracle", "liboracle_spectral.so")
+        path = os.path.join(ROOT, "oracle", "liboracle_spectral%s.so" % SUFFIX)
         if not os.path.exists(path):
-            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle_spectral.so"], stdout=subprocess.DEVNULL)
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), os.path.basename(path)], stdout=subprocess.DEVNULL)
         L = C.CDLL(path)
         L.oracle_last_error.restype = C.c_char_p
         L.oracle_scene_create.argtypes = [C.POINTER(A.SceneDesc), C.POINTER(C.c_void_p)]
