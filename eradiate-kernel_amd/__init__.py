@@ -154,6 +154,16 @@ class Film:
     def bitmap(self, raw=False):
         if self._storage is None:
             raise RuntimeError("Film.bitmap(): nothing has been rendered yet")
+        if self._storage.shape[2] != 5:
+            # AOV channels behind X, Y, Z, A, W (hdrfilm.cpp:262-320): the raw storage as a multichannel bitmap; developed: R, G, B, A
+            # and every AOV channel, all divided by the weight channel, which is dropped
+            src = Bitmap(self._storage, PixelFormat.MultiChannel)
+            if raw:
+                return src
+            rgba = np.asarray(Bitmap(self._storage[..., :5], PixelFormat.XYZAW).convert(PixelFormat.RGBA))
+            w = self._storage[..., 4:5]
+            inv = np.where(w != 0, 1.0 / np.where(w != 0, w, 1), 0).astype(np.float32)
+            return Bitmap(np.concatenate([rgba, self._storage[..., 5:] * inv], -1), PixelFormat.MultiChannel)
         src = Bitmap(self._storage, PixelFormat.XYZAW)
         if raw:
             return src
@@ -224,7 +234,7 @@ class Integrator:
                 A.check(A.lib().mts_render(scene._handle, C.byref(opts), C.c_void_p(int(device_film)), C.byref(stats)))
                 sensor._film._storage = None
             else:
-                out = np.zeros((h, w, 5), dtype=np.float32)
+                out = np.zeros((h, w, 5 + 2 * scene._desc.integrator.bin_count), dtype=np.float32)    # X, Y, Z, A, W + aov_names()
                 opts.film_on_device = 0
                 A.check(A.lib().mts_render(scene._handle, C.byref(opts), out.ctypes.data_as(C.c_void_p), C.byref(stats)))
                 sensor._film._storage = out
@@ -236,6 +246,10 @@ class Integrator:
 
     def cancel(self):
         A.lib().mts_cancel(self._scene._handle)
+
+    def aov_names(self):
+        """SamplingIntegrator::aov_names (integrator.cpp:47-49; nbins.cpp:127-134, bins.cpp:112-119)."""
+        return list(getattr(self._scene._keep, "aov_names", []))
 
     def sample(self, scene, origins, directions, seed_offset=0):
         """SamplingIntegrator.sample for a batch of rays (integrator_v.cpp:62-78): returns (rgb (n,3), valid (n,))."""
@@ -315,8 +329,27 @@ def wavefront_sampler(lanes, seed_value, count, device=0):
 def load_dict(d, device=0):
     """mitsuba.core.xml.load_dict (src/libcore/python/xml_v.cpp:23-68,100-272)."""
     _require_variant()
+    if isinstance(d, dict) and d.get("type") in ("nbins", "bins"):
+        # the reference's tests construct these integrators on their own (src/integrators/tests/test_bins.py:10-53): validated like
+        # inside a scene, and good for aov_names()
+        from . import scene_dict as SD
+        b = SD.SceneBuilder(); b.spectra = []
+        SD._SPECTRAL = b if variant() == "gpu_spectral" else None
+        try:
+            b.set_integrator(d, "integrator")
+        finally:
+            SD._SPECTRAL = None
+        return _DetachedIntegrator(b.aov_names)
     desc, keep = build_scene_desc(d, mono=(variant() == "gpu_mono"), spectral=(variant() == "gpu_spectral"))
     return Scene(desc, keep, device)
+
+
+class _DetachedIntegrator:
+    def __init__(self, names):
+        self._names = list(names)
+
+    def aov_names(self):
+        return list(self._names)
 
 
 def load_string(string, device=0, **kwargs):

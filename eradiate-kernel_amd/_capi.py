@@ -10,11 +10,11 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MTSAMD_LIB") or os.path.join(HERE, "libmtsamd.so")
 
-MTS_ABI_VERSION = 5
+MTS_ABI_VERSION = 6
 
 # enums (include/mtsamd.h)
 VOLUME_CONST, VOLUME_GRID, VOLUME_GRID_SPECTRAL = 0, 1, 2
-SPECTRUM_UNIFORM, SPECTRUM_REGULAR = 0, 1
+SPECTRUM_UNIFORM, SPECTRUM_REGULAR, SPECTRUM_IRREGULAR, SPECTRUM_DISCRETE = 0, 1, 2, 3
 FILTER_NEAREST, FILTER_TRILINEAR = 0, 1
 WRAP_REPEAT, WRAP_MIRROR, WRAP_CLAMP = 0, 1, 2
 PHASE_ISOTROPIC, PHASE_HG, PHASE_RAYLEIGH, PHASE_BLEND, PHASE_TABULATED = 0, 1, 2, 3, 4
@@ -37,7 +37,8 @@ class Transform(C.Structure):
 
 
 class Spectrum(C.Structure):
-    _fields_ = [("type", i32), ("value", f32), ("lambda_min", f32), ("lambda_max", f32), ("values", fp), ("count", i32)]
+    _fields_ = [("type", i32), ("value", f32), ("lambda_min", f32), ("lambda_max", f32), ("values", fp), ("count", i32),
+                ("wavelengths", fp), ("pmf", fp)]
 
 
 class Volume(C.Structure):
@@ -85,13 +86,13 @@ class Sensor(C.Structure):
                 ("rfilter_type", i32), ("rfilter_radius", f32), ("rfilter_stddev", f32),
                 ("sample_count", i32), ("sampler_seed", C.c_uint64), ("medium", i32),
                 ("multi_transforms", C.POINTER(C.c_float)), ("multi_count", i32),
-                ("shutter_open_time", f32), ("distant_origin_type", i32), ("distant_origin_shape", Shape)]
+                ("shutter_open_time", f32), ("distant_origin_type", i32), ("distant_origin_shape", Shape), ("srf", i32)]
 
 
 class Integrator(C.Structure):
     _fields_ = [("type", i32), ("max_depth", i32), ("rr_depth", i32), ("hide_emitters", i32),
                 ("block_size", i32), ("samples_per_pass", i32), ("timeout", f32), ("use_spectral_mis", i32), ("monochrome", i32),
-                ("spectral", i32)]
+                ("spectral", i32), ("bin_mode", i32), ("bin_count", i32), ("bin_lo", fp), ("bin_hi", fp)]
 
 
 class SceneDesc(C.Structure):

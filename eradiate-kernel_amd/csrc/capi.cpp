@@ -184,7 +184,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             pass_blocks.back().push_back(b);
             samples += (uint64_t) b.sx * b.sy * samples_per_pass;
         }
-    const size_t film_floats = (size_t) se.crop_w * se.crop_h * 5;
+    const size_t film_floats = (size_t) se.crop_w * se.crop_h * (size_t) hs.scene.film_channels;     // X, Y, Z, A, W (+ two AOV channels per spectral bin)
     RenderCache &rc = scene->cache;
     float *d_film = film;
     if (!opts.film_on_device) d_film = (float *) rc.get(0, film_floats * sizeof(float));
@@ -221,6 +221,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             if (hs.integrator.type == MTS_INTEGRATOR_VOLPATHMIS && variant > 10512) variant = 10512;     // four weight matrices per path: 512 paths fill the LDS
             if (hs.integrator.spectral && variant > 10256) variant = 10256;                               // four-wide spectra: 42 hot dwords per path; three 256-path workgroups per CU (12 waves) beat one of 512 (8 waves) by 10 %
             if (hs.integrator.spectral && variant == 1) variant = 0;                                      // no per-lane flat kernel in the spectral build
+            if (hs.scene.bin_count > 0 || hs.scene.srf >= 0) variant = 0;                                 // AOV channels / a response function: the per-lane kernel carries them
             // a workgroup of the regrouping kernel sits in ONE spiral block: blocks smaller than its path count get the largest
             // workgroup that divides them (16 x 16 -> 256 paths); only blocks below 256 pixels fall back to the per-lane kernel
             while (variant > 10256 && (block_size * block_size) % (uint32_t) (variant - 10000) != 0) variant = 10000 + (variant - 10000) / 2;

@@ -112,7 +112,10 @@ struct DSensor {
 
 // Spectra (spectral variants): `uniform` (spectra/uniform.cpp:34-62: value inside [lambda_min, lambda_max], 0 outside) and `regular`
 // (spectra/regular.cpp: a ContinuousDistribution over [lambda_min, lambda_max], core/distr_1d.h:378-400 eval_pdf)
-struct DSpectrum { int32_t type; float value, lambda_min, lambda_max; const float *values; int32_t count; float inv_interval_size; };
+// `irregular` (spectra/irregular.cpp: values at the nodes `wavelengths`) and `discrete` (spectra/discrete.cpp: a sampling-only sensor
+// response: `wavelengths`, `values` and the running sum of the pmf, DiscreteDistribution, core/distr_1d.h:49-83)
+struct DSpectrum { int32_t type; float value, lambda_min, lambda_max; const float *values; int32_t count; float inv_interval_size;
+                   const float *wavelengths, *cdf; float cdf_sum; uint32_t valid_x, valid_y; };
 enum { MTS_BSDF_SP_REFLECTANCE = 0, MTS_BSDF_SP_RHO_0, MTS_BSDF_SP_K, MTS_BSDF_SP_G, MTS_BSDF_SP_RHO_C, MTS_BSDF_SP_TRANSMITTANCE, MTS_BSDF_SP_COUNT };
 // constvolume: the spectrum of its value; gridvolume_spectral (textures/gridvolume_spectral.cpp): the spectral interval its channels cover
 struct DVolumeSp { int32_t value_sp; int32_t spectral_grid; float lambda_min, lambda_max; };
@@ -159,6 +162,12 @@ struct DScene {
     const int32_t *emitter_sp;                      // per emitter: radiance / irradiance / intensity
     const DVolumeSp *volume_sp;                     // per volume
     const float *cie;                               // CIE 1931 x, y, z, 95 samples each over 360 .. 830 nm (core/spectrum.h:127-133)
+    int32_t srf;                                    // the sensor's spectral response function: index into spectra, -1 = none (perspective.cpp:173-182)
+    // integrators/nbins.cpp (bin_mode 1: wavelength bin_lo[i] +- bin_hi[i]) / bins.cpp (2: interval [bin_lo[i], bin_hi[i]]): two AOV
+    // channels per bin behind X, Y, Z, A, W; film_channels = 5 + 2 bin_count floats per pixel
+    int32_t bin_mode, bin_count;
+    const float *bin_lo, *bin_hi;
+    int32_t film_channels;
 };
 
 // bsdf.h:38-124

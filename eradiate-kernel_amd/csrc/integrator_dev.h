@@ -376,6 +376,21 @@ DEV SpecCtx make_ctx(const DScene &sc) {
 DEV float spectrum_eval_1(const DSpectrum &s, float lambda) {
     const bool active = lambda >= s.lambda_min && lambda <= s.lambda_max;
     if (s.type == MTS_SPECTRUM_UNIFORM) return active ? s.value : 0.f;
+    if (s.type == MTS_SPECTRUM_DISCRETE) return 0.f;                       // discrete.cpp:112-116: a sampling-only response
+    if (s.type == MTS_SPECTRUM_IRREGULAR) {                                // irregular.cpp:75-84 -> IrregularContinuousDistribution::eval_pdf (distr_1d.h:655-677)
+        const MTS_GLOBAL_AS float *nodes = as_global(s.wavelengths), *vals = as_global(s.values);
+        const uint32_t size = (uint32_t) s.count;
+        uint32_t start = 0, end = size, iterations = 1;                    // enoki::binary_search(0, size, nodes[i] < x)
+        { uint32_t diff = end - start; while (diff >>= 1) iterations++; }
+        for (uint32_t i = 0; i < iterations; ++i) {
+            const uint32_t middle = (start + end) >> 1;
+            if (nodes[min(middle, size - 1u)] < lambda) start = min(middle + 1u, end); else end = middle;
+        }
+        const uint32_t index = max(min(start, size - 1u), 1u) - 1u;
+        const float x0 = nodes[index], x1 = nodes[index + 1], y0 = vals[index], y1 = vals[index + 1];
+        const float x = (lambda - x0) / (x1 - x0);
+        return active ? pm_fma(x, y1 - y0, y0) : 0.f;
+    }
     float x = (lambda - s.lambda_min) * s.inv_interval_size;
     long long xi = (long long) x;
     uint32_t index = (uint32_t) (xi < 0 ? 0 : (xi > (long long) s.count - 2 ? (long long) s.count - 2 : xi));
@@ -1614,12 +1629,17 @@ DEV Spec integrator_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, b
 // ImageBlock::put of the five film values X, Y, Z, alpha, weight of one finished sample (librender/imageblock.cpp:79-172).
 // `own` receives the samples that land in the lane's own pixel: either register accumulators (per-lane kernels) or the pixel's film
 // entry itself, updated with float atomics in sample order.
+// With AOV channels (nbins / bins) a sample carries NA more values; they go to the film entry's channels 5 .. 5 + NA with the same filter
+// weights, by atomics (one path writes them in sample order, so the sum is the block's), and the block only warns about non-finite
+// values then (integrator.cpp:114-116: warn_negative = !has_aovs).
 template <bool OWN_ATOMIC>
 DEV void splat_values_t(const DScene &sc, const DBlock &blk, uint32_t lx, uint32_t ly, F2 position_sample, const float v[5],
-                        MTS_GLOBAL_AS float *film, float *own) {
+                        MTS_GLOBAL_AS float *film, float *own, const float *aov = nullptr, int NA = 0) {
     const DSensor &se = sc.sensor;
+    const int C = sc.film_channels;
     bool ok = true;                                             // imageblock.cpp:85-109: invalid samples are dropped
-    for (int k = 0; k < 5; ++k) ok = ok && v[k] >= -1e-5f && pm_isfinite(v[k]);
+    for (int k = 0; k < 5; ++k) ok = ok && (NA > 0 || v[k] >= -1e-5f) && pm_isfinite(v[k]);
+    for (int k = 0; k < NA; ++k) ok = ok && pm_isfinite(aov[k]);
     if (!ok) return;
     const DRFilter &rf = se.rfilter;
     const int border = rf.border_size;
@@ -1642,19 +1662,25 @@ DEV void splat_values_t(const DScene &sc, const DBlock &blk, uint32_t lx, uint32
                 float weight = wy * wx;
                 int fx = blk.ox - border + x - se.crop_x;
                 if (fx >= 0 && fy >= 0 && fx < se.crop_w && fy < se.crop_h) {                         // film clipping, imageblock.cpp:49-77
-                    float *dst = (float *) (film + 5 * ((size_t) fy * se.crop_w + fx));
+                    float *dst = (float *) (film + (size_t) C * ((size_t) fy * se.crop_w + fx));
                     for (int k = 0; k < 5; ++k) atomicAdd(dst + k, v[k] * weight);
+                    for (int k = 0; k < NA; ++k) atomicAdd(dst + 5 + k, aov[k] * weight);
                 }
             }
         }
     } else {
         int lox = (int) pm_ceil(posx - .5f), loy = (int) pm_ceil(posy - .5f);
+        const bool inside = lox >= 0 && loy >= 0 && lox < sx && loy < sy;
         if (lox == (int) lx && loy == (int) ly) {
             if (OWN_ATOMIC) { for (int k = 0; k < 5; ++k) atomicAdd(own + k, v[k]); }
             else { for (int k = 0; k < 5; ++k) own[k] += v[k]; }
-        } else if (lox >= 0 && loy >= 0 && lox < sx && loy < sy) {
-            float *dst = (float *) (film + 5 * ((size_t) (blk.oy + loy - se.crop_y) * se.crop_w + (blk.ox + lox - se.crop_x)));
+        } else if (inside) {
+            float *dst = (float *) (film + (size_t) C * ((size_t) (blk.oy + loy - se.crop_y) * se.crop_w + (blk.ox + lox - se.crop_x)));
             for (int k = 0; k < 5; ++k) atomicAdd(dst + k, v[k]);
+        }
+        if (NA > 0 && inside) {
+            float *dst = (float *) (film + (size_t) C * ((size_t) (blk.oy + loy - se.crop_y) * se.crop_w + (blk.ox + lox - se.crop_x)));
+            for (int k = 0; k < NA; ++k) atomicAdd(dst + 5 + k, aov[k]);
         }
     }
 }
@@ -1673,6 +1699,42 @@ DEV Spec sample_wavelengths(float sample, float &weight) {
     for (int k = 0; k < 4; ++k) { float x = sample + (float) k / 4.f; if (x > 1.f) x -= 1.f; v[k] = x * (MTS_CIE_MAX - MTS_CIE_MIN) + MTS_CIE_MIN; }
     weight = MTS_CIE_MAX - MTS_CIE_MIN;
     return spec4(v[0], v[1], v[2], v[3]);
+}
+// The sensor's "srf" draws the wavelengths instead (perspective.cpp:173-182, radiancemeter.cpp:116-124): Texture::sample_spectrum of a
+// uniform spectrum (uniform.cpp:92-100) or of a discrete one (discrete.cpp:124-133 -> DiscreteDistribution::sample, distr_1d.h:141-151)
+DEV Spec sample_wavelengths_srf(const DScene &sc, float sample, Spec &weight) {
+    const DSpectrum r = sc.spectra[sc.srf];
+    float v[4], wgt[4];
+    for (int k = 0; k < 4; ++k) {
+        float x = sample + (float) k / 4.f; if (x > 1.f) x -= 1.f;
+        if (r.type == MTS_SPECTRUM_UNIFORM) { v[k] = r.lambda_min + (r.lambda_max - r.lambda_min) * x; wgt[k] = r.value * (r.lambda_max - r.lambda_min); }
+        else {
+            const MTS_GLOBAL_AS float *cdf = as_global(r.cdf);
+            const float value = x * r.cdf_sum;
+            uint32_t start = r.valid_x, end = r.valid_y, iterations = 0;                       // enoki::binary_search: first index with !(cdf[i] < value)
+            if (start < end) { uint32_t diff = end - start; iterations = 1; while (diff >>= 1) iterations++; }
+            for (uint32_t i = 0; i < iterations; ++i) {
+                const uint32_t middle = (start + end) >> 1;
+                if (cdf[middle] < value) start = min(middle + 1u, end); else end = middle;
+            }
+            v[k] = as_global(r.wavelengths)[start]; wgt[k] = as_global(r.values)[start];
+        }
+    }
+    weight = spec4(wgt[0], wgt[1], wgt[2], wgt[3]);
+    return spec4(v[0], v[1], v[2], v[3]);
+}
+// nbins.cpp:100-125 / bins.cpp:88-110: per bin the sum of the wrapped integrator's result over the sample's wavelengths inside the bin,
+// and their number; hsum of a 4-array: (x + y) + (z + w), as spec_hmean
+DEV void bin_aovs(const DScene &sc, Spec L, Spec wl, int i, float &value, float &population) {
+    const float lo = as_global(sc.bin_lo)[i], hi = as_global(sc.bin_hi)[i];
+    const float w4[4] = { wl.x, wl.y, wl.z, wl.w }, l4[4] = { L.x, L.y, L.z, L.w };
+    float val[4], pop[4];
+    for (int k = 0; k < 4; ++k) {
+        if (sc.bin_mode == 1) { const bool in = pm_abs(w4[k] - lo) <= hi; val[k] = in ? l4[k] : 0.f; pop[k] = in ? 1.f : 0.f; }
+        else { const float w = (w4[k] >= lo && w4[k] <= hi) ? 1.f : 0.f; val[k] = w * l4[k]; pop[k] = w; }
+    }
+    value = (val[0] + val[1]) + (val[2] + val[3]);
+    population = (pop[0] + pop[1]) + (pop[2] + pop[3]);
 }
 // cie1931_xyz + spectrum_to_xyz (core/spectrum.h:148-178,210-217): XYZ = hmean(cmf(lambda) * value)
 DEV void spectrum_to_xyz(const float *cie, Spec value, Spec wl, float xyz[3]) {

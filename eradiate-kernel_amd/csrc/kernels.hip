@@ -40,8 +40,12 @@ __device__ __forceinline__ void render_sample(const DScene &sc, Pcg32 &rng, cons
     (void) rng.next_1d();                                       // wavelength sample (integrator.cpp:252), unused in rgb
 #else
     SpecCtx cx = make_ctx(sc);
-    float wav_weight;
-    cx.wl = sample_wavelengths(rng.next_1d(), wav_weight);      // integrator.cpp:252 -> Sensor::sample_ray: perspective.cpp:169-172, distant.cpp:311-313
+    Spec wav_weight;
+    {
+        const float wavelength_sample = rng.next_1d();          // integrator.cpp:252 -> Sensor::sample_ray: perspective.cpp:169-182, distant.cpp:311-313
+        if (sc.srf >= 0) cx.wl = sample_wavelengths_srf(sc, wavelength_sample, wav_weight);
+        else { float w; cx.wl = sample_wavelengths(wavelength_sample, w); wav_weight = spec_s(w); }
+    }
 #endif
     F2 adjusted;
     adjusted.x = (position_sample.x - (float) se.crop_x) / (float) se.crop_w;
@@ -55,11 +59,13 @@ __device__ __forceinline__ void render_sample(const DScene &sc, Pcg32 &rng, cons
     splat_sample_t<false>(sc, blk, lx, ly, position_sample, L, valid, as_global(film), acc);
 #else
     Spec L = integrator_sample<COUNT, INTEG>(sc, rng, ray, se.medium, valid, cnt, cx);
+    float aov[2 * 64]; const int na = 2 * sc.bin_count;        // nbins / bins: the wrapped integrator's own result, before the ray weight
+    for (int i = 0; i < sc.bin_count; ++i) bin_aovs(sc, L, cx.wl, i, aov[2 * i], aov[2 * i + 1]);
     L = (wav_weight * ray_weight.x) * L;                        // ray_weight = wav_weight (x the sensor's grey weight), integrator.cpp:265
     float xyz[3];
     spectrum_to_xyz(sc.cie, L, cx.wl, xyz);                     // integrator.cpp:266-269
     const float v[5] = { xyz[0], xyz[1], xyz[2], valid ? 1.f : 0.f, 1.f };
-    splat_values_t<false>(sc, blk, lx, ly, position_sample, v, as_global(film), acc);
+    splat_values_t<false>(sc, blk, lx, ly, position_sample, v, as_global(film), acc, aov, na);
 #endif
 }
 
@@ -117,7 +123,12 @@ __global__ void __launch_bounds__(256, FLAT ? 1 : (INTEG == NI_PATH ? MTS_PATH_W
             if ((j & 63u) == 63u && stop_requested(stop_flag)) break;
             render_sample<COUNT, INTEG>(sc, rng, blk, lx, ly, film, acc, cnt);
         }
-        float *dst = film + 5 * ((size_t) (blk.oy + (int) ly - sc.sensor.crop_y) * sc.sensor.crop_w + (blk.ox + (int) lx - sc.sensor.crop_x));
+#if MTS_SPEC_N == 3
+        const size_t film_channels = 5;
+#else
+        const size_t film_channels = (size_t) sc.film_channels;  // X, Y, Z, A, W (+ the bins' AOV channels)
+#endif
+        float *dst = film + film_channels * ((size_t) (blk.oy + (int) ly - sc.sensor.crop_y) * sc.sensor.crop_w + (blk.ox + (int) lx - sc.sensor.crop_x));
         for (int k = 0; k < 5; ++k) atomicAdd(dst + k, acc[k]);
     }
     if (COUNT) {

@@ -201,7 +201,7 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
             const mts_spectrum &sp = d->spectra[i];
             DSpectrum ds; memset(&ds, 0, sizeof(ds));
             ds.type = sp.type; ds.value = sp.value; ds.lambda_min = sp.lambda_min; ds.lambda_max = sp.lambda_max;
-            hs.spectrum_values.emplace_back();
+            hs.spectrum_values.emplace_back(); hs.spectrum_wavelengths.emplace_back(); hs.spectrum_cdf.emplace_back();
             if (sp.type == MTS_SPECTRUM_UNIFORM) {
                 ds.lambda_min = std::max(sp.lambda_min, 280.f); ds.lambda_max = std::min(sp.lambda_max, 2400.f);       // MTS_WAVELENGTH_MIN / MAX
                 if (!(ds.lambda_min < ds.lambda_max)) throw std::runtime_error("UniformSpectrum: 'lambda_min' must be less than 'lambda_max'");
@@ -215,6 +215,33 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
                 ds.count = sp.count;
                 const double interval_size = (double(sp.lambda_max) - double(sp.lambda_min)) / (sp.count - 1);
                 ds.inv_interval_size = (float) (1. / interval_size);
+            } else if (sp.type == MTS_SPECTRUM_IRREGULAR) {                  // irregular.cpp:33-63 + IrregularContinuousDistribution (distr_1d.h:560-600)
+                if (sp.count < 2 || !sp.values || !sp.wavelengths) throw std::runtime_error("IrregularContinuousDistribution: needs at least two entries!");
+                bool mass = false;
+                for (int k = 0; k < sp.count; ++k) {
+                    if (sp.values[k] < 0.f) throw std::runtime_error("IrregularContinuousDistribution: entries must be non-negative!");
+                    if (k > 0 && !(sp.wavelengths[k] > sp.wavelengths[k - 1])) throw std::runtime_error("IrregularContinuousDistribution: node positions must be strictly increasing!");
+                    mass = mass || sp.values[k] > 0.f;
+                }
+                if (!mass) throw std::runtime_error("IrregularContinuousDistribution: no probability mass found!");
+                hs.spectrum_values.back().assign(sp.values, sp.values + sp.count);
+                hs.spectrum_wavelengths.back().assign(sp.wavelengths, sp.wavelengths + sp.count);
+                ds.count = sp.count; ds.lambda_min = sp.wavelengths[0]; ds.lambda_max = sp.wavelengths[sp.count - 1];
+            } else if (sp.type == MTS_SPECTRUM_DISCRETE) {                   // discrete.cpp:45-100 + DiscreteDistribution::update (distr_1d.h:49-83)
+                if (sp.count < 1 || !sp.values || !sp.wavelengths || !sp.pmf) throw std::runtime_error("DiscreteDistribution: empty distribution!");
+                hs.spectrum_values.back().assign(sp.values, sp.values + sp.count);
+                hs.spectrum_wavelengths.back().assign(sp.wavelengths, sp.wavelengths + sp.count);
+                std::vector<float> &cdf = hs.spectrum_cdf.back(); cdf.resize((size_t) sp.count);
+                ds.count = sp.count; ds.valid_x = ds.valid_y = (uint32_t) -1;
+                double sum = 0.0;
+                for (int k = 0; k < sp.count; ++k) {
+                    const double value = (double) sp.pmf[k];
+                    sum += value; cdf[(size_t) k] = (float) sum;
+                    if (value < 0.0) throw std::runtime_error("DiscreteDistribution: entries must be non-negative!");
+                    else if (value > 0.0) { if (ds.valid_x == (uint32_t) -1) ds.valid_x = (uint32_t) k; ds.valid_y = (uint32_t) k; }
+                }
+                if (ds.valid_x == (uint32_t) -1) throw std::runtime_error("DiscreteDistribution: no probability mass found!");
+                ds.cdf_sum = (float) sum;
             } else throw std::runtime_error("unknown spectrum type");
             hs.spectra.push_back(ds);
         }
@@ -225,7 +252,7 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
     };
     auto add_uniform_spectrum = [&](float value) {
         DSpectrum ds; memset(&ds, 0, sizeof(ds)); ds.type = MTS_SPECTRUM_UNIFORM; ds.value = value; ds.lambda_min = 280.f; ds.lambda_max = 2400.f;
-        hs.spectra.push_back(ds); hs.spectrum_values.emplace_back();
+        hs.spectra.push_back(ds); hs.spectrum_values.emplace_back(); hs.spectrum_wavelengths.emplace_back(); hs.spectrum_cdf.emplace_back();
         return (int32_t) hs.spectra.size() - 1;
     };
 
@@ -532,6 +559,29 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
     sc.integrator.use_spectral_mis = it.use_spectral_mis != 0;
     sc.integrator.monochrome = it.monochrome != 0;
     hs.integrator = it;
+    hs.integrator.bin_lo = hs.integrator.bin_hi = nullptr;                                     // copied: the caller's arrays may go away
+    // ---- nbins / bins (nbins.cpp:55-98, bins.cpp:23-85) and the sensor's srf (perspective.cpp:113-121, radiancemeter.cpp:62-68)
+    sc.srf = -1; sc.bin_mode = 0; sc.bin_count = 0; sc.bin_lo = sc.bin_hi = nullptr; sc.film_channels = 5;
+    if (it.bin_mode != 0) {
+        if (!spectral) throw std::runtime_error("This integrator can only be used with a spectral variant!");
+        if (it.bin_mode != 1 && it.bin_mode != 2) throw std::runtime_error("unknown bin mode");
+        if (it.bin_count < 0 || it.bin_count > 64 || (it.bin_count > 0 && (!it.bin_lo || !it.bin_hi))) throw std::runtime_error("bins: between 0 and 64 bins with their bounds");
+        hs.bin_lo.assign(it.bin_lo, it.bin_lo + it.bin_count); hs.bin_hi.assign(it.bin_hi, it.bin_hi + it.bin_count);
+        if (it.bin_mode == 2)                                                                  // a uniform spectrum per bin (bins.cpp:79-84, uniform.cpp:41-46)
+            for (int i = 0; i < it.bin_count; ++i) {
+                hs.bin_lo[(size_t) i] = std::max(hs.bin_lo[(size_t) i], 280.f); hs.bin_hi[(size_t) i] = std::min(hs.bin_hi[(size_t) i], 2400.f);
+                if (!(hs.bin_lo[(size_t) i] < hs.bin_hi[(size_t) i])) throw std::runtime_error("UniformSpectrum: 'lambda_min' must be less than 'lambda_max'");
+            }
+        sc.bin_mode = it.bin_mode; sc.bin_count = it.bin_count; sc.film_channels = 5 + 2 * it.bin_count;
+    } else hs.integrator.bin_count = 0;
+    if (spectral && d->sensor.srf != 0) {
+        if (d->sensor.srf < 0 || d->sensor.srf > d->spectrum_count) throw std::runtime_error("index out of range: sensor srf");
+        if (d->sensor.type != MTS_SENSOR_PERSPECTIVE && !(d->sensor.type == MTS_SENSOR_MRADIANCEMETER && d->sensor.multi_count == 1))
+            throw std::runtime_error("srf: only perspective and radiancemeter sensors sample their wavelengths from a response function");
+        const int t = hs.spectra[(size_t) d->sensor.srf - 1].type;
+        if (t != MTS_SPECTRUM_UNIFORM && t != MTS_SPECTRUM_DISCRETE) throw std::runtime_error("srf: sample_spectrum is available for uniform and discrete spectra");
+        sc.srf = d->sensor.srf - 1;
+    }
     sc.volume_count = (int) hs.volumes.size(); sc.phase_count = (int) hs.phases.size(); sc.medium_count = (int) hs.media.size();
     sc.bsdf_count = (int) hs.bsdfs.size(); sc.shape_count = (int) hs.shapes.size(); sc.prim_count = (int) hs.prims.size();
     sc.emitter_count = (int) hs.emitters.size();
@@ -685,10 +735,15 @@ void upload_host_scene(HostScene &hs, int device) {
     sc.spectra = nullptr; sc.bsdf_sp = nullptr; sc.emitter_sp = nullptr; sc.volume_sp = nullptr; sc.cie = nullptr;
     if (hs.integrator.spectral) {
         for (size_t i = 0; i < hs.spectra.size(); ++i)
-            if (hs.spectra[i].type == MTS_SPECTRUM_REGULAR) hs.spectra[i].values = upload(hs, hs.spectrum_values[i]);
+            if (hs.spectra[i].type != MTS_SPECTRUM_UNIFORM) {
+                hs.spectra[i].values = upload(hs, hs.spectrum_values[i]);
+                if (!hs.spectrum_wavelengths[i].empty()) hs.spectra[i].wavelengths = upload(hs, hs.spectrum_wavelengths[i]);
+                if (!hs.spectrum_cdf[i].empty()) hs.spectra[i].cdf = upload(hs, hs.spectrum_cdf[i]);
+            }
         sc.spectra = upload(hs, hs.spectra); sc.bsdf_sp = upload(hs, hs.bsdf_sp); sc.emitter_sp = upload(hs, hs.emitter_sp);
         sc.volume_sp = upload(hs, hs.volume_sp);
         sc.cie = upload(hs, std::vector<float>(MTS_CIE1931_XYZ, MTS_CIE1931_XYZ + 285));
+        if (sc.bin_count > 0) { sc.bin_lo = upload(hs, hs.bin_lo); sc.bin_hi = upload(hs, hs.bin_hi); }
     }
     HIP_CHECK(hipDeviceSynchronize());
     hs.uploaded = true;

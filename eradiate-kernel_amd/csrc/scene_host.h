@@ -35,7 +35,8 @@ struct HostScene {
     std::vector<float> multi_transforms;            // mradiancemeter / mdistant sub-sensor matrices
     std::vector<std::vector<float>> pair_data;       // per medium: interleaved {sigma_t, albedo} voxels (DMedium::pair_grid), or empty
     // spectral variant (DScene::spectra ...)
-    std::vector<DSpectrum> spectra; std::vector<std::vector<float>> spectrum_values;
+    std::vector<DSpectrum> spectra; std::vector<std::vector<float>> spectrum_values, spectrum_wavelengths, spectrum_cdf;
+    std::vector<float> bin_lo, bin_hi;
     std::vector<int32_t> bsdf_sp, emitter_sp; std::vector<DVolumeSp> volume_sp;
     std::vector<void *> device_allocs;
     int device = 0;

@@ -132,6 +132,42 @@ def _spectrum(v, where, default=None, emitter=False):
             b.keep.append(values)
             rec.values = values.ctypes.data_as(A.fp)
             rec.count = int(values.size)
+        elif t in ("irregular", "discrete"):
+            # spectra/irregular.cpp:33-63 (strings of comma-separated numbers, or arrays), spectra/discrete.cpp:45-100
+            def numbers(key, default=None):
+                x = p.get(key, default)
+                if x is None:
+                    raise RuntimeError("Property \"%s\" has not been specified!" % key)
+                if isinstance(x, str):
+                    try:
+                        x = [float(tok) for tok in x.replace(",", " ").split()]
+                    except ValueError as e:
+                        raise RuntimeError("Could not parse floating point value '%s'" % str(e).split("'")[-2])
+                return np.ascontiguousarray(np.asarray(x, np.float64).reshape(-1), np.float32)
+            wl = numbers("wavelengths")
+            if t == "irregular":
+                rec.type = A.SPECTRUM_IRREGULAR
+                values = numbers("values")
+                if values.size != wl.size:
+                    raise RuntimeError("IrregularSpectrum: 'wavelengths' and 'values' parameters must have the same size!")
+                pmf = None
+            else:
+                rec.type = A.SPECTRUM_DISCRETE
+                values, pmf = numbers("values", "1"), numbers("pmf", "1")
+                if values.size == 1:
+                    values = np.full(wl.size, values[0], np.float32)
+                if pmf.size == 1:
+                    pmf = np.full(wl.size, pmf[0], np.float32)
+                if values.size != wl.size:
+                    raise RuntimeError("DiscreteSpectrum: 'wavelengths' and 'values' parameters must have the same size!")
+                if pmf.size != wl.size:
+                    raise RuntimeError("DiscreteSpectrum: 'wavelengths' and 'pmf' parameters must have the same size!")
+                b.keep.append(pmf)
+                rec.pmf = pmf.ctypes.data_as(A.fp)
+            b.keep.append(wl); b.keep.append(values)
+            rec.wavelengths = wl.ctypes.data_as(A.fp)
+            rec.values = values.ctypes.data_as(A.fp)
+            rec.count = int(wl.size)
         elif t in ("rgb", "srgb", "srgb_d65"):
             raise RuntimeError("rgb colours cannot be used in the spectral variant: the sRGB upsampling model needs the coefficient data of "
                                "ext/rgb2spec, absent here; give a 'uniform' or 'regular' spectrum instead (%s)" % where)
@@ -687,6 +723,7 @@ class SceneBuilder:
             s.near_clip = float(p.get("near_clip", 1e-2))
             s.far_clip = float(p.get("far_clip", 1e4))
             p.get("focus_distance")
+            self._srf(p, s, where)                                         # perspective.cpp:113-121
             if s.near_clip <= 0:
                 raise RuntimeError("The 'near_clip' parameter must be greater than zero!")
             if s.far_clip <= s.near_clip:
@@ -731,7 +768,7 @@ class SceneBuilder:
             # src/sensors/radiancemeter.cpp:60-98: one ray along +z of to_world (or of look_at(origin, origin + direction)); it is the
             # one-sub-sensor case of mradiancemeter (same ray arithmetic, :124-127 vs mradiancemeter.cpp:150-153)
             s.type = A.SENSOR_MRADIANCEMETER
-            p.get("srf")                                                   # ignored outside spectral variants (radiancemeter.cpp:61-68)
+            self._srf(p, s, where)                                         # radiancemeter.cpp:61-68
             if p.has("to_world"):
                 p.get("direction"); p.get("origin")
                 m = p.get("to_world").matrix
@@ -826,10 +863,76 @@ class SceneBuilder:
         p.finish()
         self.sensor = s
 
+    def _srf(self, p, s, where):
+        """"srf" of perspective / radiancemeter: the spectral response function the wavelengths are sampled from.  Outside the spectral
+        variants the plugins warn and ignore it (perspective.cpp:113-121, radiancemeter.cpp:62-68)."""
+        if not p.has("srf"):
+            return
+        v = p.get("srf")
+        if _SPECTRAL is None:
+            return
+        if isinstance(v, dict) and v.get("type") not in ("uniform", "discrete"):
+            raise RuntimeError("srf: sample_spectrum is available for 'uniform' and 'discrete' spectra in this backend (%s)" % where)
+        s.srf = 1 + _spectrum(v, where + ".srf")
+
     # ------------------------------------------------------------ integrator
     def set_integrator(self, d, where):
         p = Props(d, where)
         it = A.Integrator()
+        self.aov_names = []
+        if p.type in ("nbins", "bins"):
+            # src/integrators/nbins.cpp:55-98, bins.cpp:23-85: wavelength-bin AOVs around one nested sampling integrator
+            if _SPECTRAL is None:
+                raise RuntimeError("This integrator can only be used with a spectral variant!")
+            nested = [(k, v) for k, v in sorted_items(d) if isinstance(v, dict) and k not in ("type", "id")]
+            for k, v in nested:
+                if v.get("type") not in ("path", "volpath", "volpathmis", "nbins", "bins"):
+                    raise RuntimeError("Child objects must be of type 'SamplingIntegrator'!")
+            if len(nested) > 1:
+                raise RuntimeError("More than one sub-integrator specified!")
+            if not nested:
+                raise RuntimeError("Must specify a sub-integrator!")
+            if nested[0][1].get("type") in ("nbins", "bins"):
+                raise RuntimeError("nested bin integrators are not supported by this backend")
+            lo, hi, names = [], [], []
+            if p.type == "nbins":
+                spec = p.get("wavelengths")
+                if spec is None:
+                    raise RuntimeError("Property \"wavelengths\" has not been specified!")
+                tol = float(p.get("tolerance", 1e-5))
+                for tok in str(spec).replace(",", " ").split():
+                    try:
+                        lo.append(float(tok))
+                    except ValueError:
+                        raise RuntimeError("Could not parse floating point value '%s'" % tok)
+                    hi.append(tol); names += [tok, tok + "_pop"]
+                mode = 1
+            else:
+                spec = p.get("bins")
+                if spec is None:
+                    raise RuntimeError("Property \"bins\" has not been specified!")
+                for tok in str(spec).replace(",", " ").split():
+                    item = tok.split(":")
+                    if len(item) != 3 or not all(item):
+                        continue                                            # bins.cpp:47-51: warn and skip
+                    try:
+                        lo.append(float(item[1])); hi.append(float(item[2]))
+                    except ValueError as e:
+                        raise RuntimeError("Could not parse floating point value '%s'" % str(e).split("'")[-2])
+                    names += [item[0], item[0] + "_weights"]
+                mode = 2
+            p.get(nested[0][0])
+            p.finish()
+            self.set_integrator(nested[0][1], where + "." + nested[0][0])
+            it = self.integrator
+            if len(lo) > 64:
+                raise RuntimeError("this backend supports at most 64 spectral bins")
+            it.bin_mode, it.bin_count = mode, len(lo)
+            self._bins = (np.ascontiguousarray(lo, np.float32), np.ascontiguousarray(hi, np.float32))
+            self.keep += list(self._bins)
+            it.bin_lo = self._bins[0].ctypes.data_as(A.fp); it.bin_hi = self._bins[1].ctypes.data_as(A.fp)
+            self.aov_names = names
+            return
         if p.type == "path":
             it.type = A.INTEGRATOR_PATH
         elif p.type == "volpath":
@@ -873,7 +976,7 @@ class SceneBuilder:
                 if self.sensor is not None:
                     raise RuntimeError("this backend supports a single sensor per scene")
                 self.set_sensor(v, k)
-            elif t in ("path", "volpath", "volpathmis"):
+            elif t in ("path", "volpath", "volpathmis", "nbins", "bins"):
                 if self.integrator is not None:
                     raise RuntimeError("Only one integrator can be specified per scene.")
                 self.set_integrator(v, k)

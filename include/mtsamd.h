@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MTS_ABI_VERSION 5
+#define MTS_ABI_VERSION 6
 
 /* Transform4f: row-major 4x4 matrix and its inverse transpose (transform.h:36-50). */
 typedef struct mts_transform {
@@ -47,13 +47,18 @@ typedef struct mts_transform {
  *      outside; the bounds default to, and are clamped to, MTS_WAVELENGTH_MIN / MAX = 280 / 2400 nm, core/spectrum.h:15-21) and
  *      src/spectra/regular.cpp (values at regularly spaced wavelengths over [lambda_min, lambda_max], linearly interpolated, 0 outside).
  *      `d65` (src/spectra/d65.cpp) expands to `regular` on the caller's side, as the plugin itself does. ---- */
-enum { MTS_SPECTRUM_UNIFORM = 0, MTS_SPECTRUM_REGULAR = 1 };
+/*      `irregular` (src/spectra/irregular.cpp: values at arbitrary increasing wavelengths, linearly interpolated, 0 outside) and
+ *      `discrete` (src/spectra/discrete.cpp: a sensor response that SAMPLES one of its wavelengths with probability ~ pmf and
+ *      weights it with the matching value; it evaluates to 0). */
+enum { MTS_SPECTRUM_UNIFORM = 0, MTS_SPECTRUM_REGULAR = 1, MTS_SPECTRUM_IRREGULAR = 2, MTS_SPECTRUM_DISCRETE = 3 };
 typedef struct mts_spectrum {
     int32_t type;
     float value;              /* uniform "value" */
     float lambda_min, lambda_max;
-    const float *values;      /* regular "values" */
+    const float *values;      /* regular / irregular / discrete "values" */
     int32_t count;
+    const float *wavelengths; /* irregular / discrete "wavelengths" (count entries)              */
+    const float *pmf;         /* discrete "pmf" (count entries)                                   */
 } mts_spectrum;
 
 /* ---- Volume (3-D texture): constvolume (src/textures/constant3d.cpp) / gridvolume (grid3d.cpp) /
@@ -192,6 +197,10 @@ typedef struct mts_sensor {
      * direction (rectangle, disk or sphere; a miss gives the sample a zero weight) */
     int32_t distant_origin_type;
     mts_shape distant_origin_shape;
+    /* "srf" of perspective / radiancemeter (perspective.cpp:113-116,173-182; radiancemeter.cpp:62-66,116-124): the spectral response
+       function the sample's wavelengths are drawn from (Texture::sample_spectrum of a uniform or discrete spectrum) instead of
+       sample_wavelength().  1 + index into mts_scene_desc.spectra, 0 = none (a zeroed record has none).  Spectral variant only. */
+    int32_t srf;
 } mts_sensor;
 
 /* ---- Integrator (src/integrators/{path,volpath}.cpp, src/librender/integrator.cpp:23-39,302-315) */
@@ -211,6 +220,13 @@ typedef struct mts_integrator {
     int32_t spectral;         /* 1: the semantics of scalar_spectral (is_spectral_v): Spectrum<Float, 4>, four wavelengths per sample drawn
                                  as include/mitsuba/core/spectrum.h:305-314 prescribes, colours given as spectra (mts_scene_desc.spectra),
                                  film = spectrum_to_xyz (:210-217).  Integrators: path, volpath.                          */
+    /* Eradiate's wavelength-bin integrators wrapped around `type` (spectral variant only): src/integrators/nbins.cpp (bin_mode 1:
+       bin i collects the wavelengths within bin_hi[i] = "tolerance" of bin_lo[i] = the i-th of "wavelengths") and
+       src/integrators/bins.cpp (bin_mode 2: bin i = the interval [bin_lo[i], bin_hi[i]] of "bins").  Each bin adds two AOV
+       channels to the film behind X, Y, Z, A, W: the summed radiance of the sample's wavelengths that fall into the bin and their
+       number (nbins.cpp:107-121, bins.cpp:99-107); the film then holds 5 + 2 bin_count floats per pixel.                       */
+    int32_t bin_mode, bin_count;
+    const float *bin_lo, *bin_hi;
 } mts_integrator;
 
 typedef struct mts_scene_desc {

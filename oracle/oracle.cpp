@@ -1477,10 +1477,11 @@ struct ImageBlock {
     }
     void set_size(int w_, int h_) { if (w_ == w && h_ == h) return; w = w_; h = h_; data.assign((size_t) channels * (w + 2 * border) * (h + 2 * border), 0.f); }
     void clear() { std::fill(data.begin(), data.end(), 0.f); }
+    bool warn_negative = true;                                  // integrator.cpp:114-116: !has_aovs
     // imageblock.cpp:79-172 (scalar branch: discretised filter weights)
     bool put(P2 pos_, const float *value) {
         bool active = true;
-        for (int k = 0; k < channels; ++k) active = active && value[k] >= -1e-5f && pm_isfinite(value[k]);   // :85-109 (warn + drop)
+        for (int k = 0; k < channels; ++k) active = active && (!warn_negative || value[k] >= -1e-5f) && pm_isfinite(value[k]);   // :85-109 (warn + drop)
         if (!active) return false;
         float filter_radius = filter->radius;
         int sx = w + 2 * border, sy = h + 2 * border;
@@ -1590,18 +1591,32 @@ static void render_sample(const Scene &sc, Sampler &sampler, ImageBlock &block, 
     // Sensor::sample_ray -> sample_wavelength<Float, Spectrum> (perspective.cpp:169-172, distant.cpp:311-313; core/spectrum.h:305-314):
     // math::sample_shifted (core/math.h:419-442), then sample_rgb_spectrum, which for MTS_WAVELENGTH_MIN / MAX = 280 / 2400 falls back
     // to sample_uniform_spectrum -- written over the CIE range: lambda = s (830 - 360) + 360, weight 830 - 360 (:248-252,266-285)
-    float wav_weight = 830.f - 360.f;
+    Spec wav_weight = spec_s(830.f - 360.f);
     {
-        float v[4];
-        for (int k = 0; k < 4; ++k) { float x = wavelength_sample + (float) k / 4.f; if (x > 1.f) x -= 1.f; v[k] = x * (830.f - 360.f) + 360.f; }
+        float v[4], wgt[4];
+        for (int k = 0; k < 4; ++k) {
+            float x = wavelength_sample + (float) k / 4.f; if (x > 1.f) x -= 1.f;
+            if (se.srf < 0) { v[k] = x * (830.f - 360.f) + 360.f; wgt[k] = 830.f - 360.f; }
+            else {
+                // perspective.cpp:173-182, radiancemeter.cpp:116-124: the response function draws the wavelengths
+                const SpectrumRec &r = sc.spectra[(size_t) se.srf];
+                if (r.type == MTS_SPECTRUM_UNIFORM) {                  // uniform.cpp:92-100
+                    v[k] = r.lambda_min + (r.lambda_max - r.lambda_min) * x; wgt[k] = r.value * (r.lambda_max - r.lambda_min);
+                } else {                                               // discrete.cpp:124-133: DiscreteDistribution::sample (distr_1d.h:141-151)
+                    uint32_t index = distr_binary_search(r.cdf, r.valid_x, r.valid_y, x * r.cdf_sum);
+                    v[k] = r.wavelengths[index]; wgt[k] = r.values[index];
+                }
+            }
+        }
         tls_wavelengths = spec4(v[0], v[1], v[2], v[3]);
+        wav_weight = spec4(wgt[0], wgt[1], wgt[2], wgt[3]);
     }
 #endif
     P2 adjusted = { (position_sample.x - (float) se.crop_x) / (float) se.crop_w, (position_sample.y - (float) se.crop_y) / (float) se.crop_h };
     V3 ray_weight;
     Ray ray = sensor_sample_ray(sc, adjusted, aperture_sample, &ray_weight);
     bool valid;
-    float aovs[5];
+    float aovs[5 + 2 * 64];
 #if MTS_SPEC_N == 3
     V3 L = integrator_sample(sc, sampler, ray, se.medium, &valid, cnt);
     L = ray_weight * L;
@@ -1613,6 +1628,23 @@ static void render_sample(const Scene &sc, Sampler &sampler, ImageBlock &block, 
         aovs[0] = aovs[1] = aovs[2] = L.x;
 #else
     Spec L = integrator_sample(sc, sampler, ray, se.medium, &valid, cnt);
+    // nbins.cpp:100-125 / bins.cpp:88-110: the wrapped integrator's own result (before the ray weight), per bin the sum over the
+    // sample's wavelengths inside the bin and their number (hsum of a 4-array: (x + y) + (z + w), as spec_hmean)
+    for (int i = 0; i < sc.integrator.bin_count; ++i) {
+        const float wl[4] = { tls_wavelengths.x, tls_wavelengths.y, tls_wavelengths.z, tls_wavelengths.w }, lv[4] = { L.x, L.y, L.z, L.w };
+        float val[4], pop[4];
+        for (int k = 0; k < 4; ++k) {
+            if (sc.integrator.bin_mode == 1) {
+                const bool in = pm_abs(wl[k] - sc.bin_lo[i]) <= sc.bin_hi[i];
+                val[k] = in ? lv[k] : 0.f; pop[k] = in ? 1.f : 0.f;
+            } else {
+                const float w = (wl[k] >= sc.bin_lo[i] && wl[k] <= sc.bin_hi[i]) ? 1.f : 0.f;      // UniformSpectrum(lower, upper, 1).eval
+                val[k] = w * lv[k]; pop[k] = w;
+            }
+        }
+        aovs[5 + 2 * i] = (val[0] + val[1]) + (val[2] + val[3]);
+        aovs[5 + 2 * i + 1] = (pop[0] + pop[1]) + (pop[2] + pop[3]);
+    }
     L = (wav_weight * ray_weight.x) * L;                       // ray_weight = wav_weight (x the sensor's grey weight), integrator.cpp:265
     spectrum_to_xyz(L, tls_wavelengths, aovs);                 // integrator.cpp:266-269
 #endif
@@ -1651,7 +1683,9 @@ static int render(OracleScene *os, int n_threads, int shard_index, int shard_cou
     // reference's heuristic depends on the thread count, integrator.cpp:89-97)
     uint32_t block_size = sc.integrator.block_size > 0 ? (uint32_t) sc.integrator.block_size : 32u;
     { uint32_t p = 1; while (p < block_size) p <<= 1; block_size = p; }                       // integrator.cpp:26-32
-    ImageBlock film; film.init(se.crop_w, se.crop_h, 5, nullptr, false); film.ox = se.crop_x; film.oy = se.crop_y;   // hdrfilm.cpp:201-203
+    const int channels = 5 + 2 * sc.integrator.bin_count;           // integrator.cpp:67-76: X, Y, Z, A, W + aov_names()
+    if (sc.integrator.bin_count > 64) throw std::runtime_error("at most 64 bins");
+    ImageBlock film; film.init(se.crop_w, se.crop_h, channels, nullptr, false); film.ox = se.crop_x; film.oy = se.crop_y;   // hdrfilm.cpp:201-203
     Spiral spiral; spiral.init(se.crop_w, se.crop_h, se.crop_x, se.crop_y, (int) block_size, n_passes);
     size_t total_blocks = spiral.block_count * n_passes;
     std::mutex spiral_mutex, film_mutex;
@@ -1661,7 +1695,8 @@ static int render(OracleScene *os, int n_threads, int shard_index, int shard_cou
         const unsigned saved_csr = _mm_getcsr();
         _mm_setcsr(saved_csr | 0x8040);                                                        // scoped_flush_denormals, integrator.cpp:117
         Sampler sampler; sampler.base_seed = se.seed;
-        ImageBlock block; block.init((int) block_size, (int) block_size, 5, &se.rfilter, true);
+        ImageBlock block; block.init((int) block_size, (int) block_size, channels, &se.rfilter, true);
+        block.warn_negative = sc.integrator.bin_count == 0;                                     // integrator.cpp:114-116
         Counters cnt; uint64_t my_samples = 0;
         for (;;) {
             int ox, oy, sx, sy; size_t block_id;

@@ -23,12 +23,27 @@ static inline Xf xf_from_abi(const mts_transform &t) { Xf x; memcpy(x.m, t.matri
 typedef V3 Color;
 static inline Spec color_eval(const Color &c) { return c; }
 #else
-struct SpectrumRec { int type; float value, lambda_min, lambda_max; std::vector<float> values; float inv_interval_size; };
+struct SpectrumRec { int type; float value, lambda_min, lambda_max; std::vector<float> values; float inv_interval_size;
+                     std::vector<float> wavelengths, cdf; float cdf_sum = 0.f; uint32_t valid_x = 0, valid_y = 0; };   // irregular nodes / discrete: DiscreteDistribution of the pmf
 struct Color { const SpectrumRec *s; };
 // uniform.cpp:47-57 ; regular.cpp:71-78 -> ContinuousDistribution::eval_pdf (distr_1d.h:378-400)
 static inline float spectrum_eval_1(const SpectrumRec &s, float lambda) {
     const bool active = lambda >= s.lambda_min && lambda <= s.lambda_max;
     if (s.type == MTS_SPECTRUM_UNIFORM) return active ? s.value : 0.f;
+    if (s.type == MTS_SPECTRUM_DISCRETE) return 0.f;                       // discrete.cpp:112-116: a sampling-only response
+    if (s.type == MTS_SPECTRUM_IRREGULAR) {                                // irregular.cpp:75-84 -> IrregularContinuousDistribution::eval_pdf (distr_1d.h:655-677)
+        const uint32_t size = (uint32_t) s.wavelengths.size();
+        uint32_t start = 0, end = size, iterations = 0;                    // enoki::binary_search(0, size, nodes[i] < x)
+        { uint32_t diff = end - start; iterations = 1; while (diff >>= 1) iterations++; }
+        for (uint32_t i = 0; i < iterations; ++i) {
+            uint32_t middle = (start + end) >> 1;
+            if (s.wavelengths[std::min(middle, size - 1)] < lambda) start = std::min(middle + 1, end); else end = middle;
+        }
+        uint32_t index = std::max(std::min(start, size - 1u), 1u) - 1u;
+        float x0 = s.wavelengths[index], x1 = s.wavelengths[index + 1], y0 = s.values[index], y1 = s.values[index + 1];
+        float x = (lambda - x0) / (x1 - x0);
+        return active ? pm_fma(x, y1 - y0, y0) : 0.f;
+    }
     float x = (lambda - s.lambda_min) * s.inv_interval_size;
     uint32_t index = (uint32_t) std::min(std::max((int64_t) x, (int64_t) 0), (int64_t) s.values.size() - 2);
     float y0 = active ? s.values[index] : 0.f, y1 = active ? s.values[index + 1] : 0.f;
@@ -403,6 +418,7 @@ struct Sensor {
     RFilter rfilter;
     int sample_count; uint64_t seed;
     std::vector<float> multi; int multi_count = 0;   // mradiancemeter / mdistant: m_transforms (mradiancemeter.cpp:95-113, mdistant.cpp:160-175)
+    int srf = -1;                                    // spectral variant: index of the "srf" spectrum (perspective.cpp:113-116, radiancemeter.cpp:62-66)
 };
 
 // Transform::perspective, transform.h:203-220
@@ -445,6 +461,7 @@ struct Scene {
     std::vector<Prim> prims;
 #if MTS_SPEC_N != 3
     std::deque<SpectrumRec> spectra;                                   // stable addresses: the colour parameters point at them
+    std::vector<float> bin_lo, bin_hi;                                  // nbins: wavelength, tolerance; bins: interval (integrator.bin_mode / bin_count)
 #endif
     Bsdf default_bsdf, default_emitter_bsdf;
     const Bsdf &bsdf_of(const Shape &s) const {
@@ -488,6 +505,30 @@ static inline Scene *make_scene(const mts_scene_desc *d) {
                 if (!mass) throw std::runtime_error("ContinuousDistribution: no probability mass found!");
                 r.values.assign(sp.values, sp.values + sp.count);
                 r.inv_interval_size = (float) (1. / ((double(sp.lambda_max) - double(sp.lambda_min)) / (sp.count - 1)));
+            } else if (sp.type == MTS_SPECTRUM_IRREGULAR) {                   // irregular.cpp:33-63 + distr_1d.h:560-600
+                if (sp.count < 2 || !sp.values || !sp.wavelengths) throw std::runtime_error("IrregularContinuousDistribution: needs at least two entries!");
+                bool mass = false;
+                for (int k = 0; k < sp.count; ++k) {
+                    if (sp.values[k] < 0.f) throw std::runtime_error("IrregularContinuousDistribution: entries must be non-negative!");
+                    if (k > 0 && !(sp.wavelengths[k] > sp.wavelengths[k - 1])) throw std::runtime_error("IrregularContinuousDistribution: node positions must be strictly increasing!");
+                    mass = mass || sp.values[k] > 0.f;
+                }
+                if (!mass) throw std::runtime_error("IrregularContinuousDistribution: no probability mass found!");
+                r.values.assign(sp.values, sp.values + sp.count); r.wavelengths.assign(sp.wavelengths, sp.wavelengths + sp.count);
+                r.lambda_min = sp.wavelengths[0]; r.lambda_max = sp.wavelengths[sp.count - 1];
+            } else if (sp.type == MTS_SPECTRUM_DISCRETE) {                    // discrete.cpp:45-100 + DiscreteDistribution (distr_1d.h:49-83)
+                if (sp.count < 1 || !sp.values || !sp.wavelengths || !sp.pmf) throw std::runtime_error("DiscreteDistribution: empty distribution!");
+                r.values.assign(sp.values, sp.values + sp.count); r.wavelengths.assign(sp.wavelengths, sp.wavelengths + sp.count);
+                r.cdf.resize(sp.count); r.valid_x = r.valid_y = (uint32_t) -1;
+                double sum = 0.0;
+                for (int k = 0; k < sp.count; ++k) {
+                    double value = (double) sp.pmf[k];
+                    sum += value; r.cdf[k] = (float) sum;
+                    if (value < 0.0) throw std::runtime_error("DiscreteDistribution: entries must be non-negative!");
+                    else if (value > 0.0) { if (r.valid_x == (uint32_t) -1) r.valid_x = (uint32_t) k; r.valid_y = (uint32_t) k; }
+                }
+                if (r.valid_x == (uint32_t) -1) throw std::runtime_error("DiscreteDistribution: no probability mass found!");
+                r.cdf_sum = (float) sum;
             } else throw std::runtime_error("unknown spectrum type");
             sc->spectra.push_back(r);
         }
@@ -652,6 +693,33 @@ static inline Scene *make_scene(const mts_scene_desc *d) {
             se.needs_aperture_sample = true;                                               // endpoint.h:244
         }
         sc->integrator = d->integrator;
+        sc->integrator.bin_lo = sc->integrator.bin_hi = nullptr;                             // copied below: the caller's arrays may go away
+        if (d->integrator.bin_mode != 0) {
+#if MTS_SPEC_N == 3
+            throw std::runtime_error("This integrator can only be used with a spectral variant!");   // nbins.cpp:57-58, bins.cpp:25-26
+#else
+            if (d->integrator.bin_mode != 1 && d->integrator.bin_mode != 2) throw std::runtime_error("unknown bin mode");
+            if (d->integrator.bin_count < 0 || (d->integrator.bin_count > 0 && (!d->integrator.bin_lo || !d->integrator.bin_hi))) throw std::runtime_error("bins: missing bounds");
+            sc->bin_lo.assign(d->integrator.bin_lo, d->integrator.bin_lo + d->integrator.bin_count);
+            sc->bin_hi.assign(d->integrator.bin_hi, d->integrator.bin_hi + d->integrator.bin_count);
+            if (d->integrator.bin_mode == 2)                                                 // bins.cpp:79-84: a uniform spectrum per bin (bounds clamped, uniform.cpp:41-46)
+                for (int i = 0; i < d->integrator.bin_count; ++i) {
+                    sc->bin_lo[i] = std::max(sc->bin_lo[i], 280.f); sc->bin_hi[i] = std::min(sc->bin_hi[i], 2400.f);
+                    if (!(sc->bin_lo[i] < sc->bin_hi[i])) throw std::runtime_error("UniformSpectrum: 'lambda_min' must be less than 'lambda_max'");
+                }
+#endif
+        } else sc->integrator.bin_count = 0;
+#if MTS_SPEC_N != 3
+        sc->sensor.srf = -1;
+        if (d->sensor.srf != 0) {
+            if (d->sensor.srf < 0 || d->sensor.srf > d->spectrum_count) throw std::runtime_error("index out of range: sensor srf");
+            if (d->sensor.type != MTS_SENSOR_PERSPECTIVE && !(d->sensor.type == MTS_SENSOR_MRADIANCEMETER && d->sensor.multi_count == 1))
+                throw std::runtime_error("srf: only perspective and radiancemeter sensors sample their wavelengths from a response function");
+            const SpectrumRec &r = sc->spectra[(size_t) d->sensor.srf - 1];
+            if (r.type != MTS_SPECTRUM_UNIFORM && r.type != MTS_SPECTRUM_DISCRETE) throw std::runtime_error("srf: sample_spectrum is restated for uniform and discrete spectra");
+            sc->sensor.srf = d->sensor.srf - 1;
+        }
+#endif
         if (sc->integrator.rr_depth <= 0) throw std::runtime_error("\"rr_depth\" must be set to a value greater than zero!");   // integrator.cpp:306-307
         if (sc->integrator.max_depth < 0 && sc->integrator.max_depth != -1)
             throw std::runtime_error("\"max_depth\" must be set to -1 (infinite) or a value >= 0");   // integrator.cpp:313-314

@@ -136,7 +136,7 @@ class OracleScene:
     def render(self, threads=None, shard_index=0, shard_count=1):
         s = self.desc.sensor
         h, w = s.crop_size[1], s.crop_size[0]
-        out = np.zeros((h, w, 5), dtype=np.float32)
+        out = np.zeros((h, w, 5 + 2 * self.desc.integrator.bin_count), dtype=np.float32)      # X, Y, Z, A, W + the bins' AOV channels
         st = A.Stats()
         threads = threads or os.cpu_count() or 1
         _check(self.L.oracle_render(self.h, threads, shard_index, shard_count, _p(out), C.byref(st)), self.L)

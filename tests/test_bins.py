@@ -1,0 +1,133 @@
+"""Eradiate's wavelength-bin integrators `nbins` / `bins`, the sensors' `srf`, `irregular` / `discrete` spectra --
+the reference's own tests, src/integrators/tests/test_nbins.py and test_bins.py, on the CPU restatement (spectral build), plus the
+spectra's closed forms.  The GPU side is compared with the restatement in tests/test_gpu_parity.py."""
+import importlib
+import warnings
+
+import numpy as np
+import pytest
+
+import tests.oracle_binding as ob
+
+SD = importlib.import_module("eradiate-kernel_amd.scene_dict")
+FILM1 = {"type": "hdrfilm", "width": 1, "height": 1, "rfilter": {"type": "box"}}
+
+
+def build(d):
+    return SD.build_scene_desc(d, spectral=True)
+
+
+def integrator_only(d):
+    b = SD.SceneBuilder(); b.spectra = []
+    SD._SPECTRAL = b
+    try:
+        b.set_integrator(d, "integrator")
+    finally:
+        SD._SPECTRAL = None
+    return b
+
+
+def develop(raw):
+    """hdrfilm.cpp:262-320 with AOVs: R, G, B, A, then every AOV channel divided by the weight channel."""
+    w = raw[..., 4:5]
+    return (raw[..., 5:] / w).squeeze()
+
+
+# ---------------------------------------------------------------------------------------------- construction (test_nbins.py:9-37, test_bins.py:7-53)
+def test_construct_nbins():
+    assert integrator_only({"type": "nbins", "wavelengths": "400, 500, 600, 700", "tolerance": 1e-3, "integrator": {"type": "path"}}).integrator.bin_count == 4
+    b = integrator_only({"type": "nbins", "wavelengths": "400, 500, 600, 700", "integrator": {"type": "path"}})
+    assert b.aov_names == ["400", "400_pop", "500", "500_pop", "600", "600_pop", "700", "700_pop"]
+    assert np.allclose(np.ctypeslib.as_array(b.integrator.bin_hi, (4,)), 1e-5)                       # default tolerance
+    with pytest.raises(RuntimeError):
+        integrator_only({"type": "nbins", "integrator": {"type": "path"}})
+    with pytest.raises(RuntimeError):
+        integrator_only({"type": "nbins", "wavelengths": "400, 500, 600, 700"})
+
+
+def test_construct_bins():
+    b = integrator_only({"type": "bins", "bins": "01:400:500, 02:500:600, 03:600:700, 04:700:800", "integrator": {"type": "path"}})
+    names = ["01", "01_weights", "02", "02_weights", "03", "03_weights", "04", "04_weights"]
+    assert b.aov_names == names
+    b = integrator_only({"type": "bins", "bins": "01:400:500, 02:500:600, 03:600:700, 04:700:800, oh-no", "integrator": {"type": "path"}})
+    assert b.aov_names == names                                                                          # ill-formed bins are skipped
+    assert integrator_only({"type": "bins", "bins": "oh-no", "integrator": {"type": "path"}}).aov_names == []
+    with pytest.raises(RuntimeError):
+        integrator_only({"type": "bins", "integrator": {"type": "path"}})
+    with pytest.raises(RuntimeError):
+        integrator_only({"type": "bins", "bins": "01:400:500, 02:500:600, 03:600:700, 04:700:800"})
+    with pytest.raises(RuntimeError, match="spectral variant"):                                          # nbins.cpp:57-58
+        SD.build_scene_desc({"type": "scene", "sensor": {"type": "radiancemeter", "film": FILM1}, "integrator": {"type": "bins", "bins": "a:1:2", "integrator": {"type": "path"}}})
+
+
+# ---------------------------------------------------------------------------------------------- test_nbins.py:40-166
+def nbins_scene(wavelengths, spp, radiance, tolerance=None):
+    wl = ", ".join(map(str, wavelengths))
+    integ = {"type": "nbins", "wavelengths": wl, "integrator": {"type": "path"}}
+    if tolerance is not None:
+        integ["tolerance"] = tolerance
+    return {"type": "scene", "integrator": integ,
+            "emitter": {"type": "constant", "radiance": {"type": "uniform", "value": radiance}},
+            "sensor": {"type": "radiancemeter",
+                       "film": {"type": "hdrfilm", "height": 1, "width": 1, "pixel_format": "luminance", "component_format": "float32", "rfilter": {"type": "box"}},
+                       "sampler": {"type": "independent", "sample_count": spp},
+                       "srf": {"type": "discrete", "wavelengths": wl}}}
+
+
+def run_nbins(d):
+    img = develop(ob.OracleScene(d, spectral=True).render(threads=1))
+    return img[0::2] / img[1::2]
+
+
+def test_nbins_sample():
+    lo, hi = 400.0, 800.0
+    assert np.allclose(run_nbins(nbins_scene(np.linspace(lo, hi, 4), 10, 1)), 1)                        # as many wavelengths as channels
+    assert np.allclose(run_nbins(nbins_scene(np.linspace(lo, hi, 25), 100, 1e3)), 1e3)                  # more wavelengths than channels
+    assert np.allclose(run_nbins(nbins_scene(np.linspace(lo, hi, 2), 10, 1e-3)), 1e-3)                  # fewer
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        result = run_nbins(nbins_scene(np.linspace(lo, hi, 10), 1, 1))                                  # one sample: unpopulated bins divide by zero
+    assert any(np.isnan(result))
+
+
+# ---------------------------------------------------------------------------------------------- test_bins.py:56-131
+def test_bins_sample():
+    d = {"type": "scene",
+         "integrator": {"type": "bins", "bins": "01:300:500, 02:500:600, 03:600:750", "integrator": {"type": "path"}},
+         "emitter": {"type": "constant", "radiance": {"type": "irregular", "wavelengths": "300, 400, 500, 600, 700, 800", "values": "0.0, 0.2, 0.4, 0.6, 0.4, 0.2"}},
+         "sensor": {"type": "radiancemeter",
+                    "film": {"type": "hdrfilm", "height": 1, "width": 1, "pixel_format": "luminance", "component_format": "float32", "rfilter": {"type": "box"}},
+                    "sampler": {"type": "independent", "sample_count": 1000},
+                    "srf": {"type": "uniform", "lambda_min": 400.0, "lambda_max": 800.0, "value": 1.0}}}
+    img = develop(ob.OracleScene(d, spectral=True).render(threads=1))
+    result = img[0::2] / img[1::2]
+    assert np.allclose(result, [0.3, 0.5, 0.45], rtol=3e-3)                                            # mean radiance per bin, within the srf's support
+
+
+# ---------------------------------------------------------------------------------------------- spectra
+def test_irregular_spectrum_eval():
+    """src/spectra/irregular.cpp -> IrregularContinuousDistribution::eval_pdf (distr_1d.h:655-677): linear between the nodes, zero outside."""
+    d = {"type": "scene", "sensor": {"type": "radiancemeter", "film": FILM1},
+         "emitter": {"type": "constant", "radiance": {"type": "irregular", "wavelengths": [500.0, 600.0, 650.0], "values": [1.0, 2.0, 0.5]}}}
+    desc, keep = build(d)
+    o = ob.OracleScene(desc=desc, keep=keep, spectral=True)
+    got = o.spectrum_eval(desc.emitters[0].radiance_spectrum, [450.0, 500.0, 550.0, 625.0])
+    assert np.allclose(got, [0.0, 1.0, 1.5, 1.25])
+    assert np.allclose(o.spectrum_eval(desc.emitters[0].radiance_spectrum, [650.0, 650.1, 600.0, 599.0]), [0.5, 0.0, 2.0, 1.99])
+    with pytest.raises(RuntimeError, match="same size"):
+        build({"type": "scene", "sensor": {"type": "radiancemeter", "film": FILM1}, "e": {"type": "constant", "radiance": {"type": "irregular", "wavelengths": "1, 2", "values": "1"}}})
+
+
+def test_srf_wavelengths_come_from_the_response_function():
+    """A discrete srf with one wavelength: every sample sits there, so an nbins bin at that wavelength is populated by all four
+    wavelengths of every sample, a bin elsewhere by none; a uniform srf confines the samples to its interval (bins.cpp, uniform.cpp:92-100)."""
+    d = nbins_scene([550.0], 8, 2.0)
+    d["integrator"]["wavelengths"] = "550, 600"
+    raw = ob.OracleScene(d, spectral=True).render(threads=1).reshape(-1)
+    assert raw[4] == 8 and np.allclose(raw[5:9], [8 * 4 * 2.0, 8 * 4, 0, 0])
+    d = {"type": "scene", "integrator": {"type": "bins", "bins": "in:500:520, out:520:900", "integrator": {"type": "path"}},
+         "emitter": {"type": "constant", "radiance": {"type": "uniform", "value": 1.0}},
+         "sensor": {"type": "radiancemeter", "film": {"type": "hdrfilm", "height": 1, "width": 1, "rfilter": {"type": "box"}},
+                    "sampler": {"type": "independent", "sample_count": 16}, "srf": {"type": "uniform", "lambda_min": 500.0, "lambda_max": 520.0}}}
+    raw = ob.OracleScene(d, spectral=True).render(threads=1).reshape(-1)
+    assert np.allclose(raw[5:9], [64, 64, 0, 0])

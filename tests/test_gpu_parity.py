@@ -811,3 +811,48 @@ def test_spectral_variant_against_oracle(gpu_spectral, monkeypatch, name, kernel
     assert ref[..., :3].max() > 0
     assert_parity(gpu, ref)
     assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (o.last_stats["n_iter"], o.last_stats["n_lookup"], o.last_stats["n_nee_step"])
+
+
+def test_bin_integrators_srf_and_irregular_spectra(gpu_spectral):
+    """src/integrators/nbins.cpp / bins.cpp (two AOV channels per spectral bin behind X, Y, Z, A, W), the sensors' `srf` (uniform and
+    discrete: perspective.cpp:173-182, radiancemeter.cpp:116-124) and `irregular` spectra: the reference's own two sample tests
+    (src/integrators/tests/test_nbins.py:120-166, test_bins.py:90-131) through the HIP path, and film + AOV channels against the CPU
+    restatement on a medium scene seen through a perspective camera."""
+    from tests.test_bins import nbins_scene
+    for wl, spp, radiance in ((np.linspace(400.0, 800.0, 4), 10, 1.0), (np.linspace(400.0, 800.0, 25), 100, 1e3)):
+        d = nbins_scene(wl, spp, radiance)
+        scene = gpu_spectral.load_dict(d)
+        sensor = scene.sensors()[0]
+        assert scene.integrator().aov_names() == [x for w in wl for x in (str(w), str(w) + "_pop")]
+        assert scene.integrator().render(scene, sensor)
+        raw = np.array(sensor.film().bitmap(raw=True))
+        ref = ob.OracleScene(d, spectral=True).render(threads=1)
+        assert raw.shape == ref.shape == (1, 1, 5 + 2 * len(wl)) and np.array_equal(raw, ref)
+        img = np.array(sensor.film().bitmap()).squeeze()                        # R, G, B, A, then the AOVs over the weight
+        assert np.allclose(img[4::2] / img[5::2], radiance)
+    d = {"type": "scene",
+         "integrator": {"type": "bins", "bins": "01:300:500, 02:500:600, 03:600:750", "integrator": {"type": "path"}},
+         "emitter": {"type": "constant", "radiance": {"type": "irregular", "wavelengths": "300, 400, 500, 600, 700, 800", "values": "0.0, 0.2, 0.4, 0.6, 0.4, 0.2"}},
+         "sensor": {"type": "radiancemeter",
+                    "film": {"type": "hdrfilm", "height": 1, "width": 1, "pixel_format": "luminance", "component_format": "float32", "rfilter": {"type": "box"}},
+                    "sampler": {"type": "independent", "sample_count": 1000},
+                    "srf": {"type": "uniform", "lambda_min": 400.0, "lambda_max": 800.0, "value": 1.0}}}
+    scene = gpu_spectral.load_dict(d)
+    sensor = scene.sensors()[0]
+    assert scene.integrator().render(scene, sensor)
+    img = np.array(sensor.film().bitmap()).squeeze()
+    assert np.allclose(img[4::2] / img[5::2], [0.3, 0.5, 0.45], rtol=3e-3)
+    assert np.array_equal(np.array(sensor.film().bitmap(raw=True)), ob.OracleScene(d, spectral=True).render(threads=1))
+    # a heterogeneous medium under a perspective camera with a narrow-band response, volpath inside bins, partial blocks, 2 passes
+    d = _spectral_cases()["grid_spectral_d65_rpv"]
+    d["sensor"]["srf"] = {"type": "uniform", "lambda_min": 500.0, "lambda_max": 700.0, "value": 0.5}
+    d["integrator"] = {"type": "bins", "bins": "a:500:600, b:600:700, c:650:900", "integrator": dict(d["integrator"])}
+    scene = gpu_spectral.load_dict(d)
+    sensor = scene.sensors()[0]
+    assert scene.integrator().render(scene, sensor, collect_counters=True)
+    raw = np.array(sensor.film().bitmap(raw=True))
+    o = ob.OracleScene(d, spectral=True); ref = o.render()
+    assert raw.shape[2] == 11 and ref[..., 5:].max() > 0
+    assert_parity(raw, ref)
+    st = scene.integrator().last_stats
+    assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (o.last_stats["n_iter"], o.last_stats["n_lookup"], o.last_stats["n_nee_step"])
