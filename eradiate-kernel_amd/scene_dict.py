@@ -99,8 +99,27 @@ def _spectrum(v, where, default=None, emitter=False):
         t = p.type
         if t == "spectrum":
             val = p.get("value", 1.0)
-            if p.has("filename") or isinstance(val, (list, tuple)):
-                raise RuntimeError("spectra given as wavelength / value pairs are not supported by this backend: %s" % where)
+            if p.has("filename"):
+                raise RuntimeError("spectra read from files (spectrum_from_file) are not supported by this backend: %s" % where)
+            if isinstance(val, str) and ":" in val:                         # "400:0.1, 500:0.2, ..." (xml.cpp:560-600)
+                try:
+                    val = [tuple(float(x) for x in tok.split(":")) for tok in val.replace(",", " ").split()]
+                except ValueError:
+                    raise RuntimeError("Could not parse wavelength:value pairs in %s" % where)
+            if isinstance(val, (list, tuple)):
+                # create_texture_from_spectrum, xml.cpp:1113-1150 (spectral mode): values scaled by MTS_CIE_Y_NORMALIZATION inside an
+                # emitter; `regular` when the wavelengths are equidistant (to math::Epsilon), `irregular` otherwise
+                pairs = np.asarray(val, np.float64).reshape(-1, 2)
+                f = np.float32
+                wl = pairs[:, 0].astype(np.float32)
+                vals = (pairs[:, 1].astype(np.float32) * (f(1.0 / 106.7502593994140625) if emitter else f(1.0))).astype(np.float32)
+                dist = np.diff(wl)
+                if (dist < 0).any():
+                    raise RuntimeError("Wavelengths must be specified in increasing order!")
+                p.finish()
+                if wl.size >= 2 and (np.abs(dist - dist[0]) <= 2.0 ** -24).all():
+                    return _spectrum({"type": "regular", "lambda_min": float(wl[0]), "lambda_max": float(wl[-1]), "values": vals}, where)
+                return _spectrum({"type": "irregular", "wavelengths": wl, "values": vals}, where)
             p.finish()
             return _spectrum({"type": "d65", "scale": float(val)} if emitter else {"type": "uniform", "value": float(val)}, where)
         if t == "uniform":

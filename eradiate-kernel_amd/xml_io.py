@@ -253,9 +253,11 @@ class _Parser:
             return {"type": "rgb", "value": v}
         if tag == "spectrum":
             _check_attrs(node, a, {"name", "value", "filename"}, set(), self.src)
-            if "value" not in a or ":" in a["value"] or "filename" in a:
-                _err(self.src, "spectrum: only a single uniform value is supported by this backend")
-            return {"type": "uniform", "value": _floats(a["value"], self.src, "spectrum", 1)[0]}
+            if "value" not in a or "filename" in a:
+                _err(self.src, "spectrum: files (spectrum_from_file) are not supported by this backend")
+            if ":" in a["value"]:                                # wavelength:value pairs (xml.cpp:560-600): regular / irregular in the spectral variant
+                return {"type": "spectrum", "value": a["value"]}
+            return {"type": "spectrum", "value": _floats(a["value"], self.src, "spectrum", 1)[0]}
         if tag == "transform":
             _check_attrs(node, a, {"name"}, set(), self.src)
             return _transform(node, self.params, self.src)

@@ -131,3 +131,21 @@ def test_srf_wavelengths_come_from_the_response_function():
                     "sampler": {"type": "independent", "sample_count": 16}, "srf": {"type": "uniform", "lambda_min": 500.0, "lambda_max": 520.0}}}
     raw = ob.OracleScene(d, spectral=True).render(threads=1).reshape(-1)
     assert np.allclose(raw[5:9], [64, 64, 0, 0])
+
+
+def test_spectrum_given_as_wavelength_value_pairs():
+    """create_texture_from_spectrum (src/libcore/xml.cpp:1113-1150) in spectral mode: equidistant wavelengths -> `regular`, others ->
+    `irregular`; inside an emitter the values are scaled by MTS_CIE_Y_NORMALIZATION (core/spectrum.h:133)."""
+    d = {"type": "scene", "sensor": {"type": "radiancemeter", "film": FILM1},
+         "e": {"type": "constant", "radiance": {"type": "spectrum", "value": [(400, 1.0), (500, 2.0), (700, 3.0)]}},
+         "s": {"type": "rectangle", "bsdf": {"type": "diffuse", "reflectance": {"type": "spectrum", "value": "400:0.1, 500:0.2, 600:0.3"}}}}
+    desc, keep = build(d)
+    A = importlib.import_module("eradiate-kernel_amd._capi")
+    e_sp, b_sp = desc.emitters[0].radiance_spectrum, desc.bsdfs[0].spectrum[0]
+    assert desc.spectra[e_sp].type == A.SPECTRUM_IRREGULAR and desc.spectra[b_sp].type == A.SPECTRUM_REGULAR
+    o = ob.OracleScene(desc=desc, keep=keep, spectral=True)
+    k = np.float32(1.0 / 106.7502593994140625)
+    assert np.allclose(o.spectrum_eval(e_sp, [400.0, 450.0, 600.0, 800.0]), np.array([1.0, 1.5, 2.5, 0.0]) * k, rtol=1e-6)
+    assert np.allclose(o.spectrum_eval(b_sp, [400.0, 450.0, 600.0, 601.0]), [0.1, 0.15, 0.3, 0.0], rtol=1e-6)
+    with pytest.raises(RuntimeError, match="increasing order"):
+        build({"type": "scene", "sensor": {"type": "radiancemeter", "film": FILM1}, "e": {"type": "constant", "radiance": {"type": "spectrum", "value": "500:1, 400:2"}}})
