@@ -41,10 +41,24 @@ def build_backend(force=False, verbose=True, extra=()):
     extra = list(extra) + os.environ.get("MTSAMD_EXTRA_FLAGS", "").split()
     flags = [("-fno-hip-fp32-correctly-rounded-divide-sqrt" if (os.environ.get("MTSAMD_EXP_FASTDIV") and f == "-fhip-fp32-correctly-rounded-divide-sqrt") else f)
              for f in FLAGS]                                 # MTSAMD_EXP_FASTDIV: measurement only, breaks parity
-    cmd = [HIPCC] + flags + list(extra) + ["-x", "hip"] + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    # one hipcc per translation unit, side by side (the two kernel files take ~2.5 minutes each), then one link
+    import tempfile
+    cflags = [f for f in flags if f != "-shared"]
+    with tempfile.TemporaryDirectory(prefix="mtsamd_build_") as tmp:
+        jobs = []
+        for f in SOURCES:
+            obj = os.path.join(tmp, os.path.splitext(f)[0] + ".o")
+            cmd = [HIPCC] + cflags + list(extra) + ["-x", "hip", "-c", os.path.join(CSRC, f), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            jobs.append((cmd, obj, subprocess.Popen(cmd)))
+        failed = [cmd for cmd, _, proc in jobs if proc.wait() != 0]
+        if failed:
+            raise subprocess.CalledProcessError(1, failed[0])
+        link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + [obj for _, obj, _ in jobs] + ["-o", LIB]
+        if verbose:
+            print(" ".join(link), flush=True)
+        subprocess.check_call(link)
     return LIB
 
 
