@@ -218,6 +218,9 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
                 else if (!strcmp(kv, "wga256")) variant = 10256; else if (!strcmp(kv, "wga512")) variant = 10512; else if (!strcmp(kv, "wga1024")) variant = 11024;
                 else throw std::runtime_error("MTSAMD_KERNEL must be one of nested, flat, wga256, wga512, wga1024");
             }
+            // without media there are no tracking walks to regroup: the per-lane kernels win (cornell box 512 x 512 x 256, volpath: rings 992,
+            // per lane 1242 Msamples/s; `path` per lane: 2342)
+            if (!getenv("MTSAMD_KERNEL") && hs.media.empty() && hs.integrator.type != MTS_INTEGRATOR_PATH) variant = 0;
             if (hs.integrator.type == MTS_INTEGRATOR_VOLPATHMIS && variant > 10512) variant = 10512;     // four weight matrices per path: 512 paths fill the LDS
             if (hs.integrator.spectral && variant > 10256) variant = 10256;                               // four-wide spectra: 42 hot dwords per path; three 256-path workgroups per CU (12 waves) beat one of 512 (8 waves) by 10 %
             if (hs.integrator.spectral && variant == 1) variant = 0;                                      // no per-lane flat kernel in the spectral build
