@@ -1577,6 +1577,18 @@ static inline void spectrum_to_xyz(Spec value, Spec wl, float xyz[3]) {
 }
 #endif
 
+#if MTS_SPEC_N != 3
+// Texture::sample_spectrum of the two response functions a sensor's "srf" may be: uniform.cpp:92-100, discrete.cpp:124-133
+// (DiscreteDistribution::sample, distr_1d.h:141-151)
+static inline void spectrum_sample(const SpectrumRec &r, float x, float *wavelength, float *weight) {
+    if (r.type == MTS_SPECTRUM_UNIFORM) { *wavelength = r.lambda_min + (r.lambda_max - r.lambda_min) * x; *weight = r.value * (r.lambda_max - r.lambda_min); }
+    else {
+        uint32_t index = distr_binary_search(r.cdf, r.valid_x, r.valid_y, x * r.cdf_sum);
+        *wavelength = r.wavelengths[index]; *weight = r.values[index];
+    }
+}
+#endif
+
 // ---------------------------------------------------------------- render driver
 // integrator.cpp:233-288
 static void render_sample(const Scene &sc, Sampler &sampler, ImageBlock &block, float px, float py, Counters *cnt) {
@@ -1597,16 +1609,7 @@ static void render_sample(const Scene &sc, Sampler &sampler, ImageBlock &block, 
         for (int k = 0; k < 4; ++k) {
             float x = wavelength_sample + (float) k / 4.f; if (x > 1.f) x -= 1.f;
             if (se.srf < 0) { v[k] = x * (830.f - 360.f) + 360.f; wgt[k] = 830.f - 360.f; }
-            else {
-                // perspective.cpp:173-182, radiancemeter.cpp:116-124: the response function draws the wavelengths
-                const SpectrumRec &r = sc.spectra[(size_t) se.srf];
-                if (r.type == MTS_SPECTRUM_UNIFORM) {                  // uniform.cpp:92-100
-                    v[k] = r.lambda_min + (r.lambda_max - r.lambda_min) * x; wgt[k] = r.value * (r.lambda_max - r.lambda_min);
-                } else {                                               // discrete.cpp:124-133: DiscreteDistribution::sample (distr_1d.h:141-151)
-                    uint32_t index = distr_binary_search(r.cdf, r.valid_x, r.valid_y, x * r.cdf_sum);
-                    v[k] = r.wavelengths[index]; wgt[k] = r.values[index];
-                }
-            }
+            else spectrum_sample(sc.spectra[(size_t) se.srf], x, &v[k], &wgt[k]);   // perspective.cpp:173-182, radiancemeter.cpp:116-124: the response function draws the wavelengths
         }
         tls_wavelengths = spec4(v[0], v[1], v[2], v[3]);
         wav_weight = spec4(wgt[0], wgt[1], wgt[2], wgt[3]);
@@ -1914,6 +1917,15 @@ int oracle_volume_eval_spectral(oracle_scene *s, int volume, const float *p, con
     tls_wavelengths = spec4(w[0], w[1], w[2], w[3]);
     Spec r = volume_eval(sc.volumes[volume], v3(p[0], p[1], p[2]));
     out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+    ORC_CATCH
+}
+int oracle_spectrum_sample(oracle_scene *s, int spectrum, const float *samples, int n, float *wavelengths, float *weights) {
+    ORC_TRY
+    const Scene &sc = *((OracleScene *) s)->scene;
+    if (spectrum < 0 || spectrum >= (int) sc.spectra.size()) throw std::runtime_error("spectrum index out of range");
+    const SpectrumRec &r = sc.spectra[(size_t) spectrum];
+    if (r.type != MTS_SPECTRUM_UNIFORM && r.type != MTS_SPECTRUM_DISCRETE) throw std::runtime_error("sample_spectrum is restated for uniform and discrete spectra");
+    for (int k = 0; k < n; ++k) spectrum_sample(r, samples[k], wavelengths + k, weights + k);
     ORC_CATCH
 }
 int oracle_spectrum_to_xyz(const float *value, const float *w, float *xyz) {

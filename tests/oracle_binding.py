@@ -92,6 +92,7 @@ def lib_spectral():
         L.oracle_spectrum_eval.argtypes = [C.c_void_p, C.c_int, fp, fp]
         L.oracle_volume_eval_spectral.argtypes = [C.c_void_p, C.c_int, fp, fp, fp]
         L.oracle_spectrum_to_xyz.argtypes = [fp, fp, fp]
+        L.oracle_spectrum_sample.argtypes = [C.c_void_p, C.c_int, fp, C.c_int, fp, fp]
         L.oracle_set_wavelengths.argtypes = [fp]
         L.oracle_bsdf_eval.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, fp]
         assert L.oracle_spec_n() == 4
@@ -148,6 +149,11 @@ class OracleScene:
         w = _f(wavelengths); out = np.zeros(4, np.float32)
         _check(self.L.oracle_spectrum_eval(self.h, spectrum, _p(w), _p(out)), self.L)
         return out
+
+    def spectrum_sample(self, spectrum, samples):
+        u = _f(samples); wl = np.zeros(u.size, np.float32); wt = np.zeros(u.size, np.float32)
+        _check(self.L.oracle_spectrum_sample(self.h, spectrum, _p(u), int(u.size), _p(wl), _p(wt)), self.L)
+        return wl, wt
 
     def volume_eval_spectral(self, volume, p, wavelengths):
         w = _f(wavelengths); q = _f(p); out = np.zeros(4, np.float32)

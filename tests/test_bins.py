@@ -149,3 +149,47 @@ def test_spectrum_given_as_wavelength_value_pairs():
     assert np.allclose(o.spectrum_eval(b_sp, [400.0, 450.0, 600.0, 601.0]), [0.1, 0.15, 0.3, 0.0], rtol=1e-6)
     with pytest.raises(RuntimeError, match="increasing order"):
         build({"type": "scene", "sensor": {"type": "radiancemeter", "film": FILM1}, "e": {"type": "constant", "radiance": {"type": "spectrum", "value": "500:1, 400:2"}}})
+
+
+# ---------------------------------------------------------------------------------------------- src/spectra/tests/test_discrete.py, test_irregular.py, test_uniform.py
+def _srf_scene(srf):
+    return {"type": "scene", "sensor": {"type": "radiancemeter", "film": FILM1, "srf": srf}}
+
+
+def test_discrete_spectrum_reference_vectors():
+    """src/spectra/tests/test_discrete.py:5-60 (construction rules), :63-75 (eval = pdf = 0), :78-110 (sample_spectrum literals)."""
+    wl5 = "400., 500., 600., 700., 800."
+    for extra in ({"values": "4, 5, 6, 7, 8", "pmf": "1, 1, 1, 1, 1"}, {"values": "4, 5, 6, 7, 8", "pmf": "1"}, {"values": "4, 5, 6, 7, 8"}, {"values": "5"}):
+        build(_srf_scene(dict({"type": "discrete", "wavelengths": wl5}, **extra)))
+    for bad in ({"wavelengths": wl5, "values": "5", "pmf": "1, 2"}, {"wavelengths": wl5, "values": "5, 6"}, {}):
+        with pytest.raises(RuntimeError):
+            build(_srf_scene(dict({"type": "discrete"}, **bad)))
+    desc, keep = build(_srf_scene({"type": "discrete", "wavelengths": wl5, "values": "10", "pmf": "1"}))
+    o = ob.OracleScene(desc=desc, keep=keep, spectral=True)
+    sp = desc.sensor.srf - 1
+    assert np.array_equal(o.spectrum_eval(sp, [400.0, 500.0, 650.0, 800.0]), np.zeros(4))
+    wl, wt = o.spectrum_sample(sp, [0.1, 0.3, 0.6, 0.9])
+    assert np.allclose(wl, [400, 500, 600, 800]) and np.allclose(wt, 10)
+    desc, keep = build(_srf_scene({"type": "discrete", "wavelengths": "400., 500., 600.", "values": "1, 2, 3", "pmf": "1, 0.5, 0.5"}))
+    o = ob.OracleScene(desc=desc, keep=keep, spectral=True)
+    wl, wt = o.spectrum_sample(desc.sensor.srf - 1, [0.1, 0.3, 0.6, 0.9])
+    assert np.allclose(wl, [400, 400, 500, 600]) and np.allclose(wt, [1, 1, 2, 3])
+
+
+def test_irregular_spectrum_reference_vectors():
+    """src/spectra/tests/test_irregular.py:18-27: eval at 450, 500, ..., 700 nm of the spectrum 500:1, 600:2, 650:0.5."""
+    d = {"type": "scene", "sensor": {"type": "radiancemeter", "film": FILM1},
+         "e": {"type": "constant", "radiance": {"type": "irregular", "wavelengths": "500, 600, 650", "values": "1, 2, .5"}}}
+    desc, keep = build(d)
+    o = ob.OracleScene(desc=desc, keep=keep, spectral=True)
+    values = [0, 1, 1.5, 2, .5, 0]
+    got = [float(o.spectrum_eval(desc.emitters[0].radiance_spectrum, [450.0 + 50.0 * i] * 4)[0]) for i in range(6)]
+    assert np.allclose(got, values)
+
+
+def test_uniform_spectrum_sampling():
+    """src/spectra/uniform.cpp:92-100: lambda = lambda_min + (lambda_max - lambda_min) u, weight = value (lambda_max - lambda_min)."""
+    desc, keep = build(_srf_scene({"type": "uniform", "lambda_min": 400.0, "lambda_max": 800.0, "value": 0.25}))
+    o = ob.OracleScene(desc=desc, keep=keep, spectral=True)
+    wl, wt = o.spectrum_sample(desc.sensor.srf - 1, [0.0, 0.25, 0.5, 1.0])
+    assert np.allclose(wl, [400, 500, 600, 800]) and np.allclose(wt, 100.0)

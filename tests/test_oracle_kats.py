@@ -199,6 +199,10 @@ def test_rfilter_tables():
     assert abs(f(1, 0.5, 0.5, 0.0, 0) - (1 - math.exp(-8))) < 1e-6
     assert f(1, 0.5, 0.5, 2.0, 0) == 0.0 and f(1, 0.5, 0.5, 2.0, 1) == 0.0
     assert abs(f(1, 0.5, 0.5, 1.0, 1) - f(1, 0.5, 0.5, 2.0 * 15 / 31, 0)) < 1e-7     # discretised: bin floor(|x| * 31 / r)
+    # the reference's spot checks, src/rfilters/tests/test_rfilter.py:8-22
+    assert f(0, 0.5, 0.5, 0.49, 0) == 1 and f(0, 0.5, 0.5, 0.51, 0) == 0 and f(0, 0.5, 0.5, 0.49, 1) == 1 and f(0, 0.5, 0.5, 0.51, 1) == 0
+    assert abs(f(1, 2.0, 0.5, 0.2, 0) - 0.9227) < 8e-3 and abs(f(1, 2.0, 0.5, 0.2, 1) - 0.9227) < 8e-3
+    assert f(1, 2.0, 0.5, 2.1, 0) == 0 and f(1, 2.0, 0.5, 2.1, 1) == 0
 
 
 # ---------------------------------------------------------------- scene-level known answers

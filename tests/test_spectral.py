@@ -179,3 +179,15 @@ def test_spectral_variant_refusals():
         spectral_scene(m={"type": "heterogeneous", "sigma_t": {"type": "gridvolume", "data": np.ones((2, 2, 2, 3), np.float32)}})
     desc, keep = SD.build_scene_desc(scenes.c2_homogeneous_slab(8, 8, 1))
     assert desc.integrator.spectral == 0 and desc.spectrum_count == 0 and desc.bsdfs[1].spectrum[0] == -1
+
+
+def test_reference_spot_checks_of_the_observer_and_of_d65():
+    """src/librender/tests/test_spectra.py:7-16 (cie1931_xyz(600) = 1.0622, 0.631, 0.0008) and :19-32 (d65 at 350, 456, 700, 840 nm =
+    [0, 117.49, 71.6091, 0] / 10568): the reference's own literals for the tables this backend carries."""
+    L = ob.lib_spectral()
+    out = np.zeros(3, np.float32)
+    # XYZ = hmean(cmf * value): a value of 4 at 600 nm and 0 elsewhere in the quadruple returns cmf(600)
+    L.oracle_spectrum_to_xyz(ob._p(np.array([4, 0, 0, 0], np.float32)), ob._p(np.array([600., 500., 500., 500.], np.float32)), ob._p(out))
+    assert np.allclose(out, [1.0622, 0.631, 0.0008], atol=1e-4)
+    o = spectral_scene(e={"type": "directional", "direction": [0, 0, -1]})
+    assert np.allclose(o.spectrum_eval(0, [350., 456., 700., 840.]), np.array([0, 117.49, 71.6091, 0]) / 10568.0, rtol=1e-5)
