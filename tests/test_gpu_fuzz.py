@@ -98,7 +98,7 @@ def _scene(seed):
     return d
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(48))
 @pytest.mark.parametrize("bvh", [False, True])
 def test_random_scene(gpu_rgb, monkeypatch, seed, bvh):
     if bvh:
@@ -110,6 +110,61 @@ def test_random_scene(gpu_rgb, monkeypatch, seed, bvh):
     gpu = np.array(sensor.film().bitmap(raw=True)); st = scene.integrator().last_stats
     o = ob.OracleScene(d); ref = o.render(); so = o.last_stats
     if d["sensor"]["film"]["rfilter"]["type"] == "gaussian":          # neighbouring pixels are reached by atomics in arbitrary order
+        assert np.allclose(gpu, ref, rtol=2e-4, atol=1e-6)
+    else:
+        assert np.array_equal(gpu, ref), (seed, float(np.abs(gpu - ref).max()))
+    assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
+
+
+def _to_spectral(node, rng):
+    """rgb colours -> `regular` spectra over 400 .. 700 nm (the spectral variant has no sRGB upsampling model, see scene_dict._spectrum)."""
+    if isinstance(node, dict):
+        if node.get("type") == "rgb":
+            return {"type": "regular", "lambda_min": 400.0, "lambda_max": 700.0, "values": [float(x) for x in np.atleast_1d(node["value"]).repeat(3)[:3]]}
+        return {k: _to_spectral(v, rng) for k, v in node.items()}
+    return node
+
+
+def _scene_spectral(seed):
+    rng = np.random.default_rng(1000 + seed)
+    d = _scene(seed)
+    if d["integrator"]["type"] == "volpathmis":
+        d["integrator"] = dict(d["integrator"], type="volpath")
+        d["integrator"].pop("use_spectral_mis", None)
+    d = _to_spectral(d, rng)
+    med = d.get("slab", {}).get("interior")
+    if med and med["type"] == "heterogeneous" and rng.random() < 0.6:        # spectral grids for extinction and / or albedo
+        xf = med["sigma_t"]["to_world"]
+        res, nodes = int(rng.choice([3, 5])), int(rng.choice([2, 4, 7]))
+        med["sigma_t"] = {"type": "gridvolume_spectral", "data": rng.uniform(0.1, 2.0, (res, res, res, nodes)).astype(np.float32),
+                          "lambda_min": 0.0, "lambda_max": 1000.0, "to_world": xf}
+        if rng.random() < 0.5:
+            med["albedo"] = {"type": "gridvolume_spectral", "data": rng.uniform(0.3, 0.95, (res, res, res, nodes)).astype(np.float32),
+                             "lambda_min": 0.0, "lambda_max": 1000.0, "to_world": xf}
+    return d
+
+
+@pytest.fixture(scope="module")
+def gpu_spectral(pkg):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    pkg.set_variant("gpu_spectral")
+    yield pkg
+    pkg.set_variant("gpu_rgb")
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_scene_spectral(gpu_spectral, seed):
+    """The same random scenes in the spectral variant: `volpath` on the four-wide ring machine (or per lane without media), `path`
+    per lane, spectra on every colour parameter, spectral grids -- film and counters against liboracle_spectral.so."""
+    d = _scene_spectral(seed)
+    scene = gpu_spectral.load_dict(d)
+    sensor = scene.sensors()[0]
+    assert scene.integrator().render(scene, sensor, collect_counters=True)
+    gpu = np.array(sensor.film().bitmap(raw=True)); st = scene.integrator().last_stats
+    o = ob.OracleScene(d, spectral=True); ref = o.render(); so = o.last_stats
+    if d["sensor"]["film"]["rfilter"]["type"] == "gaussian":
         assert np.allclose(gpu, ref, rtol=2e-4, atol=1e-6)
     else:
         assert np.array_equal(gpu, ref), (seed, float(np.abs(gpu - ref).max()))
