@@ -116,6 +116,30 @@ def test_random_scene(gpu_rgb, monkeypatch, seed, bvh):
     assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
 
 
+def _enlarge(d, w, h, spp):
+    """The same random scene on a film of several full blocks (every ring of a 1024-path workgroup in use)."""
+    if d["sensor"]["type"] in ("mdistant", "distantflux"):
+        return None
+    d["sensor"]["film"] = dict(d["sensor"]["film"], width=w, height=h, rfilter={"type": "box"})
+    d["sensor"]["sampler"] = dict(d["sensor"]["sampler"], sample_count=spp)
+    return d
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scene_full_blocks(gpu_rgb, seed):
+    d = _enlarge(_scene(100 + seed), 96, 72, 12)
+    if d is None or d["integrator"]["type"] == "path":
+        pytest.skip("sensor with a fixed film size / per-lane integrator")
+    gpu, st = None, None
+    scene = gpu_rgb.load_dict(d)
+    sensor = scene.sensors()[0]
+    assert scene.integrator().render(scene, sensor, collect_counters=True)
+    gpu = np.array(sensor.film().bitmap(raw=True)); st = scene.integrator().last_stats
+    o = ob.OracleScene(d); ref = o.render(); so = o.last_stats
+    assert np.array_equal(gpu, ref), (seed, float(np.abs(gpu - ref).max()))
+    assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
+
+
 def _to_spectral(node, rng):
     """rgb colours -> `regular` spectra over 400 .. 700 nm (the spectral variant has no sRGB upsampling model, see scene_dict._spectrum)."""
     if isinstance(node, dict):
