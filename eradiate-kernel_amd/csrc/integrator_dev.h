@@ -734,11 +734,16 @@ DEV_NOINLINE Spec eval_rpv_p(const RpvParams b, F3 wi, F3 wo) {
     float sin_theta2 = frame_sin_theta(wo), cos_theta2 = wo.z, tan_theta2 = frame_tan_theta(wo);
     float G = pm_safe_sqrt(tan_theta1 * tan_theta1 + tan_theta2 * tan_theta2 - 2.f * tan_theta1 * tan_theta2 * cos_phi1_minus_phi2);
     float cos_g = cos_theta1 * cos_theta2 + sin_theta1 * sin_theta2 * cos_phi1_minus_phi2;
-    float out[MTS_SPEC_N];
+    // The two powers are most of the work, and a grey parameter has the same value in every channel: equal inputs give equal
+    // results, so a channel whose g (k) equals channel 0's reuses that channel's factor instead of computing it again.
+    float out[MTS_SPEC_N], F[MTS_SPEC_N], P[MTS_SPEC_N];
     for (int c = 0; c < MTS_SPEC_N; ++c) {
-        float g = b.g[c];
-        float F = (1.f - g * g) / pm_pow((1.f + g * g + 2.f * g * cos_g), 1.5f);
-        out[c] = b.rho_0[c] * (pm_pow(cos_theta1 * cos_theta2 * (cos_theta1 + cos_theta2), b.k[c] - 1.f) * F * (1.f + (1.f - b.rho_c[c]) / (1 + G))) * MTS_INV_PI;
+        const float g = b.g[c];
+        if (c > 0 && g == b.g[0]) F[c] = F[0];
+        else F[c] = (1.f - g * g) / pm_pow((1.f + g * g + 2.f * g * cos_g), 1.5f);
+        if (c > 0 && b.k[c] == b.k[0]) P[c] = P[0];
+        else P[c] = pm_pow(cos_theta1 * cos_theta2 * (cos_theta1 + cos_theta2), b.k[c] - 1.f);
+        out[c] = b.rho_0[c] * (P[c] * F[c] * (1.f + (1.f - b.rho_c[c]) / (1 + G))) * MTS_INV_PI;
     }
 #if MTS_SPEC_N == 3
     return f3(out[0], out[1], out[2]);
