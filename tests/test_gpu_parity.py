@@ -606,8 +606,9 @@ def test_errors_surface_as_exceptions(gpu_rgb):
         scene.integrator().render(scene, scene.sensors()[0])
 
 
+@pytest.mark.parametrize("integrator", ["volpath", "volpathmis"])
 @pytest.mark.parametrize("name", ["c3", "c4"])
-def test_hip_path_agrees_with_the_independent_estimator(gpu_rgb, name):
+def test_hip_path_agrees_with_the_independent_estimator(gpu_rgb, name, integrator):
     """The HIP path itself (not via the oracle) against tests/golden/indep_pin_*.npz, the fixtures of the structurally
     different float64 estimator (tests/independent/walk.py): per-pixel Z-test with the Sidak correction of the reference's
     render tests (test_renders.py:63-137) and the image mean within 4 combined standard errors (< 1 %)."""
@@ -616,6 +617,7 @@ def test_hip_path_agrees_with_the_independent_estimator(gpu_rgb, name):
     from tests.test_independent_pin import load_pin, z_test
     mean, var, _ = load_pin(name)
     d, _, _ = getattr(problems, name)()
+    d["integrator"] = dict(d["integrator"], type=integrator)
     imgs = []
     for seed in range(16):
         dd = copy.deepcopy(d)

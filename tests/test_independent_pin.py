@@ -105,10 +105,14 @@ def test_fixture_comes_from_the_committed_estimator(name):
     assert (p > alpha).all()
 
 
+@pytest.mark.parametrize("integrator", ["volpath", "volpathmis"])
 @pytest.mark.parametrize("name", ["c3", "c4"])
-def test_oracle_agrees_with_the_independent_estimator(name):
+def test_oracle_agrees_with_the_independent_estimator(name, integrator):
+    """`volpath`, and `volpathmis` (src/integrators/volpathmis.cpp: another estimator of the same radiance, for which the reference
+    holds no vector either), against the same fixtures."""
     mean, var, _ = load_pin(name)
     d, _, _ = getattr(problems, name)()
+    d["integrator"] = dict(d["integrator"], type=integrator)
     om, ov = oracle_estimate(d)
     se_pin = math.sqrt(var.sum()) / var.size / mean.mean()
     se_orc = math.sqrt(ov.sum()) / ov.size / om.mean()
