@@ -139,3 +139,42 @@ def test_pin_rejects_the_round_1_c4_scene():
     p, alpha, z = z_test(om, ov, mean, var)
     assert (p > alpha).mean() < 0.9 and z.max() > 5.0
     assert om.mean() / mean.mean() - 1.0 < -1.5e-2
+
+
+def test_spectral_oracle_agrees_with_the_independent_estimator():
+    """The spectral variant on the grey C3 miniature: every sample draws four wavelengths, the film holds hmean(cmf(lambda) L(lambda)) x
+    470 nm (core/spectrum.h:210-217, 250-254), so Y / W estimates L x the integral of the piecewise-linear y-bar table over 360 ..
+    830 nm (106.857 for the 5 nm table of libcore/spectrum.cpp).  Divided by that constant the spectral render must agree with the
+    independent estimator like the rgb one does -- wavelength sampling, CIE weighting and the four-wide transport included."""
+    import re
+    mean, var, _ = load_pin("c3")
+    d, _, _ = problems.c3()
+
+    def grey(node):                                           # grey rgb colours -> uniform spectra (the variant has no sRGB upsampling model)
+        if isinstance(node, dict):
+            if node.get("type") == "rgb":
+                v = np.atleast_1d(np.asarray(node["value"], np.float64))
+                assert np.all(v == v[0])
+                return float(v[0])
+            return {k: grey(x) for k, x in node.items()}
+        return node
+    d = grey(d)
+    tbl = np.array([float(x) for x in re.findall(r"([0-9.eE+-]+)f", open(os.path.join(os.path.dirname(GOLDEN), "..", "eradiate-kernel_amd", "csrc", "cie_tables.h")).read().split("{")[1])], np.float64).reshape(3, 95)
+    y_integral = float(((tbl[1][:-1] + tbl[1][1:]) * 0.5 * 5.0).sum())
+    assert abs(y_integral - 106.857) < 1e-2
+
+    def one(seed):
+        dd = copy.deepcopy(d)
+        dd["sensor"]["sampler"]["sample_count"] = 512
+        dd["sensor"]["sampler"]["seed"] = seed
+        img = ob.OracleScene(dd, spectral=True).render(threads=1)
+        return img[..., 1] / img[..., 4] / y_integral
+    with ThreadPoolExecutor(min(8, os.cpu_count() or 1)) as ex:
+        imgs = np.array(list(ex.map(one, range(16))), np.float64)
+    om, ov = imgs.mean(0), imgs.var(0, ddof=1) / len(imgs)
+    se = math.hypot(math.sqrt(var.sum()) / var.size / mean.mean(), math.sqrt(ov.sum()) / ov.size / om.mean())
+    rel = om.mean() / mean.mean() - 1.0
+    print("c3 spectral: image mean %.6f, independent %.6f, difference %+.3f %% +- %.3f %%" % (om.mean(), mean.mean(), 100 * rel, 100 * se))
+    assert se < 6e-3 and abs(rel) < 4 * se and abs(rel) < 1.5e-2
+    p, alpha, z = z_test(om, ov, mean, var)
+    assert (p > alpha).mean() >= 0.9975
