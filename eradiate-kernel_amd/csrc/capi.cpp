@@ -216,19 +216,25 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             if (const char *kv = getenv("MTSAMD_KERNEL")) {
                 if (!strcmp(kv, "nested")) variant = 0; else if (!strcmp(kv, "flat")) variant = 1;
                 else if (!strcmp(kv, "wga256")) variant = 10256; else if (!strcmp(kv, "wga512")) variant = 10512; else if (!strcmp(kv, "wga1024")) variant = 11024;
-                else throw std::runtime_error("MTSAMD_KERNEL must be one of nested, flat, wga256, wga512, wga1024");
+                else if (!strcmp(kv, "wgl1024")) variant = 21024;
+                else throw std::runtime_error("MTSAMD_KERNEL must be one of nested, flat, wga256, wga512, wga1024, wgl1024");
             }
             // without media there are no tracking walks to regroup: the per-lane kernels win (cornell box 512 x 512 x 256, volpath: rings 992,
             // per lane 1242 Msamples/s; `path` per lane: 2342)
             if (!getenv("MTSAMD_KERNEL") && hs.media.empty() && hs.integrator.type != MTS_INTEGRATOR_PATH) variant = 0;
-            if (hs.integrator.type == MTS_INTEGRATOR_VOLPATHMIS && variant > 10512) variant = 10512;     // four weight matrices per path: 512 paths fill the LDS
-            if (hs.integrator.spectral && variant > 10256) variant = 10256;                               // four-wide spectra: 42 hot dwords per path; three 256-path workgroups per CU (12 waves) beat one of 512 (8 waves) by 10 %
+            // variant = family * 10000 + paths per workgroup (family 1: ring driver, 2: lane-affine driver)
+            if (variant >= 10000) {
+                int family = variant / 10000, wg = variant % 10000;
+                if (hs.integrator.type == MTS_INTEGRATOR_VOLPATHMIS) { family = 1; wg = std::min(wg, 512); }   // four weight matrices per path: 512 paths fill the LDS
+                if (hs.integrator.spectral) { family = 1; wg = std::min(wg, 256); }   // four-wide spectra: 42 hot dwords per path; three 256-path workgroups per CU (12 waves) beat one of 512 (8 waves) by 10 %
+                // a workgroup of the regrouping kernels sits in ONE spiral block: blocks smaller than its path count get the largest
+                // workgroup that divides them (16 x 16 -> 256 paths); only blocks below 256 pixels fall back to the per-lane kernel
+                while (wg > 256 && (block_size * block_size) % (uint32_t) wg != 0) wg /= 2;
+                if (wg != 1024) family = 1;                       // the lane-affine driver is built for 1024 paths only
+                variant = (block_size * block_size) % (uint32_t) wg != 0 ? 1 : family * 10000 + wg;
+            }
             if (hs.integrator.spectral && variant == 1) variant = 0;                                      // no per-lane flat kernel in the spectral build
             if (hs.scene.bin_count > 0 || hs.scene.srf >= 0) variant = 0;                                 // AOV channels / a response function: the per-lane kernel carries them
-            // a workgroup of the regrouping kernel sits in ONE spiral block: blocks smaller than its path count get the largest
-            // workgroup that divides them (16 x 16 -> 256 paths); only blocks below 256 pixels fall back to the per-lane kernel
-            while (variant > 10256 && (block_size * block_size) % (uint32_t) (variant - 10000) != 0) variant = 10000 + (variant - 10000) / 2;
-            if (variant > 1 && (block_size * block_size) % (uint32_t) (variant - 10000) != 0) variant = 1;
             int wg_threads = 0;                                     // MTSAMD_WG_THREADS: threads per workgroup of the wga kernels (<= paths; default = paths)
             if (const char *tv = getenv("MTSAMD_WG_THREADS")) wg_threads = atoi(tv);
             float *d_ws = (float *) rc.get(3, render_workspace_floats((uint32_t) blocks.size(), block_size, variant) * sizeof(float));
@@ -252,7 +258,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
         HIP_CHECK(hipMemcpyAsync(h_counters, d_counters, sizeof(h_counters), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
         if (h_counters[4] != 0)                                      // a bounded ring wait gave up (volpath_flat.h): an error, never a hang
-            throw std::runtime_error("render kernel: ring stall (" + std::string(h_counters[4] == 1 ? "consumer" : "producer") + ", ring " + std::to_string(h_counters[5]) +
+            throw std::runtime_error("render kernel: " + std::string(h_counters[4] == 3 ? "lost path (lane-affine driver: nothing waiting, finished paths = tail" : h_counters[4] == 1 ? "ring stall (consumer" : "ring stall (producer") + ", ring " + std::to_string(h_counters[5]) +
                                      ", index " + std::to_string(h_counters[6]) + ", head " + std::to_string(h_counters[7]) + ", tail " + std::to_string(h_counters[8]) +
                                      ", workgroup " + std::to_string(h_counters[9]) + ")");
         const bool cancelled = hs.stop.load() != 0;                  // render() returns !m_stop (integrator.cpp:178): a timeout alone is not a cancellation

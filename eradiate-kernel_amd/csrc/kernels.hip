@@ -155,6 +155,20 @@ __global__ void __launch_bounds__(NT, WPE) render_kernel_wga(DScene sc, const DB
 }
 static_assert(sizeof(WgArgs) % 4 == 0, "WgArgs mirrors the kernel parameters");
 
+// The same machine on the lane-affine driver (volpath_flat.h, driver 3): conflict-free LDS state, mask claims instead of rings.
+template <bool COUNT, int WG, int NT, int WPE>
+__global__ void __launch_bounds__(NT, WPE) render_kernel_wgl(DScene sc, const DBlock *blocks, uint32_t n_blocks, uint32_t block_size,
+                                                           uint32_t sample_count, float *film, float *cold_g, uint32_t cold_stride,
+                                                           unsigned long long *counters, const uint32_t *stop_flag) {
+    Counters cnt = {};
+    workgroup_lanes<COUNT, WG, NT, VolpathLanes<COUNT, WG>>((const MTS_CONST_AS void *) __builtin_amdgcn_kernarg_segment_ptr(), cnt);
+    if (COUNT) {
+        atomicAdd(counters + 0, (unsigned long long) cnt.n_iter);
+        atomicAdd(counters + 1, (unsigned long long) cnt.n_lookup);
+        atomicAdd(counters + 2, (unsigned long long) cnt.n_nee_step);
+    }
+}
+
 #if MTS_SPEC_N == 3
 // The same driver for volpathmis (volpathmis_flat.h): four weight matrices per path, 512 paths per workgroup, two waves per SIMD.
 template <bool COUNT, bool SPEC, int WG, int NT>
@@ -237,6 +251,7 @@ hipError_t launch_wavefront_sampler(int32_t lanes, uint64_t seed_value, int32_t 
 
 size_t render_workspace_floats(uint32_t n_blocks, uint32_t block_size, int variant) {
     if (variant < 256) return 0;
+    if (variant >= 20000) variant -= 20000;
     if (variant >= 10000) variant -= 10000;
     const uint64_t threads = (uint64_t) n_blocks * block_size * block_size;
     const uint64_t padded = (threads + variant - 1) / variant * variant;
@@ -252,6 +267,18 @@ hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks,
     const uint64_t threads = (uint64_t) n_blocks * block_size * block_size;
     if (threads + 1024 >= ((uint64_t) 1 << 32)) return hipErrorInvalidValue;      // thread and path indices are 32 bit (mts_render launches in chunks)
 #if MTS_SPEC_N == 3
+    if (variant >= 20000 && sc.integrator.type == MTS_INTEGRATOR_VOLPATH) {        // lane-affine regrouping, variant = 20000 + paths per workgroup
+        const uint32_t wg = (uint32_t) (variant - 20000);
+        const uint32_t grid = (uint32_t) ((threads + wg - 1) / wg);
+        const uint32_t stride = grid * wg;
+        const int nt = wg_threads > 0 ? wg_threads : (int) wg;
+#define LAUNCH_WGL(W, T, E) do { if (count) hipLaunchKernelGGL((render_kernel_wgl<true, W, T, E>), dim3(grid), dim3(T), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag); \
+                                 else hipLaunchKernelGGL((render_kernel_wgl<false, W, T, E>), dim3(grid), dim3(T), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag); } while (0)
+        if (wg == 1024 && nt == 1024) LAUNCH_WGL(1024, 1024, 4);
+        else return hipErrorInvalidConfiguration;
+#undef LAUNCH_WGL
+        return hipGetLastError();
+    }
     if (variant >= 10000 && sc.integrator.type == MTS_INTEGRATOR_VOLPATH) {        // asynchronous regrouping, variant = 10000 + paths per workgroup
         const uint32_t wg = (uint32_t) (variant - 10000);
         const uint32_t grid = (uint32_t) ((threads + wg - 1) / wg);

@@ -786,6 +786,14 @@ enum : uint32_t { G_RNG = 1, G_O = 2, G_D = 4 /* d and 1/d */, G_MINT = 8, G_MAX
 #else
                   G_WL = 16384 /* read by every block that evaluates a spectrum, written by NEW */, G_ALL = 32767 };
 #endif
+// Measurement build (-DMTS_FUSE_INT=1, round 3): scenes without a BVH run the intersection of a freshly spawned ray at the end of
+// the block that spawned it (PHASE, SCATTER, walk SURFACE, SURFACE + BSDF, NEW) instead of queueing the path for an INTERSECT visit,
+// which saves 14 of 64 visits per sample on the metric scene (claim, state load / store, push).  Bit-identical; measured 546 -> 537
+// Msamples/s on C3 (512 x 512 x 256): the twelve triangle tests then run at the 45 - 50 lanes of the host blocks instead of the 54
+// of a class of their own, which costs what the saved visits gain.  Off by default.
+#ifndef MTS_FUSE_INT
+#define MTS_FUSE_INT 0
+#endif
 // What block class C (followed by top()) may read (`load`, a superset of `store`) and write (`store`).  end_nee / end_direct touch
 // almost everything; the classes with partial sets run them deferred (VolpathMachine::finish on the full state).
 template <int C> struct ClassFields { static constexpr uint32_t load = G_ALL, store = G_ALL; static constexpr bool defer = false; };
@@ -802,11 +810,11 @@ template <> struct ClassFields<B_INT> {          // every lane of the class want
     static constexpr bool defer = true; };
 template <> struct ClassFields<B_SCATTER> {
     static constexpr uint32_t load = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_MED | G_THR | G_TRANS | G_WA | G_WB | G_WL,
-                              store = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_TRANS | G_WA | G_WB;
+                              store = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_TRANS | G_WA | G_WB | (MTS_FUSE_INT ? G_SIX : 0u);
     static constexpr bool defer = true; };
 template <> struct ClassFields<B_PHASE> {
     static constexpr uint32_t load = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_MED | G_THR | G_ETA | G_WL,
-                              store = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_THR;
+                              store = G_RNG | G_O | G_D | G_MINT | G_MAXT | G_SIT | G_THR | (MTS_FUSE_INT ? G_SIX : 0u);
     static constexpr bool defer = true; };
 
 template <int WG>
@@ -933,6 +941,10 @@ static __device__ WG_BLOCK_ATTR int wg_block(const MTS_CONST_AS void *kernarg_, 
         vm.template run<CF::defer, true>(p, e, C);
         if (COUNT && C == B_MED) MTS_SEG(*cnt, 3);
         vm.template top<CF::defer>(p, e);
+        if (MTS_FUSE_INT && (C == B_PHASE || C == B_SCATTER || C == B_WSURF || C == B_SURF || C == B_NEW) && a.sc.bvh_node_count == 0) {
+            vm.blk_int(p, e);                                // acts on the lanes whose new ray can reach the scene (wants_int)
+            vm.template top<CF::defer>(p, e);                // start_direct() leaves a direct-light walk at its loop head
+        }
         if (COUNT && C == B_MED) MTS_SEG(*cnt, 4);
         cls = vm.classify(p);
         if (!(C == B_MED || C == B_MEDW) || cls != C || rounds >= 16) break;
@@ -1196,6 +1208,205 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Driver 3: lane-affine regrouping.  As driver 2 a wave runs ONE block class at a time with the hot state in LDS, but a path is bound
+// to a lane: path `pid` is only ever executed by lane (pid mod 64) of whichever wave takes it.  That one rule pays three times:
+//   * LDS banks: field k of path p lives at word k * WG + p, i.e. in bank p mod 32 for the dword accesses (MI355X_MICROARCH.md,
+//     "LDS").  With the rings a wave's lanes hold arbitrary ids -- 32 random ids on 32 banks are a ~3.5-way conflict, the measured
+//     SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.67 of round 2.  Here lane L holds an id = L mod 64: every state access of every
+//     block is conflict-free.
+//   * No rings: what waits for class c on lane L is a 16-bit mask (bit j = path L + 64 j).  Push = one atomic OR into the lane's own
+//     word (64 lanes, 64 addresses, 32 banks x 2 groups: one LDS pass, where the ring tails serialised 64 same-address atomics);
+//     claim = the wave reads its 64 mask records, votes for the class that serves most lanes (eight ballots), and every lane clears
+//     one bit of its own word with an atomic AND.  No head / tail counters, no compare-and-swap that one lane wins for the wave
+//     (61 % of those were lost), no slot hand-over and hence no wait that could stall.
+//   * Waves do not queue behind one shared counter: sixteen waves that want the same class take different bits (each wave starts
+//     its search at slot (wave id) mod 16), a lost bit is retried from the value the atomic returned.
+// The price is that a lane can only be filled from its own <= 16 paths: a class with n waiting paths serves 64 (1 - exp(-n / 64))
+// lanes on average instead of min(n, 64).
+// q_mask[k][L]: classes 2k (low half) and 2k + 1 (high half) of lane L.  q_ctl[0] counts finished paths, q_ctl[1] is the stop word.
+// Stopping needs no second exit: a raised stop word makes the vote come out empty, which is the (rare) path that already looks at
+// the finished count.  After a stop the workgroup adds the accumulators of its unfinished pixels to the film, as the reference puts
+// a partially rendered block on the film (integrator.cpp:120-130, 213-216).
+#define MTS_IDLE_LIMIT (1u << 22)      // naps without anything waiting anywhere before a wave reports a lost path (never seen; about a second)
+template <bool COUNT, int WG, int NT, class M /* machine: HOT dwords per path, PACKED_AT, init(), block() */>
+DEV void workgroup_lanes(const MTS_CONST_AS void *kernarg, Counters &cnt) {
+    constexpr int PPL = WG / 64;                              // paths per lane
+    static_assert(WG % 64 == 0 && NT % 64 == 0 && NT <= WG && PPL <= 16 && B_DONE == 8, "whole waves, 16-bit masks, eight classes in four words");
+    __shared__ uint32_t hot_lds[M::HOT * WG];
+    __shared__ uint32_t q_mask[4][64];
+    __shared__ uint32_t q_ctl[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wg_base = blockIdx.x * WG;
+    if (tid < 256u) (&q_mask[0][0])[tid] = 0u;
+    if (tid < 4u) q_ctl[tid] = 0u;
+    __syncthreads();
+#pragma unroll 1
+    for (uint32_t pid0 = tid; pid0 < (uint32_t) WG; pid0 += NT) {   // ---- initialise the paths (integrator.cpp:198) and queue them
+        const int cls = M::init(kernarg, hot_lds, wg_base, pid0, &cnt);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        const uint32_t j = pid0 >> 6;
+        if (cls != B_DONE) atomicOr(&q_mask[cls >> 1][lane], 1u << (j + 16u * ((uint32_t) cls & 1u)));
+        const unsigned long long dm = __builtin_amdgcn_ballot_w64(cls == B_DONE);
+        if (dm != 0ull && lane == (uint32_t) __builtin_ctzll(dm)) atomicAdd(&q_ctl[0], (uint32_t) __popcll(dm));
+    }
+    const uint32_t rot = (tid >> 6) & 15u;                    // where this wave starts looking in a mask
+#if defined(MTSAMD_BLOCKSTATS)
+    long long bs_t0 = clock64(); unsigned long long bs_loc[45] = {};                      // laid out like g_blockstats
+#endif
+    uint32_t poll_ticks = (tid >> 6) * 2048u, idle_naps = 0;  // poll_ticks paces the reads of the host's stop word (see driver 2)
+#pragma unroll 1
+    for (;;) {
+        int sel = 0; bool finished = false, mine = false; uint32_t j = 0;
+#pragma unroll 1
+        for (;;) {                                            // ---- the claim: snapshot, vote, one atomic AND per lane
+            const uint32_t m0 = __atomic_load_n(&q_mask[0][lane], __ATOMIC_RELAXED), m1 = __atomic_load_n(&q_mask[1][lane], __ATOMIC_RELAXED),
+                           m2 = __atomic_load_n(&q_mask[2][lane], __ATOMIC_RELAXED), m3 = __atomic_load_n(&q_mask[3][lane], __ATOMIC_RELAXED);
+            const uint32_t stop = (uint32_t) __builtin_amdgcn_readfirstlane((int) __atomic_load_n(&q_ctl[1], __ATOMIC_RELAXED));
+            uint32_t best = 0;
+#define MTS_VOTE(c, expr) do { const uint32_t v_ = (uint32_t) __popcll(__builtin_amdgcn_ballot_w64((expr) != 0u)); if (v_ > best) { best = v_; sel = (c); } } while (0)
+            MTS_VOTE(0, m0 & 0xFFFFu); MTS_VOTE(1, m0 >> 16); MTS_VOTE(2, m1 & 0xFFFFu); MTS_VOTE(3, m1 >> 16);
+            MTS_VOTE(4, m2 & 0xFFFFu); MTS_VOTE(5, m2 >> 16); MTS_VOTE(6, m3 & 0xFFFFu); MTS_VOTE(7, m3 >> 16);
+#undef MTS_VOTE
+            if (stop != STOP_NONE) best = 0;
+            if (best == 0) {
+                // nothing waits: every path has finished, or is being executed by another wave, or the workgroup was stopped
+                if (stop != STOP_NONE || (uint32_t) __builtin_amdgcn_readfirstlane((int) __atomic_load_n(&q_ctl[0], __ATOMIC_RELAXED)) == (uint32_t) WG) { finished = true; break; }
+                if ((poll_ticks += 1u) >= 32768u) {           // Integrator::should_stop(): see driver 2 for the pacing
+                    poll_ticks = 0;
+                    if (lane == 0 && __hip_atomic_load(cload_k<WgArgs>(kernarg).stop_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
+                        atomicCAS(&q_ctl[1], (uint32_t) STOP_NONE, (uint32_t) STOP_CANCEL);
+                }
+                if (++idle_naps > MTS_IDLE_LIMIT) {           // a path was lost: report instead of waiting for ever
+                    if (lane == 0 && atomicCAS(&q_ctl[1], (uint32_t) STOP_NONE, (uint32_t) STOP_STALL) == STOP_NONE) {
+                        unsigned long long *counters = cload_k<WgArgs>(kernarg).counters;
+                        if (atomicCAS(counters + MTS_DIAG_BASE, 0ull, 3ull) == 0ull) {
+                            counters[MTS_DIAG_BASE + 1] = 0ull; counters[MTS_DIAG_BASE + 2] = 0ull; counters[MTS_DIAG_BASE + 3] = 0ull;
+                            counters[MTS_DIAG_BASE + 4] = __atomic_load_n(&q_ctl[0], __ATOMIC_RELAXED); counters[MTS_DIAG_BASE + 5] = blockIdx.x;
+                        }
+                    }
+                }
+                __builtin_amdgcn_s_sleep(2);
+#if defined(MTSAMD_BLOCKSTATS)
+                if (COUNT) { long long t = clock64(); bs_loc[42] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
+#endif
+                continue;
+            }
+            idle_naps = 0;
+#if defined(MTSAMD_BLOCKSTATS)
+            if (COUNT) bs_loc[10] += 1ull;                    // claim attempts
+#endif
+            const uint32_t w = sel < 4 ? (sel < 2 ? m0 : m1) : (sel < 6 ? m2 : m3), sh = 16u * ((uint32_t) sel & 1u);
+            uint32_t f = (w >> sh) & 0xFFFFu;
+            uint32_t *word = &q_mask[sel >> 1][lane];
+#pragma nounroll
+            while (__builtin_amdgcn_ballot_w64(f != 0u) != 0ull) {      // one round unless another wave took the same bit
+                if (f != 0u) {
+                    const uint32_t fr = f & (0xFFFFu << rot), src = fr != 0u ? fr : f;
+                    j = (uint32_t) __builtin_ctz(src);
+                    const uint32_t bit = 1u << (j + sh);
+                    const uint32_t old = atomicAnd(word, ~bit);
+                    if (old & bit) { mine = true; f = 0u; }
+                    else f = (old >> sh) & 0xFFFFu;
+                }
+#if defined(MTSAMD_BLOCKSTATS)
+                if (COUNT) bs_loc[11] += 1ull;                // rounds of the per-lane take
+#endif
+            }
+            if (__builtin_amdgcn_ballot_w64(mine) != 0ull) break;
+        }
+        if (finished) break;
+        const uint32_t pid = lane + 64u * j;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#if defined(MTSAMD_BLOCKSTATS)
+        if (COUNT) { bs_loc[sel] += 1ull; bs_loc[12 + sel] += (unsigned long long) __popcll(__builtin_amdgcn_ballot_w64(mine));
+                     long long t = clock64(); bs_loc[44] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
+#endif
+        int cls = B_DONE;
+        if (mine) cls = M::block(sel, kernarg, hot_lds, wg_base, pid, &cnt);
+#if defined(MTSAMD_BLOCKSTATS)
+        if (COUNT) { long long t = clock64(); bs_loc[24 + sel] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
+#endif
+        if (sel == B_NEW && (poll_ticks += 256u) >= 32768u) {
+            poll_ticks = 0;
+            if (lane == 0 && __hip_atomic_load(cload_k<WgArgs>(kernarg).stop_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
+                atomicCAS(&q_ctl[1], (uint32_t) STOP_NONE, (uint32_t) STOP_CANCEL);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (mine && cls != B_DONE) atomicOr(&q_mask[cls >> 1][lane], 1u << (j + 16u * ((uint32_t) cls & 1u)));
+        const unsigned long long dm = __builtin_amdgcn_ballot_w64(mine && cls == B_DONE);
+        if (dm != 0ull && lane == (uint32_t) __builtin_ctzll(dm)) atomicAdd(&q_ctl[0], (uint32_t) __popcll(dm));
+#if defined(MTSAMD_BLOCKSTATS)
+        if (COUNT) { long long t = clock64(); bs_loc[43] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
+#endif
+    }
+#if defined(MTSAMD_BLOCKSTATS)
+    if (COUNT) {
+        long long t = clock64(); bs_loc[44] += (unsigned long long) (t - bs_t0);
+        for (int k = 0; k < 6; ++k) bs_loc[36 + k] = cnt.seg[k];
+        if (lane == 0) for (int k = 0; k < 45; ++k) atomicAdd(&g_blockstats[k], bs_loc[k]);
+    }
+#endif
+    // ---- stopped (cancel / timeout / stall): the samples the unfinished pixels have accumulated go to the film
+    __syncthreads();
+    if (__atomic_load_n(&q_ctl[1], __ATOMIC_RELAXED) != STOP_NONE) {
+        const WgArgs a = cload_k<WgArgs>(kernarg);
+#pragma unroll 1
+        for (uint32_t pid = tid; pid < (uint32_t) WG; pid += NT) {
+            if ((hot_lds[M::PACKED_AT * WG + pid] & 15u) == S_DONE) continue;
+            PathEnvT<ColdStoreHbm> e;
+            if (!wg_env<WG>(a, wg_base, pid, e)) continue;
+            const int fc = M::film_channels(a.sc);
+            float *own = (float *) (e.film + (size_t) fc * ((size_t) (e.blk.oy + (int) e.ly - a.sc.sensor.crop_y) * a.sc.sensor.crop_w + (e.blk.ox + (int) e.lx - a.sc.sensor.crop_x)));
+            for (int k = 0; k < 5; ++k) atomicAdd(own + k, e.cold.f(C_ACC + k));
+        }
+    }
+}
+
+// The volpath machine on driver 3
+template <bool COUNT, int WG>
+struct VolpathLanes {
+    static constexpr int HOT = H_COUNT, PACKED_AT = H_PACKED;
+    DEV static int film_channels(const DScene &) { return 5; }
+    DEV static int init(const MTS_CONST_AS void *kernarg, uint32_t *hot_lds, uint32_t wg_base, uint32_t pid0, Counters *cnt) {
+        const WgArgs a = cload_k<WgArgs>(kernarg);
+        VolpathMachine<COUNT> vm(a.sc, *cnt);
+        PathEnvT<ColdStoreHbm> e; PathState p;
+        HotStore<WG> hs; hs.base = hot_lds + pid0;
+        const bool ok = wg_env<WG>(a, wg_base, pid0, e);
+        p.rng.state = 0; p.rng.inc = 0;
+        p.ray = make_ray(f3s(0.f), f3(0.f, 0.f, 1.f), 0.f, 0.f); p.si.t = pm_inf(); p.si.p = f3s(0.f); p.si.uv.x = p.si.uv.y = 0.f; p.si.shape = -1; p.si.prim = 0;
+        p.medium = -1; p.thr = p.res = p.trans = spec_s(0.f); p.eta = 1.f; p.depth = 0; p.channel = 0; p.mode = M_MAIN; p.flags = 0; p.wa = p.wb = 0.f;
+#if MTS_SPEC_N != 3
+        p.wl = spec_s(0.f);
+#endif
+        p.st = S_DONE;
+        if (ok) {
+            const uint32_t ppb = a.block_size * a.block_size;
+            const uint32_t i = (wg_base % ppb) + pid0;
+            p.rng.seed(a.sc.sensor.seed + (uint64_t) e.blk.id * ppb + i, PCG32_DEFAULT_STREAM);     // sampler.cpp:83-96
+            for (int k = 0; k < 5; ++k) e.cold.f(C_ACC + k) = 0.f;
+            e.cold.f(C_SAMPLE) = __uint_as_float(0u);
+            vm.begin_sample(p, e);
+            vm.top(p, e);
+        }
+        const int cls = vm.classify(p);
+        hs.store(p, cls);
+        return cls;
+    }
+    DEV static int block(int sel, const MTS_CONST_AS void *kernarg, uint32_t *hot_lds, uint32_t wg_base, uint32_t pid, Counters *cnt) {
+        switch (sel) {                                          // wave-uniform
+            case B_INT: return wg_block<COUNT, WG, B_INT>(kernarg, hot_lds, wg_base, pid, cnt);
+            case B_MED: return wg_block<COUNT, WG, B_MED>(kernarg, hot_lds, wg_base, pid, cnt);
+            case B_MEDW: return wg_block<COUNT, WG, B_MEDW>(kernarg, hot_lds, wg_base, pid, cnt);
+            case B_SCATTER: return wg_block<COUNT, WG, B_SCATTER>(kernarg, hot_lds, wg_base, pid, cnt);
+            case B_WSURF: return wg_block<COUNT, WG, B_WSURF>(kernarg, hot_lds, wg_base, pid, cnt);
+            case B_SURF: return wg_block<COUNT, WG, B_SURF>(kernarg, hot_lds, wg_base, pid, cnt);
+            case B_PHASE: return wg_block<COUNT, WG, B_PHASE>(kernarg, hot_lds, wg_base, pid, cnt);
+            default: return wg_block<COUNT, WG, B_NEW>(kernarg, hot_lds, wg_base, pid, cnt);
+        }
+    }
+};
 
 } // inline namespace
 } // namespace mtsamd

@@ -204,7 +204,8 @@ def test_full_size_properties(gpu_rgb):
 
 
 @pytest.mark.parametrize("kernel,threads", [("nested", None), ("flat", None), ("wga256", None), ("wga512", None), ("wga512", "256"),
-                                            ("wga1024", "1024"), ("wga1024", "768"), ("wga1024", "512")])
+                                            ("wga1024", "1024"), ("wga1024", "768"), ("wga1024", "512"),
+                                            ("wgl1024", "1024")])
 def test_every_kernel_formulation_matches_the_oracle(gpu_rgb, monkeypatch, kernel, threads):
     """All kernel formulations (nested loops, per-lane state machine, asynchronous regrouping with several workgroup shapes)
     must produce the oracle's film and loop counters bit for bit: heterogeneous medium + cornell box (area light, BSDF
