@@ -234,6 +234,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
                 variant = (block_size * block_size) % (uint32_t) wg != 0 ? 1 : family * 10000 + wg;
             }
             if (hs.integrator.spectral && variant == 1) variant = 0;                                      // no per-lane flat kernel in the spectral build
+            if (hs.integrator.spectral && hs.integrator.type == MTS_INTEGRATOR_VOLPATHMIS) variant = 0;   // spectral volpathmis (4 x 4 weight matrices): the nested per-lane kernel
             if (hs.scene.bin_count > 0 || hs.scene.srf >= 0) variant = 0;                                 // AOV channels / a response function: the per-lane kernel carries them
             int wg_threads = 0;                                     // MTSAMD_WG_THREADS: threads per workgroup of the wga kernels (<= paths; default = paths)
             if (const char *tv = getenv("MTSAMD_WG_THREADS")) wg_threads = atoi(tv);

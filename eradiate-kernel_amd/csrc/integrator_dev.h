@@ -704,10 +704,10 @@ DEV F3 phase_sample_leaf_pdf(const DPhase &ph, const Frame3 &frame, F2 sample2, 
     float sin_phi, cos_phi; pm_sincos(2.f * MTS_PI * sample2.y, &sin_phi, &cos_phi);
     return to_world(frame, f3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta));
 }
-DEV F3 phase_sample_pdf(const DScene &sc, int phase, const Frame3 &frame, F3 p, float sample1, F2 sample2, float &pdf) {
+DEV F3 phase_sample_pdf(const DScene &sc, int phase, const Frame3 &frame, F3 p, float sample1, F2 sample2, float &pdf, const SpecCtx &cx = SpecCtx()) {
     const DPhase &ph = sc.phases[phase];
     if (ph.type != MTS_PHASE_BLEND) return phase_sample_leaf_pdf(ph, frame, sample2, pdf);
-    float w = volume_eval_1(sc.volumes[ph.weight_volume], p);
+    float w = volume_eval_1(sc.volumes[ph.weight_volume], p, cx, ph.weight_volume);
     float weight = pm_min(pm_max(w, 0.f), 1.f);
     if (sample1 > weight) return phase_sample_leaf_pdf(sc.phases[ph.child[0]], frame, sample2, pdf);
     return phase_sample_leaf_pdf(sc.phases[ph.child[1]], frame, sample2, pdf);
@@ -1260,63 +1260,88 @@ DEV Spec volpath_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, bool
 }
 
 // ---------------------------------------------------------------- volpathmis
-#if MTS_SPEC_N == 3         // the spectral build carries path and volpath (the loader refuses volpathmis there)
 // integrators/volpathmis.cpp (nested formulation, statement for statement the CPU restatement in oracle/oracle.cpp).
-// WeightMatrix: 3 rows of probability ratios with `use_spectral_mis` (default), one row without (:38-46).
-template <bool SPEC> struct MisWeights { F3 r[SPEC ? 3 : 1]; };
-template <bool SPEC> DEV MisWeights<SPEC> mw_full(float v) { MisWeights<SPEC> w; for (int i = 0; i < (SPEC ? 3 : 1); ++i) w.r[i] = f3s(v); return w; }
+// WeightMatrix (:66-69): n rows of n probability ratios with `use_spectral_mis` (default), n = array_size_v<UnpolarizedSpectrum> = 3 in
+// the rgb variants and 4 in the spectral one; one row without (:38-46).  Outside the rgb variants index_spectrum is spec[0] (:74-84,
+// `pick`) and `channel` stays 0 (:118-124).
+DEV float sget(const Spec &a, int i) {
+#if MTS_SPEC_N == 3
+    return i == 0 ? a.x : (i == 1 ? a.y : a.z);
+#else
+    return i == 0 ? a.x : (i == 1 ? a.y : (i == 2 ? a.z : a.w));
+#endif
+}
 DEV float mw_fin(float x) { return pm_isfinite(x) ? x : 0.f; }
 DEV float mw_nan0(float x) { return x != x ? 0.f : x; }
+#if MTS_SPEC_N == 3
+DEV Spec spec_map_fin(Spec a) { return f3(mw_fin(a.x), mw_fin(a.y), mw_fin(a.z)); }
+DEV Spec spec_map_nan0(Spec a) { return f3(mw_nan0(a.x), mw_nan0(a.y), mw_nan0(a.z)); }
+DEV Spec spec_div_s(Spec p, float f) { return f3(p.x / f, p.y / f, p.z / f); }              // true divisions (spectrum / coefficient, :456)
+DEV Spec spec_s_div(float p, Spec f) { return f3(p / f.x, p / f.y, p / f.z); }
+DEV Spec spec_of(float a, float b, float c, float) { return f3(a, b, c); }
+DEV float spec_hsum(Spec a) { return (a.x + a.y) + a.z; }
+DEV float spec_hmin_abs(Spec a) { return pm_min(pm_min(pm_abs(a.x), pm_abs(a.y)), pm_abs(a.z)); }
+#else
+DEV Spec spec_map_fin(Spec a) { return spec4(mw_fin(a.x), mw_fin(a.y), mw_fin(a.z), mw_fin(a.w)); }
+DEV Spec spec_map_nan0(Spec a) { return spec4(mw_nan0(a.x), mw_nan0(a.y), mw_nan0(a.z), mw_nan0(a.w)); }
+DEV Spec spec_div_s(Spec p, float f) { return spec4(p.x / f, p.y / f, p.z / f, p.w / f); }
+DEV Spec spec_s_div(float p, Spec f) { return spec4(p / f.x, p / f.y, p / f.z, p / f.w); }
+DEV Spec spec_of(float a, float b, float c, float d) { return spec4(a, b, c, d); }
+DEV float spec_hsum(Spec a) { return (a.x + a.y) + (a.z + a.w); }                             // hsum of a 4-array: pairwise, as spec_hmean (dmath.h)
+DEV float spec_hmin_abs(Spec a) { return pm_min(pm_min(pm_abs(a.x), pm_abs(a.y)), pm_min(pm_abs(a.z), pm_abs(a.w))); }
+#endif
+template <bool SPEC> struct MisWeights { Spec r[SPEC ? MTS_SPEC_N : 1]; };
+template <bool SPEC> DEV MisWeights<SPEC> mw_full(float v) { MisWeights<SPEC> w; for (int i = 0; i < (SPEC ? MTS_SPEC_N : 1); ++i) w.r[i] = spec_s(v); return w; }
 template <bool SPEC>
-DEV void update_weights(MisWeights<SPEC> &w, F3 p, F3 f, uint32_t channel, bool active) {       // volpathmis.cpp:447-466
+DEV void update_weights(MisWeights<SPEC> &w, Spec p, Spec f, uint32_t channel, bool active) {       // volpathmis.cpp:447-466
     if (SPEC) {
-        for (int i = 0; i < 3; ++i) {
-            float fi = pick(f, (uint32_t) i);
-            F3 ratio = f3(mw_fin(p.x / fi), mw_fin(p.y / fi), mw_fin(p.z / fi));
+#pragma unroll
+        for (int i = 0; i < MTS_SPEC_N; ++i) {
+            Spec ratio = spec_map_fin(spec_div_s(p, sget(f, i)));
             ratio = ratio * w.r[i];
-            if (active) w.r[i] = f3(mw_nan0(ratio.x), mw_nan0(ratio.y), mw_nan0(ratio.z));
+            if (active) w.r[i] = spec_map_nan0(ratio);
         }
     } else {
         float pdf = pick(p, channel);
-        F3 ratio = w.r[0] * f3(pdf / f.x, pdf / f.y, pdf / f.z);
-        if (active) w.r[0] = f3(mw_fin(ratio.x), mw_fin(ratio.y), mw_fin(ratio.z));
+        Spec ratio = w.r[0] * spec_s_div(pdf, f);
+        if (active) w.r[0] = spec_map_fin(ratio);
     }
 }
-template <bool SPEC> DEV void update_weights(MisWeights<SPEC> &w, float p, F3 f, uint32_t c, bool a) { update_weights(w, f3s(p), f, c, a); }
-template <bool SPEC> DEV void update_weights(MisWeights<SPEC> &w, F3 p, float f, uint32_t c, bool a) { update_weights(w, p, f3s(f), c, a); }
-template <bool SPEC> DEV void update_weights(MisWeights<SPEC> &w, float p, float f, uint32_t c, bool a) { update_weights(w, f3s(p), f3s(f), c, a); }
+template <bool SPEC> DEV void update_weights(MisWeights<SPEC> &w, float p, Spec f, uint32_t c, bool a) { update_weights(w, spec_s(p), f, c, a); }
+template <bool SPEC> DEV void update_weights(MisWeights<SPEC> &w, Spec p, float f, uint32_t c, bool a) { update_weights(w, p, spec_s(f), c, a); }
+template <bool SPEC> DEV void update_weights(MisWeights<SPEC> &w, float p, float f, uint32_t c, bool a) { update_weights(w, spec_s(p), spec_s(f), c, a); }
 template <bool SPEC>
-DEV F3 mis_weight_w(const MisWeights<SPEC> &w) {                                                 // volpathmis.cpp:468-481
+DEV Spec mis_weight_w(const MisWeights<SPEC> &w) {                                               // volpathmis.cpp:468-481
     if (SPEC) {
-        float o[3];
-        for (int i = 0; i < 3; ++i) { float sum = (w.r[i].x + w.r[i].y) + w.r[i].z; o[i] = sum == 0.f ? 0.f : 3.f / sum; }
-        return f3(o[0], o[1], o[2]);
+        float o[4] = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+        for (int i = 0; i < MTS_SPEC_N; ++i) { float sum = spec_hsum(w.r[i]); o[i] = sum == 0.f ? 0.f : (float) MTS_SPEC_N / sum; }
+        return spec_of(o[0], o[1], o[2], o[3]);
     }
-    F3 a = w.r[0];
-    bool invalid = pm_min(pm_min(pm_abs(a.x), pm_abs(a.y)), pm_abs(a.z)) == 0.f;
-    return invalid ? f3s(0.f) : f3(1.f / a.x, 1.f / a.y, 1.f / a.z);
+    Spec a = w.r[0];
+    return spec_hmin_abs(a) == 0.f ? spec_s(0.f) : spec_s_div(1.f, a);
 }
 template <bool SPEC>
-DEV F3 mis_weight_w(const MisWeights<SPEC> &a, const MisWeights<SPEC> &b) {                      // volpathmis.cpp:484-498
+DEV Spec mis_weight_w(const MisWeights<SPEC> &a, const MisWeights<SPEC> &b) {                    // volpathmis.cpp:484-498
     if (SPEC) {
-        float o[3];
-        for (int i = 0; i < 3; ++i) { F3 r = a.r[i] + b.r[i]; float sum = (r.x + r.y) + r.z; o[i] = sum == 0.f ? 0.f : 3.f / sum; }
-        return f3(o[0], o[1], o[2]);
+        float o[4] = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+        for (int i = 0; i < MTS_SPEC_N; ++i) { float sum = spec_hsum(a.r[i] + b.r[i]); o[i] = sum == 0.f ? 0.f : (float) MTS_SPEC_N / sum; }
+        return spec_of(o[0], o[1], o[2], o[3]);
     }
-    F3 sum = a.r[0] + b.r[0];
-    bool zero = pm_min(pm_min(pm_abs(sum.x), pm_abs(sum.y)), pm_abs(sum.z)) == 0.f;
-    return zero ? f3s(0.f) : f3(1.f / sum.x, 1.f / sum.y, 1.f / sum.z);
+    Spec sum = a.r[0] + b.r[0];
+    return spec_hmin_abs(sum) == 0.f ? spec_s(0.f) : spec_s_div(1.f, sum);
 }
 
 // volpathmis.cpp:330-445
 template <bool COUNT, bool SPEC>
-DEV F3 volpathmis_sample_emitter(const DScene &sc, F3 ref_p, bool is_medium_interaction, Pcg32 &rng, int medium, const MisWeights<SPEC> &p_over_f,
-                                          uint32_t channel, MisWeights<SPEC> &nee_out, MisWeights<SPEC> &uni_out, DirSample &ds, Counters &cnt) {
+DEV Spec volpathmis_sample_emitter(const DScene &sc, F3 ref_p, bool is_medium_interaction, Pcg32 &rng, int medium, const MisWeights<SPEC> &p_over_f,
+                                          uint32_t channel, MisWeights<SPEC> &nee_out, MisWeights<SPEC> &uni_out, DirSample &ds, Counters &cnt, const SpecCtx &cx = SpecCtx()) {
     MisWeights<SPEC> p_over_f_nee = p_over_f, p_over_f_uni = p_over_f;
-    F3 emitter_sample_weight;
-    ds = sample_emitter_direction(sc, ref_p, rng.next_2d(), false, emitter_sample_weight);
-    F3 emitter_val = emitter_sample_weight * ds.pdf;
-    if (ds.pdf == 0.f) emitter_val = f3s(0.f);
+    Spec emitter_sample_weight;
+    ds = sample_emitter_direction(sc, ref_p, rng.next_2d(), false, emitter_sample_weight, cx);
+    Spec emitter_val = emitter_sample_weight * ds.pdf;
+    if (ds.pdf == 0.f) emitter_val = spec_s(0.f);
     bool active = ds.pdf != 0.f;
     update_weights(p_over_f_nee, ds.pdf, 1.0f, channel, active);
     if (!active) { nee_out = p_over_f_nee; uni_out = p_over_f_uni; return emitter_val; }
@@ -1334,7 +1359,7 @@ DEV F3 volpathmis_sample_emitter(const DScene &sc, F3 ref_p, bool is_medium_inte
         bool escaped_medium = false, active_medium = medium >= 0, active_surface = !active_medium;
         if (active_medium) {
             const DMedium &m = sc.media[medium];
-            MediumSample mi = medium_sample_interaction<COUNT>(sc, medium, ray, rng.next_1d(), channel, cnt);
+            MediumSample mi = medium_sample_interaction<COUNT>(sc, medium, ray, rng.next_1d(), channel, cnt, cx);
             if (m.is_homogeneous && ms_valid(mi)) ray.maxt = pm_min(mi.t, remaining_dist);
             if (needs_intersection) si = ray_intersect(sc, ray);
             if (si.t < mi.t) mi.t = pm_inf();
@@ -1342,8 +1367,8 @@ DEV F3 volpathmis_sample_emitter(const DScene &sc, F3 ref_p, bool is_medium_inte
             bool is_spectral = m.has_spectral_extinction != 0, not_spectral = !is_spectral;
             if (is_spectral) {
                 float t = pm_min(remaining_dist, pm_min(mi.t, si.t)) - mi.mint;
-                F3 tr = transmittance_exp(t, mi.combined);
-                F3 free_flight_pdf = (si.t < mi.t || mi.t > remaining_dist) ? tr : tr * mi.combined;
+                Spec tr = transmittance_exp(t, mi.combined);
+                Spec free_flight_pdf = (si.t < mi.t || mi.t > remaining_dist) ? tr : tr * mi.combined;
                 update_weights(p_over_f_nee, free_flight_pdf, tr, channel, true);
                 update_weights(p_over_f_uni, free_flight_pdf, tr, channel, true);
             }
@@ -1371,7 +1396,7 @@ DEV F3 volpathmis_sample_emitter(const DScene &sc, F3 ref_p, bool is_medium_inte
         if (active_surface) total_dist += si.t;
         active_surface = active_surface && hit_valid(si) && active && !active_medium;
         if (active_surface) {
-            F3 bsdf_val = null_transmission(sc, sc.shapes[si.shape]);
+            Spec bsdf_val = null_transmission(sc, sc.shapes[si.shape]);
             update_weights(p_over_f_nee, 1.0f, bsdf_val, channel, true);
             update_weights(p_over_f_uni, 1.0f, bsdf_val, channel, true);
         }
@@ -1388,21 +1413,25 @@ DEV F3 volpathmis_sample_emitter(const DScene &sc, F3 ref_p, bool is_medium_inte
 
 // volpathmis.cpp:86-328
 template <bool COUNT, bool SPEC>
-DEV F3 volpathmis_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, bool &valid_out, Counters &cnt) {
+DEV Spec volpathmis_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, bool &valid_out, Counters &cnt, const SpecCtx &cx = SpecCtx()) {
     const uint32_t max_depth = (uint32_t) sc.integrator.max_depth, rr_depth = (uint32_t) sc.integrator.rr_depth;
     const bool hide_emitters = sc.integrator.hide_emitters != 0;
     bool valid_ray = !hide_emitters && sc.environment >= 0;
     float eta = 1.f;
-    F3 result = f3s(0.f);
+    Spec result = spec_s(0.f);
     bool active = true, specular_chain = !hide_emitters;
     uint32_t depth = 0;
     MisWeights<SPEC> p_over_f = mw_full<SPEC>(1.f), p_over_f_nee = mw_full<SPEC>(1.f);
+#if MTS_SPEC_N == 3
     uint32_t channel = sc.integrator.monochrome ? 0u : (uint32_t) pm_min(rng.next_1d() * 3.f, 2.f);   // volpathmis.cpp:120-124
+#else
+    const uint32_t channel = 0;                                                               // :120-124: a draw in the rgb variants only
+#endif
     Hit si; si.t = pm_inf(); si.shape = -1; si.prim = 0; si.p = f3s(0.f); si.uv.x = si.uv.y = 0.f;
     bool needs_intersection = true, last_event_was_null = false;
     F3 last_scatter_p = f3s(0.f);                                                             // last_scatter_event: only .p is read
     for (;;) {
-        F3 mis_throughput = mis_weight_w(p_over_f);
+        Spec mis_throughput = mis_weight_w(p_over_f);
         float q = pm_min(hmax(mis_throughput) * (eta * eta), .95f);
         bool perform_rr = active && !last_event_was_null && (depth > rr_depth);
         active = active && !(rng.next_1d() >= q && perform_rr);
@@ -1420,15 +1449,15 @@ DEV F3 volpathmis_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, boo
         if (active_medium) { is_spectral = is_spectral && sc.media[medium].has_spectral_extinction != 0; not_spectral = !is_spectral && active_medium; }
         if (active_medium) {
             const DMedium &m = sc.media[medium];
-            mi = medium_sample_interaction<COUNT>(sc, medium, ray, rng.next_1d(), channel, cnt);
+            mi = medium_sample_interaction<COUNT>(sc, medium, ray, rng.next_1d(), channel, cnt, cx);
             if (m.is_homogeneous && ms_valid(mi)) ray.maxt = mi.t;
             if (needs_intersection) si = ray_intersect(sc, ray);
             needs_intersection = false;
             if (si.t < mi.t) mi.t = pm_inf();
             if (is_spectral) {
                 float t = pm_min(mi.t, si.t) - mi.mint;                                       // medium.cpp:77-89
-                F3 tr = transmittance_exp(t, mi.combined);
-                F3 free_flight_pdf = si.t < mi.t ? tr : tr * mi.combined;
+                Spec tr = transmittance_exp(t, mi.combined);
+                Spec free_flight_pdf = si.t < mi.t ? tr : tr * mi.combined;
                 update_weights(p_over_f, free_flight_pdf, tr, channel, true);
                 update_weights(p_over_f_nee, free_flight_pdf, tr, channel, true);
             }
@@ -1465,8 +1494,8 @@ DEV F3 volpathmis_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, boo
                 F3 wi = -ray.d;
                 if (sample_emitters) {
                     MisWeights<SPEC> nee_end, uni_end; DirSample ds;
-                    F3 emitted = volpathmis_sample_emitter<COUNT, SPEC>(sc, mi.p, true, rng, medium, p_over_f, channel, nee_end, uni_end, ds, cnt);
-                    float phase_val = phase_eval(sc, m.phase, wi, mi.p, ds.d);
+                    Spec emitted = volpathmis_sample_emitter<COUNT, SPEC>(sc, mi.p, true, rng, medium, p_over_f, channel, nee_end, uni_end, ds, cnt, cx);
+                    float phase_val = phase_eval(sc, m.phase, wi, mi.p, ds.d, cx);
                     update_weights(nee_end, 1.0f, phase_val, channel, true);
                     update_weights(uni_end, ds.delta ? 0.f : phase_val, phase_val, channel, true);
                     result = result + mis_weight_w(nee_end, uni_end) * emitted;
@@ -1474,7 +1503,7 @@ DEV F3 volpathmis_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, boo
                 p_over_f_nee = p_over_f;
                 float s1 = rng.next_1d(); F2 s2 = rng.next_2d();                              // left-to-right (SURVEY.md 8(a'))
                 float phase_pdf;
-                F3 wo = phase_sample_pdf(sc, m.phase, make_frame(ray.d), mi.p, s1, s2, phase_pdf);
+                F3 wo = phase_sample_pdf(sc, m.phase, make_frame(ray.d), mi.p, s1, s2, phase_pdf, cx);
                 ray = spawn_ray(mi.p, wo); ray.mint = 0.0f;
                 needs_intersection = true;
                 update_weights(p_over_f, phase_pdf, phase_pdf, channel, true);
@@ -1500,8 +1529,8 @@ DEV F3 volpathmis_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, boo
                     float emitter_pdf = pdf_emitter_direction(sc, last_scatter_p, ds);
                     update_weights(p_over_f_nee, emitter_pdf, 1.f, channel, true);
                 }
-                F3 emitted = emitter_eval(sc, emitter, sf.wi.z);
-                F3 contrib = count_direct ? mis_weight_w(p_over_f) * emitted : mis_weight_w(p_over_f, p_over_f_nee) * emitted;
+                Spec emitted = emitter_eval(sc, emitter, sf.wi.z, cx);
+                Spec contrib = count_direct ? mis_weight_w(p_over_f) * emitted : mis_weight_w(p_over_f, p_over_f_nee) * emitted;
                 result = result + contrib;
             }
         }
@@ -1512,17 +1541,17 @@ DEV F3 volpathmis_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, boo
             bool active_e = (bsdf.flags & F_Smooth) != 0 && (depth + 1 < max_depth);
             if (active_e) {
                 MisWeights<SPEC> nee_end, uni_end; DirSample ds;
-                F3 emitted = volpathmis_sample_emitter<COUNT, SPEC>(sc, si.p, false, rng, medium, p_over_f, channel, nee_end, uni_end, ds, cnt);
+                Spec emitted = volpathmis_sample_emitter<COUNT, SPEC>(sc, si.p, false, rng, medium, p_over_f, channel, nee_end, uni_end, ds, cnt, cx);
                 F3 wo_local = to_local(sf.sh, ds.d);
-                F3 bsdf_val = bsdf_eval(bsdf, sf.wi, wo_local);
-                float bpdf = bsdf_pdf(bsdf, sf.wi, wo_local);
+                Spec bsdf_val = bsdf_eval(bsdf, sf.wi, wo_local, cx, shape.bsdf);
+                float bpdf = bsdf_pdf(bsdf, sf.wi, wo_local, cx, shape.bsdf);
                 update_weights(nee_end, 1.0f, bsdf_val, channel, true);
                 update_weights(uni_end, ds.delta ? 0.f : bpdf, bsdf_val, channel, true);
                 result = result + mis_weight_w(nee_end, uni_end) * emitted;
             }
             float s1 = rng.next_1d(); F2 s2 = rng.next_2d();
             BSDFSample bs;
-            F3 bsdf_weight = bsdf_sample(bsdf, sf.wi, s1, s2, bs);
+            Spec bsdf_weight = bsdf_sample(bsdf, sf.wi, s1, s2, bs, cx, shape.bsdf);
             bool invalid_bsdf_sample = bs.pdf == 0.f;
             active_surface = active_surface && bs.pdf > 0.f;
             if (active_surface) eta *= bs.eta;
@@ -1544,7 +1573,6 @@ DEV F3 volpathmis_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, boo
     return result;
 }
 
-#endif // MTS_SPEC_N == 3
 // ---------------------------------------------------------------- path
 // integrators/path.cpp:100-211
 template <bool COUNT>
@@ -1616,16 +1644,12 @@ template <bool COUNT, int INTEG = NI_ANY>
 DEV Spec integrator_sample(const DScene &sc, Pcg32 &rng, DRay ray, int medium, bool &valid, Counters &cnt, const SpecCtx &cx = SpecCtx()) {
     if (INTEG == NI_PATH) return path_sample<COUNT>(sc, rng, ray, valid, cnt, cx);
     if (INTEG == NI_VOLPATH) return volpath_sample<COUNT>(sc, rng, ray, medium, valid, cnt, cx);
-#if MTS_SPEC_N == 3
-    if (INTEG == NI_VOLPATHMIS) return volpathmis_sample<COUNT, true>(sc, rng, ray, medium, valid, cnt);
-    if (INTEG == NI_VOLPATHMIS_NOSPEC) return volpathmis_sample<COUNT, false>(sc, rng, ray, medium, valid, cnt);
-#endif
+    if (INTEG == NI_VOLPATHMIS) return volpathmis_sample<COUNT, true>(sc, rng, ray, medium, valid, cnt, cx);
+    if (INTEG == NI_VOLPATHMIS_NOSPEC) return volpathmis_sample<COUNT, false>(sc, rng, ray, medium, valid, cnt, cx);
     if (sc.integrator.type == MTS_INTEGRATOR_VOLPATH) return volpath_sample<COUNT>(sc, rng, ray, medium, valid, cnt, cx);
-#if MTS_SPEC_N == 3
     if (sc.integrator.type == MTS_INTEGRATOR_VOLPATHMIS)
-        return sc.integrator.use_spectral_mis ? volpathmis_sample<COUNT, true>(sc, rng, ray, medium, valid, cnt)
-                                              : volpathmis_sample<COUNT, false>(sc, rng, ray, medium, valid, cnt);
-#endif
+        return sc.integrator.use_spectral_mis ? volpathmis_sample<COUNT, true>(sc, rng, ray, medium, valid, cnt, cx)
+                                              : volpathmis_sample<COUNT, false>(sc, rng, ray, medium, valid, cnt, cx);
     return path_sample<COUNT>(sc, rng, ray, valid, cnt, cx);
 }
 

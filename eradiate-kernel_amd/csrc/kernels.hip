@@ -313,7 +313,6 @@ hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks,
     }
     const bool flat = variant != 0;
 #else
-    if (sc.integrator.type == MTS_INTEGRATOR_VOLPATHMIS) return hipErrorInvalidValue;
     if (variant >= 10000 && sc.integrator.type == MTS_INTEGRATOR_VOLPATH) {        // four-wide state: 42 hot dwords per path, 512 paths fill the LDS
         const uint32_t wg = (uint32_t) (variant - 10000);
         const uint32_t grid = (uint32_t) ((threads + wg - 1) / wg);
@@ -338,10 +337,8 @@ hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks,
 #endif
     if (sc.integrator.type == MTS_INTEGRATOR_PATH) LAUNCH_C(false, NI_PATH);
     else if (sc.integrator.type == MTS_INTEGRATOR_VOLPATH) LAUNCH_C(false, NI_VOLPATH);
-#if MTS_SPEC_N == 3
     else if (sc.integrator.use_spectral_mis) LAUNCH_C(false, NI_VOLPATHMIS);
     else LAUNCH_C(false, NI_VOLPATHMIS_NOSPEC);
-#endif
 #undef LAUNCH_C
 #undef LAUNCH
     (void) use_flat;

@@ -195,7 +195,6 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
     const bool spectral = d->integrator.spectral != 0;
     // ---- spectra (spectral variant; uniform.cpp:34-52, regular.cpp:27-58 + distr_1d.h:318-345)
     if (spectral) {
-        if (d->integrator.type == MTS_INTEGRATOR_VOLPATHMIS) throw std::runtime_error("volpathmis is not available in the spectral variant of this backend");
         if (d->integrator.monochrome) throw std::runtime_error("a scene is either monochromatic or spectral");
         for (int i = 0; i < d->spectrum_count; ++i) {
             const mts_spectrum &sp = d->spectra[i];

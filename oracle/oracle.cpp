@@ -1017,68 +1017,90 @@ static Spec volpath_sample(const Scene &sc, Sampler &sampler, Ray ray, int mediu
     return result;
 }
 
-#if MTS_SPEC_N == 3         // volpathmis is restated for the rgb / mono variants only
 // ---------------------------------------------------------------- volpathmis
-// src/integrators/volpathmis.cpp: the volumetric path tracer with spectral multiple importance sampling.  WeightMatrix is a
-// 3 x 3 matrix (one row of probability ratios per colour channel) with `use_spectral_mis` (the default, :29,38-46), a single
-// row without.  hsum is evaluated left to right.
-template <bool SPEC> struct MisWeights { V3 r[SPEC ? 3 : 1]; };
-template <bool SPEC> static inline MisWeights<SPEC> mw_full(float v) { MisWeights<SPEC> w; for (auto &x : w.r) x = v3(v, v, v); return w; }
+// src/integrators/volpathmis.cpp: the volumetric path tracer with spectral multiple importance sampling.  WeightMatrix (:66-69) is
+// an n x n matrix with n = array_size_v<UnpolarizedSpectrum> -- 3 x 3 in the rgb variants, 4 x 4 in the spectral one (one row of
+// probability ratios per colour channel / wavelength) -- with `use_spectral_mis` (the default, :29,38-46), a single spectrum without.
+// Outside the rgb variants index_spectrum returns spec[0] (:74-84) and `channel` stays 0 without a draw (:118-124).
+// hsum of a 3-array is evaluated left to right, of a 4-array pairwise (as spec_hmean, oracle_math.h).
+static inline float sget(const Spec &a, int i) { return (&a.x)[i]; }
+static inline void sset(Spec &a, int i, float v) { (&a.x)[i] = v; }
+static inline float spec_hsum(Spec a) {
+#if MTS_SPEC_N == 3
+    return (a.x + a.y) + a.z;
+#else
+    return (a.x + a.y) + (a.z + a.w);
+#endif
+}
+static inline float spec_hmin_abs(Spec a) {
+    float m = pm_min(pm_min(pm_abs(a.x), pm_abs(a.y)), pm_abs(a.z));
+#if MTS_SPEC_N != 3
+    m = pm_min(pm_min(pm_abs(a.x), pm_abs(a.y)), pm_min(pm_abs(a.z), pm_abs(a.w)));
+#endif
+    return m;
+}
+template <bool SPEC> struct MisWeights { Spec r[SPEC ? MTS_SPEC_N : 1]; };
+template <bool SPEC> static inline MisWeights<SPEC> mw_full(float v) { MisWeights<SPEC> w; for (auto &x : w.r) x = spec_s(v); return w; }
 static inline bool finite3(float x) { return pm_isfinite(x); }
 // volpathmis.cpp:447-466
 template <bool SPEC>
-static inline void update_weights(MisWeights<SPEC> &w, V3 p, V3 f, uint32_t channel, bool active) {
+static inline void update_weights(MisWeights<SPEC> &w, Spec p, Spec f, uint32_t channel, bool active) {
     if (SPEC) {
-        for (int i = 0; i < 3; ++i) {
-            float fi = idx(f, (uint32_t) i);
-            V3 ratio = v3(p.x / fi, p.y / fi, p.z / fi);
-            ratio = v3(finite3(ratio.x) ? ratio.x : 0.f, finite3(ratio.y) ? ratio.y : 0.f, finite3(ratio.z) ? ratio.z : 0.f);
+        for (int i = 0; i < MTS_SPEC_N; ++i) {
+            float fi = sget(f, i);
+            Spec ratio;
+            for (int j = 0; j < MTS_SPEC_N; ++j) { float r = sget(p, j) / fi; sset(ratio, j, finite3(r) ? r : 0.f); }
             ratio = ratio * w.r[i];
-            if (active) w.r[i] = v3(ratio.x != ratio.x ? 0.f : ratio.x, ratio.y != ratio.y ? 0.f : ratio.y, ratio.z != ratio.z ? 0.f : ratio.z);
+            if (active) for (int j = 0; j < MTS_SPEC_N; ++j) { float r = sget(ratio, j); sset(w.r[i], j, r != r ? 0.f : r); }
         }
     } else {
         float pdf = idx(p, channel);
-        V3 ratio = w.r[0] * v3(pdf / f.x, pdf / f.y, pdf / f.z);
-        if (active) w.r[0] = v3(finite3(ratio.x) ? ratio.x : 0.f, finite3(ratio.y) ? ratio.y : 0.f, finite3(ratio.z) ? ratio.z : 0.f);
+        Spec ratio;
+        for (int j = 0; j < MTS_SPEC_N; ++j) sset(ratio, j, pdf / sget(f, j));
+        ratio = w.r[0] * ratio;
+        if (active) for (int j = 0; j < MTS_SPEC_N; ++j) { float r = sget(ratio, j); sset(w.r[0], j, finite3(r) ? r : 0.f); }
     }
 }
-template <bool SPEC> static inline void update_weights(MisWeights<SPEC> &w, float p, V3 f, uint32_t c, bool a) { update_weights(w, v3(p, p, p), f, c, a); }
-template <bool SPEC> static inline void update_weights(MisWeights<SPEC> &w, V3 p, float f, uint32_t c, bool a) { update_weights(w, p, v3(f, f, f), c, a); }
-template <bool SPEC> static inline void update_weights(MisWeights<SPEC> &w, float p, float f, uint32_t c, bool a) { update_weights(w, v3(p, p, p), v3(f, f, f), c, a); }
+template <bool SPEC> static inline void update_weights(MisWeights<SPEC> &w, float p, Spec f, uint32_t c, bool a) { update_weights(w, spec_s(p), f, c, a); }
+template <bool SPEC> static inline void update_weights(MisWeights<SPEC> &w, Spec p, float f, uint32_t c, bool a) { update_weights(w, p, spec_s(f), c, a); }
+template <bool SPEC> static inline void update_weights(MisWeights<SPEC> &w, float p, float f, uint32_t c, bool a) { update_weights(w, spec_s(p), spec_s(f), c, a); }
 // volpathmis.cpp:468-481
 template <bool SPEC>
-static inline V3 mis_weight_w(const MisWeights<SPEC> &w) {
+static inline Spec mis_weight_w(const MisWeights<SPEC> &w) {
     if (SPEC) {
-        float o[3];
-        for (int i = 0; i < 3; ++i) { float sum = (w.r[i].x + w.r[i].y) + w.r[i].z; o[i] = sum == 0.f ? 0.f : 3.f / sum; }
-        return v3(o[0], o[1], o[2]);
+        Spec o;
+        for (int i = 0; i < MTS_SPEC_N; ++i) { float sum = spec_hsum(w.r[i]); sset(o, i, sum == 0.f ? 0.f : (float) MTS_SPEC_N / sum); }
+        return o;
     }
-    V3 a = w.r[0];
-    bool invalid = pm_min(pm_min(pm_abs(a.x), pm_abs(a.y)), pm_abs(a.z)) == 0.f;
-    return invalid ? v3(0.f, 0.f, 0.f) : v3(1.f / a.x, 1.f / a.y, 1.f / a.z);
+    Spec a = w.r[0];
+    if (spec_hmin_abs(a) == 0.f) return spec_s(0.f);
+    Spec o;
+    for (int j = 0; j < MTS_SPEC_N; ++j) sset(o, j, 1.f / sget(a, j));
+    return o;
 }
 // volpathmis.cpp:484-498
 template <bool SPEC>
-static inline V3 mis_weight_w(const MisWeights<SPEC> &a, const MisWeights<SPEC> &b) {
+static inline Spec mis_weight_w(const MisWeights<SPEC> &a, const MisWeights<SPEC> &b) {
     if (SPEC) {
-        float o[3];
-        for (int i = 0; i < 3; ++i) { V3 r = a.r[i] + b.r[i]; float sum = (r.x + r.y) + r.z; o[i] = sum == 0.f ? 0.f : 3.f / sum; }
-        return v3(o[0], o[1], o[2]);
+        Spec o;
+        for (int i = 0; i < MTS_SPEC_N; ++i) { float sum = spec_hsum(a.r[i] + b.r[i]); sset(o, i, sum == 0.f ? 0.f : (float) MTS_SPEC_N / sum); }
+        return o;
     }
-    V3 sum = a.r[0] + b.r[0];
-    bool zero = pm_min(pm_min(pm_abs(sum.x), pm_abs(sum.y)), pm_abs(sum.z)) == 0.f;
-    return zero ? v3(0.f, 0.f, 0.f) : v3(1.f / sum.x, 1.f / sum.y, 1.f / sum.z);
+    Spec sum = a.r[0] + b.r[0];
+    if (spec_hmin_abs(sum) == 0.f) return spec_s(0.f);
+    Spec o;
+    for (int j = 0; j < MTS_SPEC_N; ++j) sset(o, j, 1.f / sget(sum, j));
+    return o;
 }
-
 // volpathmis.cpp:330-445
 template <bool SPEC>
-static V3 volpathmis_sample_emitter(const Scene &sc, V3 ref_p, bool is_medium_interaction, Sampler &sampler, int medium, const MisWeights<SPEC> &p_over_f,
+static Spec volpathmis_sample_emitter(const Scene &sc, V3 ref_p, bool is_medium_interaction, Sampler &sampler, int medium, const MisWeights<SPEC> &p_over_f,
                                     uint32_t channel, MisWeights<SPEC> *nee_out, MisWeights<SPEC> *uni_out, DirectionSample *ds_out, Counters *cnt) {
     MisWeights<SPEC> p_over_f_nee = p_over_f, p_over_f_uni = p_over_f;
-    V3 emitter_sample_weight;
+    Spec emitter_sample_weight;
     DirectionSample ds = sample_emitter_direction(sc, ref_p, sampler.next_2d(), false, &emitter_sample_weight);
-    V3 emitter_val = emitter_sample_weight * ds.pdf;
-    if (ds.pdf == 0.f) emitter_val = v3(0.f, 0.f, 0.f);
+    Spec emitter_val = emitter_sample_weight * ds.pdf;
+    if (ds.pdf == 0.f) emitter_val = spec_s(0.f);
     bool active = ds.pdf != 0.f;
     update_weights(p_over_f_nee, ds.pdf, 1.0f, channel, active);
     *ds_out = ds;
@@ -1105,8 +1127,8 @@ static V3 volpathmis_sample_emitter(const Scene &sc, V3 ref_p, bool is_medium_in
             bool is_spectral = m.has_spectral_extinction, not_spectral = !is_spectral;
             if (is_spectral) {
                 float t = pm_min(remaining_dist, pm_min(mi.t, si.t)) - mi.mint;
-                V3 tr = v3(pm_exp(-t * mi.combined_extinction.x), pm_exp(-t * mi.combined_extinction.y), pm_exp(-t * mi.combined_extinction.z));
-                V3 free_flight_pdf = (si.t < mi.t || mi.t > remaining_dist) ? tr : tr * mi.combined_extinction;
+                Spec tr = transmittance_exp(t, mi.combined_extinction);
+                Spec free_flight_pdf = (si.t < mi.t || mi.t > remaining_dist) ? tr : tr * mi.combined_extinction;
                 update_weights(p_over_f_nee, free_flight_pdf, tr, channel, true);
                 update_weights(p_over_f_uni, free_flight_pdf, tr, channel, true);
             }
@@ -1134,7 +1156,7 @@ static V3 volpathmis_sample_emitter(const Scene &sc, V3 ref_p, bool is_medium_in
         if (active_surface) total_dist += si.t;
         active_surface = active_surface && si.is_valid() && active && !active_medium;
         if (active_surface) {
-            V3 bsdf_val = bsdf_eval_null_transmission(sc.bsdf_of(sc.shapes[si.shape]));
+            Spec bsdf_val = bsdf_eval_null_transmission(sc.bsdf_of(sc.shapes[si.shape]));
             update_weights(p_over_f_nee, 1.0f, bsdf_val, channel, true);
             update_weights(p_over_f_uni, 1.0f, bsdf_val, channel, true);
         }
@@ -1151,22 +1173,26 @@ static V3 volpathmis_sample_emitter(const Scene &sc, V3 ref_p, bool is_medium_in
 
 // volpathmis.cpp:86-328
 template <bool SPEC>
-static V3 volpathmis_sample(const Scene &sc, Sampler &sampler, Ray ray, int medium, bool *valid_out, Counters *cnt) {
+static Spec volpathmis_sample(const Scene &sc, Sampler &sampler, Ray ray, int medium, bool *valid_out, Counters *cnt) {
     const uint32_t max_depth = (uint32_t) sc.integrator.max_depth, rr_depth = (uint32_t) sc.integrator.rr_depth;
     const bool hide_emitters = sc.integrator.hide_emitters != 0;
     bool valid_ray = !hide_emitters && sc.environment >= 0;
     float eta = 1.f;
-    V3 result = v3(0.f, 0.f, 0.f);
+    Spec result = spec_s(0.f);
     MediumInteraction mi; memset(&mi, 0, sizeof(mi)); mi.t = pm_inf();
     bool active = true, specular_chain = !hide_emitters;
     uint32_t depth = 0;
     MisWeights<SPEC> p_over_f = mw_full<SPEC>(1.f), p_over_f_nee = mw_full<SPEC>(1.f);
+#if MTS_SPEC_N == 3
     uint32_t channel = sc.integrator.monochrome ? 0u : (uint32_t) pm_min(sampler.next_1d() * 3.f, 2.f);   // volpathmis.cpp:120-124
+#else
+    uint32_t channel = 0;                                                                     // :120-124: a draw in the rgb variants only
+#endif
     SurfaceInteraction si; memset(&si, 0, sizeof(si)); si.t = pm_inf(); si.shape = -1;
     bool needs_intersection = true, last_event_was_null = false;
     V3 last_scatter_p = v3(0.f, 0.f, 0.f);                                                    // last_scatter_event: only .p is read
     for (;;) {
-        V3 mis_throughput = mis_weight_w(p_over_f);
+        Spec mis_throughput = mis_weight_w(p_over_f);
         float q = pm_min(hmax(mis_throughput) * (eta * eta), .95f);
         bool perform_rr = active && !last_event_was_null && (depth > rr_depth);
         active = active && !(sampler.next_1d() >= q && perform_rr);
@@ -1190,8 +1216,8 @@ static V3 volpathmis_sample(const Scene &sc, Sampler &sampler, Ray ray, int medi
             if (si.t < mi.t) mi.t = pm_inf();
             if (is_spectral) {
                 float t = pm_min(mi.t, si.t) - mi.mint;                                       // medium.cpp:77-89
-                V3 tr = v3(pm_exp(-t * mi.combined_extinction.x), pm_exp(-t * mi.combined_extinction.y), pm_exp(-t * mi.combined_extinction.z));
-                V3 free_flight_pdf = si.t < mi.t ? tr : tr * mi.combined_extinction;
+                Spec tr = transmittance_exp(t, mi.combined_extinction);
+                Spec free_flight_pdf = si.t < mi.t ? tr : tr * mi.combined_extinction;
                 update_weights(p_over_f, free_flight_pdf, tr, channel, true);
                 update_weights(p_over_f_nee, free_flight_pdf, tr, channel, true);
             }
@@ -1226,7 +1252,7 @@ static V3 volpathmis_sample(const Scene &sc, Sampler &sampler, Ray ray, int medi
                 valid_ray = true;
                 if (sample_emitters) {
                     MisWeights<SPEC> nee_end, uni_end; DirectionSample ds;
-                    V3 emitted = volpathmis_sample_emitter<SPEC>(sc, mi.p, true, sampler, medium, p_over_f, channel, &nee_end, &uni_end, &ds, cnt);
+                    Spec emitted = volpathmis_sample_emitter<SPEC>(sc, mi.p, true, sampler, medium, p_over_f, channel, &nee_end, &uni_end, &ds, cnt);
                     bool active_e = true;
                     float phase_val = phase_eval(sc, m.phase, mi, ds.d);
                     update_weights(nee_end, 1.0f, phase_val, channel, active_e);
@@ -1260,8 +1286,8 @@ static V3 volpathmis_sample(const Scene &sc, Sampler &sampler, Ray ray, int medi
                     float emitter_pdf = pdf_emitter_direction(sc, last_scatter_p, ds);
                     update_weights(p_over_f_nee, emitter_pdf, 1.f, channel, true);
                 }
-                V3 emitted = emitter_eval(sc, emitter, si);
-                V3 contrib = count_direct ? mis_weight_w(p_over_f) * emitted : mis_weight_w(p_over_f, p_over_f_nee) * emitted;
+                Spec emitted = emitter_eval(sc, emitter, si);
+                Spec contrib = count_direct ? mis_weight_w(p_over_f) * emitted : mis_weight_w(p_over_f, p_over_f_nee) * emitted;
                 result = result + contrib;
             }
         }
@@ -1272,9 +1298,9 @@ static V3 volpathmis_sample(const Scene &sc, Sampler &sampler, Ray ray, int medi
             bool active_e = (bsdf.flags & F_Smooth) != 0 && (depth + 1 < max_depth);
             if (active_e) {
                 MisWeights<SPEC> nee_end, uni_end; DirectionSample ds;
-                V3 emitted = volpathmis_sample_emitter<SPEC>(sc, si.p, false, sampler, medium, p_over_f, channel, &nee_end, &uni_end, &ds, cnt);
+                Spec emitted = volpathmis_sample_emitter<SPEC>(sc, si.p, false, sampler, medium, p_over_f, channel, &nee_end, &uni_end, &ds, cnt);
                 V3 wo_local = si.to_local(ds.d);
-                V3 bsdf_val = bsdf_eval(bsdf, si, wo_local);
+                Spec bsdf_val = bsdf_eval(bsdf, si, wo_local);
                 float bpdf = bsdf_pdf(bsdf, si, wo_local);
                 update_weights(nee_end, 1.0f, bsdf_val, channel, true);
                 update_weights(uni_end, ds.delta ? 0.f : bpdf, bsdf_val, channel, true);
@@ -1282,7 +1308,7 @@ static V3 volpathmis_sample(const Scene &sc, Sampler &sampler, Ray ray, int medi
             }
             float s1 = sampler.next_1d(); P2 s2 = sampler.next_2d();
             BSDFSample bs;
-            V3 bsdf_weight = bsdf_sample(bsdf, si, s1, s2, &bs);
+            Spec bsdf_weight = bsdf_sample(bsdf, si, s1, s2, &bs);
             bool invalid_bsdf_sample = bs.pdf == 0.f;
             active_surface = active_surface && bs.pdf > 0.f;
             if (active_surface) eta *= bs.eta;
@@ -1304,7 +1330,6 @@ static V3 volpathmis_sample(const Scene &sc, Sampler &sampler, Ray ray, int medi
     return result;
 }
 
-#endif // MTS_SPEC_N == 3
 // path.cpp:100-211
 static Spec path_sample(const Scene &sc, Sampler &sampler, Ray ray, bool *valid_out, Counters *cnt) {
     const int max_depth = sc.integrator.max_depth, rr_depth = sc.integrator.rr_depth;
@@ -1363,10 +1388,8 @@ static Spec path_sample(const Scene &sc, Sampler &sampler, Ray ray, bool *valid_
 static Spec integrator_sample(const Scene &sc, Sampler &sampler, Ray ray, int medium, bool *valid, Counters *cnt) {
     switch (sc.integrator.type) {
         case MTS_INTEGRATOR_VOLPATH: return volpath_sample(sc, sampler, ray, medium, valid, cnt);
-#if MTS_SPEC_N == 3
         case MTS_INTEGRATOR_VOLPATHMIS: return sc.integrator.use_spectral_mis ? volpathmis_sample<true>(sc, sampler, ray, medium, valid, cnt)
                                                                              : volpathmis_sample<false>(sc, sampler, ray, medium, valid, cnt);
-#endif
         default: return path_sample(sc, sampler, ray, valid, cnt);
     }
 }

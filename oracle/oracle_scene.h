@@ -490,7 +490,6 @@ static inline Scene *make_scene(const mts_scene_desc *d) {
         if (d->integrator.spectral) throw std::runtime_error("liboracle.so is the rgb / mono build; spectral scenes need liboracle_spectral.so");
 #else
         if (!d->integrator.spectral) throw std::runtime_error("liboracle_spectral.so renders scenes of the spectral variant only");
-        if (d->integrator.type == MTS_INTEGRATOR_VOLPATHMIS) throw std::runtime_error("volpathmis is not restated for the spectral variant");
         for (int i = 0; i < d->spectrum_count; ++i) {                      // uniform.cpp:34-52, regular.cpp:27-58 + distr_1d.h:318-345
             const mts_spectrum &sp = d->spectra[i];
             SpectrumRec r; r.type = sp.type; r.value = sp.value; r.lambda_min = sp.lambda_min; r.lambda_max = sp.lambda_max; r.inv_interval_size = 0.f;

@@ -816,6 +816,22 @@ def test_spectral_variant_against_oracle(gpu_spectral, monkeypatch, name, kernel
     assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (o.last_stats["n_iter"], o.last_stats["n_lookup"], o.last_stats["n_nee_step"])
 
 
+@pytest.mark.parametrize("use_spectral_mis", [True, False])
+@pytest.mark.parametrize("name", ["slab_regular_reflectance", "slab_chromatic_medium", "grid_spectral_d65_rpv", "cornell_path", "c4_atmosphere",
+                                  "c5s_atmosphere"])
+def test_spectral_volpathmis_against_oracle(gpu_spectral, name, use_spectral_mis):
+    """src/integrators/volpathmis.cpp in the spectral variant (WeightMatrix = 4 x 4, `channel` 0, index_spectrum -> spec[0]: :66-84,
+    118-122), with and without spectral MIS, against liboracle_spectral.so: films and loop counters identical."""
+    d = _spectral_cases()[name]
+    d["integrator"] = dict(d["integrator"], type="volpathmis", use_spectral_mis=use_spectral_mis)
+    gpu, st = gpu_render(gpu_spectral, d, collect_counters=True)
+    o = ob.OracleScene(d, spectral=True)
+    ref = o.render()
+    assert ref[..., :3].max() > 0
+    assert_parity(gpu, ref)
+    assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (o.last_stats["n_iter"], o.last_stats["n_lookup"], o.last_stats["n_nee_step"])
+
+
 def test_bin_integrators_srf_and_irregular_spectra(gpu_spectral):
     """src/integrators/nbins.cpp / bins.cpp (two AOV channels per spectral bin behind X, Y, Z, A, W), the sensors' `srf` (uniform and
     discrete: perspective.cpp:173-182, radiancemeter.cpp:116-124) and `irregular` spectra: the reference's own two sample tests
