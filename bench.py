@@ -31,7 +31,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
 CONFIG_SIZES = {"C1": (256, 256, 64), "C2": (512, 512, 256), "C3": (512, 512, 1024), "C4": (1024, 1024, 4096), "C5": (1024, 1024, 4096),
-                "C5S": (1024, 1024, 256), "C3M": (512, 512, 1024), "C1L": (512, 512, 256)}      # C5S: the same atmosphere in the spectral variant (gpu_spectral), 256 spp
+                "C5S": (1024, 1024, 256), "C5SM": (1024, 1024, 256), "C3M": (512, 512, 1024), "C1L": (512, 512, 256)}      # C5S: the same atmosphere in the spectral variant (gpu_spectral), 256 spp
 C5_WAVELENGTHS = 16        # BASELINE.json configs[4]: the C4 atmosphere as a 16-wavelength batch
 
 
@@ -50,8 +50,10 @@ def build_scene_dict(scenes, config, width, height, spp, samples_per_pass=-1, re
         d = scenes.c4_atmosphere(width, height, spp)
     elif config == "C5":
         d = scenes.c4_atmosphere(width, height, spp, rayleigh_scale=c5_rayleigh_scale(wavelength))
-    elif config == "C5S":
+    elif config in ("C5S", "C5SM"):
         d = scenes.c5_atmosphere_spectral(width, height, spp)
+        if config == "C5SM":                                        # the spectral atmosphere under volpathmis (4 x 4 weight matrices)
+            d["integrator"]["type"] = "volpathmis"
     else:
         d = scenes.c3_heterogeneous(width, height, spp, res=res)
         if config == "C3M":                                         # the metric scene under volpathmis (side measurement)
@@ -67,7 +69,7 @@ class Job:
         import torch
         self.torch, self.rank, self.n, self.backend = torch, rank, n, backend
         # C5: monochromatic batches (scalar_mono semantics), one per wavelength; C5S: the spectral variant
-        variant = {"C5": "gpu_mono", "C5S": "gpu_spectral"}.get(args.config, "gpu_rgb")
+        variant = {"C5": "gpu_mono", "C5S": "gpu_spectral", "C5SM": "gpu_spectral"}.get(args.config, "gpu_rgb")
         pkg.set_variant(variant)
         self.dicts = [build_scene_dict(scenes, args.config, args.width, args.height, spp_total, samples_per_pass, args.res, k)
                       for k in range(C5_WAVELENGTHS if args.config == "C5" else 1)]
@@ -212,12 +214,12 @@ def main():
     elif kv == "flat" and integ_type == "volpath":
         kernel_name = "render_kernel<false, true, 1>"
     elif integ_type == "volpathmis":
-        kernel_name = "render_kernel_wga_mis<false, true, 512, 512>"
+        kernel_name = "v_spectral::render_kernel_wga_mis<false, true, 256, 256>" if args.config == "C5SM" else "render_kernel_wga_mis<false, true, 512, 512>"
     elif args.config == "C5S":
         kernel_name = "v_spectral::render_kernel_wga<false, 256, 256, 2>"
     else:
         paths = int(kv[3:]); nt = int(os.environ.get("MTSAMD_WG_THREADS", str(paths)))
-        kernel_name = "render_kernel_wga<false, %d, %d, %d>" % (paths, nt, {1: 4, 0.75: 3, 0.5: 2}[nt / paths])
+        kernel_name = "render_kernel_%s<false, %d, %d, %d>" % (kv[:3], paths, nt, {1: 4, 0.75: 3, 0.5: 2}[nt / paths])
     # `achieved` / `frac` follow the contract: ALGORITHMIC bytes (a wavefront formulation's state round trips) over
     # the kernel's measured time.  This kernel keeps path state in LDS, so its real HBM traffic is several times lower and its
     # bound is latency at 4 waves per SIMD; `traffic*` and `valu_pipe_busy` (rocprofv3 --pmc, profiles/) say so whenever this run
@@ -266,7 +268,7 @@ def main():
         cores = os.cpu_count() or 1
         def cpu_render(spp):
             osc = ob.OracleScene(build_scene_dict(scenes, args.config, args.width, args.height, spp, -1, args.res, 0), mono=args.config == "C5",
-                                 spectral=args.config == "C5S")
+                                 spectral=args.config in ("C5S", "C5SM"))
             tc0 = time.perf_counter()
             osc.render(threads=cores)
             return time.perf_counter() - tc0
@@ -283,6 +285,7 @@ def main():
         workload = {"C1": "C1 path cornell box", "C1L": "C1L = the C1 cornell box at 512x512x256 (262144 pixel streams: one per lane of the chip)", "C2": "C2 volpath homogeneous slab", "C4": "C4 volpath layered atmosphere, blend/tabulated phase, RPV ground",
                     "C5": "C5 = C4 as %d monochromatic wavelength batches (Rayleigh ~ lambda^-4), gpu_mono" % C5_WAVELENGTHS,
                     "C5S": "C5S = the C4 atmosphere in the spectral variant (gpu_spectral: 4 wavelengths per sample, gridvolume_spectral grids, global majorant)",
+                    "C5SM": "C5SM = C5S under volpathmis (spectral MIS with the 4 x 4 weight matrix of volpathmis.cpp:66-69), regrouping kernel compiled four wide",
                     "C3M": "C3M = the C3 scene under volpathmis (spectral MIS), regrouping kernel of volpathmis_flat.h",
                     "C3": "C3 volpath heterogeneous %d^3 grid + HG g=0.8" % args.res}[args.config]
         out = {"metric": "Msamples/s volpath 512x512x1024spp plane-parallel atmosphere" if args.config == "C3" else "Msamples/s %s (side measurement)" % args.config,

@@ -110,7 +110,7 @@ class SceneDesc(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("n_iter", C.c_uint64), ("n_lookup", C.c_uint64),
                 ("n_nee_step", C.c_uint64), ("kernel_ms", C.c_double), ("wall_ms", C.c_double),
-                ("kernel_launches", i32), ("cancelled", i32), ("timed_out", i32), ("reserved_", i32)]
+                ("kernel_launches", i32), ("cancelled", i32), ("timed_out", i32), ("kernel_variant", i32)]
 
 
 class RenderOpts(C.Structure):

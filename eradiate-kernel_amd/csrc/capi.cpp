@@ -194,7 +194,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
     HIP_CHECK(hipMemsetAsync(d_counters, 0, N_COUNTERS * sizeof(unsigned long long), stream));
     rc.events();
     hipEvent_t ev0 = rc.ev0, ev1 = rc.ev1;
-    double kernel_ms = 0.0; int launches = 0; bool timed_out = false;
+    double kernel_ms = 0.0; int launches = 0, last_variant = 0; bool timed_out = false;
     const float timeout = hs.integrator.timeout;
     *scene->stop_word = 0;
     if (hs.stop.load()) *scene->stop_word = 1;                      // cancel() raced the start of the render
@@ -234,7 +234,6 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
                 variant = (block_size * block_size) % (uint32_t) wg != 0 ? 1 : family * 10000 + wg;
             }
             if (hs.integrator.spectral && variant == 1) variant = 0;                                      // no per-lane flat kernel in the spectral build
-            if (hs.integrator.spectral && hs.integrator.type == MTS_INTEGRATOR_VOLPATHMIS) variant = 0;   // spectral volpathmis (4 x 4 weight matrices): the nested per-lane kernel
             if (hs.scene.bin_count > 0 || hs.scene.srf >= 0) variant = 0;                                 // AOV channels / a response function: the per-lane kernel carries them
             int wg_threads = 0;                                     // MTSAMD_WG_THREADS: threads per workgroup of the wga kernels (<= paths; default = paths)
             if (const char *tv = getenv("MTSAMD_WG_THREADS")) wg_threads = atoi(tv);
@@ -243,6 +242,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
                           hs.scene, d_blocks, (uint32_t) blocks.size(), block_size, (uint32_t) samples_per_pass, d_film, d_counters,
                           opts.collect_counters != 0, variant, wg_threads, d_ws, (const uint32_t *) scene->stop_word, stream));
             HIP_CHECK(hipEventRecord(ev1, stream));
+            last_variant = variant;
             // wait for the launch as a watchdog: cancel() and the timeout reach the kernel through the stop word
             for (;;) {
                 hipError_t q = hipEventQuery(ev1);
@@ -266,7 +266,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
         if (stats) {
             memset(stats, 0, sizeof(*stats));
             stats->samples = samples; stats->n_iter = h_counters[0]; stats->n_lookup = h_counters[1]; stats->n_nee_step = h_counters[2];
-            stats->kernel_ms = kernel_ms; stats->kernel_launches = launches; stats->cancelled = cancelled ? 1 : 0; stats->timed_out = timed_out ? 1 : 0;
+            stats->kernel_ms = kernel_ms; stats->kernel_launches = launches; stats->cancelled = cancelled ? 1 : 0; stats->timed_out = timed_out ? 1 : 0; stats->kernel_variant = last_variant;
             stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
     } catch (...) { (void) hipStreamSynchronize(stream); throw; }     // nothing of this render may still be using the cached buffers

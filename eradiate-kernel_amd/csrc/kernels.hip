@@ -11,8 +11,8 @@
 #include <hip/hip_runtime.h>
 #include "integrator_dev.h"
 #include "volpath_flat.h"
-#if MTS_SPEC_N == 3
 #include "volpathmis_flat.h"
+#if MTS_SPEC_N == 3
 #define MTS_LAUNCHER(name) name
 #else
 #define MTS_LAUNCHER(name) name##_spectral
@@ -169,10 +169,9 @@ __global__ void __launch_bounds__(NT, WPE) render_kernel_wgl(DScene sc, const DB
     }
 }
 
-#if MTS_SPEC_N == 3
 // The same driver for volpathmis (volpathmis_flat.h): four weight matrices per path, 512 paths per workgroup, two waves per SIMD.
 template <bool COUNT, bool SPEC, int WG, int NT>
-__global__ void __launch_bounds__(NT, 2) render_kernel_wga_mis(DScene sc, const DBlock *blocks, uint32_t n_blocks, uint32_t block_size,
+__global__ void __launch_bounds__(NT, MTS_SPEC_N == 3 ? 2 : (SPEC ? 1 : 2)) render_kernel_wga_mis(DScene sc, const DBlock *blocks, uint32_t n_blocks, uint32_t block_size,
                                                                uint32_t sample_count, float *film, float *cold_g, uint32_t cold_stride,
                                                                unsigned long long *counters, const uint32_t *stop_flag) {
     Counters cnt = {};
@@ -184,6 +183,7 @@ __global__ void __launch_bounds__(NT, 2) render_kernel_wga_mis(DScene sc, const 
     }
 }
 
+#if MTS_SPEC_N == 3
 // SamplingIntegrator::sample for caller-supplied rays (librender/python/integrator_v.cpp:62-78)
 __global__ void __launch_bounds__(256) sample_kernel(DScene sc, int32_t n, uint64_t seed_offset, const float *__restrict__ rays /* 6 SoA rows */,
                                                      float *__restrict__ out_rgb, uint8_t *__restrict__ out_valid) {
@@ -323,6 +323,18 @@ hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks,
         else if (wg == 256) LAUNCH_WGA(256);
         else return hipErrorInvalidConfiguration;
 #undef LAUNCH_WGA
+        return hipGetLastError();
+    }
+    if (variant >= 10000 && sc.integrator.type == MTS_INTEGRATOR_VOLPATHMIS) {     // 4 x 4 weight matrices: 101 hot dwords per path with spectral MIS (256 paths, one workgroup per CU), 53 without
+        const uint32_t wg = (uint32_t) (variant - 10000);
+        const uint32_t grid = (uint32_t) ((threads + wg - 1) / wg);
+        const uint32_t stride = grid * wg;
+        const bool spec = sc.integrator.use_spectral_mis != 0;
+        if (wg != 256) return hipErrorInvalidConfiguration;
+#define LAUNCH_MIS(C, S) hipLaunchKernelGGL((render_kernel_wga_mis<C, S, 256, 256>), dim3(grid), dim3(256), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag)
+        if (count) { if (spec) LAUNCH_MIS(true, true); else LAUNCH_MIS(true, false); }
+        else { if (spec) LAUNCH_MIS(false, true); else LAUNCH_MIS(false, false); }
+#undef LAUNCH_MIS
         return hipGetLastError();
     }
     const bool flat = false; (void) wg_threads; (void) d_workspace;               // path: the per-lane kernel

@@ -7,6 +7,8 @@
 // SURFACE, path SURFACE + BSDF, PHASE, NEW sample -- and the workgroup regroups its paths by the block they wait for through the LDS
 // rings of volpath_flat.h (same protocol: wga_push, wga_slot_wait, wga_raise_stop).  The hot state is 67 dwords per path with the
 // four 3 x 3 matrices (43 with `use_spectral_mis = false`), so a workgroup holds 512 paths (137 KB of LDS) served by 512 threads.
+// The spectral build (MTS_SPEC_N = 4: 4 x 4 matrices, volpathmis.cpp:66-69) carries 101 dwords per path with spectral MIS -- 256 paths
+// per workgroup (103 KB), one workgroup per CU -- and 53 without (256 paths, three workgroups per CU).
 // The draws happen in the order of the nested formulation (integrator_dev.h, volpathmis_sample) -- results are bit-identical to it
 // and to the CPU restatement.  Citations are relative to /root/reference.
 #pragma once
@@ -15,7 +17,14 @@
 namespace mtsamd {
 inline namespace MTS_VARIANT_NS {
 
-enum { C_PDFV = 30 };          // cold record: (delta ? 0 : phase / bsdf pdf) of the pending emitter sample; C_CW holds the phase / bsdf value
+// cold record: (delta ? 0 : phase / bsdf pdf) of the pending emitter sample; C_CW holds the phase / bsdf value.  The spectral build's
+// record is full (C_COUNT = 32); a walk parks either the scattering position (C_SO) or the surface hit (C_SHIT), never both, so the
+// pdf takes the first slot of the one that is free.
+#if MTS_SPEC_N == 3
+DEV int c_pdfv(bool) { return 30; }
+#else
+DEV int c_pdfv(bool from_medium) { return from_medium ? C_SHIT : C_SO; }
+#endif
 
 template <bool SPEC>
 struct MisPathState {
@@ -23,7 +32,10 @@ struct MisPathState {
     DRay ray; Hit si; int medium;
     MisWeights<SPEC> pf, pn;       // path: p_over_f, p_over_f_nee (volpathmis.cpp:117-118)
     MisWeights<SPEC> wn, wu;       // walk: p_over_f_nee / p_over_f_uni of sample_emitter (:345-346)
-    F3 res, lsp;                   // result; last_scatter_event.p (:131-132: only the position is read)
+    Spec res; F3 lsp;              // result; last_scatter_event.p (:131-132: only the position is read)
+#if MTS_SPEC_N != 3
+    Spec wl;                       // the sample's wavelengths (integrator.cpp:252)
+#endif
     float eta, wa, wb;             // walk: wa = total_dist, wb = ds.dist
     uint32_t depth, channel, st, mode, flags;
 };
@@ -35,6 +47,11 @@ struct VolpathMisMachine {
     const DScene &sc;
     Counters &cnt;
     DEV VolpathMisMachine(const DScene &sc_, Counters &cnt_) : sc(sc_), cnt(cnt_) {}
+#if MTS_SPEC_N == 3
+    DEV SpecCtx ctx(const P &) const { return SpecCtx(); }
+#else
+    DEV SpecCtx ctx(const P &p) const { SpecCtx cx = make_ctx(sc); cx.wl = p.wl; return cx; }
+#endif
 
     DEV void queue_intersection(P &p) const {                  // as VolpathMachine::queue_intersection
         float bmint, bmaxt;
@@ -54,7 +71,12 @@ struct VolpathMisMachine {
         F2 aperture_sample; aperture_sample.x = .5f; aperture_sample.y = .5f;
         if (se.needs_aperture_sample) aperture_sample = p.rng.next_2d();
         if (se.shutter_open_time > 0.f) (void) p.rng.next_1d();
+#if MTS_SPEC_N == 3
         (void) p.rng.next_1d();                                // wavelength sample, unused in rgb
+#else
+        float wav_weight;                                      // constant (sample_uniform_spectrum); blk_new recomputes it
+        p.wl = sample_wavelengths(p.rng.next_1d(), wav_weight);
+#endif
         F2 adjusted;
         adjusted.x = (position_sample.x - (float) se.crop_x) / (float) se.crop_w;
         adjusted.y = (position_sample.y - (float) se.crop_y) / (float) se.crop_h;
@@ -62,9 +84,13 @@ struct VolpathMisMachine {
         p.ray = sensor_sample_ray(sc, adjusted, aperture_sample, rw);
         e.cold.f(C_POS) = position_sample.x; e.cold.f(C_POS + 1) = position_sample.y; e.cold.f(C_RAYW) = rw.x;
         p.medium = se.medium;
-        p.res = f3s(0.f); p.lsp = f3s(0.f); p.eta = 1.f; p.depth = 0;
+        p.res = spec_s(0.f); p.lsp = f3s(0.f); p.eta = 1.f; p.depth = 0;
         p.pf = mw_full<SPEC>(1.f); p.pn = mw_full<SPEC>(1.f); p.wn = mw_full<SPEC>(1.f); p.wu = mw_full<SPEC>(1.f);
+#if MTS_SPEC_N == 3
         p.channel = sc.integrator.monochrome ? 0u : (uint32_t) pm_min(p.rng.next_1d() * 3.f, 2.f);     // volpathmis.cpp:120-124
+#else
+        p.channel = 0u;                                        // :120-124: a draw in the rgb variants only
+#endif
         p.si.p = f3s(0.f); p.si.uv.x = p.si.uv.y = 0.f; p.si.prim = 0; p.si.shape = -1;
         const bool hide_emitters = sc.integrator.hide_emitters != 0;
         p.flags = FL_ALIVE | ((!hide_emitters && sc.environment >= 0) ? FL_VALID_RAY : 0u) | (!hide_emitters ? FL_SPEC_CHAIN : 0u);
@@ -74,8 +100,8 @@ struct VolpathMisMachine {
     }
     // emitter-sampling walk finished (volpathmis.cpp:443-444 + :233-236 / :297-299): MIS-weighted contribution, resume the path
     template <class E> DEV void end_nee(P &p, const E &e) const {
-        const F3 fval = e.cold.get3(C_CW), emitted = e.cold.get3(C_EMIT);
-        const float pdfv = e.cold.f(C_PDFV);
+        const Spec fval = e.cold.get_spec(C_CW), emitted = e.cold.get_spec(C_EMIT);
+        const float pdfv = e.cold.f(c_pdfv((p.flags & FL_FROM_MEDIUM) != 0));
         update_weights(p.wn, 1.0f, fval, p.channel, true);
         update_weights(p.wu, pdfv, fval, p.channel, true);
         p.res = p.res + mis_weight_w(p.wn, p.wu) * emitted;
@@ -94,7 +120,7 @@ struct VolpathMisMachine {
         const uint32_t max_depth = (uint32_t) sc.integrator.max_depth, rr_depth = (uint32_t) sc.integrator.rr_depth;
         if (p.mode == M_MAIN) {
             bool active = (p.flags & FL_ALIVE) != 0;
-            F3 mis_throughput = mis_weight_w(p.pf);
+            Spec mis_throughput = mis_weight_w(p.pf);
             float q = pm_min(hmax(mis_throughput) * (p.eta * p.eta), .95f);
             bool perform_rr = active && (p.depth > rr_depth);                          // last_event_was_null is never set (:146)
             active = active && !(p.rng.next_1d() >= q && perform_rr);
@@ -129,7 +155,18 @@ struct VolpathMisMachine {
         F2 position_sample; position_sample.x = e.cold.f(C_POS); position_sample.y = e.cold.f(C_POS + 1);
         float acc[5];
         for (int k = 0; k < 5; ++k) acc[k] = e.cold.f(C_ACC + k);
+#if MTS_SPEC_N == 3
         splat_sample_t<false>(sc, e.blk, e.lx, e.ly, position_sample, f3s(e.cold.f(C_RAYW)) * p.res, (p.flags & FL_VALID_RAY) != 0, e.film, acc);
+#else
+        {
+            float wav_weight; (void) sample_wavelengths(0.f, wav_weight);
+            const Spec L = (wav_weight * e.cold.f(C_RAYW)) * p.res;     // ray_weight = wav_weight (x the sensor's grey weight), integrator.cpp:265
+            float xyz[3];
+            spectrum_to_xyz(sc.cie, L, p.wl, xyz);                      // integrator.cpp:266-269
+            const float v[5] = { xyz[0], xyz[1], xyz[2], (p.flags & FL_VALID_RAY) != 0 ? 1.f : 0.f, 1.f };
+            splat_values_t<false>(sc, e.blk, e.lx, e.ly, position_sample, v, e.film, acc);
+        }
+#endif
         const uint32_t sample_idx = __float_as_uint(e.cold.f(C_SAMPLE)) + 1u;
         if (sample_idx == e.sample_count) {
             float *own = (float *) (e.film + 5 * ((size_t) (e.blk.oy + (int) e.ly - se.crop_y) * se.crop_w + (e.blk.ox + (int) e.lx - se.crop_x)));
@@ -153,16 +190,17 @@ struct VolpathMisMachine {
         const uint32_t max_depth = (uint32_t) sc.integrator.max_depth, channel = p.channel;
         const float u = p.rng.next_1d();
         MedStep mi;
+        const SpecCtx cx = ctx(p); (void) cx;
         WATERFALL_BEGIN(p.medium, mu)
-            mi = medium_step<COUNT>(sc, cload(sc.media + mu), p.ray, u, channel, true, cnt);
+            mi = medium_step<COUNT>(sc, cload(sc.media + mu), p.ray, u, channel, true, cnt MTS_CX);
         WATERFALL_END
         if (p.si.t < mi.t) mi.t = pm_inf();
         const bool spectral = (mi.info & MI_SPECTRAL) != 0, homogeneous = (mi.info & MI_HOMOGENEOUS) != 0;
-        const F3 sigma_n = homogeneous ? f3s(0.f) : mi.combined - mi.sigma_t;
+        const Spec sigma_n = homogeneous ? spec_s(0.f) : mi.combined - mi.sigma_t;
         if (spectral) {
             float t = pm_min(mi.t, p.si.t) - mi.mint;                                  // medium.cpp:77-89
-            F3 tr = transmittance_exp(t, mi.combined);
-            F3 free_flight_pdf = p.si.t < mi.t ? tr : tr * mi.combined;
+            Spec tr = transmittance_exp(t, mi.combined);
+            Spec free_flight_pdf = p.si.t < mi.t ? tr : tr * mi.combined;
             update_weights(p.pf, free_flight_pdf, tr, channel, true);
             update_weights(p.pn, free_flight_pdf, tr, channel, true);
         }
@@ -191,16 +229,17 @@ struct VolpathMisMachine {
         p.st = sample_emitters ? S_SCATTER : S_PHASE;
     }
     // ================================================================= SCATTER: emitter sampling at a medium interaction (:228-237 -> :330-356)
-    template <bool DEFER, class E> DEV void start_walk(P &p, const E &e, F3 ref_p, const DirSample &ds, F3 emitter_sample_weight, F3 fval, float pdfv, bool from_medium) const {
+    template <bool DEFER, class E> DEV void start_walk(P &p, const E &e, F3 ref_p, const DirSample &ds, Spec emitter_sample_weight, Spec fval, float pdfv, bool from_medium) const {
         p.wn = p.pf; p.wu = p.pf;
-        F3 emitter_val = emitter_sample_weight * ds.pdf;
-        if (ds.pdf == 0.f) emitter_val = f3s(0.f);
+        Spec emitter_val = emitter_sample_weight * ds.pdf;
+        if (ds.pdf == 0.f) emitter_val = spec_s(0.f);
         const bool active = ds.pdf != 0.f;
         update_weights(p.wn, ds.pdf, 1.0f, p.channel, active);
-        e.cold.put3(C_CW, fval); e.cold.put3(C_EMIT, emitter_val); e.cold.f(C_PDFV) = pdfv;
+        e.cold.put_spec(C_CW, fval); e.cold.put_spec(C_EMIT, emitter_val);
         e.cold.put3(C_SD, p.ray.d); e.cold.f(C_SMED) = __int_as_float(p.medium);
         if (from_medium) { e.cold.put3(C_SO, p.ray.o); p.flags |= FL_FROM_MEDIUM; }
         else { e.cold.put_hit(p.si); p.flags &= ~FL_FROM_MEDIUM; }
+        e.cold.f(c_pdfv(from_medium)) = pdfv;
         p.mode = M_NEE;
         if (!active) { nee_done<DEFER>(p, e); return; }
         p.wa = 0.f; p.wb = ds.dist;
@@ -211,13 +250,14 @@ struct VolpathMisMachine {
     }
     template <bool DEFER = false, class E> DEV void blk_scatter(P &p, const E &e) const {
         if (p.st != S_SCATTER) return;
-        F3 esw;
-        DirSample ds = sample_emitter_direction(sc, p.ray.o, p.rng.next_2d(), false, esw);
+        Spec esw;
+        const SpecCtx cx = ctx(p); (void) cx;
+        DirSample ds = sample_emitter_direction(sc, p.ray.o, p.rng.next_2d(), false, esw MTS_CX);
         float phase_val = 0.f;
         WATERFALL_BEGIN(p.medium, mu)
-            phase_val = phase_eval<true>(sc, cload(sc.media + mu).phase, -p.ray.d, p.ray.o, ds.d);
+            phase_val = phase_eval<true>(sc, cload(sc.media + mu).phase, -p.ray.d, p.ray.o, ds.d MTS_CX);
         WATERFALL_END
-        start_walk<DEFER>(p, e, p.ray.o, ds, esw, f3s(phase_val), ds.delta ? 0.f : phase_val, true);
+        start_walk<DEFER>(p, e, p.ray.o, ds, esw, spec_s(phase_val), ds.delta ? 0.f : phase_val, true);
     }
     // ================================================================= MEDIUM step of a walk (volpathmis.cpp:364-411)
     template <bool DEFER = false, class E> DEV void blk_medw(P &p, const E &e) const {
@@ -225,17 +265,18 @@ struct VolpathMisMachine {
         const uint32_t channel = p.channel;
         const float u = p.rng.next_1d();
         MedStep mi;
+        const SpecCtx cx = ctx(p); (void) cx;
         WATERFALL_BEGIN(p.medium, mu)
-            mi = medium_step<COUNT>(sc, cload(sc.media + mu), p.ray, u, channel, false, cnt);
+            mi = medium_step<COUNT>(sc, cload(sc.media + mu), p.ray, u, channel, false, cnt MTS_CX);
         WATERFALL_END
         if (p.si.t < mi.t) mi.t = pm_inf();
         const bool spectral = (mi.info & MI_SPECTRAL) != 0, homogeneous = (mi.info & MI_HOMOGENEOUS) != 0;
-        const F3 sigma_n = homogeneous ? f3s(0.f) : mi.combined - mi.sigma_t;
+        const Spec sigma_n = homogeneous ? spec_s(0.f) : mi.combined - mi.sigma_t;
         const float remaining_dist = p.ray.maxt;
         if (spectral) {
             float t = pm_min(remaining_dist, pm_min(mi.t, p.si.t)) - mi.mint;
-            F3 tr = transmittance_exp(t, mi.combined);
-            F3 free_flight_pdf = (p.si.t < mi.t || mi.t > remaining_dist) ? tr : tr * mi.combined;
+            Spec tr = transmittance_exp(t, mi.combined);
+            Spec free_flight_pdf = (p.si.t < mi.t || mi.t > remaining_dist) ? tr : tr * mi.combined;
             update_weights(p.wn, free_flight_pdf, tr, channel, true);
             update_weights(p.wu, free_flight_pdf, tr, channel, true);
         }
@@ -259,10 +300,10 @@ struct VolpathMisMachine {
         const bool hit = hit_valid(p.si);
         p.wa += p.si.t;
         if (!hit) { end_nee(p, e); return; }
-        F3 nt = f3s(0.f), n = f3s(0.f); int is_tr = 0, ext = -1, inte = -1;
+        Spec nt = spec_s(0.f); F3 n = f3s(0.f); int is_tr = 0, ext = -1, inte = -1;
         WATERFALL_BEGIN(p.si.shape, su)
             const DShape s = cload(sc.shapes + su);
-            nt = s.bsdf_type == MTS_BSDF_NULL ? f3s(1.f) : f3s(0.f);
+            nt = s.bsdf_type == MTS_BSDF_NULL ? spec_s(1.f) : spec_s(0.f);
             is_tr = s.is_medium_transition; ext = s.exterior; inte = s.interior;
             if (is_tr) n = hit_geo_normal(sc, s, p.si);
         WATERFALL_END
@@ -290,6 +331,7 @@ struct VolpathMisMachine {
             WATERFALL_END
         }
         const bool count_direct = p.depth == 0 || (p.flags & FL_SPEC_CHAIN);
+        const SpecCtx cx = ctx(p); (void) cx;
         if (emitter >= 0 && !(p.depth == 0 && hide_emitters)) {
             if (!count_direct) {
                 DirSample ds;                                                          // records.h:168-174
@@ -299,7 +341,7 @@ struct VolpathMisMachine {
                 float emitter_pdf = pdf_emitter_direction(sc, p.lsp, ds);
                 update_weights(p.pn, emitter_pdf, 1.f, p.channel, true);
             }
-            F3 emitted = emitter_eval(sc, emitter, sf.wi.z);
+            Spec emitted = emitter_eval(sc, emitter, sf.wi.z MTS_CX);
             p.res = p.res + (count_direct ? mis_weight_w(p.pf) * emitted : mis_weight_w(p.pf, p.pn) * emitted);
         }
         if (!hit) { p.flags &= ~FL_ALIVE; p.st = S_TOP; return; }
@@ -309,14 +351,14 @@ struct VolpathMisMachine {
             active_e = (cload(sc.bsdfs + bu).flags & F_Smooth) != 0 && (p.depth + 1 < max_depth);
         WATERFALL_END
         if (!active_e) return;
-        F3 esw;
-        DirSample ds = sample_emitter_direction(sc, p.si.p, p.rng.next_2d(), false, esw);
+        Spec esw;
+        DirSample ds = sample_emitter_direction(sc, p.si.p, p.rng.next_2d(), false, esw MTS_CX);
         F3 wo = to_local(sf.sh, ds.d);
-        F3 bsdf_val; float bpdf;
+        Spec bsdf_val; float bpdf;
         WATERFALL_BEGIN(bsdf_id, bu)
             const DBsdf bsdf = cload(sc.bsdfs + bu);
-            bsdf_val = bsdf_eval(bsdf, sf.wi, wo);
-            bpdf = bsdf_pdf(bsdf, sf.wi, wo);
+            bsdf_val = bsdf_eval(bsdf, sf.wi, wo MTS_CXI(bu));
+            bpdf = bsdf_pdf(bsdf, sf.wi, wo MTS_CXI(bu));
         WATERFALL_END
         start_walk<false>(p, e, p.si.p, ds, esw, bsdf_val, ds.delta ? 0.f : bpdf, false);
     }
@@ -330,10 +372,11 @@ struct VolpathMisMachine {
             bsdf_id = s.bsdf; is_tr = s.is_medium_transition; ext = s.exterior; inte = s.interior;
         WATERFALL_END
         const float s1 = p.rng.next_1d(); const F2 s2 = p.rng.next_2d();
-        BSDFSample bs; F3 bsdf_weight;
+        BSDFSample bs; Spec bsdf_weight;
+        const SpecCtx cx = ctx(p); (void) cx;
         WATERFALL_BEGIN(bsdf_id, bu)
             const DBsdf bsdf = cload(sc.bsdfs + bu);
-            bsdf_weight = bsdf_sample(bsdf, sf.wi, s1, s2, bs);
+            bsdf_weight = bsdf_sample(bsdf, sf.wi, s1, s2, bs MTS_CXI(bu));
         WATERFALL_END
         const bool invalid_bsdf_sample = bs.pdf == 0.f;
         const bool active_surface = bs.pdf > 0.f;
@@ -356,8 +399,9 @@ struct VolpathMisMachine {
         p.pn = p.pf;                                                                   // :240: a real interaction resets p_over_f_nee
         const float s1 = p.rng.next_1d(); const F2 s2 = p.rng.next_2d();
         F3 wo; float phase_pdf = 0.f;
+        const SpecCtx cx = ctx(p); (void) cx;
         WATERFALL_BEGIN(p.medium, mu)
-            wo = phase_sample_pdf(sc, cload(sc.media + mu).phase, make_frame(p.ray.d), p.ray.o, s1, s2, phase_pdf);
+            wo = phase_sample_pdf(sc, cload(sc.media + mu).phase, make_frame(p.ray.d), p.ray.o, s1, s2, phase_pdf MTS_CX);
         WATERFALL_END
         p.ray = spawn_ray(p.ray.o, wo); p.ray.mint = 0.0f;
         queue_intersection(p);
@@ -384,42 +428,59 @@ struct VolpathMisMachine {
 // groups its class can read / write (MisClassFields); at two waves per SIMD the register budget of 256 VGPRs holds the whole state.
 enum : uint32_t { K_RNG = 1, K_O = 2, K_D = 4 /* d and 1/d */, K_MINT = 8, K_MAXT = 16, K_SIT = 32, K_SIX = 64 /* rest of si */, K_MED = 128,
                   K_PF = 256, K_PN = 512, K_WN = 1024, K_WU = 2048, K_RES = 4096, K_LSP = 8192, K_ETA = 16384, K_WA = 32768, K_WB = 65536,
-                  K_ALL = 131071 };
+#if MTS_SPEC_N == 3
+                  K_WL = 0, K_ALL = 131071 };
+#else
+                  K_WL = 131072 /* the sample's wavelengths: read by every block that evaluates a spectrum, written by NEW */, K_ALL = 262143 };
+#endif
 // What block class C (followed by top()) may read (`load`, a superset of `store`) and write (`store`); `defer`: the end of a walk,
 // which touches almost everything, runs afterwards on the full state (VolpathMisMachine::finish).
 template <int C> struct MisClassFields { static constexpr uint32_t load = K_ALL, store = K_ALL; static constexpr bool defer = false; };
 template <> struct MisClassFields<B_INT> {
     static constexpr uint32_t load = K_O | K_D | K_MINT | K_MAXT, store = K_SIT | K_SIX; static constexpr bool defer = true; };
 template <> struct MisClassFields<B_MED> {       // the path: p_over_f, p_over_f_nee; the loop head reads eta
-    static constexpr uint32_t load = K_RNG | K_O | K_D | K_MINT | K_MAXT | K_SIT | K_MED | K_PF | K_PN | K_ETA | K_LSP,
+    static constexpr uint32_t load = K_RNG | K_O | K_D | K_MINT | K_MAXT | K_SIT | K_MED | K_PF | K_PN | K_ETA | K_LSP | K_WL,
                               store = K_RNG | K_O | K_MINT | K_SIT | K_PF | K_PN | K_LSP;
     static constexpr bool defer = true; };
 template <> struct MisClassFields<B_MEDW> {      // a walk: its two matrices and its distance budget
-    static constexpr uint32_t load = K_RNG | K_O | K_D | K_MINT | K_MAXT | K_SIT | K_MED | K_WN | K_WU | K_WA | K_WB,
+    static constexpr uint32_t load = K_RNG | K_O | K_D | K_MINT | K_MAXT | K_SIT | K_MED | K_WN | K_WU | K_WA | K_WB | K_WL,
                               store = K_RNG | K_O | K_MINT | K_MAXT | K_SIT | K_WN | K_WU | K_WA;
     static constexpr bool defer = true; };
 template <> struct MisClassFields<B_SCATTER> {
-    static constexpr uint32_t load = K_RNG | K_O | K_D | K_MINT | K_MAXT | K_SIT | K_MED | K_PF | K_WA | K_WB,
+    static constexpr uint32_t load = K_RNG | K_O | K_D | K_MINT | K_MAXT | K_SIT | K_MED | K_PF | K_WA | K_WB | K_WL,
                               store = K_RNG | K_O | K_D | K_MINT | K_MAXT | K_SIT | K_WN | K_WU | K_WA | K_WB;
     static constexpr bool defer = true; };
 template <> struct MisClassFields<B_PHASE> {
-    static constexpr uint32_t load = K_RNG | K_O | K_D | K_MINT | K_MAXT | K_SIT | K_MED | K_PF | K_ETA,
+    static constexpr uint32_t load = K_RNG | K_O | K_D | K_MINT | K_MAXT | K_SIT | K_MED | K_PF | K_ETA | K_WL,
                               store = K_RNG | K_O | K_D | K_MINT | K_MAXT | K_SIT | K_PF | K_PN;
     static constexpr bool defer = true; };
 
 template <int WG, bool SPEC>
 struct MisHotStore {
-    static constexpr int NW = SPEC ? 9 : 3;                     // floats per weight matrix
+    static constexpr int NW = SPEC ? MTS_SPEC_N * MTS_SPEC_N : MTS_SPEC_N;      // floats per weight matrix
     enum { M_RNG = 0, M_O = 2, M_D = 5, M_DRCP = 8, M_MINT = 11, M_MAXT = 12, M_SIT = 13, M_MEDIUM = 14, M_PACKED = 15, M_WA = 16, M_WB = 17,
-           M_ETA = 18, M_RES = 19, M_LSP = 22, M_SIX = 25, M_W = 32, M_COUNT = 32 + 4 * NW };
+           M_ETA = 18, M_RES = 19, M_LSP = M_RES + MTS_SPEC_DW, M_SIX = M_LSP + 3,
+#if MTS_SPEC_N == 3
+           M_W = 32,
+#else
+           M_WL = M_SIX + 7, M_W = M_WL + 4,                    // 37
+#endif
+           M_COUNT = M_W + 4 * NW };
     uint32_t *base;
     DEV uint32_t &u(int k) const { return base[k * WG]; }
     DEV float f(int k) const { return __uint_as_float(base[k * WG]); }
     DEV void putf(int k, float v) const { base[k * WG] = __float_as_uint(v); }
     DEV void put3(int k, F3 v) const { putf(k, v.x); putf(k + 1, v.y); putf(k + 2, v.z); }
     DEV F3 get3(int k) const { return f3(f(k), f(k + 1), f(k + 2)); }
-    DEV void putw(int k, const MisWeights<SPEC> &w) const { for (int i = 0; i < NW / 3; ++i) put3(k + 3 * i, w.r[i]); }
-    DEV MisWeights<SPEC> getw(int k) const { MisWeights<SPEC> w; for (int i = 0; i < NW / 3; ++i) w.r[i] = get3(k + 3 * i); return w; }
+#if MTS_SPEC_N == 3
+    DEV void put_spec(int k, Spec v) const { put3(k, v); }
+    DEV Spec get_spec(int k) const { return get3(k); }
+#else
+    DEV void put_spec(int k, Spec v) const { putf(k, v.x); putf(k + 1, v.y); putf(k + 2, v.z); putf(k + 3, v.w); }
+    DEV Spec get_spec(int k) const { return spec4(f(k), f(k + 1), f(k + 2), f(k + 3)); }
+#endif
+    DEV void putw(int k, const MisWeights<SPEC> &w) const { for (int i = 0; i < NW / MTS_SPEC_N; ++i) put_spec(k + MTS_SPEC_N * i, w.r[i]); }
+    DEV MisWeights<SPEC> getw(int k) const { MisWeights<SPEC> w; for (int i = 0; i < NW / MTS_SPEC_N; ++i) w.r[i] = get_spec(k + MTS_SPEC_N * i); return w; }
     template <uint32_t M> DEV void store_m(const MisPathState<SPEC> &p, int cls) const {
         if (M & K_RNG) { u(M_RNG) = (uint32_t) p.rng.state; u(M_RNG + 1) = (uint32_t) (p.rng.state >> 32); }
         if (M & K_O) put3(M_O, p.ray.o);
@@ -433,8 +494,11 @@ struct MisHotStore {
         if (M & K_WA) putf(M_WA, p.wa);
         if (M & K_WB) putf(M_WB, p.wb);
         if (M & K_ETA) putf(M_ETA, p.eta);
-        if (M & K_RES) put3(M_RES, p.res);
+        if (M & K_RES) put_spec(M_RES, p.res);
         if (M & K_LSP) put3(M_LSP, p.lsp);
+#if MTS_SPEC_N != 3
+        if (M & K_WL) put_spec(M_WL, p.wl);
+#endif
         if (M & K_PF) putw(M_W, p.pf);
         if (M & K_PN) putw(M_W + NW, p.pn);
         if (M & K_WN) putw(M_W + 2 * NW, p.wn);
@@ -453,7 +517,10 @@ struct MisHotStore {
         const uint32_t pk = u(M_PACKED);
         p.st = pk & 15u; p.mode = (pk >> 4) & 3u; p.channel = (pk >> 6) & 3u; p.flags = (pk >> 8) & 31u; p.depth = pk >> 17;
         p.wa = (M & K_WA) ? f(M_WA) : 0.f; p.wb = (M & K_WB) ? f(M_WB) : 0.f; p.eta = (M & K_ETA) ? f(M_ETA) : 1.f;
-        p.res = (M & K_RES) ? get3(M_RES) : f3s(0.f); p.lsp = (M & K_LSP) ? get3(M_LSP) : f3s(0.f);
+        p.res = (M & K_RES) ? get_spec(M_RES) : spec_s(0.f); p.lsp = (M & K_LSP) ? get3(M_LSP) : f3s(0.f);
+#if MTS_SPEC_N != 3
+        p.wl = (M & K_WL) ? get_spec(M_WL) : spec_s(0.f);
+#endif
         p.pf = (M & K_PF) ? getw(M_W) : mw_full<SPEC>(1.f); p.pn = (M & K_PN) ? getw(M_W + NW) : mw_full<SPEC>(1.f);
         p.wn = (M & K_WN) ? getw(M_W + 2 * NW) : mw_full<SPEC>(1.f); p.wu = (M & K_WU) ? getw(M_W + 3 * NW) : mw_full<SPEC>(1.f);
     }
@@ -525,7 +592,10 @@ DEV void volpathmis_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &
         const bool ok = wg_env<WG>(a, wg_base, pid0, e);
         p.rng.state = 0; p.rng.inc = 0;
         p.ray = make_ray(f3s(0.f), f3(0.f, 0.f, 1.f), 0.f, 0.f); p.si.t = pm_inf(); p.si.p = f3s(0.f); p.si.uv.x = p.si.uv.y = 0.f; p.si.shape = -1; p.si.prim = 0;
-        p.medium = -1; p.res = p.lsp = f3s(0.f); p.eta = 1.f; p.depth = 0; p.channel = 0; p.mode = M_MAIN; p.flags = 0; p.wa = p.wb = 0.f;
+        p.medium = -1; p.res = spec_s(0.f); p.lsp = f3s(0.f); p.eta = 1.f; p.depth = 0; p.channel = 0; p.mode = M_MAIN; p.flags = 0; p.wa = p.wb = 0.f;
+#if MTS_SPEC_N != 3
+        p.wl = spec_s(0.f);
+#endif
         p.pf = p.pn = p.wn = p.wu = mw_full<SPEC>(1.f);
         p.st = S_DONE;
         if (ok) {

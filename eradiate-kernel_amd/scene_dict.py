@@ -10,6 +10,8 @@ Only the plugins of the path / volpath hot path are known (SURVEY.md section 8(b
 """
 import ctypes as C
 import math
+import threading
+
 import numpy as np
 
 from . import _capi as A
@@ -77,6 +79,7 @@ def _xf(t):
 
 
 _MONO = False      # set by build_scene_desc(mono=True): colours become their luminance (src/spectra/srgb.cpp in *_mono variants)
+_BUILD_LOCK = threading.RLock()
 _SPECTRAL = None   # set by build_scene_desc(spectral=True): the SceneBuilder that collects the scene's spectra
 
 
@@ -1042,13 +1045,14 @@ def build_scene_desc(d, mono=False, spectral=False):
     global _MONO, _SPECTRAL
     b = SceneBuilder()
     b.spectra = []
-    _MONO = bool(mono)
-    _SPECTRAL = b if spectral else None
-    try:
-        desc = b.load(d)
-    finally:
-        _MONO = False
-        _SPECTRAL = None
+    with _BUILD_LOCK:                    # the variant of the scene being built is module state: one build at a time (threads may load scenes side by side)
+        _MONO = bool(mono)
+        _SPECTRAL = b if spectral else None
+        try:
+            desc = b.load(d)
+        finally:
+            _MONO = False
+            _SPECTRAL = None
     desc.integrator.monochrome = int(bool(mono))
     desc.integrator.spectral = int(bool(spectral))
     return desc, b

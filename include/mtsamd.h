@@ -256,7 +256,8 @@ typedef struct mts_stats {
     int32_t cancelled;        /* 1 if mts_cancel stopped the render (render() == false, integrator.cpp:178) */
     int32_t timed_out;        /* 1 if the "timeout" of the integrator stopped it (should_stop(), integrator.h:143-146;
                                  like the reference, render() still returns true then)            */
-    int32_t reserved_;
+    int32_t kernel_variant;   /* kernel formulation of the last launch: 0 = nested per-lane loops, 1 = per-lane state machine,
+                                 10000 + P = regrouping machine on LDS rings with P paths per workgroup, 20000 + P = lane-affine driver */
 } mts_stats;
 
 typedef struct mts_render_opts {

@@ -816,15 +816,20 @@ def test_spectral_variant_against_oracle(gpu_spectral, monkeypatch, name, kernel
     assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (o.last_stats["n_iter"], o.last_stats["n_lookup"], o.last_stats["n_nee_step"])
 
 
+@pytest.mark.parametrize("kernel", [None, "nested"])
 @pytest.mark.parametrize("use_spectral_mis", [True, False])
 @pytest.mark.parametrize("name", ["slab_regular_reflectance", "slab_chromatic_medium", "grid_spectral_d65_rpv", "cornell_path", "c4_atmosphere",
                                   "c5s_atmosphere"])
-def test_spectral_volpathmis_against_oracle(gpu_spectral, name, use_spectral_mis):
+def test_spectral_volpathmis_against_oracle(gpu_spectral, monkeypatch, name, use_spectral_mis, kernel):
     """src/integrators/volpathmis.cpp in the spectral variant (WeightMatrix = 4 x 4, `channel` 0, index_spectrum -> spec[0]: :66-84,
-    118-122), with and without spectral MIS, against liboracle_spectral.so: films and loop counters identical."""
+    118-122), with and without spectral MIS, against liboracle_spectral.so: films and loop counters identical -- on the regrouping
+    machine (volpathmis_flat.h compiled four wide: 256-path workgroups; the default) and in the nested per-lane formulation."""
+    if kernel:
+        monkeypatch.setenv("MTSAMD_KERNEL", kernel)
     d = _spectral_cases()[name]
     d["integrator"] = dict(d["integrator"], type="volpathmis", use_spectral_mis=use_spectral_mis)
     gpu, st = gpu_render(gpu_spectral, d, collect_counters=True)
+    assert st["kernel_variant"] == (0 if kernel or name == "cornell_path" else 10256)       # no medium: per lane (capi.cpp)
     o = ob.OracleScene(d, spectral=True)
     ref = o.render()
     assert ref[..., :3].max() > 0

@@ -141,8 +141,10 @@ def test_pin_rejects_the_round_1_c4_scene():
     assert om.mean() / mean.mean() - 1.0 < -1.5e-2
 
 
-def test_spectral_oracle_agrees_with_the_independent_estimator():
-    """The spectral variant on the grey C3 miniature: every sample draws four wavelengths, the film holds hmean(cmf(lambda) L(lambda)) x
+@pytest.mark.parametrize("integrator", ["volpath", "volpathmis", "volpathmis_no_spectral_mis"])
+def test_spectral_oracle_agrees_with_the_independent_estimator(integrator):
+    """The spectral variant on the grey C3 miniature (under `volpath`, and under `volpathmis` with and without spectral MIS: the 4 x 4
+    WeightMatrix of volpathmis.cpp:66-69): every sample draws four wavelengths, the film holds hmean(cmf(lambda) L(lambda)) x
     470 nm (core/spectrum.h:210-217, 250-254), so Y / W estimates L x the integral of the piecewise-linear y-bar table over 360 ..
     830 nm (106.857 for the 5 nm table of libcore/spectrum.cpp).  Divided by that constant the spectral render must agree with the
     independent estimator like the rgb one does -- wavelength sampling, CIE weighting and the four-wide transport included."""
@@ -159,6 +161,8 @@ def test_spectral_oracle_agrees_with_the_independent_estimator():
             return {k: grey(x) for k, x in node.items()}
         return node
     d = grey(d)
+    if integrator != "volpath":
+        d["integrator"] = dict(d["integrator"], type="volpathmis", use_spectral_mis=integrator == "volpathmis")
     tbl = np.array([float(x) for x in re.findall(r"([0-9.eE+-]+)f", open(os.path.join(os.path.dirname(GOLDEN), "..", "eradiate-kernel_amd", "csrc", "cie_tables.h")).read().split("{")[1])], np.float64).reshape(3, 95)
     y_integral = float(((tbl[1][:-1] + tbl[1][1:]) * 0.5 * 5.0).sum())
     assert abs(y_integral - 106.857) < 1e-2
@@ -174,7 +178,7 @@ def test_spectral_oracle_agrees_with_the_independent_estimator():
     om, ov = imgs.mean(0), imgs.var(0, ddof=1) / len(imgs)
     se = math.hypot(math.sqrt(var.sum()) / var.size / mean.mean(), math.sqrt(ov.sum()) / ov.size / om.mean())
     rel = om.mean() / mean.mean() - 1.0
-    print("c3 spectral: image mean %.6f, independent %.6f, difference %+.3f %% +- %.3f %%" % (om.mean(), mean.mean(), 100 * rel, 100 * se))
+    print("c3 spectral " + integrator + ": image mean %.6f, independent %.6f, difference %+.3f %% +- %.3f %%" % (om.mean(), mean.mean(), 100 * rel, 100 * se))
     assert se < 6e-3 and abs(rel) < 4 * se and abs(rel) < 1.5e-2
     p, alpha, z = z_test(om, ov, mean, var)
     assert (p > alpha).mean() >= 0.9975
