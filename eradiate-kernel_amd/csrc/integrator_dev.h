@@ -640,10 +640,53 @@ DEV float phase_eval_leaf(const DPhase &ph, F3 wi, F3 wo) {
         default: return MTS_INV_FOUR_PI;                                                      // isotropic.cpp:43-47
     }
 }
+// A blendphase whose children are blendphases (blendphase.cpp:42-66 holds two arbitrary PhaseFunction children; multi-species
+// atmospheres are built as such trees).  DPhase::size of a blend node is the depth of the tree below it (1: two leaves, the common
+// case, handled in line by the callers); deeper trees are walked here, out of line and per lane.  The host admits MTS_BLEND_MAX_DEPTH
+// levels and children that precede their parent (no cycles).  Arguments by value: a reference to the scene record would pin it in scratch.
+#define MTS_BLEND_MAX_DEPTH 8
+DEV float phase_eval_leaf(const DPhase &ph, F3 wi, F3 wo);
+DEV_NOINLINE float phase_eval_tree(const DPhase *phases, const DVolume *volumes, int root, F3 wi, F3 p, F3 wo, const SpecCtx cx) {
+    // post-order walk: value(node) = value(child 0) * (1 - weight) + value(child 1) * weight, blendphase.cpp:137-138
+    float w_st[MTS_BLEND_MAX_DEPTH], v0_st[MTS_BLEND_MAX_DEPTH]; int c1_st[MTS_BLEND_MAX_DEPTH]; bool second[MTS_BLEND_MAX_DEPTH];
+    int sp = 0, cur = root;
+    for (int guard = 0; guard < (2 << MTS_BLEND_MAX_DEPTH); ++guard) {
+        const DPhase ph = phases[cur];
+        if (ph.type == MTS_PHASE_BLEND && sp < MTS_BLEND_MAX_DEPTH) {
+            const float w = volume_eval_1(volumes[ph.weight_volume], p, cx, ph.weight_volume);
+            w_st[sp] = pm_min(pm_max(w, 0.f), 1.f); c1_st[sp] = ph.child[1]; second[sp] = false; ++sp;
+            cur = ph.child[0];
+            continue;
+        }
+        float value = phase_eval_leaf(ph, wi, wo);
+        for (;;) {                                            // return to the parents
+            if (sp == 0) return value;
+            if (!second[sp - 1]) { v0_st[sp - 1] = value; second[sp - 1] = true; cur = c1_st[sp - 1]; break; }
+            value = v0_st[sp - 1] * (1 - w_st[sp - 1]) + value * w_st[sp - 1];
+            --sp;
+        }
+    }
+    return 0.f;
+}
+// The leaf a nested blendphase samples (blendphase.cpp:92-108: the child below `weight` gets sample1 / weight, the other one
+// (sample1 - weight) / (1 - weight)); the leaves themselves only read sample2
+DEV_NOINLINE int phase_pick_leaf(const DPhase *phases, const DVolume *volumes, int root, F3 p, float sample1, const SpecCtx cx) {
+    int node = root;
+    for (int level = 0; level <= MTS_BLEND_MAX_DEPTH; ++level) {
+        if (phases[node].type != MTS_PHASE_BLEND) break;
+        const int wv = phases[node].weight_volume;
+        const float w = volume_eval_1(volumes[wv], p, cx, wv);
+        const float weight = pm_min(pm_max(w, 0.f), 1.f);
+        if (sample1 > weight) { sample1 = (sample1 - weight) / (1 - weight); node = phases[node].child[0]; }
+        else { sample1 = sample1 / weight; node = phases[node].child[1]; }
+    }
+    return node;
+}
 template <bool U = false>
 DEV float phase_eval(const DScene &sc, int phase, F3 wi, F3 p, F3 wo, const SpecCtx &cx = SpecCtx()) {
     const DPhase ph = rload<U>(sc.phases, phase);
     if (ph.type != MTS_PHASE_BLEND) return phase_eval_leaf(ph, wi, wo);
+    if (ph.size > 1) return phase_eval_tree(sc.phases, sc.volumes, phase, wi, p, wo, cx);
     float w = volume_eval_1(rload<U>(sc.volumes, ph.weight_volume), p, cx, ph.weight_volume);  // blendphase.cpp:113-139
     float weight = pm_min(pm_max(w, 0.f), 1.f);
     return phase_eval_leaf(rload<U>(sc.phases, ph.child[0]), wi, wo) * (1 - weight) + phase_eval_leaf(rload<U>(sc.phases, ph.child[1]), wi, wo) * weight;
@@ -672,6 +715,7 @@ template <bool U = false>
 DEV F3 phase_sample(const DScene &sc, int phase, const Frame3 &frame, F3 p, float sample1, F2 sample2, const SpecCtx &cx = SpecCtx()) {
     const DPhase ph = rload<U>(sc.phases, phase);
     if (ph.type != MTS_PHASE_BLEND) return phase_sample_leaf(ph, frame, sample2);
+    if (ph.size > 1) return phase_sample_leaf(sc.phases[phase_pick_leaf(sc.phases, sc.volumes, phase, p, sample1, cx)], frame, sample2);
     float w = volume_eval_1(rload<U>(sc.volumes, ph.weight_volume), p, cx, ph.weight_volume);  // blendphase.cpp:68-111
     float weight = pm_min(pm_max(w, 0.f), 1.f);
     if (sample1 > weight) return phase_sample_leaf(rload<U>(sc.phases, ph.child[0]), frame, sample2);
@@ -707,6 +751,7 @@ DEV F3 phase_sample_leaf_pdf(const DPhase &ph, const Frame3 &frame, F2 sample2, 
 DEV F3 phase_sample_pdf(const DScene &sc, int phase, const Frame3 &frame, F3 p, float sample1, F2 sample2, float &pdf, const SpecCtx &cx = SpecCtx()) {
     const DPhase &ph = sc.phases[phase];
     if (ph.type != MTS_PHASE_BLEND) return phase_sample_leaf_pdf(ph, frame, sample2, pdf);
+    if (ph.size > 1) return phase_sample_leaf_pdf(sc.phases[phase_pick_leaf(sc.phases, sc.volumes, phase, p, sample1, cx)], frame, sample2, pdf);
     float w = volume_eval_1(sc.volumes[ph.weight_volume], p, cx, ph.weight_volume);
     float weight = pm_min(pm_max(w, 0.f), 1.f);
     if (sample1 > weight) return phase_sample_leaf_pdf(sc.phases[ph.child[0]], frame, sample2, pdf);

@@ -308,8 +308,14 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
             check_index(p.child[0], d->phase_count, "blendphase child", false);
             check_index(p.child[1], d->phase_count, "blendphase child", false);
             check_index(p.weight_volume, d->volume_count, "blendphase weight", false);
-            if (d->phases[p.child[0]].type == MTS_PHASE_BLEND || d->phases[p.child[1]].type == MTS_PHASE_BLEND)
-                throw std::runtime_error("nested blendphase plugins are not supported by this backend");
+            // nested blendphase plugins (blendphase.cpp:42-66: two arbitrary PhaseFunction children): children come before their parent
+            // in the description (the order a loader constructs them in; rules out cycles), DPhase::size = depth of the tree below
+            if (p.child[0] >= i || p.child[1] >= i) throw std::runtime_error("blendphase: a nested phase function must precede the blendphase that holds it");
+            int depth = 1;
+            for (int c = 0; c < 2; ++c)
+                if (d->phases[p.child[c]].type == MTS_PHASE_BLEND) depth = std::max(depth, 1 + hs.phases[(size_t) p.child[c]].size);
+            if (depth > 8) throw std::runtime_error("blendphase: more than 8 nested levels are not supported by this backend");
+            dp.size = depth;
         } else if (p.type == MTS_PHASE_TABULATED) {
             size_t size = (size_t) p.tab_count;
             if (size < 2 || !p.tab_values) throw std::runtime_error("ContinuousDistribution: needs at least two entries!");

@@ -755,6 +755,10 @@ DEV void volpath_pixel_flat(const DScene &sc, Pcg32 &rng, const DBlock &blk, uin
 #endif
         vm.run(p, e, sel);
     }
+    if (p.st != S_DONE) {                                     // stopped (should_stop()): the finished samples of this pixel go to the film, integrator.cpp:120-130
+        float *own = (float *) (e.film + 5 * ((size_t) (blk.oy + (int) ly - sc.sensor.crop_y) * sc.sensor.crop_w + (blk.ox + (int) lx - sc.sensor.crop_x)));
+        for (int k = 0; k < 5; ++k) atomicAdd(own + k, e.cold.f(C_ACC + k));
+    }
 #if defined(MTSAMD_BLOCKSTATS)
     if (COUNT && __builtin_amdgcn_readfirstlane((int) (threadIdx.x & 63)) == (int) (threadIdx.x & 63))
         for (int k = 0; k < 45; ++k) atomicAdd(&g_blockstats[k], bs_loc[k]);
@@ -1045,6 +1049,24 @@ DEV void wga_push(int cls, uint32_t pid, bool valid, uint16_t (*q_ids)[WG], uint
     if (__builtin_amdgcn_ballot_w64(pending) != 0ull) (void) wga_slot_wait<WG, false>(pending, slot, pid, q_ctl, counters, cls, idx);
 }
 
+// A stopped workgroup (Integrator::cancel(), the integrator's timeout, a stall) adds the accumulators of its unfinished pixels to the
+// film: the reference puts a partially rendered block on the film as well (integrator.cpp:120-130: render_block returns early on
+// should_stop(), film->put(block) follows; :213-216).  The sample in flight is dropped, W counts the finished ones.  Runs behind a
+// workgroup barrier, when no wave touches the path state any more; `packed_at` = the hot dword that holds a path's state (S_DONE:
+// already on the film).
+template <int WG, int NT>
+DEV void wg_flush_unfinished(const MTS_CONST_AS void *kernarg, const uint32_t *hot_lds, int packed_at, uint32_t wg_base) {
+    const WgArgs a = cload_k<WgArgs>(kernarg);
+#pragma unroll 1
+    for (uint32_t pid = threadIdx.x; pid < (uint32_t) WG; pid += NT) {
+        if ((hot_lds[packed_at * WG + pid] & 15u) == S_DONE) continue;
+        PathEnvT<ColdStoreHbm> e;
+        if (!wg_env<WG>(a, wg_base, pid, e)) continue;
+        float *own = (float *) (e.film + 5 * ((size_t) (e.blk.oy + (int) e.ly - a.sc.sensor.crop_y) * a.sc.sensor.crop_w + (e.blk.ox + (int) e.lx - a.sc.sensor.crop_x)));
+        for (int k = 0; k < 5; ++k) atomicAdd(own + k, e.cold.f(C_ACC + k));
+    }
+}
+
 template <bool COUNT, int WG /* paths */, int NT /* threads: fewer threads than paths keeps the rings fuller */>
 DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt) {
     constexpr int NQ = B_DONE;
@@ -1206,6 +1228,8 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         if (lane == 0) for (int k = 0; k < 45; ++k) atomicAdd(&g_blockstats[k], bs_loc[k]);
     }
 #endif
+    __syncthreads();                                          // every wave has left the loop: the path state is final
+    if (__atomic_load_n(&q_ctl[2 * B_COUNT], __ATOMIC_RELAXED) != STOP_NONE) wg_flush_unfinished<WG, NT>(kernarg, hot_lds, H_PACKED, wg_base);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1349,25 +1373,13 @@ DEV void workgroup_lanes(const MTS_CONST_AS void *kernarg, Counters &cnt) {
 #endif
     // ---- stopped (cancel / timeout / stall): the samples the unfinished pixels have accumulated go to the film
     __syncthreads();
-    if (__atomic_load_n(&q_ctl[1], __ATOMIC_RELAXED) != STOP_NONE) {
-        const WgArgs a = cload_k<WgArgs>(kernarg);
-#pragma unroll 1
-        for (uint32_t pid = tid; pid < (uint32_t) WG; pid += NT) {
-            if ((hot_lds[M::PACKED_AT * WG + pid] & 15u) == S_DONE) continue;
-            PathEnvT<ColdStoreHbm> e;
-            if (!wg_env<WG>(a, wg_base, pid, e)) continue;
-            const int fc = M::film_channels(a.sc);
-            float *own = (float *) (e.film + (size_t) fc * ((size_t) (e.blk.oy + (int) e.ly - a.sc.sensor.crop_y) * a.sc.sensor.crop_w + (e.blk.ox + (int) e.lx - a.sc.sensor.crop_x)));
-            for (int k = 0; k < 5; ++k) atomicAdd(own + k, e.cold.f(C_ACC + k));
-        }
-    }
+    if (__atomic_load_n(&q_ctl[1], __ATOMIC_RELAXED) != STOP_NONE) wg_flush_unfinished<WG, NT>(kernarg, hot_lds, M::PACKED_AT, wg_base);
 }
 
 // The volpath machine on driver 3
 template <bool COUNT, int WG>
 struct VolpathLanes {
     static constexpr int HOT = H_COUNT, PACKED_AT = H_PACKED;
-    DEV static int film_channels(const DScene &) { return 5; }
     DEV static int init(const MTS_CONST_AS void *kernarg, uint32_t *hot_lds, uint32_t wg_base, uint32_t pid0, Counters *cnt) {
         const WgArgs a = cload_k<WgArgs>(kernarg);
         VolpathMachine<COUNT> vm(a.sc, *cnt);

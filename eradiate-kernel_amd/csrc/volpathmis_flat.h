@@ -684,6 +684,8 @@ DEV void volpathmis_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         wga_push<WG>(cls, pid, mine, q_ids, q_ctl, cload_k<WgArgs>(kernarg).counters);
     }
+    __syncthreads();                                          // stopped: the unfinished pixels' samples go to the film (volpath_flat.h)
+    if (__atomic_load_n(&q_ctl[2 * B_COUNT], __ATOMIC_RELAXED) != STOP_NONE) wg_flush_unfinished<WG, NT>(kernarg, hot_lds, Hot::M_PACKED, wg_base);
 }
 
 } // inline namespace

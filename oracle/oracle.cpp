@@ -493,6 +493,33 @@ static void phase_sample(const Scene &sc, int phase, const MediumInteraction &mi
     }
 }
 
+// PhaseFunctionContext::component (include/mitsuba/render/phase.h): blendphase.cpp:75-87 (sample), :119-134 (eval) address one
+// component of the tree -- a blendphase lists the components of its first child, then those of its second (:58-61).  The
+// integrators never select a component (ctx.component = -1); these two serve the reference's unit tests (test_blendphase.py:111-200).
+static int phase_component_count(const Scene &sc, int phase) {
+    const Phase &ph = sc.phases[phase];
+    return ph.type == MTS_PHASE_BLEND ? phase_component_count(sc, ph.child[0]) + phase_component_count(sc, ph.child[1]) : 1;
+}
+static float phase_eval_component(const Scene &sc, int phase, const MediumInteraction &mi, V3 wo, int component) {
+    const Phase &ph = sc.phases[phase];
+    if (component < 0 || ph.type != MTS_PHASE_BLEND) return phase_eval(sc, phase, mi, wo);
+    float weight = std::min(std::max(volume_eval_1(sc.volumes[ph.weight_volume], mi.p), 0.f), 1.f);
+    const int n0 = phase_component_count(sc, ph.child[0]);
+    const bool sample_first = component < n0;
+    if (!sample_first) component -= n0; else weight = 1.f - weight;
+    return weight * phase_eval_component(sc, ph.child[sample_first ? 0 : 1], mi, wo, component);
+}
+static void phase_sample_component(const Scene &sc, int phase, const MediumInteraction &mi, float sample1, P2 sample2, int component, V3 *wo, float *pdf) {
+    const Phase &ph = sc.phases[phase];
+    if (component < 0 || ph.type != MTS_PHASE_BLEND) { phase_sample(sc, phase, mi, sample1, sample2, wo, pdf); return; }
+    float weight = std::min(std::max(volume_eval_1(sc.volumes[ph.weight_volume], mi.p), 0.f), 1.f);
+    const int n0 = phase_component_count(sc, ph.child[0]);
+    const bool sample_first = component < n0;
+    if (!sample_first) component -= n0; else weight = 1.f - weight;
+    phase_sample_component(sc, ph.child[sample_first ? 0 : 1], mi, sample1, sample2, component, wo, pdf);
+    *pdf *= weight;
+}
+
 // ---------------------------------------------------------------- BSDFs
 struct BSDFSample { V3 wo; float pdf, eta; uint32_t sampled_type; };
 // frame.h:67-70,107-118
@@ -1873,6 +1900,25 @@ int oracle_phase_sample(oracle_scene *s, int phase, const float *wi, const float
     mi.wi = v3(wi[0], wi[1], wi[2]); mi.sh_frame = frame_from_normal(-mi.wi); mi.p = v3(p[0], p[1], p[2]);
     P2 s2 = { s2x, s2y }; V3 w;
     phase_sample(sc, phase, mi, s1, s2, &w, pdf);
+    wo[0] = w.x; wo[1] = w.y; wo[2] = w.z;
+    ORC_CATCH
+}
+int oracle_phase_eval_component(oracle_scene *s, int phase, int component, const float *wi, const float *p, const float *wo, float *out, int *component_count) {
+    ORC_TRY
+    const Scene &sc = *((OracleScene *) s)->scene;
+    MediumInteraction mi; memset(&mi, 0, sizeof(mi));
+    mi.wi = v3(wi[0], wi[1], wi[2]); mi.sh_frame = frame_from_normal(-mi.wi); mi.p = v3(p[0], p[1], p[2]);
+    *out = phase_eval_component(sc, phase, mi, v3(wo[0], wo[1], wo[2]), component);
+    *component_count = phase_component_count(sc, phase);
+    ORC_CATCH
+}
+int oracle_phase_sample_component(oracle_scene *s, int phase, int component, const float *wi, const float *p, float s1, float s2x, float s2y, float *wo, float *pdf) {
+    ORC_TRY
+    const Scene &sc = *((OracleScene *) s)->scene;
+    MediumInteraction mi; memset(&mi, 0, sizeof(mi));
+    mi.wi = v3(wi[0], wi[1], wi[2]); mi.sh_frame = frame_from_normal(-mi.wi); mi.p = v3(p[0], p[1], p[2]);
+    P2 s2 = { s2x, s2y }; V3 w;
+    phase_sample_component(sc, phase, mi, s1, s2, component, &w, pdf);
     wo[0] = w.x; wo[1] = w.y; wo[2] = w.z;
     ORC_CATCH
 }

@@ -556,6 +556,8 @@ static inline Scene *make_scene(const mts_scene_desc *d) {
                 check_index(d->phases[i].child[0], d->phase_count, "blendphase child", false);
                 check_index(d->phases[i].child[1], d->phase_count, "blendphase child", false);
                 check_index(d->phases[i].weight_volume, d->volume_count, "blendphase weight", false);
+                // nested blendphase plugins recurse (oracle.cpp, phase_eval / phase_sample): children first, so that no cycle can form
+                if (d->phases[i].child[0] >= i || d->phases[i].child[1] >= i) throw std::runtime_error("blendphase: a nested phase function must precede the blendphase that holds it");
             }
         }
         for (int i = 0; i < d->medium_count; ++i) {

@@ -45,6 +45,8 @@ def lib():
         L.oracle_rfilter_eval.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, C.c_int]; L.oracle_rfilter_eval.restype = C.c_float
         L.oracle_phase_eval.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, fp]
         L.oracle_phase_sample.argtypes = [C.c_void_p, C.c_int, fp, fp, C.c_float, C.c_float, C.c_float, fp, fp]
+        L.oracle_phase_eval_component.argtypes = [C.c_void_p, C.c_int, C.c_int, fp, fp, fp, fp, C.POINTER(C.c_int)]
+        L.oracle_phase_sample_component.argtypes = [C.c_void_p, C.c_int, C.c_int, fp, fp, C.c_float, C.c_float, C.c_float, fp, fp]
         L.oracle_bsdf_eval.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, fp]
         L.oracle_bsdf_sample.argtypes = [C.c_void_p, C.c_int, fp, C.c_float, C.c_float, C.c_float, fp, fp, fp, C.POINTER(C.c_uint32)]
         L.oracle_volume_eval.argtypes = [C.c_void_p, C.c_int, C.c_int, fp, fp]
@@ -187,6 +189,17 @@ class OracleScene:
     def phase_sample(self, phase, wi, s1, s2, p=(0, 0, 0)):
         wo = np.zeros(3, np.float32); pdf = C.c_float()
         _check(lib().oracle_phase_sample(self.h, phase, _p(_f(wi)), _p(_f(p)), s1, s2[0], s2[1], _p(wo), C.byref(pdf)))
+        return wo, pdf.value
+
+    def phase_eval_component(self, phase, component, wi, wo, p=(0, 0, 0)):
+        """PhaseFunction::eval with ctx.component = component; returns (value, component_count)."""
+        out = C.c_float(); n = C.c_int()
+        _check(lib().oracle_phase_eval_component(self.h, phase, component, _p(_f(wi)), _p(_f(p)), _p(_f(wo)), C.byref(out), C.byref(n)))
+        return out.value, n.value
+
+    def phase_sample_component(self, phase, component, wi, s1, s2, p=(0, 0, 0)):
+        wo = np.zeros(3, np.float32); pdf = C.c_float()
+        _check(lib().oracle_phase_sample_component(self.h, phase, component, _p(_f(wi)), _p(_f(p)), s1, s2[0], s2[1], _p(wo), C.byref(pdf)))
         return wo, pdf.value
 
     def bsdf_eval(self, bsdf, wi, wo):

@@ -89,7 +89,9 @@ def test_default_kernel_resource_budget(tmp_path):
         return found[0]
     d = one("5v_rgb17render_kernel_wgaILb0ELi1024ELi1024ELi4E")
     assert d["vgpr_count"] <= 128                       # 4 waves per SIMD (launch bounds 1024 threads x 4)
-    assert d["private_segment_fixed_size"] <= 256 and d["vgpr_spill_count"] <= 8, d
+    # scratch: the frames of the real (out-of-line) functions -- sphere / BVH intersection, generic volume lookups and, since round 3, the
+    # walk of nested blendphase trees (four 8-entry stacks); none of it is touched by the atmosphere scenes
+    assert d["private_segment_fixed_size"] <= 384 and d["vgpr_spill_count"] <= 8, d
     assert d["sgpr_spill_count"] <= 400, d
     assert d["group_segment_fixed_size"] <= 160 * 1024, d
     # volpathmis on the rings: 512 paths x 68 state dwords, two waves per SIMD

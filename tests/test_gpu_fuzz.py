@@ -23,7 +23,9 @@ def _bsdf(rng):
     return {"type": "diffuse", "reflectance": float(rng.uniform(0.1, 0.9))}
 
 
-def _phase(rng):
+def _phase(rng, depth=0):
+    if depth < 2 and rng.random() < 0.25:            # a blendphase holding blendphases (blendphase.cpp:42-66), up to depth 2
+        return {"type": "blendphase", "phase_0": _phase(rng, depth + 1), "phase_1": _phase(rng, depth + 1), "weight": float(rng.uniform(0.1, 0.9))}
     k = rng.integers(0, 5)
     if k == 0: return {"type": "isotropic"}
     if k == 1: return {"type": "hg", "g": float(rng.uniform(-0.8, 0.9))}

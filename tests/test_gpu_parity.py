@@ -42,7 +42,25 @@ def test_golden_fixtures(gpu_rgb, name):
     assert [st["n_iter"], st["n_lookup"], st["n_nee_step"], st["samples"]] == list(counters)
 
 
+def three_species_atmosphere(width=24, height=24, spp=8, chain=False):
+    """The C4 miniature with a third species: blend(blend(rayleigh, tabulated aerosol; w_a), hg cloud droplets; w_c) -- a blendphase
+    inside a blendphase (blendphase.cpp:42-66), every weight a grid over the layers.  chain=True nests three levels on the right."""
+    d = scenes.c4_atmosphere(width, height, spp, layers=8)
+    ph = d["atmosphere"]["interior"]["phase"]
+    xf = ph["weight"]["to_world"]
+    layers = ph["weight"]["data"].shape[0]
+    wc = np.ascontiguousarray(np.broadcast_to((0.15 + 0.6 * np.exp(-np.arange(layers) / 2.0)).astype(np.float32)[:, None, None], (layers, 2, 2)))
+    tree = {"type": "blendphase", "phase_0": ph, "phase_1": {"type": "hg", "g": 0.85}, "weight": {"type": "gridvolume", "data": wc, "to_world": xf}}
+    if chain:
+        tree = {"type": "blendphase", "phase_0": {"type": "isotropic"}, "phase_1": {"type": "blendphase", "phase_0": {"type": "hg", "g": -0.3}, "phase_1": tree, "weight": 0.7},
+                "weight": {"type": "gridvolume", "data": np.ascontiguousarray(1.0 - 0.5 * wc), "to_world": xf}}
+    d["atmosphere"]["interior"]["phase"] = tree
+    return d
+
+
 CASES = {
+    "three_species_atmosphere": three_species_atmosphere,
+    "four_level_blend_chain": lambda: three_species_atmosphere(20, 16, 8, chain=True),
     "c3_ragged_100x70": lambda: scenes.c3_heterogeneous(100, 70, 8, res=16),
     "c3_tiny_5x3": lambda: scenes.c3_heterogeneous(5, 3, 32, res=8),
     "c2_hg_phase": lambda: scenes.c2_homogeneous_slab(48, 48, 16, phase={"type": "hg", "g": -0.4}),
@@ -605,6 +623,32 @@ def test_errors_surface_as_exceptions(gpu_rgb):
     scene = gpu_rgb.load_dict(d)
     with pytest.raises(RuntimeError, match="multiple of samples_per_pass"):       # integrator.cpp:61-63
         scene.integrator().render(scene, scene.sensors()[0])
+
+
+@pytest.mark.parametrize("integrator,kernel", [("volpath", None), ("volpathmis", None), ("volpath", "flat"), ("volpath", "nested"), ("volpath", "wgl1024")])
+def test_stopped_render_keeps_the_finished_samples(gpu_rgb, monkeypatch, integrator, kernel):
+    """A render cut short by the integrator's `timeout` returns the samples finished so far: the reference puts the partially rendered
+    block on the film (integrator.cpp:120-130, 213-216).  Every pixel of the stopped film carries a whole number 0 < W < spp of
+    samples, and X, Y, Z / W estimate the same image as a finished render (10 % on 16 x 16 tiles, 1 % on the image mean)."""
+    if kernel:
+        monkeypatch.setenv("MTSAMD_KERNEL", kernel)
+    spp = 1 << 16
+    d = scenes.c3_heterogeneous(512, 512, spp)
+    d["integrator"].update(type=integrator, timeout=0.3)
+    scene = gpu_rgb.load_dict(d)
+    sensor = scene.sensors()[0]
+    assert scene.integrator().render(scene, sensor) is True and scene.integrator().last_stats["timed_out"] == 1
+    raw = np.array(sensor.film().bitmap(raw=True))
+    W = raw[..., 4]
+    assert np.isfinite(raw).all() and (W == np.round(W)).all() and W.max() < spp
+    assert (W > 0).mean() > 0.999 and W.mean() > 8, (float((W > 0).mean()), float(W.mean()))
+    assert np.array_equal(raw[..., 3], W)                                   # alpha: every primary ray of this scene hits the ground or the medium
+    dref = scenes.c3_heterogeneous(512, 512, 64)
+    dref["integrator"]["type"] = integrator
+    ref, _ = gpu_render(gpu_rgb, dref)
+    a = raw[..., 1].reshape(32, 16, 32, 16).sum((1, 3)) / np.maximum(W.reshape(32, 16, 32, 16).sum((1, 3)), 1)
+    b = ref[..., 1].reshape(32, 16, 32, 16).sum((1, 3)) / ref[..., 4].reshape(32, 16, 32, 16).sum((1, 3))
+    assert abs(a.mean() / b.mean() - 1) < 0.01 and np.abs(a / b - 1).max() < 0.10, (a.mean() / b.mean(), np.abs(a / b - 1).max())
 
 
 @pytest.mark.parametrize("integrator", ["volpath", "volpathmis"])

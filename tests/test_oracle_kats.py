@@ -316,6 +316,47 @@ def test_blendphase_eval_and_component_choice(plugin_scene):
     assert np.array_equal(wo_b, wo_h) and pdf_b == pdf_h
 
 
+def test_blendphase_components_and_nested_trees():
+    """src/phase/tests/test_blendphase.py:111-200 (test04 / test05: ctx.component addresses one component, its value and pdf carry the
+    blending weight) on the reference's own two-component phase function, and the same rules one level down: a blendphase whose second
+    child is a blendphase (blendphase.cpp:42-66 holds arbitrary children, :58-61 concatenates their components, :92-108 hands the
+    rescaled sample1 down)."""
+    w, g = 0.2, 0.2
+    base = {"type": "scene", "integrator": {"type": "volpath"},
+            "sensor": {"type": "perspective", "film": {"type": "hdrfilm", "width": 4, "height": 4, "rfilter": {"type": "box"}}}}
+    o = ob.OracleScene(dict(base, ph={"type": "blendphase", "phase1": {"type": "isotropic"}, "phase2": {"type": "hg", "g": g}, "weight": w}))
+    root = o.desc.phase_count - 1
+    wi = [0, 0, 1]; wo = [0, 0, 1]
+    inv4pi = 1 / (4 * np.pi)
+    hg_fwd = inv4pi * (1 - g) / (1 + g) ** 2                            # eval_hg at cos = 1 (wo = wi: back scattering in the phase convention)
+    v0, n = o.phase_eval_component(root, 0, wi, wo)
+    v1, _ = o.phase_eval_component(root, 1, wi, wo)
+    assert n == 2 and np.isclose(v0, (1 - w) * inv4pi) and np.isclose(v1, w * hg_fwd)                   # test04
+    for s1 in (0.3, 0.1):                                                                               # test05: the selected component is always sampled
+        assert np.isclose(o.phase_sample_component(root, 0, wi, s1, (0.5, 0.5))[1], (1 - w) * inv4pi)
+        assert np.isclose(o.phase_sample_component(root, 1, wi, s1, (0.0, 0.0))[1], w * hg_fwd)
+    # ---- nested: blend(iso, blend(hg(g), rayleigh; w2); w1)
+    w1, w2 = 0.6, 0.25
+    o = ob.OracleScene(dict(base, ph={"type": "blendphase", "a": {"type": "isotropic"},
+                                      "b": {"type": "blendphase", "a": {"type": "hg", "g": g}, "b": {"type": "rayleigh"}, "weight": w2}, "weight": w1}))
+    root = o.desc.phase_count - 1
+    assert [o.desc.phases[i].type for i in range(o.desc.phase_count)] == [0, 1, 2, 3, 3]                # children first
+    ray = 3 / (16 * np.pi) * 2.0
+    full = o.phase_eval(root, wi, wo)
+    parts = [o.phase_eval_component(root, c, wi, wo) for c in range(3)]
+    assert all(n == 3 for _, n in parts)
+    assert np.allclose([v for v, _ in parts], [(1 - w1) * inv4pi, w1 * (1 - w2) * hg_fwd, w1 * w2 * ray], rtol=1e-6)
+    assert np.isclose(sum(v for v, _ in parts), full, rtol=1e-6)
+    # sample1 > w1: isotropic; else the inner blend sees sample1 / w1: > w2 -> hg, <= w2 -> rayleigh (blendphase.cpp:92-108)
+    hg_i, ray_i = 1, 2
+    for s1, leaf in ((0.9, 0), (0.3, hg_i), (0.12, ray_i), (0.15 + 1e-4, hg_i), (0.15 - 1e-4, ray_i)):
+        wo_t, pdf_t = o.phase_sample(root, wi, s1, (0.35, 0.8))
+        wo_l, pdf_l = o.phase_sample(leaf, wi, 0.5, (0.35, 0.8))
+        assert np.array_equal(wo_t, wo_l) and pdf_t == pdf_l, (s1, leaf)
+    # a component of the inner blend: pdf carries both weights
+    assert np.isclose(o.phase_sample_component(root, 2, wi, 0.9, (0.35, 0.8))[1], w1 * w2 * o.phase_sample(ray_i, wi, 0.5, (0.35, 0.8))[1])
+
+
 def test_diffuse_bsdf(plugin_scene):
     """src/bsdfs/tests/test_diffuse.py:16-38: eval = rho cos/pi, pdf = cos/pi with rho = 0.5"""
     o, _ = plugin_scene

@@ -35,7 +35,7 @@ if __name__ == "__main__":
         lib = sys.argv[sys.argv.index("--lib") + 1]; args = [a for a in args if a != lib]
     pat = args[0] if args else ""
     for name, d in sorted(kernel_resources(lib).items()):
-        if pat in name:
-            dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip().replace("mtsamd::", "")
+        dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip().replace("mtsamd::", "")
+        if pat in name or pat in dem:
             print("%-90s vgpr %3d sgpr %3d vspill %3d sspill %3d scratch %4d lds %6d" % (dem[:90], d["vgpr_count"], d["sgpr_count"], d["vgpr_spill_count"],
                   d["sgpr_spill_count"], d["private_segment_fixed_size"], d["group_segment_fixed_size"]))
