@@ -629,7 +629,7 @@ def test_errors_surface_as_exceptions(gpu_rgb):
 def test_stopped_render_keeps_the_finished_samples(gpu_rgb, monkeypatch, integrator, kernel):
     """A render cut short by the integrator's `timeout` returns the samples finished so far: the reference puts the partially rendered
     block on the film (integrator.cpp:120-130, 213-216).  Every pixel of the stopped film carries a whole number 0 < W < spp of
-    samples, and X, Y, Z / W estimate the same image as a finished render (10 % on 16 x 16 tiles, 1 % on the image mean)."""
+    samples, and X, Y, Z / W estimate the same image as a finished render (16 x 16 tiles and the image mean, tolerances below)."""
     if kernel:
         monkeypatch.setenv("MTSAMD_KERNEL", kernel)
     spp = 1 << 16
@@ -648,7 +648,11 @@ def test_stopped_render_keeps_the_finished_samples(gpu_rgb, monkeypatch, integra
     ref, _ = gpu_render(gpu_rgb, dref)
     a = raw[..., 1].reshape(32, 16, 32, 16).sum((1, 3)) / np.maximum(W.reshape(32, 16, 32, 16).sum((1, 3)), 1)
     b = ref[..., 1].reshape(32, 16, 32, 16).sum((1, 3)) / ref[..., 4].reshape(32, 16, 32, 16).sum((1, 3))
-    assert abs(a.mean() / b.mean() - 1) < 0.01 and np.abs(a / b - 1).max() < 0.10, (a.mean() / b.mean(), np.abs(a / b - 1).max())
+    # A render stopped at a fixed TIME is not an unbiased estimate: the sample in flight when the clock runs out is more likely a long
+    # (multiply scattered, bright) one, and it is the one that is dropped -- here as in the reference, which looks at should_stop()
+    # between samples.  The deficit is of the order of one sample in W, hence the 2 / W term.
+    n = float(W.mean())
+    assert abs(a.mean() / b.mean() - 1) < 0.01 + 2.0 / n and np.abs(a / b - 1).max() < 0.05 + 1.5 / np.sqrt(n), (n, a.mean() / b.mean(), np.abs(a / b - 1).max())
 
 
 @pytest.mark.parametrize("integrator", ["volpath", "volpathmis"])
