@@ -31,7 +31,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
 CONFIG_SIZES = {"C1": (256, 256, 64), "C2": (512, 512, 256), "C3": (512, 512, 1024), "C4": (1024, 1024, 4096), "C5": (1024, 1024, 4096),
-                "C5S": (1024, 1024, 256), "C5SM": (1024, 1024, 256), "C3M": (512, 512, 1024), "C1L": (512, 512, 256)}      # C5S: the same atmosphere in the spectral variant (gpu_spectral), 256 spp
+                "C5S": (1024, 1024, 256), "C5SM": (1024, 1024, 256), "C5SB": (1024, 1024, 256), "C3M": (512, 512, 1024), "C1L": (512, 512, 256)}      # C5S: the same atmosphere in the spectral variant (gpu_spectral), 256 spp
 C5_WAVELENGTHS = 16        # BASELINE.json configs[4]: the C4 atmosphere as a 16-wavelength batch
 
 
@@ -50,15 +50,17 @@ def build_scene_dict(scenes, config, width, height, spp, samples_per_pass=-1, re
         d = scenes.c4_atmosphere(width, height, spp)
     elif config == "C5":
         d = scenes.c4_atmosphere(width, height, spp, rayleigh_scale=c5_rayleigh_scale(wavelength))
-    elif config in ("C5S", "C5SM"):
+    elif config in ("C5S", "C5SM", "C5SB"):
         d = scenes.c5_atmosphere_spectral(width, height, spp)
+        if config == "C5SB":                                        # the same under Eradiate's wavelength-bin integrator: 16 bins, 32 AOV channels
+            d["integrator"] = {"type": "nbins", "wavelengths": ", ".join("%g" % (360.0 + 470.0 * k / 16) for k in range(17)), "integrator": d["integrator"]}
         if config == "C5SM":                                        # the spectral atmosphere under volpathmis (4 x 4 weight matrices)
             d["integrator"]["type"] = "volpathmis"
     else:
         d = scenes.c3_heterogeneous(width, height, spp, res=res)
         if config == "C3M":                                         # the metric scene under volpathmis (side measurement)
             d["integrator"]["type"] = "volpathmis"
-    d["integrator"]["samples_per_pass"] = samples_per_pass
+    (d["integrator"].get("integrator") or d["integrator"])["samples_per_pass"] = samples_per_pass      # nbins / bins wrap the sampling integrator
     return d
 
 
@@ -69,12 +71,13 @@ class Job:
         import torch
         self.torch, self.rank, self.n, self.backend = torch, rank, n, backend
         # C5: monochromatic batches (scalar_mono semantics), one per wavelength; C5S: the spectral variant
-        variant = {"C5": "gpu_mono", "C5S": "gpu_spectral", "C5SM": "gpu_spectral"}.get(args.config, "gpu_rgb")
+        variant = {"C5": "gpu_mono", "C5S": "gpu_spectral", "C5SM": "gpu_spectral", "C5SB": "gpu_spectral"}.get(args.config, "gpu_rgb")
         pkg.set_variant(variant)
         self.dicts = [build_scene_dict(scenes, args.config, args.width, args.height, spp_total, samples_per_pass, args.res, k)
                       for k in range(C5_WAVELENGTHS if args.config == "C5" else 1)]
         self.scenes = [pkg.load_dict(d, device=local_rank) for d in self.dicts]       # grids uploaded to HBM here (outside the timed region)
-        self.films = [torch.zeros((args.height, args.width, 5), dtype=torch.float32, device="cuda") for _ in self.scenes]
+        # X, Y, Z, A, W (+ two AOV channels per spectral bin under nbins / bins)
+        self.films = [torch.zeros((args.height, args.width, 5 + 2 * sc._desc.integrator.bin_count), dtype=torch.float32, device="cuda") for sc in self.scenes]
         self.stream = torch.cuda.current_stream().cuda_stream
         self.samples_step = args.width * args.height * spp_total * len(self.scenes)      # all ranks, one step
 
@@ -83,7 +86,7 @@ class Job:
         for scene, film in zip(self.scenes, self.films):
             integ = scene.integrator()
             integ.render(scene, scene.sensors()[0], shard_index=shard_index, shard_count=shard_count, device_film=film.data_ptr(),
-                         stream=self.stream, collect_counters=collect_counters)
+                         device_film_floats=film.numel(), stream=self.stream, collect_counters=collect_counters)
             stats.append(integ.last_stats)
         return stats
 
@@ -207,7 +210,7 @@ def main():
     avg_launch_ms = kernel_ms / max(launches, 1)
     bytes_per_launch = bytes_per_sample * samples_rank * (args.steps / max(launches, 1))
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
-    integ_type = job.dicts[0]["integrator"]["type"]
+    integ_type = (job.dicts[0]["integrator"].get("integrator") or job.dicts[0]["integrator"])["type"]
     kv = os.environ.get("MTSAMD_KERNEL", "wga1024")
     if integ_type == "path" or kv == "nested":
         kernel_name = "render_kernel<false, false, %d>" % {"path": 0, "volpath": 1, "volpathmis": 2}.get(integ_type, 0)
@@ -215,7 +218,7 @@ def main():
         kernel_name = "render_kernel<false, true, 1>"
     elif integ_type == "volpathmis":
         kernel_name = "v_spectral::render_kernel_wga_mis<false, true, 256, 256>" if args.config == "C5SM" else "render_kernel_wga_mis<false, true, 512, 512>"
-    elif args.config == "C5S":
+    elif args.config in ("C5S", "C5SB"):
         kernel_name = "v_spectral::render_kernel_wga<false, 256, 256, 2>"
     else:
         paths = int(kv[3:]); nt = int(os.environ.get("MTSAMD_WG_THREADS", str(paths)))
@@ -268,7 +271,7 @@ def main():
         cores = os.cpu_count() or 1
         def cpu_render(spp):
             osc = ob.OracleScene(build_scene_dict(scenes, args.config, args.width, args.height, spp, -1, args.res, 0), mono=args.config == "C5",
-                                 spectral=args.config in ("C5S", "C5SM"))
+                                 spectral=args.config in ("C5S", "C5SM", "C5SB"))
             tc0 = time.perf_counter()
             osc.render(threads=cores)
             return time.perf_counter() - tc0
@@ -285,6 +288,7 @@ def main():
         workload = {"C1": "C1 path cornell box", "C1L": "C1L = the C1 cornell box at 512x512x256 (262144 pixel streams: one per lane of the chip)", "C2": "C2 volpath homogeneous slab", "C4": "C4 volpath layered atmosphere, blend/tabulated phase, RPV ground",
                     "C5": "C5 = C4 as %d monochromatic wavelength batches (Rayleigh ~ lambda^-4), gpu_mono" % C5_WAVELENGTHS,
                     "C5S": "C5S = the C4 atmosphere in the spectral variant (gpu_spectral: 4 wavelengths per sample, gridvolume_spectral grids, global majorant)",
+                    "C5SB": "C5SB = C5S inside nbins (16 wavelength bins over 360 .. 830 nm: 32 AOV channels behind X, Y, Z, A, W), regrouping kernel",
                     "C5SM": "C5SM = C5S under volpathmis (spectral MIS with the 4 x 4 weight matrix of volpathmis.cpp:66-69), regrouping kernel compiled four wide",
                     "C3M": "C3M = the C3 scene under volpathmis (spectral MIS), regrouping kernel of volpathmis_flat.h",
                     "C3": "C3 volpath heterogeneous %d^3 grid + HG g=0.8" % args.res}[args.config]

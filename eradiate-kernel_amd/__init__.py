@@ -202,7 +202,7 @@ class Integrator:
         self.last_stats = None
 
     def render(self, scene, sensor, shard_index=0, shard_count=1, device_film=None, stream=None,
-               collect_counters=False):
+               collect_counters=False, device_film_floats=None):
         """Integrator.render(scene, sensor) -> bool: `not m_stop` (integrator.cpp:178), i.e. False iff cancel() stopped it; a render
         cut short by the integrator's "timeout" returns True like the reference's (last_stats["timed_out"] tells).
 
@@ -210,7 +210,9 @@ class Integrator:
         (integrator_v.cpp:124-156); ctypes releases the GIL for the duration of mts_render, and the
         SIGINT handler below calls mts_cancel.  Extra keyword arguments are extensions used by the
         multi-GPU path: `shard_*` selects the blocks this rank renders, `device_film` is a device
-        pointer (e.g. torch tensor data_ptr) receiving the XYZAW film instead of host memory.
+        pointer (e.g. torch tensor data_ptr) receiving the film instead of host memory: crop_height x crop_width x (5 + 2 x bins)
+        floats -- X, Y, Z, A, W and, under `nbins` / `bins`, two AOV channels per spectral bin.  `device_film_floats` is the size of
+        that buffer in floats (default: height x width x 5, the plain XYZAW film); mts_render refuses a buffer that is too small.
         """
         if scene is not self._scene:
             raise RuntimeError("Integrator.render(): the integrator belongs to another scene")
@@ -231,11 +233,13 @@ class Integrator:
         try:
             if device_film is not None:
                 opts.film_on_device = 1
+                opts.film_capacity = int(device_film_floats) if device_film_floats is not None else h * w * 5
                 A.check(A.lib().mts_render(scene._handle, C.byref(opts), C.c_void_p(int(device_film)), C.byref(stats)))
                 sensor._film._storage = None
             else:
                 out = np.zeros((h, w, 5 + 2 * scene._desc.integrator.bin_count), dtype=np.float32)    # X, Y, Z, A, W + aov_names()
                 opts.film_on_device = 0
+                opts.film_capacity = out.size
                 A.check(A.lib().mts_render(scene._handle, C.byref(opts), out.ctypes.data_as(C.c_void_p), C.byref(stats)))
                 sensor._film._storage = out
         finally:
@@ -356,8 +360,16 @@ def load_string(string, device=0, **kwargs):
     """mitsuba.core.xml.load_string(string, variant, **parameters) (src/libcore/python/xml_v.cpp:76-98): the XML is turned into
     a scene dictionary (xml_io.py), keyword arguments fill `$parameters`."""
     from .xml_io import xml_to_dict
+    from .fresolver import FileResolver, file_resolver, set_file_resolver
     kwargs.pop("variant", None)
-    return load_dict(xml_to_dict(string, kwargs), device)
+    # as load_file: the parser (a <path> tag prepends to it) works on a copy of the FileResolver, the caller's comes back afterwards
+    # (xml.cpp:1238-1240, 1275 do so for both entry points)
+    backup = file_resolver()
+    set_file_resolver(FileResolver(list(backup)))
+    try:
+        return load_dict(xml_to_dict(string, kwargs), device)
+    finally:
+        set_file_resolver(backup)
 
 
 def load_file(path, device=0, **kwargs):

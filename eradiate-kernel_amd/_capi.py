@@ -7,10 +7,12 @@ loader fails loudly: there is no CPU fallback for the product path.
 import ctypes as C
 import os
 
+from . import _buildid
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MTSAMD_LIB") or os.path.join(HERE, "libmtsamd.so")
 
-MTS_ABI_VERSION = 6
+MTS_ABI_VERSION = 7
 
 # enums (include/mtsamd.h)
 VOLUME_CONST, VOLUME_GRID, VOLUME_GRID_SPECTRAL = 0, 1, 2
@@ -115,7 +117,7 @@ class Stats(C.Structure):
 
 class RenderOpts(C.Structure):
     _fields_ = [("shard_index", i32), ("shard_count", i32), ("device", i32), ("stream", C.c_void_p),
-                ("film_on_device", i32), ("collect_counters", i32)]
+                ("film_on_device", i32), ("collect_counters", i32), ("film_capacity", C.c_int64)]
 
 
 ABI_STRUCTS = {"mts_spectrum": Spectrum, "mts_transform": Transform, "mts_volume": Volume, "mts_phase": Phase, "mts_medium": Medium,
@@ -124,7 +126,7 @@ ABI_STRUCTS = {"mts_spectrum": Spectrum, "mts_transform": Transform, "mts_volume
                "mts_render_opts": RenderOpts}
 
 # every symbol include/mtsamd.h declares
-ABI_SYMBOLS = ["mts_abi_version", "mts_last_error", "mts_device_count", "mts_scene_create", "mts_scene_destroy",
+ABI_SYMBOLS = ["mts_abi_version", "mts_build_id", "mts_last_error", "mts_device_count", "mts_scene_create", "mts_scene_destroy",
                "mts_render", "mts_cancel", "mts_sample", "mts_ray_intersect", "mts_abi_sizeof", "mts_sample_tea", "mts_wavefront_sampler"]
 
 _lib = None
@@ -159,6 +161,14 @@ def lib():
     L.mts_abi_sizeof.restype = C.c_int
     if L.mts_abi_version() != MTS_ABI_VERSION:
         raise BackendError("libmtsamd.so ABI version %d != %d" % (L.mts_abi_version(), MTS_ABI_VERSION))
+    # the binary must be the one this tree builds (a stale or foreign library would render with other kernels); an explicit MTSAMD_LIB
+    # (side-by-side measurement builds with extra flags) is taken as it is
+    L.mts_build_id.restype = C.c_char_p
+    if not os.environ.get("MTSAMD_LIB"):
+        built, tree = L.mts_build_id().decode(), _buildid.tree_build_id()
+        if built != tree:
+            raise BackendError("%s was built from other sources or flags (build id %s, this tree: %s) -- run `python eradiate-kernel_amd/build.py`"
+                               % (LIB_PATH, built, tree))
     _lib = L
     return L
 

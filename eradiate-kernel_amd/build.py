@@ -16,31 +16,22 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.environ.get("MTSAMD_LIB_OUT") or os.path.join(HERE, "libmtsamd.so")   # MTSAMD_LIB_OUT: A/B builds next to the product
-SOURCES = ["kernels.hip", "kernels_spectral.hip", "scene_host.cpp", "capi.cpp"]
-HEADERS = ["pmath.h", "dmath.h", "dscene.h", "integrator_dev.h", "volpath_flat.h", "volpathmis_flat.h", "launch.h", "scene_host.h", "cie_tables.h"]
+sys.path.insert(0, HERE)
+import _buildid                                          # noqa: E402  (plain module: build.py also runs as a script)
+SOURCES, HEADERS = _buildid.SOURCES, _buildid.HEADERS
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-         "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fgpu-flush-denormals-to-zero",
-         "-mfma", "-fno-fast-math",
-         # machine LICM hoists the materialisation of constants out of the path loop and pays for it with registers: without it the
-         # default kernel fits 128 VGPRs without a spill (four waves per SIMD: +9 % on the metric scene)
-         "-mllvm", "-disable-machine-licm", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
-
-
-def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+FLAGS = _buildid.FLAGS
 
 
 def build_backend(force=False, verbose=True, extra=()):
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(ROOT, "include", "mtsamd.h"), __file__]
-    if not force and not _stale(LIB, deps):
-        return LIB
     extra = list(extra) + os.environ.get("MTSAMD_EXTRA_FLAGS", "").split()
     flags = [("-fno-hip-fp32-correctly-rounded-divide-sqrt" if (os.environ.get("MTSAMD_EXP_FASTDIV") and f == "-fhip-fp32-correctly-rounded-divide-sqrt") else f)
              for f in FLAGS]                                 # MTSAMD_EXP_FASTDIV: measurement only, breaks parity
+    # The binary says which sources it was built from (mts_build_id): rebuild iff that differs from the tree -- not by mtimes, which
+    # a checkout, a copy to another box or a reverted experiment all falsify.
+    build_id = _buildid.tree_build_id(flags + extra)
+    if not force and _buildid.binary_build_id(LIB) == build_id:
+        return LIB
     # one hipcc per translation unit, side by side (the two kernel files take ~2.5 minutes each), then one link
     import tempfile
     cflags = [f for f in flags if f != "-shared"]
@@ -48,7 +39,7 @@ def build_backend(force=False, verbose=True, extra=()):
         jobs = []
         for f in SOURCES:
             obj = os.path.join(tmp, os.path.splitext(f)[0] + ".o")
-            cmd = [HIPCC] + cflags + list(extra) + ["-x", "hip", "-c", os.path.join(CSRC, f), "-o", obj]
+            cmd = [HIPCC] + cflags + list(extra) + ['-DMTSAMD_BUILD_ID="%s"' % build_id, "-x", "hip", "-c", os.path.join(CSRC, f), "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             jobs.append((cmd, obj, subprocess.Popen(cmd)))

@@ -95,6 +95,11 @@ template <typename T> struct DeviceBuffer {
 extern "C" {
 
 int mts_abi_version(void) { return MTS_ABI_VERSION; }
+#ifndef MTSAMD_BUILD_ID
+#define MTSAMD_BUILD_ID "unidentified...."
+#endif
+static const char g_build_id[] = "MTSAMD_BUILD_ID=" MTSAMD_BUILD_ID;   // also readable from the file without loading it (eradiate-kernel_amd/_buildid.py)
+const char *mts_build_id(void) { return g_build_id + 16; }
 const char *mts_last_error(void) { return g_error.c_str(); }
 
 int mts_abi_sizeof(const char *name) {
@@ -185,6 +190,9 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             samples += (uint64_t) b.sx * b.sy * samples_per_pass;
         }
     const size_t film_floats = (size_t) se.crop_w * se.crop_h * (size_t) hs.scene.film_channels;     // X, Y, Z, A, W (+ two AOV channels per spectral bin)
+    if (opts.film_capacity > 0 && (uint64_t) opts.film_capacity < (uint64_t) film_floats)
+        throw std::runtime_error("mts_render: the film buffer holds " + std::to_string(opts.film_capacity) + " floats, this scene writes " + std::to_string(film_floats) +
+                                 " (crop_width x crop_height x " + std::to_string(hs.scene.film_channels) + " channels: X, Y, Z, A, W + two per spectral bin)");
     RenderCache &rc = scene->cache;
     float *d_film = film;
     if (!opts.film_on_device) d_film = (float *) rc.get(0, film_floats * sizeof(float));
@@ -234,7 +242,10 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
                 variant = (block_size * block_size) % (uint32_t) wg != 0 ? 1 : family * 10000 + wg;
             }
             if (hs.integrator.spectral && variant == 1) variant = 0;                                      // no per-lane flat kernel in the spectral build
-            if (hs.scene.bin_count > 0 || hs.scene.srf >= 0) variant = 0;                                 // AOV channels / a response function: the per-lane kernel carries them
+            // AOV channels (nbins / bins) and a sensor response function: `volpath` carries them on the regrouping machine (NEW block of
+            // volpath_flat.h); `path`, `volpathmis` and a discrete response function with repeated wavelengths stay per lane
+            if ((hs.scene.bin_count > 0 || hs.scene.srf >= 0) &&
+                !(variant >= 10000 && hs.integrator.type == MTS_INTEGRATOR_VOLPATH && hs.srf_lookup_by_wavelength)) variant = 0;
             int wg_threads = 0;                                     // MTSAMD_WG_THREADS: threads per workgroup of the wga kernels (<= paths; default = paths)
             if (const char *tv = getenv("MTSAMD_WG_THREADS")) wg_threads = atoi(tv);
             float *d_ws = (float *) rc.get(3, render_workspace_floats((uint32_t) blocks.size(), block_size, variant) * sizeof(float));

@@ -181,6 +181,18 @@ DM_HD void tea_rounds(uint32_t &v0, uint32_t &v1, int rounds) {
 DM_HD uint32_t sample_tea_32(uint32_t v0, uint32_t v1, int rounds = 4) { tea_rounds(v0, v1, rounds); return v1; }
 DM_HD uint64_t sample_tea_64(uint32_t v0, uint32_t v1, int rounds = 4) { tea_rounds(v0, v1, rounds); return (uint64_t) v0 + ((uint64_t) v1 << 32); }
 DM_HD float sample_tea_float32(uint32_t v0, uint32_t v1, int rounds = 4) { return pm_from_bits((sample_tea_32(v0, v1, rounds) >> 9) | 0x3f800000u) - 1.0f; }
+// The same template instantiated with 64-bit arrays, as PCG32Sampler::seed of the wavefront variants calls it (librender/sampler.cpp:
+// 89-92: sample_tea_64(UInt64(seed_value), idx) with idx = arange<UInt64>): every operation of core/random.h:106-116 then runs in
+// 64-bit arithmetic -- no wrap at 2^32 inside the rounds -- and the result is v0 + (v1 << 32) modulo 2^64.
+DM_HD uint64_t sample_tea_64_u64(uint64_t v0, uint64_t v1, int rounds = 4) {
+    uint64_t sum = 0;
+    for (int i = 0; i < rounds; ++i) {
+        sum += 0x9e3779b9ull;
+        v0 += ((v1 << 4) + 0xa341316cull) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4ull);
+        v1 += ((v0 << 4) + 0xad90777dull) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eull);
+    }
+    return v0 + (v1 << 32);
+}
 
 // enoki::morton_decode (librender/integrator.cpp:200)
 DM_HD uint32_t compact_bits(uint32_t x) {

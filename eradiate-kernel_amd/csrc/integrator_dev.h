@@ -1797,6 +1797,21 @@ DEV Spec sample_wavelengths_srf(const DScene &sc, float sample, Spec &weight) {
     weight = spec4(wgt[0], wgt[1], wgt[2], wgt[3]);
     return spec4(v[0], v[1], v[2], v[3]);
 }
+// The weights sample_wavelengths_srf returned, recovered from the wavelengths themselves (the regrouping machine keeps a sample's
+// wavelengths in its hot state, not its weights): a uniform response has one weight; a discrete one is looked up by wavelength (the
+// host sends discrete response functions with repeated wavelengths to the per-lane kernel).
+DEV Spec srf_weights_of(const DScene &sc, Spec wl) {
+    const DSpectrum r = sc.spectra[sc.srf];
+    if (r.type == MTS_SPECTRUM_UNIFORM) return spec_s(r.value * (r.lambda_max - r.lambda_min));
+    const MTS_GLOBAL_AS float *wavelengths = as_global(r.wavelengths), *values = as_global(r.values);
+    const float w4[4] = { wl.x, wl.y, wl.z, wl.w }; float wgt[4];
+    for (int k = 0; k < 4; ++k) {
+        int lo = 0, hi = r.count - 1;                           // first index with wavelengths[i] >= w4[k]
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (wavelengths[mid] < w4[k]) lo = mid + 1; else hi = mid; }
+        wgt[k] = values[lo];
+    }
+    return spec4(wgt[0], wgt[1], wgt[2], wgt[3]);
+}
 // nbins.cpp:100-125 / bins.cpp:88-110: per bin the sum of the wrapped integrator's result over the sample's wavelengths inside the bin,
 // and their number; hsum of a 4-array: (x + y) + (z + w), as spec_hmean
 DEV void bin_aovs(const DScene &sc, Spec L, Spec wl, int i, float &value, float &population) {
@@ -1809,6 +1824,53 @@ DEV void bin_aovs(const DScene &sc, Spec L, Spec wl, int i, float &value, float 
     }
     value = (val[0] + val[1]) + (val[2] + val[3]);
     population = (pop[0] + pop[1]) + (pop[2] + pop[3]);
+}
+// The same splat for a scene with wavelength bins, without staging the AOV values in an array (the regrouping machine's NEW block):
+// the bins are walked twice, once to test the values the reference tests (imageblock.cpp:85-109), once to add them.  Box filter: the
+// AOV channels of the pixel the sample lands in; wider filters: every tap.  Same arithmetic and order as splat_values_t(aov, NA).
+DEV void splat_values_bins(const DScene &sc, const DBlock &blk, uint32_t lx, uint32_t ly, F2 position_sample, const float v[5], Spec L_raw, Spec wl,
+                           MTS_GLOBAL_AS float *film, float *own) {
+    const DSensor &se = sc.sensor;
+    const int C = sc.film_channels, nb = sc.bin_count;
+    bool ok = true;
+    for (int k = 0; k < 5; ++k) ok = ok && pm_isfinite(v[k]);
+    for (int i = 0; i < nb; ++i) { float a, b; bin_aovs(sc, L_raw, wl, i, a, b); ok = ok && pm_isfinite(a) && pm_isfinite(b); }
+    if (!ok) return;
+    const DRFilter &rf = se.rfilter;
+    const int border = rf.border_size;
+    const int sx = blk.sx + 2 * border, sy = blk.sy + 2 * border;
+    float posx = position_sample.x - ((float) (blk.ox - border) + .5f), posy = position_sample.y - ((float) (blk.oy - border) + .5f);
+    if (rf.radius > 0.5f + MTS_RAY_EPSILON) {
+        int lox = max((int) pm_ceil(posx - rf.radius), 0), loy = max((int) pm_ceil(posy - rf.radius), 0);
+        int hix = min((int) pm_floor(posx + rf.radius), sx - 1), hiy = min((int) pm_floor(posy + rf.radius), sy - 1);
+        uint32_t n = (uint32_t) pm_ceil((rf.radius - 2.f * MTS_RAY_EPSILON) * 2.f);
+        float basex = (float) lox - posx, basey = (float) loy - posy;
+        for (uint32_t yr = 0; yr < n; ++yr) {
+            int y = loy + (int) yr;
+            if (y > hiy) break;
+            float wy = as_global(rf.values)[min((int) pm_abs((basey + (float) yr) * rf.scale_factor), 31)];
+            int fy = blk.oy - border + y - se.crop_y;
+            for (uint32_t xr = 0; xr < n; ++xr) {
+                int x = lox + (int) xr;
+                if (x > hix) break;
+                float wx = as_global(rf.values)[min((int) pm_abs((basex + (float) xr) * rf.scale_factor), 31)];
+                float weight = wy * wx;
+                int fx = blk.ox - border + x - se.crop_x;
+                if (fx >= 0 && fy >= 0 && fx < se.crop_w && fy < se.crop_h) {
+                    float *dst = (float *) (film + (size_t) C * ((size_t) fy * se.crop_w + fx));
+                    for (int k = 0; k < 5; ++k) atomicAdd(dst + k, v[k] * weight);
+                    for (int i = 0; i < nb; ++i) { float a, b; bin_aovs(sc, L_raw, wl, i, a, b); atomicAdd(dst + 5 + 2 * i, a * weight); atomicAdd(dst + 6 + 2 * i, b * weight); }
+                }
+            }
+        }
+    } else {
+        int lox = (int) pm_ceil(posx - .5f), loy = (int) pm_ceil(posy - .5f);
+        const bool inside = lox >= 0 && loy >= 0 && lox < sx && loy < sy;
+        float *dst = (float *) (film + (size_t) C * ((size_t) (blk.oy + loy - se.crop_y) * se.crop_w + (blk.ox + lox - se.crop_x)));
+        if (lox == (int) lx && loy == (int) ly) { for (int k = 0; k < 5; ++k) own[k] += v[k]; }
+        else if (inside) { for (int k = 0; k < 5; ++k) atomicAdd(dst + k, v[k]); }
+        if (inside) for (int i = 0; i < nb; ++i) { float a, b; bin_aovs(sc, L_raw, wl, i, a, b); atomicAdd(dst + 5 + 2 * i, a); atomicAdd(dst + 6 + 2 * i, b); }
+    }
 }
 // cie1931_xyz + spectrum_to_xyz (core/spectrum.h:148-178,210-217): XYZ = hmean(cmf(lambda) * value)
 DEV void spectrum_to_xyz(const float *cie, Spec value, Spec wl, float xyz[3]) {

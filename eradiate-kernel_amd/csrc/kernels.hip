@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(256) wavefront_sampler_kernel(int32_t lanes, u
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= lanes) return;
     Pcg32 rng;
-    rng.seed(sample_tea_64((uint32_t) seed_value, (uint32_t) i), sample_tea_64((uint32_t) i, (uint32_t) seed_value));
+    rng.seed(sample_tea_64_u64(seed_value, (uint64_t) i), sample_tea_64_u64((uint64_t) i, seed_value));        // UInt64 instantiation, dmath.h
     for (int k = 0; k < count; ++k) out[(size_t) i * count + k] = rng.next_1d();
 }
 

@@ -586,6 +586,10 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
         const int t = hs.spectra[(size_t) d->sensor.srf - 1].type;
         if (t != MTS_SPECTRUM_UNIFORM && t != MTS_SPECTRUM_DISCRETE) throw std::runtime_error("srf: sample_spectrum is available for uniform and discrete spectra");
         sc.srf = d->sensor.srf - 1;
+        if (t == MTS_SPECTRUM_DISCRETE) {                                                      // srf_weights_of (integrator_dev.h) looks a weight up by its wavelength
+            const std::vector<float> &w = hs.spectrum_wavelengths[(size_t) sc.srf];
+            for (size_t k = 1; k < w.size(); ++k) if (!(w[k] > w[k - 1])) hs.srf_lookup_by_wavelength = false;
+        }
     }
     sc.volume_count = (int) hs.volumes.size(); sc.phase_count = (int) hs.phases.size(); sc.medium_count = (int) hs.media.size();
     sc.bsdf_count = (int) hs.bsdfs.size(); sc.shape_count = (int) hs.shapes.size(); sc.prim_count = (int) hs.prims.size();

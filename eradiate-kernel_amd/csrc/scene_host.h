@@ -37,6 +37,7 @@ struct HostScene {
     // spectral variant (DScene::spectra ...)
     std::vector<DSpectrum> spectra; std::vector<std::vector<float>> spectrum_values, spectrum_wavelengths, spectrum_cdf;
     std::vector<float> bin_lo, bin_hi;
+    bool srf_lookup_by_wavelength = true;            // the response function's weights can be recovered from the sampled wavelengths (regrouping kernel)
     std::vector<int32_t> bsdf_sp, emitter_sp; std::vector<DVolumeSp> volume_sp;
     std::vector<void *> device_allocs;
     int device = 0;

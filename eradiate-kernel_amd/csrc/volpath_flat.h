@@ -36,6 +36,11 @@ inline namespace MTS_VARIANT_NS {
 #define MTS_SPEC_DW 4
 #endif
 
+#if MTS_SPEC_N == 3
+#define MTS_FILM_STRIDE(sc) ((size_t) 5)
+#else
+#define MTS_FILM_STRIDE(sc) ((size_t) (sc).film_channels)          // X, Y, Z, A, W (+ two AOV channels per spectral bin: nbins / bins)
+#endif
 #define MTS_REPEAT_MIN 32          // lanes that must stay in a MEDIUM class for the block to run again in place (wg_block)
 
 enum : uint32_t { S_TOP = 0, S_MED = 1, S_SURF = 2, S_PHASE = 3, S_BSDF = 4, S_DIRB = 5, S_NEW = 6, S_DONE = 7, S_SCATTER = 8,
@@ -339,8 +344,11 @@ struct VolpathMachine {
 #if MTS_SPEC_N == 3
         (void) p.rng.next_1d();                                // wavelength sample, unused in rgb
 #else
-        float wav_weight;                                      // constant (sample_uniform_spectrum); blk_new recomputes it
-        p.wl = sample_wavelengths(p.rng.next_1d(), wav_weight); // integrator.cpp:252 -> perspective.cpp:169-172, distant.cpp:311-313
+        {                                                      // integrator.cpp:252 -> perspective.cpp:169-182, distant.cpp:311-313; blk_new recomputes the weights
+            const float wavelength_sample = p.rng.next_1d();
+            float wav_weight; Spec srf_weight;
+            p.wl = sc.srf >= 0 ? sample_wavelengths_srf(sc, wavelength_sample, srf_weight) : sample_wavelengths(wavelength_sample, wav_weight);
+        }
 #endif
         F2 adjusted;
         adjusted.x = (position_sample.x - (float) se.crop_x) / (float) se.crop_w;
@@ -429,16 +437,18 @@ struct VolpathMachine {
 #else
         {
             float wav_weight; (void) sample_wavelengths(0.f, wav_weight);
-            const Spec L = (wav_weight * e.cold.f(C_RAYW)) * p.res;     // ray_weight = wav_weight (x the sensor's grey weight), integrator.cpp:265
+            const Spec ww = sc.srf >= 0 ? srf_weights_of(sc, p.wl) : spec_s(wav_weight);
+            const Spec L = (ww * e.cold.f(C_RAYW)) * p.res;             // ray_weight = wav_weight (x the sensor's grey weight), integrator.cpp:265
             float xyz[3];
             spectrum_to_xyz(sc.cie, L, p.wl, xyz);                      // integrator.cpp:266-269
             const float v[5] = { xyz[0], xyz[1], xyz[2], (p.flags & FL_VALID_RAY) != 0 ? 1.f : 0.f, 1.f };
-            splat_values_t<false>(sc, e.blk, e.lx, e.ly, position_sample, v, e.film, acc);
+            if (sc.bin_count == 0) splat_values_t<false>(sc, e.blk, e.lx, e.ly, position_sample, v, e.film, acc);
+            else splat_values_bins(sc, e.blk, e.lx, e.ly, position_sample, v, p.res, p.wl, e.film, acc);
         }
 #endif
         const uint32_t sample_idx = __float_as_uint(e.cold.f(C_SAMPLE)) + 1u;
         if (sample_idx == e.sample_count) {                    // block -> film (hdrfilm.cpp:207-211)
-            float *own = (float *) (e.film + 5 * ((size_t) (e.blk.oy + (int) e.ly - se.crop_y) * se.crop_w + (e.blk.ox + (int) e.lx - se.crop_x)));
+            float *own = (float *) (e.film + MTS_FILM_STRIDE(sc) * ((size_t) (e.blk.oy + (int) e.ly - se.crop_y) * se.crop_w + (e.blk.ox + (int) e.lx - se.crop_x)));
             for (int k = 0; k < 5; ++k) atomicAdd(own + k, acc[k]);
             p.st = S_DONE;
         } else {
@@ -979,6 +989,10 @@ static __device__ WG_BLOCK_ATTR int wg_block(const MTS_CONST_AS void *kernarg_, 
 //   producer: release fence (state in LDS / HBM is written), tail++ -> index, wait until the slot is empty, store the id;
 //   consumer: head: h -> h + n by compare-and-swap (n <= tail - h of a snapshot: those indices are already handed out), wait until
 //             the slot holds an id, take it and store 0xFFFF AT ONCE, acquire fence.
+// The hand-over of a slot is a load followed by a store, not one atomic: it is exact as long as at most one producer and one consumer
+// work on a slot at a time, which holds unless a lane sits between its tail++ (or its claim) and its slot access for as long as the
+// workgroup needs to push WG further ids through the same ring -- a few instructions against thousands of cycles of block executions.
+// Should it ever happen an id is lost or taken twice; the former ends in the bounded idle wait below (diagnostic code 3), not in a hang.
 // A consumer can be ahead of its producer (index handed out, id not stored yet) and a producer ahead of the previous lap's consumer
 // (slot claimed, not yet emptied); with WG slots per ring and WG paths neither wait lasts.  The first look is inline; a lane that
 // has to wait does so in a wave-uniform loop whose body does the per-lane hand-over, so a lane's store never waits for another
@@ -989,6 +1003,7 @@ static __device__ WG_BLOCK_ATTR int wg_block(const MTS_CONST_AS void *kernarg_, 
 // first lane to raise the stop word adds 2^31 to every head, which makes every ring look empty to every wave (a count above WG is no
 // count, see the snapshot) and every pending claim fail; a wave that finds every ring empty looks at the stop word before it naps.
 #define MTS_RING_SPIN_LIMIT (1u << 22)
+#define MTS_IDLE_LIMIT (1u << 22)      // naps in a row with nothing waiting anywhere before a wave reports a lost path (never seen; about a second)
 #define MTS_DIAG_BASE 4            // counters[MTS_DIAG_BASE + 0..5]: code (1 consumer / 2 producer), ring, index, head, tail, workgroup
 enum : uint32_t { STOP_NONE = 0, STOP_CANCEL = 1, STOP_STALL = 2 };
 
@@ -1062,7 +1077,7 @@ DEV void wg_flush_unfinished(const MTS_CONST_AS void *kernarg, const uint32_t *h
         if ((hot_lds[packed_at * WG + pid] & 15u) == S_DONE) continue;
         PathEnvT<ColdStoreHbm> e;
         if (!wg_env<WG>(a, wg_base, pid, e)) continue;
-        float *own = (float *) (e.film + 5 * ((size_t) (e.blk.oy + (int) e.ly - a.sc.sensor.crop_y) * a.sc.sensor.crop_w + (e.blk.ox + (int) e.lx - a.sc.sensor.crop_x)));
+        float *own = (float *) (e.film + MTS_FILM_STRIDE(a.sc) * ((size_t) (e.blk.oy + (int) e.ly - a.sc.sensor.crop_y) * a.sc.sensor.crop_w + (e.blk.ox + (int) e.lx - a.sc.sensor.crop_x)));
         for (int k = 0; k < 5; ++k) atomicAdd(own + k, e.cold.f(C_ACC + k));
     }
 }
@@ -1115,7 +1130,7 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
 #if defined(MTSAMD_BLOCKSTATS)
     long long bs_t0 = clock64(); unsigned long long bs_loc[45] = {};                      // laid out like g_blockstats
 #endif
-    uint32_t poll_ticks = (tid >> 6) * 2048u;                // per wave, staggered: paces the polls of the host's stop word
+    uint32_t poll_ticks = (tid >> 6) * 2048u, idle_naps = 0; // per wave, staggered: paces the polls of the host's stop word
 #pragma unroll 1
     for (;;) {
       uint32_t n = 0, h = 0; int sel = 0; bool finished = false;
@@ -1155,12 +1170,16 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
                 if (lane == 0 && __hip_atomic_load(cload_k<WgArgs>(kernarg).stop_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
                     (void) wga_raise_stop<WG>(q_ctl, STOP_CANCEL);
             }
+            // a path that never comes back (a lost hand-over, see the protocol notes) would leave the finished count short for ever:
+            // after MTS_IDLE_LIMIT naps in a row with every ring empty the wave reports it (diagnostic code 3) instead
+            if (++idle_naps > MTS_IDLE_LIMIT) wga_stall<WG>(3u, B_DONE, 0u, q_ctl, cload_k<WgArgs>(kernarg).counters);
             __builtin_amdgcn_s_sleep(2);
 #if defined(MTSAMD_BLOCKSTATS)
             if (COUNT) { long long t = clock64(); bs_loc[42] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
 #endif
             continue;
         }
+        idle_naps = 0;
         // ---- claim up to 64 ids
         n = best < 64u ? best : 64u;
         h = (uint32_t) __builtin_amdgcn_readlane((int) hd, sel);
@@ -1252,7 +1271,6 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
 // Stopping needs no second exit: a raised stop word makes the vote come out empty, which is the (rare) path that already looks at
 // the finished count.  After a stop the workgroup adds the accumulators of its unfinished pixels to the film, as the reference puts
 // a partially rendered block on the film (integrator.cpp:120-130, 213-216).
-#define MTS_IDLE_LIMIT (1u << 22)      // naps without anything waiting anywhere before a wave reports a lost path (never seen; about a second)
 template <bool COUNT, int WG, int NT, class M /* machine: HOT dwords per path, PACKED_AT, init(), block() */>
 DEV void workgroup_lanes(const MTS_CONST_AS void *kernarg, Counters &cnt) {
     constexpr int PPL = WG / 64;                              // paths per lane

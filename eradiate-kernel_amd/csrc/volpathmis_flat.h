@@ -612,7 +612,7 @@ DEV void volpathmis_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         wga_push<WG>(cls, pid0, true, q_ids, q_ctl, cload_k<WgArgs>(kernarg).counters);
     }
-    uint32_t poll_ticks = (tid >> 6) * 2048u;
+    uint32_t poll_ticks = (tid >> 6) * 2048u, idle_naps = 0;
 #pragma unroll 1
     for (;;) {
       uint32_t n = 0, h = 0; int sel = 0; bool finished = false;
@@ -638,9 +638,11 @@ DEV void volpathmis_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &
                 if (lane == 0 && __hip_atomic_load(cload_k<WgArgs>(kernarg).stop_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
                     (void) wga_raise_stop<WG>(q_ctl, STOP_CANCEL);
             }
+            if (++idle_naps > MTS_IDLE_LIMIT) wga_stall<WG>(3u, B_DONE, 0u, q_ctl, cload_k<WgArgs>(kernarg).counters);   // a lost path: report, do not hang
             __builtin_amdgcn_s_sleep(2);
             continue;
         }
+        idle_naps = 0;
         n = best < 64u ? best : 64u;
         h = (uint32_t) __builtin_amdgcn_readlane((int) hd, sel);
         uint32_t won = 0;

@@ -101,14 +101,13 @@ def _spectrum(v, where, default=None, emitter=False):
         p = Props(v, where)
         t = p.type
         if t == "spectrum":
-            val = p.get("value", 1.0)
+            val = _spectrum_pairs(v, where)                                 # inline pairs or spectrum_from_file (xml.cpp:823-851)
             if p.has("filename"):
-                raise RuntimeError("spectra read from files (spectrum_from_file) are not supported by this backend: %s" % where)
-            if isinstance(val, str) and ":" in val:                         # "400:0.1, 500:0.2, ..." (xml.cpp:560-600)
-                try:
-                    val = [tuple(float(x) for x in tok.split(":")) for tok in val.replace(",", " ").split()]
-                except ValueError:
-                    raise RuntimeError("Could not parse wavelength:value pairs in %s" % where)
+                p.get("filename")
+            if val is None:
+                val = p.get("value", 1.0)
+            elif p.has("value"):
+                p.get("value")
             if isinstance(val, (list, tuple)):
                 # create_texture_from_spectrum, xml.cpp:1113-1150 (spectral mode): values scaled by MTS_CIE_Y_NORMALIZATION inside an
                 # emitter; `regular` when the wavelengths are equidistant (to math::Epsilon), `irregular` otherwise
@@ -206,9 +205,91 @@ def _spectrum(v, where, default=None, emitter=False):
     return len(b.spectra) - 1
 
 
-def _color(v, where, default=None):
+def spectrum_from_file(filename):
+    """src/libcore/spectrum.cpp:9-39: `wavelength value` per line, empty lines and lines starting with '#' skipped, anything after the
+    pair is an error; the name goes through the FileResolver."""
+    import os
+    path = file_resolver().resolve(filename)
+    if not os.path.exists(path):
+        raise RuntimeError("\"%s\": file does not exist!" % path)
+    pairs = []
+    with open(path) as f:
+        for line in f:
+            line = line.rstrip("\r\n")
+            if len(line) == 0 or line[0] == "#":
+                continue
+            tok = line.split()
+            if len(tok) > 2:
+                raise RuntimeError("\"%s\": excess tokens after wavlengths-value pair in file:\n%s!" % (path, line))
+            if len(tok) < 2:                                 # `iss >> value` fails: the reference keeps whatever the variables held; not reproduced
+                raise RuntimeError("\"%s\": could not parse wavelength-value pair:\n%s" % (path, line))
+            pairs.append((float(np.float32(tok[0])), float(np.float32(tok[1]))))
+    return pairs
+
+
+def _spectrum_pairs(v, where):
+    """The wavelength:value pairs of a {"type": "spectrum"} dictionary (inline string / list, or a file), or None for a constant."""
+    if "filename" in v:
+        if "value" in v:
+            raise RuntimeError("'spectrum' tag requires one of \"value\" or \"filename\" attributes")      # xml.cpp:815-816
+        return spectrum_from_file(v["filename"])
+    val = v.get("value", 1.0)
+    if isinstance(val, str) and ":" in val:                                 # "400:0.1, 500:0.2, ..." (xml.cpp:823-846)
+        try:
+            return [tuple(float(x) for x in tok.split(":")) for tok in val.replace(",", " ").split()]
+        except ValueError:
+            raise RuntimeError("Could not parse wavelength:value pairs in %s" % where)
+    if isinstance(val, (list, tuple, np.ndarray)):
+        return [tuple(x) for x in np.asarray(val, np.float64).reshape(-1, 2)]
+    return None
+
+
+def _cie1931_xyz(x):
+    """core/spectrum.h:148-178 in float32: linear interpolation of the 5 nm tables over 360 .. 830 nm, zero outside."""
+    from .spectra_data import CIE_1931
+    f = np.float32
+    t = f(f(f(x) - f(360.0)) * f(f(94) / f(f(830.0) - f(360.0))))
+    if not (x >= 360.0 and x <= 830.0):
+        return np.zeros(3, np.float32)
+    i0 = int(min(max(int(t), 0), 93)); i1 = i0 + 1
+    w1 = f(t - f(i0)); w0 = f(f(1.0) - w1)
+    return np.array([f(f(w0 * f(CIE_1931[c][i0])) + f(w1 * f(CIE_1931[c][i1]))) for c in range(3)], np.float32)       # fmadd(w0, v0, w1 * v1): differs in the last bit at most
+
+
+def spectrum_to_rgb(wavelengths, values, bounded=True):
+    """src/libcore/spectrum.cpp:41-89: pre-integration of a tabulated spectrum against the CIE 1931 curves (1000 steps over
+    MTS_WAVELENGTH_MIN .. MAX = 280 .. 2400 nm, this fork's range), XYZ -> linear sRGB, clamped (to [0, 1] when `bounded`)."""
+    f = np.float32
+    wl = [f(w) for w in wavelengths]; vs = [f(v) for v in values]
+    color = np.zeros(3, np.float32)
+    steps = 1000
+    for i in range(steps):
+        x = f(f(WAVELENGTH_MIN) + f(f(i) / f(steps - 1)) * f(f(WAVELENGTH_MAX) - f(WAVELENGTH_MIN)))
+        if x < wl[0] or x > wl[-1]:
+            continue
+        # math::find_interval(size, pred): the last index with pred true, clamped to [0, size - 2]
+        index = 0
+        for k in range(len(wl)):
+            if wl[k] <= x:
+                index = k
+        index = min(max(index, 0), len(wl) - 2)
+        x0, x1, y0, y1 = wl[index], wl[index + 1], vs[index], vs[index + 1]
+        y = f(f(f(f(f(x * y0) - f(x1 * y0)) - f(x * y1)) + f(x0 * y1)) / f(x0 - x1))
+        color = (color + _cie1931_xyz(x) * y).astype(np.float32)
+    color = (color * f(f(f(WAVELENGTH_MAX) - f(WAVELENGTH_MIN)) / f(steps))).astype(np.float32)
+    m = np.array([[3.240479, -1.537150, -0.498535], [-0.969256, 1.875991, 0.041556], [0.055648, -0.204043, 1.057311]], np.float32)   # xyz_to_srgb, spectrum.h:229-235
+    color = (m @ color).astype(np.float32)
+    color = np.clip(color, 0.0, 1.0) if bounded else np.maximum(color, 0.0)
+    return tuple(float(c) for c in color)
+
+
+CIE_Y_NORMALIZATION = 1.0 / 106.856895                     # MTS_CIE_Y_NORMALIZATION, core/spectrum.h:136
+_UNBOUNDED_NAMES = ("eta", "k", "int_ior", "ext_ior")      # is_unbounded_spectrum, xml.cpp:142-144
+
+
+def _color(v, where, default=None, emitter=False):
     """float | [r,g,b] | {"type":"rgb","value":..} | {"type":"spectrum"/"uniform","value":x} -> (r,g,b)."""
-    c = _color_rgb(v, where, default)
+    c = _color_rgb(v, where, default, emitter)
     if _MONO and not (c[0] == c[1] == c[2]):
         f = np.float32
         lum = float(f(f(f(c[0]) * f(0.212671) + f(c[1]) * f(0.715160)) + f(c[2]) * f(0.072169)))      # spectrum.h:246-248
@@ -216,7 +297,7 @@ def _color(v, where, default=None):
     return c
 
 
-def _color_rgb(v, where, default=None):
+def _color_rgb(v, where, default=None, emitter=False):
     if v is None:
         v = default
     if isinstance(v, dict):
@@ -228,10 +309,24 @@ def _color_rgb(v, where, default=None):
             if c.size == 1:
                 c = np.repeat(c, 3)
             return tuple(float(x) for x in c[:3])
-        if t in ("spectrum", "uniform"):
+        if t == "spectrum":
+            pairs = _spectrum_pairs(v, where)
+            if pairs is not None:
+                # create_texture_from_spectrum in the non-spectral modes (xml.cpp:1113-1170): values x MTS_CIE_Y_NORMALIZATION, wavelengths
+                # in increasing order, pre-integrated against the CIE curves -> `srgb` (bounded) / `srgb_d65` (emitters) colour
+                f = np.float32
+                wl = [p_[0] for p_ in pairs]
+                if any(b_ - a_ < 0 for a_, b_ in zip(wl, wl[1:])):
+                    raise RuntimeError("Wavelengths must be specified in increasing order!")
+                if len(wl) < 2:
+                    raise RuntimeError("a tabulated spectrum needs at least two wavelength:value pairs: %s" % where)
+                name = where.rsplit(".", 1)[-1]
+                return spectrum_to_rgb(wl, [f(f(p_[1]) * f(CIE_Y_NORMALIZATION)) for p_ in pairs], bounded=not (emitter or name in _UNBOUNDED_NAMES))
+            return (float(v.get("value", 1.0)),) * 3
+        if t == "uniform":
             val = v.get("value", 1.0)
-            if isinstance(val, (list, tuple)):
-                raise RuntimeError("wavelength-dependent spectra are not supported by the rgb backend: %s" % where)
+            if isinstance(val, (list, tuple, str)):
+                raise RuntimeError("'uniform' takes one value: %s" % where)
             return (float(val),) * 3
         if t in ("srgb", "srgb_d65"):
             c = np.asarray(v.get("color"), dtype=np.float32).reshape(-1)
@@ -631,7 +726,7 @@ class SceneBuilder:
         if _SPECTRAL is not None:
             e.radiance_spectrum = _spectrum(v, where, emitter=True)
         else:
-            e.radiance[:] = _color(v, where, default=1.0)
+            e.radiance[:] = _color(v, where, default=1.0, emitter=True)
 
     def add_emitter(self, d, where):
         p = Props(d, where)

@@ -15,3 +15,17 @@ D65 = [
     51.959, 54.6998, 57.4406, 58.8765, 60.3125,
 ]
 D65_NORMALIZATION = 1.0 / 10568.0
+
+
+def _cie_1931_from_header():
+    """The CIE 1931 2-degree observer, 95 samples per curve every 5 nm over 360 .. 830 nm: read from the one place this repository keeps
+    the table (csrc/cie_tables.h, the array the kernels use; /root/reference/include/mitsuba/core/spectrum.h:127-133 declares it)."""
+    import os
+    import re
+    text = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "cie_tables.h")).read()
+    vals = [float(x) for x in re.findall(r"([0-9.eE+-]+)f", text.split("{")[1])]
+    assert len(vals) == 3 * 95, len(vals)
+    return [vals[0:95], vals[95:190], vals[190:285]]
+
+
+CIE_1931 = _cie_1931_from_header()

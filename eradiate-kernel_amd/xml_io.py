@@ -253,8 +253,10 @@ class _Parser:
             return {"type": "rgb", "value": v}
         if tag == "spectrum":
             _check_attrs(node, a, {"name", "value", "filename"}, set(), self.src)
-            if "value" not in a or "filename" in a:
-                _err(self.src, "spectrum: files (spectrum_from_file) are not supported by this backend")
+            if ("value" in a) == ("filename" in a):              # xml.cpp:815-816
+                _err(self.src, "'spectrum' tag requires one of \"value\" or \"filename\" attributes")
+            if "filename" in a:                                  # spectrum_from_file (libcore/spectrum.cpp:9-39), read by the loader through the FileResolver
+                return {"type": "spectrum", "filename": a["filename"]}
             if ":" in a["value"]:                                # wavelength:value pairs (xml.cpp:560-600): regular / irregular in the spectral variant
                 return {"type": "spectrum", "value": a["value"]}
             return {"type": "spectrum", "value": _floats(a["value"], self.src, "spectrum", 1)[0]}

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MTS_ABI_VERSION 6
+#define MTS_ABI_VERSION 7
 
 /* Transform4f: row-major 4x4 matrix and its inverse transpose (transform.h:36-50). */
 typedef struct mts_transform {
@@ -267,10 +267,14 @@ typedef struct mts_render_opts {
     void *stream;             /* hipStream_t to launch on, NULL = default stream                 */
     int32_t film_on_device;   /* 0: `film` is host memory; 1: `film` is a device pointer         */
     int32_t collect_counters; /* 1: fill n_iter / n_lookup / n_nee_step (slower kernel variant)  */
+    int64_t film_capacity;    /* floats the caller's `film` buffer holds; mts_render refuses a buffer smaller than
+                                 crop_width x crop_height x (5 + 2 x spectral bins).  0: unchecked                */
 } mts_render_opts;
 
 /* Library / device queries */
 int  mts_abi_version(void);
+const char *mts_build_id(void);                 /* 16 hex digits: hash of the sources, headers and compiler flags this library was built from
+                                                   (eradiate-kernel_amd/_buildid.py); the binding refuses a library that is not the tree's */
 const char *mts_last_error(void);
 int  mts_device_count(int *count);
 int  mts_abi_sizeof(const char *struct_name);   /* sizeof(<struct_name>) as compiled, -1 if unknown (binding self-check) */

@@ -1853,7 +1853,7 @@ void oracle_sampler_stream(uint64_t base_seed, uint64_t seed_offset, int n, floa
 // PCG32Sampler::seed of the wavefront variants (sampler.cpp:83-92): lane idx seeded with (tea64(seed_value, idx), tea64(idx, seed_value))
 void oracle_wavefront_sampler(int lanes, uint64_t seed_value, int count, float *out) {
     for (int i = 0; i < lanes; ++i) {
-        PCG32 rng; rng.seed(sample_tea_64((uint32_t) seed_value, (uint32_t) i), sample_tea_64((uint32_t) i, (uint32_t) seed_value));
+        PCG32 rng; rng.seed(sample_tea_64_u64(seed_value, (uint64_t) i), sample_tea_64_u64((uint64_t) i, seed_value));
         for (int k = 0; k < count; ++k) out[(size_t) i * count + k] = rng.next_float32();
     }
 }

@@ -100,3 +100,33 @@ def test_default_kernel_resource_budget(tmp_path):
     # the spectral variant's volpath: 256 paths x 42 state dwords, three workgroups per CU
     sp = one("10v_spectral17render_kernel_wgaILb0ELi256ELi256ELi2E")
     assert sp["vgpr_count"] <= 168 and sp["vgpr_spill_count"] == 0 and 3 * sp["group_segment_fixed_size"] <= 160 * 1024, sp
+
+
+def test_binary_identifies_its_sources(L, tmp_path, monkeypatch):
+    """mts_build_id(): the library carries a hash of the sources, headers and flags it was built from; the build script rebuilds when
+    the tree's hash differs (no mtimes), and the binding refuses a library that is not the tree's -- a header touched without a
+    rebuild makes set_variant fail loudly instead of rendering with the old kernels."""
+    import shutil
+    B = importlib.import_module("eradiate-kernel_amd._buildid")
+    lib_path = os.path.join(ROOT, "eradiate-kernel_amd", "libmtsamd.so")
+    L.mts_build_id.restype = C.c_char_p
+    built = L.mts_build_id().decode()
+    assert re.fullmatch(r"[0-9a-f]{16}", built)
+    assert built == B.tree_build_id() == B.binary_build_id(lib_path)            # from the symbol, from the tree, from the file's bytes
+    # the same sources with one byte appended to a header: another id
+    csrc = tmp_path / "csrc"
+    shutil.copytree(B.CSRC, csrc)
+    with open(csrc / "dmath.h", "a") as f:
+        f.write("\n")
+    changed = B.tree_build_id(csrc=str(csrc))
+    assert changed != built and B.tree_build_id(flags=B.FLAGS + ["-DX"]) != built
+    # ... which the binding notices when it loads the (now stale) library
+    monkeypatch.setattr(A, "_lib", None)
+    monkeypatch.setattr(B, "tree_build_id", lambda *a, **k: changed)
+    monkeypatch.delenv("MTSAMD_LIB", raising=False)
+    with pytest.raises(A.BackendError, match="built from other sources"):
+        A.lib()
+    pkg = importlib.import_module("eradiate-kernel_amd")
+    with pytest.raises(A.BackendError, match="built from other sources"):
+        pkg.set_variant("gpu_rgb")
+    assert B.binary_build_id(str(tmp_path / "missing.so")) is None

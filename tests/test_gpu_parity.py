@@ -885,6 +885,54 @@ def test_spectral_volpathmis_against_oracle(gpu_spectral, monkeypatch, name, use
     assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (o.last_stats["n_iter"], o.last_stats["n_lookup"], o.last_stats["n_nee_step"])
 
 
+@pytest.mark.parametrize("kernel", [None, "nested"])
+@pytest.mark.parametrize("wrap", ["nbins", "bins_discrete_srf"])
+def test_bins_on_the_regrouping_machine(gpu_spectral, monkeypatch, wrap, kernel):
+    """nbins / bins around `volpath` and a sensor response function run on v_spectral::render_kernel_wga (AOV values splatted by the NEW
+    block, response-function weights recovered from the sampled wavelengths) and give the film and AOV channels of the oracle -- as does
+    the per-lane kernel they ran on before (MTSAMD_KERNEL=nested)."""
+    if kernel:
+        monkeypatch.setenv("MTSAMD_KERNEL", kernel)
+    if wrap == "nbins":
+        d = _spectral_cases()["c5s_atmosphere"]                                          # distant sensor, gridvolume_spectral, 40 x 32 (partial blocks)
+        d["integrator"] = {"type": "nbins", "wavelengths": "400, 480, 560, 640, 720, 800", "integrator": dict(d["integrator"])}
+        channels = 5 + 2 * 6
+    else:
+        d = _spectral_cases()["grid_spectral_d65_rpv"]                                   # perspective camera: the sensors that take an srf
+        d["sensor"]["srf"] = {"type": "discrete", "wavelengths": "450, 550, 650, 750", "values": "0.5, 1.0, 0.75, 0.25"}
+        d["integrator"] = {"type": "bins", "bins": "a:400:500, b:500:600, c:600:800", "integrator": dict(d["integrator"])}
+        channels = 5 + 2 * 3
+    scene = gpu_spectral.load_dict(d)
+    sensor = scene.sensors()[0]
+    assert scene.integrator().render(scene, sensor, collect_counters=True)
+    raw = np.array(sensor.film().bitmap(raw=True))
+    st = scene.integrator().last_stats
+    assert st["kernel_variant"] == (0 if kernel else 10256)
+    o = ob.OracleScene(d, spectral=True); ref = o.render()
+    assert raw.shape[2] == channels and ref[..., 5:].max() > 0
+    assert_parity(raw, ref)
+    assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (o.last_stats["n_iter"], o.last_stats["n_lookup"], o.last_stats["n_nee_step"])
+
+
+def test_device_film_buffer_must_hold_the_aov_channels(gpu_spectral):
+    """mts_render writes crop_w x crop_h x (5 + 2 bins) floats: a device film sized for plain XYZAW is refused (mts_render_opts.film_capacity)
+    instead of being overrun."""
+    import torch
+    d = _spectral_cases()["c5s_atmosphere"]
+    d["integrator"] = {"type": "nbins", "wavelengths": "400, 500, 600, 700", "integrator": dict(d["integrator"])}
+    scene = gpu_spectral.load_dict(d)
+    sensor = scene.sensors()[0]
+    h, w = 32, 40
+    small = torch.zeros((h, w, 5), dtype=torch.float32, device="cuda")
+    with pytest.raises(RuntimeError, match="film buffer holds"):
+        scene.integrator().render(scene, sensor, device_film=small.data_ptr())
+    film = torch.zeros((h, w, 5 + 2 * 4), dtype=torch.float32, device="cuda")
+    assert scene.integrator().render(scene, sensor, device_film=film.data_ptr(), device_film_floats=film.numel())
+    torch.cuda.synchronize()
+    host, _ = gpu_render(gpu_spectral, d)
+    assert np.array_equal(film.cpu().numpy(), host)
+
+
 def test_bin_integrators_srf_and_irregular_spectra(gpu_spectral):
     """src/integrators/nbins.cpp / bins.cpp (two AOV channels per spectral bin behind X, Y, Z, A, W), the sensors' `srf` (uniform and
     discrete: perspective.cpp:173-182, radiancemeter.cpp:116-124) and `irregular` spectra: the reference's own two sample tests
@@ -927,4 +975,5 @@ def test_bin_integrators_srf_and_irregular_spectra(gpu_spectral):
     assert raw.shape[2] == 11 and ref[..., 5:].max() > 0
     assert_parity(raw, ref)
     st = scene.integrator().last_stats
+    assert st["kernel_variant"] == 10256                        # bins + srf on the regrouping machine (v_spectral::render_kernel_wga), not per lane
     assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (o.last_stats["n_iter"], o.last_stats["n_lookup"], o.last_stats["n_nee_step"])

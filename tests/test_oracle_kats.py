@@ -53,6 +53,48 @@ def test_independent_sampler_is_default_pcg32():
     assert ((a >= 0) & (a < 1)).all()
 
 
+def test_wavefront_seeding_uses_the_64_bit_instantiation_of_tea():
+    """librender/sampler.cpp:89-92 seeds lane idx of a wavefront with rng.seed(sample_tea_64(UInt64(seed), idx), sample_tea_64(idx,
+    UInt64(seed))), idx = arange<UInt64>: the template of core/random.h:106-116 instantiated with 64-bit arrays, so sums, shifts and
+    xors run in 64 bits (no wrap at 2^32 inside the rounds) and the result is v0 + (v1 << 32) mod 2^64.  Pinned by an evaluation of the
+    template written out here in Python integers (by hand from the source text; pcg32 = the published algorithm)."""
+    M = (1 << 64) - 1
+
+    def tea64_u64(v0, v1, rounds=4):
+        total = 0
+        for _ in range(rounds):
+            total = (total + 0x9e3779b9) & M
+            v0 = (v0 + ((((v1 << 4) & M) + 0xa341316c & M) ^ ((v1 + total) & M) ^ (((v1 >> 5) + 0xc8013ea4) & M))) & M
+            v1 = (v1 + ((((v0 << 4) & M) + 0xad90777d & M) ^ ((v0 + total) & M) ^ (((v0 >> 5) + 0x7e95761e) & M))) & M
+        return (v0 + ((v1 << 32) & M)) & M
+
+    class Pcg:
+        def __init__(self, initstate, initseq):
+            self.state, self.inc = 0, ((initseq << 1) | 1) & M
+            self.next(); self.state = (self.state + initstate) & M; self.next()
+
+        def next(self):
+            old = self.state
+            self.state = (old * 0x5851f42d4c957f2d + self.inc) & M
+            xorshifted = (((old >> 18) ^ old) >> 27) & 0xFFFFFFFF
+            rot = old >> 59
+            return ((xorshifted >> rot) | (xorshifted << ((-rot) & 31))) & 0xFFFFFFFF
+
+        def next_float32(self):
+            return float(np.array([(self.next() >> 9) | 0x3f800000], np.uint32).view(np.float32)[0] - np.float32(1.0))
+
+    # the first round already differs from the 32-bit instantiation: (v1 << 4) keeps its upper bits
+    assert tea64_u64(1, 1) != L().oracle_tea64(1, 1, 4) and tea64_u64(1, 1) >> 40 != 0
+    lanes, count = 40, 6
+    for seed in (7, (1 << 40) + 12345):
+        out = np.zeros((lanes, count), np.float32)
+        L().oracle_wavefront_sampler.argtypes = [C.c_int, C.c_uint64, C.c_int, ob.fp]
+        L().oracle_wavefront_sampler(lanes, seed, count, out.ctypes.data_as(ob.fp))
+        for i in (0, 1, 2, 17, 39):
+            rng = Pcg(tea64_u64(seed, i), tea64_u64(i, seed))
+            assert [float(x) for x in out[i]] == [rng.next_float32() for _ in range(count)], (seed, i)
+
+
 # ---------------------------------------------------------------- warps / frames
 def warp(kind, u, v):
     out = np.zeros(3, np.float32)

@@ -168,3 +168,72 @@ def test_file_resolver_and_path_tag(tmp_path):
             xml_io.xml_to_dict('<scene version="2.0.0"><path value="nowhere"/></scene>', base_dir=str(tmp_path))
     finally:
         fresolver.set_file_resolver(backup)
+
+
+def test_tabulated_spectra_inline_and_from_files(tmp_path):
+    """<spectrum value="w:v, ..."/> and <spectrum filename=".."/> (xml.cpp:806-860, libcore/spectrum.cpp:9-39): regular / irregular
+    spectra in the spectral variant; in the rgb / mono variants the pairs are pre-integrated against the CIE 1931 curves into a linear
+    sRGB colour (create_texture_from_spectrum, xml.cpp:1113-1170 -> spectrum_to_rgb, libcore/spectrum.cpp:41-89)."""
+    SD = importlib.import_module("eradiate-kernel_amd.scene_dict")
+    data = importlib.import_module("eradiate-kernel_amd.spectra_data")
+    fresolver = importlib.import_module("eradiate-kernel_amd.fresolver")
+    pkg = importlib.import_module("eradiate-kernel_amd")
+    # "Values are scaled so that integrating the spectrum against the CIE curves and converting to sRGB yields (1, 1, 1) for D65"
+    # (xml.cpp:1114-1115): D65 in the units of the d65 plugin (table / 10568) times 1 / MTS_CIE_Y_NORMALIZATION
+    wl = [360.0 + 5 * i for i in range(95)]
+    d65 = [v / 10568.0 / SD.CIE_Y_NORMALIZATION for v in data.D65]
+    (tmp_path / "spd").mkdir()
+    with open(tmp_path / "spd" / "d65.spd", "w") as f:
+        f.write("# CIE D65\n\n")
+        f.writelines("%g %.9g\n" % (w, v) for w, v in zip(wl, d65))
+    (tmp_path / "spd" / "bad.spd").write_text("400 1.0\n500 2.0 surplus\n")
+    backup = fresolver.file_resolver()
+    fresolver.set_file_resolver(fresolver.FileResolver([str(tmp_path / "spd")]))
+    try:
+        pairs = SD.spectrum_from_file("d65.spd")
+        assert len(pairs) == 95 and pairs[0][0] == 360.0 and pairs[-1][0] == 830.0
+        with pytest.raises(RuntimeError, match="excess tokens"):
+            SD.spectrum_from_file("bad.spd")
+        with pytest.raises(RuntimeError, match="file does not exist"):
+            SD.spectrum_from_file("nowhere.spd")
+        white = SD.spectrum_to_rgb(wl, [np.float32(v) * np.float32(SD.CIE_Y_NORMALIZATION) for v in d65], bounded=False)
+        assert np.allclose(white, 1.0, atol=2e-3), white
+        # rgb variant: a reflectance from a file is clamped to [0, 1] (bounded), an emitter's spectrum is not (srgb_d65)
+        d = scenes.c2_homogeneous_slab(8, 8, 1)
+        d["ground"]["bsdf"]["reflectance"] = {"type": "spectrum", "filename": "d65.spd"}
+        d["sun"]["irradiance"] = {"type": "spectrum", "value": ", ".join("%g:%.9g" % (w, 2.5 * v) for w, v in zip(wl, d65))}
+        desc, keep = SD.build_scene_desc(d)
+        refl = [b for b in desc.bsdfs[:desc.bsdf_count] if b.type == 0][0]
+        assert np.allclose(list(refl.reflectance), np.clip(white, 0, 1), atol=1e-6)
+        assert np.allclose(list(desc.emitters[0].radiance), 2.5 * np.array(white), rtol=1e-5)
+        # a narrow green band is out of gamut: clamped at 0 for a reflectance
+        green = SD._color_rgb({"type": "spectrum", "value": "500:0.0, 520:40.0, 540:0.0"}, "bsdf.reflectance")
+        assert green[0] == 0.0 and green[1] > 0.05 and green[2] >= 0.0
+        with pytest.raises(RuntimeError, match="increasing order"):
+            SD._color_rgb({"type": "spectrum", "value": "500:1, 400:1"}, "bsdf.reflectance")
+        # mono variant: the luminance of that colour (xml.cpp:1159-1162)
+        desc_m, _ = SD.build_scene_desc(d, mono=True)
+        lum = 0.212671 * white[0] + 0.715160 * white[1] + 0.072169 * white[2]
+        assert np.allclose(list([b for b in desc_m.bsdfs[:desc_m.bsdf_count] if b.type == 0][0].reflectance), min(lum, 1.0), atol=1e-3)
+        # spectral variant: the file becomes a `regular` spectrum (equidistant wavelengths), evaluated by the oracle
+        o = ob.OracleScene({"type": "scene", "integrator": {"type": "path"},
+                            "sensor": {"type": "perspective", "film": {"type": "hdrfilm", "width": 4, "height": 4, "rfilter": {"type": "box"}}},
+                            "s": {"type": "rectangle", "bsdf": {"type": "diffuse", "reflectance": {"type": "spectrum", "filename": "d65.spd"}}}}, spectral=True)
+        assert np.allclose(o.spectrum_eval(0, [360., 560., 700., 832.]), [d65[0], d65[40], d65[68], 0.0], rtol=1e-5)
+        # XML: the tag reaches the loader as a dictionary; value and filename exclude each other
+        xd = xml_io.xml_to_dict('<scene version="2.0.0"><bsdf type="diffuse" id="b"><spectrum name="reflectance" filename="d65.spd"/></bsdf></scene>')
+        assert xd["_arg_0"]["reflectance"] == {"type": "spectrum", "filename": "d65.spd"}
+        with pytest.raises(xml_io.XMLError, match="requires one of"):
+            xml_io.xml_to_dict('<scene version="2.0.0"><bsdf type="diffuse"><spectrum name="reflectance" filename="a" value="1"/></bsdf></scene>')
+        # load_string works on a copy of the resolver like load_file (xml.cpp:1238-1240, 1275): a <path> tag does not leak
+        before = list(fresolver.file_resolver())
+        seen = {}
+        monkey_dict = pkg.load_dict
+        try:
+            pkg.load_dict = lambda d, device=0: seen.setdefault("paths", list(fresolver.file_resolver()))      # no GPU here: stop before the backend
+            pkg.load_string('<scene version="2.0.0"><path value="%s"/></scene>' % str(tmp_path))
+        finally:
+            pkg.load_dict = monkey_dict
+        assert seen["paths"][0] == str(tmp_path) and list(fresolver.file_resolver()) == before
+    finally:
+        fresolver.set_file_resolver(backup)
