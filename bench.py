@@ -53,7 +53,8 @@ def build_scene_dict(scenes, config, width, height, spp, samples_per_pass=-1, re
     elif config in ("C5S", "C5SM", "C5SB"):
         d = scenes.c5_atmosphere_spectral(width, height, spp)
         if config == "C5SB":                                        # the same under Eradiate's wavelength-bin integrator: 16 bins, 32 AOV channels
-            d["integrator"] = {"type": "nbins", "wavelengths": ", ".join("%g" % (360.0 + 470.0 * k / 16) for k in range(17)), "integrator": d["integrator"]}
+            d["integrator"] = {"type": "nbins", "wavelengths": ", ".join("%g" % (360.0 + 470.0 * (k + 0.5) / 16) for k in range(16)), "tolerance": 470.0 / 32,
+                               "integrator": d["integrator"]}
         if config == "C5SM":                                        # the spectral atmosphere under volpathmis (4 x 4 weight matrices)
             d["integrator"]["type"] = "volpathmis"
     else:

@@ -895,7 +895,7 @@ def test_bins_on_the_regrouping_machine(gpu_spectral, monkeypatch, wrap, kernel)
         monkeypatch.setenv("MTSAMD_KERNEL", kernel)
     if wrap == "nbins":
         d = _spectral_cases()["c5s_atmosphere"]                                          # distant sensor, gridvolume_spectral, 40 x 32 (partial blocks)
-        d["integrator"] = {"type": "nbins", "wavelengths": "400, 480, 560, 640, 720, 800", "integrator": dict(d["integrator"])}
+        d["integrator"] = {"type": "nbins", "wavelengths": "400, 480, 560, 640, 720, 800", "tolerance": 30.0, "integrator": dict(d["integrator"])}
         channels = 5 + 2 * 6
     else:
         d = _spectral_cases()["grid_spectral_d65_rpv"]                                   # perspective camera: the sensors that take an srf
