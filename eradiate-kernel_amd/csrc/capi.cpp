@@ -230,6 +230,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             // without media there are no tracking walks to regroup: the per-lane kernels win (cornell box 512 x 512 x 256, volpath: rings 992,
             // per lane 1242 Msamples/s; `path` per lane: 2342)
             if (!getenv("MTSAMD_KERNEL") && hs.media.empty() && hs.integrator.type != MTS_INTEGRATOR_PATH) variant = 0;
+            if (hs.integrator.type == MTS_INTEGRATOR_PATH) variant = (variant != 0 && !hs.integrator.spectral) ? 1 : 0;   // per lane: flat loop with regeneration (rgb / mono), or nested
             // variant = family * 10000 + paths per workgroup (family 1: ring driver, 2: lane-affine driver)
             if (variant >= 10000) {
                 int family = variant / 10000, wg = variant % 10000;

@@ -69,6 +69,104 @@ __device__ __forceinline__ void render_sample(const DScene &sc, Pcg32 &rng, cons
 #endif
 }
 
+#if MTS_SPEC_N == 3
+// `path` (integrators/path.cpp:100-211) for one pixel as ONE flat loop over path segments with regeneration: a lane whose path has ended
+// splats its sample and starts the pixel's next one at once, instead of idling until the longest path of the wave's 64 pixels has ended
+// (path lengths under Russian roulette are roughly geometric: the longest of 64 is several times the mean).  One ray_intersect site
+// serves camera rays and BSDF-sampled rays alike.  The lane draws exactly the numbers path_sample (integrator_dev.h) draws, in the
+// same order, and sums its samples in the same order: bit-identical to the nested formulation and to the CPU restatement.
+template <bool COUNT>
+__device__ __forceinline__ void path_pixel_flat(const DScene &sc, Pcg32 &rng, const DBlock &blk, uint32_t lx, uint32_t ly, uint32_t sample_count,
+                                                float *__restrict__ film, float acc[5], Counters &cnt, const uint32_t *stop_flag) {
+    const DSensor &se = sc.sensor;
+    const int max_depth = sc.integrator.max_depth, rr_depth = sc.integrator.rr_depth;
+    const float px = (float) (lx + (uint32_t) blk.ox), py = (float) (ly + (uint32_t) blk.oy);
+    F2 position_sample; float ray_weight = 1.f;
+    DRay ray;
+    F3 throughput = f3s(1.f), result = f3s(0.f), ref_p = f3s(0.f);
+    float eta = 1.f, emission_weight = 1.f, bs_pdf = 0.f;
+    uint32_t bs_type = 0;
+    bool valid_ray = false;
+    int depth = 0;                                              // 0: the camera ray of a fresh sample has not been traced yet
+    auto begin_sample = [&]() {                                 // integrator.cpp:242-264, path.cpp:106-119
+        F2 u = rng.next_2d();
+        position_sample.x = px + u.x; position_sample.y = py + u.y;
+        F2 aperture_sample; aperture_sample.x = .5f; aperture_sample.y = .5f;
+        if (se.needs_aperture_sample) aperture_sample = rng.next_2d();
+        if (se.shutter_open_time > 0.f) (void) rng.next_1d();
+        (void) rng.next_1d();                                   // wavelength sample, unused in rgb
+        F2 adjusted;
+        adjusted.x = (position_sample.x - (float) se.crop_x) / (float) se.crop_w;
+        adjusted.y = (position_sample.y - (float) se.crop_y) / (float) se.crop_h;
+        F3 rw;
+        ray = sensor_sample_ray(sc, adjusted, aperture_sample, rw);
+        ray_weight = rw.x;
+        throughput = f3s(1.f); result = f3s(0.f); eta = 1.f; emission_weight = 1.f; depth = 0;
+    };
+    begin_sample();
+    uint32_t j = 0;
+    for (uint32_t it = 0;; ++it) {
+        if ((it & 1023u) == 1023u && stop_requested(stop_flag)) break;      // should_stop(), integrator.h:143-146
+        const Hit si = ray_intersect(sc, ray);
+        const int emitter = hit_emitter(sc, si);
+        if (depth == 0) valid_ray = hit_valid(si);               // path.cpp:113-115
+        else if (emitter >= 0) {                                 // :193-205: MIS weight of the emitter the BSDF sample found
+            Surf sb; sb.wi = -ray.d; sb.sh.n = f3s(0.f);
+            if (hit_valid(si)) complete_surface(sc, si, ray.d, sb);
+            DirSample ds;                                        // render/records.h:168-174
+            ds.p = si.p; ds.n = sb.sh.n; ds.d = si.p - ref_p; ds.dist = norm(ds.d); ds.d = ds.d / ds.dist;
+            if (!hit_valid(si)) ds.d = -sb.wi;
+            ds.emitter = emitter; ds.pdf = 0.f; ds.delta = false;
+            const float emitter_pdf = !(bs_type & F_Delta) ? pdf_emitter_direction(sc, ref_p, ds) : 0.f;
+            emission_weight = mis_weight(bs_pdf, emitter_pdf);
+        }
+        depth += 1;
+        // ---- one iteration of the loop of path.cpp:121-207
+        if (COUNT) cnt.n_iter++;
+        Surf sf; sf.wi = -ray.d;
+        if (hit_valid(si)) complete_surface(sc, si, ray.d, sf);
+        if (emitter >= 0) result = result + emission_weight * throughput * emitter_eval(sc, emitter, sf.wi.z);
+        bool active = hit_valid(si);
+        if (depth > rr_depth) {
+            float q = pm_min(hmax(throughput) * (eta * eta), .95f);
+            active = active && rng.next_1d() < q;
+            throughput = throughput * pm_rcp(q);
+        }
+        bool ended = (uint32_t) depth >= (uint32_t) max_depth || !active;
+        if (!ended) {
+            const int bsdf_id = sc.shapes[si.shape].bsdf;
+            const DBsdf &bsdf = sc.bsdfs[bsdf_id];
+            bool active_e = (bsdf.flags & F_Smooth) != 0;
+            if (active_e) {
+                F3 emitter_val;
+                DirSample ds = sample_emitter_direction(sc, si.p, rng.next_2d(), true, emitter_val);
+                active_e = active_e && ds.pdf != 0.f;
+                F3 wo = to_local(sf.sh, ds.d);
+                F3 bsdf_val = bsdf_eval(bsdf, sf.wi, wo);
+                float bpdf = bsdf_pdf(bsdf, sf.wi, wo);
+                float mis = ds.delta ? 1.f : mis_weight(ds.pdf, bpdf);
+                if (active_e) result = result + mis * throughput * bsdf_val * emitter_val;
+            }
+            float s1 = rng.next_1d(); F2 s2 = rng.next_2d();
+            BSDFSample bs;
+            F3 bsdf_val = bsdf_sample(bsdf, sf.wi, s1, s2, bs);
+            throughput = throughput * bsdf_val;
+            ended = !any_nonzero(throughput);
+            if (!ended) {
+                eta *= bs.eta;
+                ref_p = si.p; bs_pdf = bs.pdf; bs_type = bs.sampled_type;
+                ray = spawn_ray(si.p, to_world(sf.sh, bs.wo));
+            }
+        }
+        if (ended) {                                             // integrator.cpp:265-288: splat, next sample of this pixel
+            splat_sample_t<false>(sc, blk, lx, ly, position_sample, f3s(ray_weight) * result, valid_ray, as_global(film), acc);
+            if (++j == sample_count) break;
+            begin_sample();
+        }
+    }
+}
+#endif
+
 // librender/integrator.cpp:181-209 (scalar branch) for every block of this launch at once.
 // FLAT = true: volpath as the flat state machine of volpath_flat.h (the production kernel of the metric);
 // FLAT = false: the nested formulation of integrator_dev.h (path and volpathmis; volpath cross-check, MTSAMD_KERNEL=nested),
@@ -83,7 +181,7 @@ __device__ __forceinline__ void render_sample(const DScene &sc, Pcg32 &rng, cons
 #define MTS_PATH_WAVES 4      // measured on the cornell box: 1 -> 1631, 3 -> 1717, 4 -> 2355, 5 -> 1870, 6 -> 1241 Msamples/s
 #endif
 template <bool COUNT, bool FLAT, int INTEG>
-__global__ void __launch_bounds__(256, FLAT ? 1 : (INTEG == NI_PATH ? MTS_PATH_WAVES : MTS_NESTED_WAVES)) render_kernel(DScene sc, const DBlock *__restrict__ blocks, uint32_t n_blocks, uint32_t block_size,
+__global__ void __launch_bounds__(256, (FLAT && INTEG != NI_PATH) ? 1 : (INTEG == NI_PATH ? MTS_PATH_WAVES : MTS_NESTED_WAVES)) render_kernel(DScene sc, const DBlock *__restrict__ blocks, uint32_t n_blocks, uint32_t block_size,
                                                      uint32_t sample_count, float *__restrict__ film, unsigned long long *__restrict__ counters,
                                                      const uint32_t *__restrict__ stop_flag) {
     // LDS-staged BVH top: the breadth-first top levels of the host-built BVH (dscene.h), shared by the workgroup's traversals
@@ -109,7 +207,7 @@ __global__ void __launch_bounds__(256, FLAT ? 1 : (INTEG == NI_PATH ? MTS_PATH_W
     rng.seed(sc.sensor.seed + (uint64_t) blk.id * ppb + i, PCG32_DEFAULT_STREAM);             // sampler.cpp:83-96, integrator.cpp:198
     Counters cnt = {};
 #if MTS_SPEC_N == 3
-    if (FLAT) {
+    if (FLAT && INTEG != NI_PATH) {
         __shared__ float cold_lds[C_COUNT * 256];
         ColdStore cold; cold.base = cold_lds + threadIdx.x; cold.stride = 256;
         volpath_pixel_flat<COUNT>(sc, rng, blk, lx, ly, sample_count, film, cold, cnt, stop_flag);
@@ -117,6 +215,10 @@ __global__ void __launch_bounds__(256, FLAT ? 1 : (INTEG == NI_PATH ? MTS_PATH_W
 #endif
     {
         float acc[5] = { 0.f, 0.f, 0.f, 0.f, 0.f };
+#if MTS_SPEC_N == 3
+        if (INTEG == NI_PATH && FLAT) path_pixel_flat<COUNT>(sc, rng, blk, lx, ly, sample_count, film, acc, cnt, stop_flag);
+        else
+#endif
         for (uint32_t j = 0; j < sample_count; ++j) {
             // should_stop(), integrator.h:143-146: the reference looks at its flag once per sample; here one lane of the wave reads the
             // host-visible word every 64 samples
@@ -347,7 +449,13 @@ hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks,
     if (use_flat) LAUNCH_C(true, NI_VOLPATH);
     else
 #endif
-    if (sc.integrator.type == MTS_INTEGRATOR_PATH) LAUNCH_C(false, NI_PATH);
+    if (sc.integrator.type == MTS_INTEGRATOR_PATH) {
+#if MTS_SPEC_N == 3
+        if (flat) LAUNCH_C(true, NI_PATH);                         // one flat loop over path segments with regeneration (path_pixel_flat)
+        else
+#endif
+        LAUNCH_C(false, NI_PATH);
+    }
     else if (sc.integrator.type == MTS_INTEGRATOR_VOLPATH) LAUNCH_C(false, NI_VOLPATH);
     else if (sc.integrator.use_spectral_mis) LAUNCH_C(false, NI_VOLPATHMIS);
     else LAUNCH_C(false, NI_VOLPATHMIS_NOSPEC);
