@@ -186,8 +186,21 @@ def main():
         while args.spp % spp_pass:
             spp_pass -= 1
     job = Job(pkg, scenes, args, rank, n, local_rank, backend, args.spp, spp_pass if n > 1 else -1)
+    # every rank should get at least one workgroup per CU (256) per launch, or the GPUs run partly empty: the reason the N-rank job is
+    # cut into N passes.  Checked for the configurations at their BASELINE sizes (a rehearsal on a small film cannot meet it).
+    blocks_total = -(-args.width // 32) * -(-args.height // 32) * (args.spp // spp_pass if n > 1 else 1)
+    workgroups_per_rank = blocks_total // n
+    if (args.width, args.height, args.spp) == CONFIG_SIZES[args.config] and args.config not in ("C1",) and workgroups_per_rank < 256:
+        raise SystemExit("bench.py: %d workgroups per rank (< 256 CUs) at --gpus %d" % (workgroups_per_rank, n))
     elapsed, kernel_ms, launches, samples_rank = timed(job, args.steps, args.warmup, barrier, all_max)
     value = job.samples_step * args.steps / elapsed / 1e6
+    # kernel time per step of every rank (HIP events around the launches): a SCALE record shows load imbalance directly
+    per_rank_ms = [kernel_ms / args.steps]
+    if n > 1:
+        t = torch.tensor([kernel_ms / args.steps], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
+        gathered = [torch.zeros_like(t) for _ in range(n)]
+        dist.all_gather(gathered, t)
+        per_rank_ms = [float(g.item()) for g in gathered]
 
     film_check = None
     if n > 1 and not args.no_film_check:
@@ -228,9 +241,12 @@ def main():
     # the kernel's measured time.  This kernel keeps path state in LDS, so its real HBM traffic is several times lower and its
     # bound is latency at 4 waves per SIMD; `traffic*` and `valu_pipe_busy` (rocprofv3 --pmc, profiles/) say so whenever this run
     # matches the profiled configuration.
-    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    # `bound`: what the counters say limits this kernel (rocprofv3 --pmc, profiles/: latency at 4 waves per SIMD, vector pipes half busy, HBM
+    # at ~15 % of peak).  `achieved` / `peak` / `frac` stay the contract's HBM-roofline figure, which is a MODEL here (`model_bound`):
+    # the algorithmic bytes of a wavefront formulation that round-trips path state through HBM, over the measured launch time.
+    roofline = {"bound": "latency", "model_bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "achieved_is": "algorithmic bytes per launch / measured launch time (SURVEY.md 8(d)); not a bandwidth measurement",
+                "achieved_is": "algorithmic bytes per launch / measured launch time (SURVEY.md 8(d)): a modelling figure, not a bandwidth measurement",
                 "kernel": kernel_name, "avg_launch_ms": round(avg_launch_ms, 3),
                 "bytes_per_sample": round(bytes_per_sample, 1),
                 "n_iter_per_sample": round(c_iter / c_samp, 3),
@@ -302,6 +318,8 @@ def main():
                           "integrator": integ_type, "sampler": "independent seed 0", "block_size": 32, "rfilter": "box",
                           "sharding": "(pass, block) pairs: block_id %% %d round-robin, %d workgroups per GPU + RCCL film reduce" % (n, -(-args.width // 32) * -(-args.height // 32) * (args.spp // spp_pass) // n)
                                       if n > 1 else "single GPU"},
+               "kernel_ms_per_step": {"per_rank": [round(x, 3) for x in per_rank_ms], "max_over_min": round(max(per_rank_ms) / max(min(per_rank_ms), 1e-9), 4)},
+               "workgroups_per_rank_per_launch": workgroups_per_rank,
                "roofline": roofline, "cpu_baseline": cpu_baseline}
         if film_check is not None:
             out["film_check"] = film_check

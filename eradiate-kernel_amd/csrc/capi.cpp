@@ -3,6 +3,7 @@
 // mts_render mirrors SamplingIntegrator::render (/root/reference/src/librender/integrator.cpp:51-179):
 // pass / block bookkeeping on the host, one kernel launch per pass over every spiral block this shard
 // owns.  No exception crosses the boundary: errors become a non-zero status + mts_last_error().
+#include <algorithm>
 #include <chrono>
 #include <cstring>
 #include <cstdlib>
@@ -196,8 +197,10 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
     RenderCache &rc = scene->cache;
     float *d_film = film;
     if (!opts.film_on_device) d_film = (float *) rc.get(0, film_floats * sizeof(float));
-    constexpr int N_COUNTERS = 16;                                   // [0..2] loop counters, [4..9] ring-stall record (volpath_flat.h, MTS_DIAG_BASE)
-    unsigned long long *d_counters = (unsigned long long *) rc.get(1, N_COUNTERS * sizeof(unsigned long long));
+    constexpr int N_COUNTERS = 16;                                   // [0..2] loop counters, [4..9] ring-stall record (volpath_flat.h, MTS_DIAG_BASE), [15] cost-recording flag
+    size_t max_chunk = 0;
+    for (const auto &pb : pass_blocks) max_chunk = std::max(max_chunk, pb.size());
+    unsigned long long *d_counters = (unsigned long long *) rc.get(1, (N_COUNTERS + max_chunk) * sizeof(unsigned long long));   // [16 + b]: cost of block b of a calibration launch
     HIP_CHECK(hipMemsetAsync(d_film, 0, film_floats * sizeof(float), stream));               // hdrfilm.cpp:201-203 (storage cleared by prepare())
     HIP_CHECK(hipMemsetAsync(d_counters, 0, N_COUNTERS * sizeof(unsigned long long), stream));
     rc.events();
@@ -212,50 +215,48 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
         return false;
     };
     try {
-        for (size_t pass = 0; pass < pass_blocks.size(); ++pass) {
-            if (should_stop()) break;
-            const std::vector<DBlock> &blocks = pass_blocks[pass];
-            if (blocks.empty()) continue;
+        // ---- kernel variant: MTSAMD_KERNEL = nested | flat | wga256 | wga512 | wga1024 (default) | wgl1024
+        int variant = 11024;                                       // asynchronous regrouping, 1024 paths served by 1024 threads
+        if (const char *kv = getenv("MTSAMD_KERNEL")) {
+            if (!strcmp(kv, "nested")) variant = 0; else if (!strcmp(kv, "flat")) variant = 1;
+            else if (!strcmp(kv, "wga256")) variant = 10256; else if (!strcmp(kv, "wga512")) variant = 10512; else if (!strcmp(kv, "wga1024")) variant = 11024;
+            else if (!strcmp(kv, "wgl1024")) variant = 21024;
+            else throw std::runtime_error("MTSAMD_KERNEL must be one of nested, flat, wga256, wga512, wga1024, wgl1024");
+        }
+        // without media there are no tracking walks to regroup: the per-lane kernels win (cornell box 512 x 512 x 256, volpath: rings 992,
+        // per lane 1242 Msamples/s; `path` per lane: 2342, as one flat loop with regeneration 2910)
+        if (!getenv("MTSAMD_KERNEL") && hs.media.empty() && hs.integrator.type != MTS_INTEGRATOR_PATH) variant = 0;
+        if (hs.integrator.type == MTS_INTEGRATOR_PATH) variant = (variant != 0 && !hs.integrator.spectral) ? 1 : 0;   // per lane: flat loop with regeneration (rgb / mono), or nested
+        // variant = family * 10000 + paths per workgroup (family 1: ring driver, 2: lane-affine driver)
+        if (variant >= 10000) {
+            int family = variant / 10000, wg = variant % 10000;
+            if (hs.integrator.type == MTS_INTEGRATOR_VOLPATHMIS) { family = 1; wg = std::min(wg, 512); }   // four weight matrices per path: 512 paths fill the LDS
+            if (hs.integrator.spectral) { family = 1; wg = std::min(wg, 256); }   // four-wide spectra: 42 hot dwords per path; three 256-path workgroups per CU (12 waves) beat one of 512 (8 waves) by 10 %
+            // a workgroup of the regrouping kernels sits in ONE spiral block: blocks smaller than its path count get the largest
+            // workgroup that divides them (16 x 16 -> 256 paths); only blocks below 256 pixels fall back to the per-lane kernel
+            while (wg > 256 && (block_size * block_size) % (uint32_t) wg != 0) wg /= 2;
+            if (wg != 1024) family = 1;                           // the lane-affine driver is built for 1024 paths only
+            variant = (block_size * block_size) % (uint32_t) wg != 0 ? 1 : family * 10000 + wg;
+        }
+        if (hs.integrator.spectral && variant == 1) variant = 0;                                      // no per-lane flat kernel in the spectral build
+        // AOV channels (nbins / bins) and a sensor response function: `volpath` carries them on the regrouping machine (NEW block of
+        // volpath_flat.h); `path`, `volpathmis` and a discrete response function with repeated wavelengths stay per lane
+        if ((hs.scene.bin_count > 0 || hs.scene.srf >= 0) &&
+            !(variant >= 10000 && hs.integrator.type == MTS_INTEGRATOR_VOLPATH && hs.srf_lookup_by_wavelength)) variant = 0;
+        int wg_threads = 0;                                         // MTSAMD_WG_THREADS: threads per workgroup of the wga kernels (<= paths; default = paths)
+        if (const char *tv = getenv("MTSAMD_WG_THREADS")) wg_threads = atoi(tv);
+        last_variant = variant;
+
+        // one launch over `blocks` with `spp` samples per pixel, watched for cancel() / the timeout (which reach the kernel through the stop word)
+        auto launch = [&](const std::vector<DBlock> &blocks, uint32_t spp) {
             DBlock *d_blocks = (DBlock *) rc.get(2, blocks.size() * sizeof(DBlock));
             HIP_CHECK(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(DBlock), hipMemcpyHostToDevice, stream));
             HIP_CHECK(hipEventRecord(ev0, stream));
-            // kernel variant: MTSAMD_KERNEL = nested | flat | wga256 | wga512 | wga1024 (default)
-            int variant = 11024;                                   // asynchronous regrouping, 1024 paths served by 1024 threads
-            if (const char *kv = getenv("MTSAMD_KERNEL")) {
-                if (!strcmp(kv, "nested")) variant = 0; else if (!strcmp(kv, "flat")) variant = 1;
-                else if (!strcmp(kv, "wga256")) variant = 10256; else if (!strcmp(kv, "wga512")) variant = 10512; else if (!strcmp(kv, "wga1024")) variant = 11024;
-                else if (!strcmp(kv, "wgl1024")) variant = 21024;
-                else throw std::runtime_error("MTSAMD_KERNEL must be one of nested, flat, wga256, wga512, wga1024, wgl1024");
-            }
-            // without media there are no tracking walks to regroup: the per-lane kernels win (cornell box 512 x 512 x 256, volpath: rings 992,
-            // per lane 1242 Msamples/s; `path` per lane: 2342)
-            if (!getenv("MTSAMD_KERNEL") && hs.media.empty() && hs.integrator.type != MTS_INTEGRATOR_PATH) variant = 0;
-            if (hs.integrator.type == MTS_INTEGRATOR_PATH) variant = (variant != 0 && !hs.integrator.spectral) ? 1 : 0;   // per lane: flat loop with regeneration (rgb / mono), or nested
-            // variant = family * 10000 + paths per workgroup (family 1: ring driver, 2: lane-affine driver)
-            if (variant >= 10000) {
-                int family = variant / 10000, wg = variant % 10000;
-                if (hs.integrator.type == MTS_INTEGRATOR_VOLPATHMIS) { family = 1; wg = std::min(wg, 512); }   // four weight matrices per path: 512 paths fill the LDS
-                if (hs.integrator.spectral) { family = 1; wg = std::min(wg, 256); }   // four-wide spectra: 42 hot dwords per path; three 256-path workgroups per CU (12 waves) beat one of 512 (8 waves) by 10 %
-                // a workgroup of the regrouping kernels sits in ONE spiral block: blocks smaller than its path count get the largest
-                // workgroup that divides them (16 x 16 -> 256 paths); only blocks below 256 pixels fall back to the per-lane kernel
-                while (wg > 256 && (block_size * block_size) % (uint32_t) wg != 0) wg /= 2;
-                if (wg != 1024) family = 1;                       // the lane-affine driver is built for 1024 paths only
-                variant = (block_size * block_size) % (uint32_t) wg != 0 ? 1 : family * 10000 + wg;
-            }
-            if (hs.integrator.spectral && variant == 1) variant = 0;                                      // no per-lane flat kernel in the spectral build
-            // AOV channels (nbins / bins) and a sensor response function: `volpath` carries them on the regrouping machine (NEW block of
-            // volpath_flat.h); `path`, `volpathmis` and a discrete response function with repeated wavelengths stay per lane
-            if ((hs.scene.bin_count > 0 || hs.scene.srf >= 0) &&
-                !(variant >= 10000 && hs.integrator.type == MTS_INTEGRATOR_VOLPATH && hs.srf_lookup_by_wavelength)) variant = 0;
-            int wg_threads = 0;                                     // MTSAMD_WG_THREADS: threads per workgroup of the wga kernels (<= paths; default = paths)
-            if (const char *tv = getenv("MTSAMD_WG_THREADS")) wg_threads = atoi(tv);
             float *d_ws = (float *) rc.get(3, render_workspace_floats((uint32_t) blocks.size(), block_size, variant) * sizeof(float));
             HIP_CHECK((hs.integrator.spectral ? launch_render_spectral : launch_render)(
-                          hs.scene, d_blocks, (uint32_t) blocks.size(), block_size, (uint32_t) samples_per_pass, d_film, d_counters,
+                          hs.scene, d_blocks, (uint32_t) blocks.size(), block_size, spp, d_film, d_counters,
                           opts.collect_counters != 0, variant, wg_threads, d_ws, (const uint32_t *) scene->stop_word, stream));
             HIP_CHECK(hipEventRecord(ev1, stream));
-            last_variant = variant;
-            // wait for the launch as a watchdog: cancel() and the timeout reach the kernel through the stop word
             for (;;) {
                 hipError_t q = hipEventQuery(ev1);
                 if (q == hipSuccess) break;
@@ -265,6 +266,50 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             }
             float ms = 0.f; HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
             kernel_ms += ms; ++launches;
+        };
+
+        // ---- Expensive blocks first.  A launch with more workgroups than the GPU holds at once runs them in rounds, in array order, and
+        // the blocks of a scene differ in cost (the horizon of an atmosphere costs a multiple of its zenith): in spiral order the tail of
+        // the launch waits for whichever expensive block happened to start last -- 27 % of the C4 render (measured: the same job cut
+        // into 8 passes, i.e. 8 x as many, shorter workgroups: 283 -> 361 Msamples/s).  So the regrouping kernels first render a few
+        // samples per pixel with the workgroups' residence times recorded (kernels.hip, record_block_cost; < 0.5 % of the job,
+        // results discarded -- the film is cleared again), and every launch then starts its blocks by descending cost (longest
+        // processing time first).  Which pixel receives which samples does not depend on the order of the blocks: same film.
+        std::vector<std::pair<uint64_t, uint64_t>> cost_of;      // (block position, ticks), sorted by position
+        {
+            int cu_count = 0;
+            HIP_CHECK(hipDeviceGetAttribute(&cu_count, hipDeviceAttributeMultiprocessorCount, hs.device));
+            const char *lpt = getenv("MTSAMD_LPT");                // 0: spiral order as it is
+            const uint32_t cal_spp = (uint32_t) std::min<size_t>(4, samples_per_pass / 128);
+            if (variant >= 10000 && (!lpt || atoi(lpt) != 0) && cal_spp > 0 && pass_blocks[0].size() > (size_t) std::max(cu_count, 1) && !should_stop()) {
+                std::vector<DBlock> cal(pass_blocks[0]);           // the distinct block positions of the first chunk
+                auto pos = [](const DBlock &b) { return ((uint64_t) (uint32_t) b.ox << 32) | (uint32_t) b.oy; };
+                std::sort(cal.begin(), cal.end(), [&](const DBlock &x, const DBlock &y) { return pos(x) < pos(y); });
+                cal.erase(std::unique(cal.begin(), cal.end(), [&](const DBlock &x, const DBlock &y) { return pos(x) == pos(y); }), cal.end());
+                const unsigned long long flag = 1ull;
+                HIP_CHECK(hipMemcpyAsync(d_counters + 15, &flag, sizeof(flag), hipMemcpyHostToDevice, stream));
+                HIP_CHECK(hipMemsetAsync(d_counters + N_COUNTERS, 0, cal.size() * sizeof(unsigned long long), stream));
+                launch(cal, cal_spp);
+                std::vector<unsigned long long> ticks(cal.size());
+                HIP_CHECK(hipMemcpyAsync(ticks.data(), d_counters + N_COUNTERS, cal.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));
+                for (size_t k = 0; k < cal.size(); ++k) cost_of.emplace_back(((uint64_t) (uint32_t) cal[k].ox << 32) | (uint32_t) cal[k].oy, ticks[k]);
+                std::sort(cost_of.begin(), cost_of.end());
+                HIP_CHECK(hipMemsetAsync(d_film, 0, film_floats * sizeof(float), stream));          // the calibration samples are not part of the image
+                HIP_CHECK(hipMemsetAsync(d_counters, 0, N_COUNTERS * sizeof(unsigned long long), stream));
+            }
+        }
+        auto cost = [&](const DBlock &b) -> uint64_t {
+            const uint64_t key = ((uint64_t) (uint32_t) b.ox << 32) | (uint32_t) b.oy;
+            auto it = std::lower_bound(cost_of.begin(), cost_of.end(), std::make_pair(key, (uint64_t) 0));
+            return it != cost_of.end() && it->first == key ? it->second : 0;
+        };
+        for (size_t pass = 0; pass < pass_blocks.size(); ++pass) {
+            if (should_stop()) break;
+            std::vector<DBlock> &blocks = pass_blocks[pass];
+            if (blocks.empty()) continue;
+            if (!cost_of.empty()) std::stable_sort(blocks.begin(), blocks.end(), [&](const DBlock &x, const DBlock &y) { return cost(x) > cost(y); });
+            launch(blocks, (uint32_t) samples_per_pass);
         }
         if (!opts.film_on_device) HIP_CHECK(hipMemcpyAsync(film, d_film, film_floats * sizeof(float), hipMemcpyDeviceToHost, stream));
         unsigned long long h_counters[N_COUNTERS] = {};

@@ -240,6 +240,15 @@ __global__ void __launch_bounds__(256, (FLAT && INTEG != NI_PATH) ? 1 : (INTEG =
     }
 }
 
+// Cost of a spiral block as the hardware sees it: the shader-clock ticks its workgroup(s) stayed resident, recorded when the host asks
+// for it (counters[MTS_COST_FLAG] != 0: the short calibration launch of mts_render, which then starts the expensive blocks first).
+#define MTS_COST_FLAG 15
+#define MTS_COST_BASE 16
+__device__ __forceinline__ void record_block_cost(unsigned long long *counters, uint32_t first_path, uint32_t block_size, long long t0) {
+    if ((threadIdx.x & 63u) == 0u && counters[MTS_COST_FLAG] != 0ull)
+        atomicMax(counters + MTS_COST_BASE + first_path / (block_size * block_size), (unsigned long long) (clock64() - t0));
+}
+
 // Asynchronous-regrouping variant of the volpath render kernel (volpath_flat.h, driver 2).  The parameter list must stay in
 // sync with WgArgs: the block functions re-read it from the kernarg segment with scalar loads.  WG paths are served by NT threads;
 // WPE = waves per SIMD the register budget is sized for (512 / WPE VGPRs).
@@ -248,7 +257,9 @@ __global__ void __launch_bounds__(NT, WPE) render_kernel_wga(DScene sc, const DB
                                                            uint32_t sample_count, float *film, float *cold_g, uint32_t cold_stride,
                                                            unsigned long long *counters, const uint32_t *stop_flag) {
     Counters cnt = {};
+    const long long t0 = clock64();
     volpath_workgroup_async<COUNT, WG, NT>((const MTS_CONST_AS void *) __builtin_amdgcn_kernarg_segment_ptr(), cnt);
+    record_block_cost(counters, blockIdx.x * WG, block_size, t0);
     if (COUNT) {
         atomicAdd(counters + 0, (unsigned long long) cnt.n_iter);
         atomicAdd(counters + 1, (unsigned long long) cnt.n_lookup);
@@ -263,7 +274,9 @@ __global__ void __launch_bounds__(NT, WPE) render_kernel_wgl(DScene sc, const DB
                                                            uint32_t sample_count, float *film, float *cold_g, uint32_t cold_stride,
                                                            unsigned long long *counters, const uint32_t *stop_flag) {
     Counters cnt = {};
+    const long long t0 = clock64();
     workgroup_lanes<COUNT, WG, NT, VolpathLanes<COUNT, WG>>((const MTS_CONST_AS void *) __builtin_amdgcn_kernarg_segment_ptr(), cnt);
+    record_block_cost(counters, blockIdx.x * WG, block_size, t0);
     if (COUNT) {
         atomicAdd(counters + 0, (unsigned long long) cnt.n_iter);
         atomicAdd(counters + 1, (unsigned long long) cnt.n_lookup);
@@ -277,7 +290,9 @@ __global__ void __launch_bounds__(NT, MTS_SPEC_N == 3 ? 2 : (SPEC ? 1 : 2)) rend
                                                                uint32_t sample_count, float *film, float *cold_g, uint32_t cold_stride,
                                                                unsigned long long *counters, const uint32_t *stop_flag) {
     Counters cnt = {};
+    const long long t0 = clock64();
     volpathmis_workgroup_async<COUNT, SPEC, WG, NT>((const MTS_CONST_AS void *) __builtin_amdgcn_kernarg_segment_ptr(), cnt);
+    record_block_cost(counters, blockIdx.x * WG, block_size, t0);
     if (COUNT) {
         atomicAdd(counters + 0, (unsigned long long) cnt.n_iter);
         atomicAdd(counters + 1, (unsigned long long) cnt.n_lookup);

@@ -1046,8 +1046,50 @@ DEV uint32_t wga_slot_wait(bool pending, uint16_t *slot, uint32_t id, uint32_t *
     return out;
 }
 
+// Round 3: TAGGED slots.  A slot holds (lap << log2(WG)) | id, lap = (ring index / WG) mod 2^(16 - log2(WG)): the consumer of index i
+// accepts the slot only when it carries i's lap, so a slot need not be emptied after use and a producer need not look at it before it
+// stores -- the push is one atomic add and one store (no load, no wait), the claim reads its slots TOGETHER with the compare-and-swap
+// on the head instead of after it, and never writes them: two dependent LDS round trips less per block visit (claim + push were 28 %
+// of a wave's time).  A slot is overwritten one lap (WG pushes through this ring) after it was written; its consumer reads it within
+// a few instructions of its claim.  Should a lane ever sit between claim and read for a whole lap, it finds a newer lap in its slot,
+// waits out its bound and the render fails with the diagnostic -- the same outcome as any other lost hand-over.
+#ifndef MTS_RING_TAGGED
+#define MTS_RING_TAGGED 1
+#endif
+template <int WG> struct RingSlot {
+    static constexpr uint32_t IDBITS = WG == 1024 ? 10 : WG == 512 ? 9 : WG == 256 ? 8 : WG == 128 ? 7 : 6;
+    static_assert((1u << IDBITS) == (uint32_t) WG, "paths per workgroup: 64 .. 1024, a power of two");
+    static constexpr uint32_t TAGMASK = (1u << (16 - IDBITS)) - 1u;
+    DEV static uint32_t tag_of(uint32_t index) { return (index >> IDBITS) & TAGMASK; }
+    DEV static uint32_t make(uint32_t index, uint32_t pid) { return (tag_of(index) << IDBITS) | pid; }
+    DEV static bool matches(uint32_t v, uint32_t index) { return (v >> IDBITS) == tag_of(index); }
+    DEV static uint32_t id(uint32_t v) { return v & (uint32_t) (WG - 1); }
+};
+// a lane ahead of its producer: wait (wave-uniform loop, bounded) until the slot carries the lane's lap
+template <int WG>
+DEV uint32_t wga_tag_wait(bool pending, uint16_t *slot, uint32_t *q_ctl, unsigned long long *counters, int ring, uint32_t index) {
+    uint32_t out = 0xFFFFu;
+#pragma nounroll
+    for (uint32_t spins = 0;; ++spins) {
+        if (pending) {
+            const uint32_t v = __atomic_load_n(slot, __ATOMIC_RELAXED);
+            if (RingSlot<WG>::matches(v, index)) { out = RingSlot<WG>::id(v); pending = false; }
+        }
+        if (!__builtin_amdgcn_ballot_w64(pending)) break;
+        if (spins > MTS_RING_SPIN_LIMIT) { if (pending) wga_stall<WG>(1u, ring, index, q_ctl, counters); break; }
+        if (__atomic_load_n(&q_ctl[2 * B_COUNT], __ATOMIC_RELAXED) != STOP_NONE) break;
+    }
+    return out;
+}
+
 template <int WG>
 DEV void wga_push(int cls, uint32_t pid, bool valid, uint16_t (*q_ids)[WG], uint32_t *q_ctl, unsigned long long *counters) {
+#if MTS_RING_TAGGED
+    (void) counters;
+    uint32_t ti = 0;
+    if (valid) ti = atomicAdd(&q_ctl[2 * cls + 1], 1u);          // the value returned IS the lane's ring index
+    if (valid && cls != B_DONE) __atomic_store_n(&q_ids[cls][ti & (uint32_t) (WG - 1)], (uint16_t) RingSlot<WG>::make(ti, pid), __ATOMIC_RELAXED);
+#else
     // One LDS atomic per lane: the tail value it returns IS the lane's slot; the LDS unit serialises the lanes that share a ring.
     // (Ranking the lanes first -- nine ballots, per-class counts, one atomic per class -- took 45 to 100 VALU instructions per push
     // and measured 1 to 3 % slower; the order of the ids inside a ring is immaterial.)
@@ -1062,6 +1104,7 @@ DEV void wga_push(int cls, uint32_t pid, bool valid, uint16_t (*q_ids)[WG], uint
     // the previous lap's consumer has not emptied the slot yet (rare).  The test is wave-uniform on purpose: every ready lane has
     // stored its id by now, whatever order the compiler gives to divergent branches.
     if (__builtin_amdgcn_ballot_w64(pending) != 0ull) (void) wga_slot_wait<WG, false>(pending, slot, pid, q_ctl, counters, cls, idx);
+#endif
 }
 
 // A stopped workgroup (Integrator::cancel(), the integrator's timeout, a stall) adds the accumulators of its unfinished pixels to the
@@ -1133,7 +1176,7 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
     uint32_t poll_ticks = (tid >> 6) * 2048u, idle_naps = 0; // per wave, staggered: paces the polls of the host's stop word
 #pragma unroll 1
     for (;;) {
-      uint32_t n = 0, h = 0; int sel = 0; bool finished = false;
+      uint32_t n = 0, h = 0, spec_slot = 0xFFFFu; int sel = 0; bool finished = false;
       // ---- the claim: an inner loop of its own (snapshot, vote, compare-and-swap), left with a claim or when the workgroup is done.
       // (As `continue`s of the outer loop the retries dragged eighteen register copies of dead path state through every round.)
 #pragma unroll 1
@@ -1184,6 +1227,10 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         n = best < 64u ? best : 64u;
         h = (uint32_t) __builtin_amdgcn_readlane((int) hd, sel);
         uint32_t won = 0;
+#if MTS_RING_TAGGED
+        // the slots are read together with the compare-and-swap (both depend on the snapshot only); a lost claim discards them
+        if (lane < n) spec_slot = __atomic_load_n(&q_ids[sel][(h + lane) & (uint32_t) (WG - 1)], __ATOMIC_RELAXED);
+#endif
         if (lane == 0) won = atomicCAS(&q_ctl[2 * sel], h, h + n) == h ? 1u : 0u;
 #if defined(MTSAMD_BLOCKSTATS)
         if (COUNT) { bs_loc[10] += 1ull; if (!__builtin_amdgcn_readfirstlane((int) won)) bs_loc[11] += 1ull; }      // claim attempts / lost compare-and-swaps
@@ -1193,6 +1240,18 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
       if (finished) break;
         uint32_t pid = 0xFFFFu;
         bool mine = lane < n;
+#if MTS_RING_TAGGED
+        {
+            uint16_t *slot = &q_ids[sel][(h + lane) & (uint32_t) (WG - 1)];
+            const bool ready = mine && RingSlot<WG>::matches(spec_slot, h + lane);
+            if (ready) pid = RingSlot<WG>::id(spec_slot);
+            if (__builtin_amdgcn_ballot_w64(mine && !ready) != 0ull) {           // a lane ahead of its producer (rare)
+                const uint32_t got = wga_tag_wait<WG>(mine && !ready, slot, q_ctl, cload_k<WgArgs>(kernarg).counters, sel, h + lane);
+                if (mine && !ready) pid = got;
+                mine = mine && pid != 0xFFFFu;                // 0xFFFF: the workgroup is stopping, the lane drops out
+            }
+        }
+#else
         {
             uint16_t *slot = &q_ids[sel][(h + lane) & (uint32_t) (WG - 1)];     // relaxed atomics, not volatile: volatile accesses stay FLAT
             if (mine) {
@@ -1206,6 +1265,7 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
                 mine = mine && pid != 0xFFFFu;                // 0xFFFF: the workgroup is stopping, the lane drops out
             }
         }
+#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #if defined(MTSAMD_BLOCKSTATS)
         if (COUNT) { bs_loc[sel] += 1ull; bs_loc[12 + sel] += (unsigned long long) n;

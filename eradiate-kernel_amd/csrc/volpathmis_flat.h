@@ -615,7 +615,7 @@ DEV void volpathmis_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &
     uint32_t poll_ticks = (tid >> 6) * 2048u, idle_naps = 0;
 #pragma unroll 1
     for (;;) {
-      uint32_t n = 0, h = 0; int sel = 0; bool finished = false;
+      uint32_t n = 0, h = 0, spec_slot = 0xFFFFu; int sel = 0; bool finished = false;
 #pragma unroll 1
       for (;;) {                                                // the claim: snapshot, vote, compare-and-swap (see volpath_flat.h)
         uint32_t hd = 0, avail = 0;
@@ -646,12 +646,27 @@ DEV void volpathmis_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &
         n = best < 64u ? best : 64u;
         h = (uint32_t) __builtin_amdgcn_readlane((int) hd, sel);
         uint32_t won = 0;
+#if MTS_RING_TAGGED
+        if (lane < n) spec_slot = __atomic_load_n(&q_ids[sel][(h + lane) & (uint32_t) (WG - 1)], __ATOMIC_RELAXED);     // tagged slots: read with the claim (volpath_flat.h)
+#endif
         if (lane == 0) won = atomicCAS(&q_ctl[2 * sel], h, h + n) == h ? 1u : 0u;
         if (__builtin_amdgcn_readfirstlane((int) won)) break;
       }
       if (finished) break;
         uint32_t pid = 0xFFFFu;
         bool mine = lane < n;
+#if MTS_RING_TAGGED
+        {
+            uint16_t *slot = &q_ids[sel][(h + lane) & (uint32_t) (WG - 1)];
+            const bool ready = mine && RingSlot<WG>::matches(spec_slot, h + lane);
+            if (ready) pid = RingSlot<WG>::id(spec_slot);
+            if (__builtin_amdgcn_ballot_w64(mine && !ready) != 0ull) {
+                const uint32_t got = wga_tag_wait<WG>(mine && !ready, slot, q_ctl, cload_k<WgArgs>(kernarg).counters, sel, h + lane);
+                if (mine && !ready) pid = got;
+                mine = mine && pid != 0xFFFFu;
+            }
+        }
+#else
         {
             uint16_t *slot = &q_ids[sel][(h + lane) & (uint32_t) (WG - 1)];
             if (mine) {
@@ -664,6 +679,7 @@ DEV void volpathmis_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &
                 mine = mine && pid != 0xFFFFu;
             }
         }
+#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         int cls = B_DONE;
         if (mine) {

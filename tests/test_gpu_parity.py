@@ -128,6 +128,15 @@ def test_bench_strong_scaling_rehearsal(gpu_rgb, tmp_path):
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["film_check"]["ok"]
     assert "2 passes of 32 spp" in line["config"]["workload"] and line["weak"]["value"] > 0 and line["value"] > 0
+    assert len(line["kernel_ms_per_step"]["per_rank"]) == 2 and line["roofline"]["bound"] == "latency" and line["roofline"]["model_bound"] == "hbm"
+    # the C4 job (the Eradiate atmosphere: distant sensor, blend / tabulated phase, RPV) through the same path: 2 passes x 12 blocks
+    cmd4 = cmd[:cmd.index("--width")] + ["--config", "C4", "--width", "128", "--height", "96", "--spp", "32", "--no-weak"]
+    cmd4[cmd4.index("--master-port") + 1] = "29534"
+    out = subprocess.run(cmd4, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line4 = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line4["n_gpus"] == 2 and line4["film_check"]["ok"] and "2 passes of 16 spp" in line4["config"]["workload"]
+    assert line4["workgroups_per_rank_per_launch"] == 12 and line4["kernel_ms_per_step"]["max_over_min"] < 3.0
     # the same job through the Python surface: two shards of the 2-pass job add up to the unsharded render
     d = scenes.c3_heterogeneous(128, 96, 64, res=16, samples_per_pass=32)
     full, st = gpu_render(gpu_rgb, d)
