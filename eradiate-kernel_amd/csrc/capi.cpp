@@ -4,6 +4,7 @@
 // pass / block bookkeeping on the host, one kernel launch per pass over every spiral block this shard
 // owns.  No exception crosses the boundary: errors become a non-zero status + mts_last_error().
 #include <algorithm>
+#include <cstdio>
 #include <chrono>
 #include <cstring>
 #include <cstdlib>
@@ -281,7 +282,8 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             HIP_CHECK(hipDeviceGetAttribute(&cu_count, hipDeviceAttributeMultiprocessorCount, hs.device));
             const char *lpt = getenv("MTSAMD_LPT");                // 0: spiral order as it is
             const uint32_t cal_spp = (uint32_t) std::min<size_t>(4, samples_per_pass / 128);
-            if (variant >= 10000 && (!lpt || atoi(lpt) != 0) && cal_spp > 0 && pass_blocks[0].size() > (size_t) std::max(cu_count, 1) && !should_stop()) {
+            const bool force = lpt && atoi(lpt) == 2;              // 2: calibrate whatever the block count (diagnostic, with MTSAMD_LPT_DEBUG)
+            if (variant >= 10000 && (!lpt || atoi(lpt) != 0) && cal_spp > 0 && (force || pass_blocks[0].size() > (size_t) std::max(cu_count, 1)) && !should_stop()) {
                 std::vector<DBlock> cal(pass_blocks[0]);           // the distinct block positions of the first chunk
                 auto pos = [](const DBlock &b) { return ((uint64_t) (uint32_t) b.ox << 32) | (uint32_t) b.oy; };
                 std::sort(cal.begin(), cal.end(), [&](const DBlock &x, const DBlock &y) { return pos(x) < pos(y); });
@@ -295,6 +297,12 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
                 HIP_CHECK(hipStreamSynchronize(stream));
                 for (size_t k = 0; k < cal.size(); ++k) cost_of.emplace_back(((uint64_t) (uint32_t) cal[k].ox << 32) | (uint32_t) cal[k].oy, ticks[k]);
                 std::sort(cost_of.begin(), cost_of.end());
+                if (getenv("MTSAMD_LPT_DEBUG")) {                  // spread of the block costs: what a static one-block-per-CU launch loses to its slowest block
+                    double sum = 0.0; unsigned long long lo = ~0ull, hi = 0;
+                    for (unsigned long long t : ticks) { sum += (double) t; lo = std::min(lo, t); hi = std::max(hi, t); }
+                    fprintf(stderr, "[mtsamd] block costs over %zu blocks (%u spp): min %.3g mean %.3g max %.3g ticks, max / mean %.3f\n", ticks.size(), cal_spp,
+                            (double) lo, sum / (double) ticks.size(), (double) hi, (double) hi * (double) ticks.size() / sum);
+                }
                 HIP_CHECK(hipMemsetAsync(d_film, 0, film_floats * sizeof(float), stream));          // the calibration samples are not part of the image
                 HIP_CHECK(hipMemsetAsync(d_counters, 0, N_COUNTERS * sizeof(unsigned long long), stream));
             }
@@ -309,7 +317,22 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             std::vector<DBlock> &blocks = pass_blocks[pass];
             if (blocks.empty()) continue;
             if (!cost_of.empty()) std::stable_sort(blocks.begin(), blocks.end(), [&](const DBlock &x, const DBlock &y) { return cost(x) > cost(y); });
+            const bool dbg = getenv("MTSAMD_LPT_DEBUG") != nullptr && variant >= 10000;      // diagnostic: residence times of the workgroups of the launch itself
+            if (dbg) {
+                const unsigned long long flag = 1ull;
+                HIP_CHECK(hipMemcpyAsync(d_counters + 15, &flag, sizeof(flag), hipMemcpyHostToDevice, stream));
+                HIP_CHECK(hipMemsetAsync(d_counters + N_COUNTERS, 0, blocks.size() * sizeof(unsigned long long), stream));
+            }
             launch(blocks, (uint32_t) samples_per_pass);
+            if (dbg) {
+                std::vector<unsigned long long> ticks(blocks.size());
+                HIP_CHECK(hipMemcpyAsync(ticks.data(), d_counters + N_COUNTERS, blocks.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));
+                double sum = 0.0; unsigned long long lo = ~0ull, hi = 0;
+                for (unsigned long long t : ticks) { sum += (double) t; lo = std::min(lo, t); hi = std::max(hi, t); }
+                fprintf(stderr, "[mtsamd] launch of %zu blocks x %zu spp: workgroup residence min %.4g mean %.4g max %.4g ticks, max / mean %.3f\n", ticks.size(), samples_per_pass,
+                        (double) lo, sum / (double) ticks.size(), (double) hi, (double) hi * (double) ticks.size() / sum);
+            }
         }
         if (!opts.film_on_device) HIP_CHECK(hipMemcpyAsync(film, d_film, film_floats * sizeof(float), hipMemcpyDeviceToHost, stream));
         unsigned long long h_counters[N_COUNTERS] = {};
