@@ -88,7 +88,7 @@ class Sensor(C.Structure):
                 ("rfilter_type", i32), ("rfilter_radius", f32), ("rfilter_stddev", f32),
                 ("sample_count", i32), ("sampler_seed", C.c_uint64), ("medium", i32),
                 ("multi_transforms", C.POINTER(C.c_float)), ("multi_count", i32),
-                ("shutter_open_time", f32), ("distant_origin_type", i32), ("distant_origin_shape", Shape), ("srf", i32)]
+                ("shutter_open_time", f32), ("distant_origin_type", i32), ("distant_origin_shape", Shape), ("srf", i32), ("sampler_wavefront", i32)]
 
 
 class Integrator(C.Structure):

@@ -178,6 +178,19 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
     // flight) stays below 1 GiB however many passes samples_per_pass asks for, and thread indices stay far below 2^32.
     // should_stop() (integrator.h:143-146) is honoured inside a launch: the kernels poll the scene's stop word.
     const size_t MAX_BLOCKS_PER_LAUNCH = std::max<size_t>(1, ((size_t) 8 << 20) / ((size_t) block_size * block_size));
+    // Wavefront (gpu_*) streams make the samples of a pixel independent of each other (one stream per (pixel, sample)), so a film with
+    // fewer pixels than the GPU has lanes to fill is spread over more workgroups: `split` entries per spiral block, each rendering
+    // sample_count / split samples of every pixel of the block (DBlock::sample_base); their sums meet in the film by atomics.
+    size_t split = 1;
+    if (se.wavefront) {
+        int cus = 0;
+        HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, hs.device));
+        const size_t pixels = (size_t) se.crop_w * se.crop_h, target = (size_t) std::max(cus, 1) * 4096;      // four 1024-path workgroups' worth per CU
+        if (const char *sv = getenv("MTSAMD_WAVEFRONT_SPLIT")) split = (size_t) std::max(1, atoi(sv));
+        else while (pixels * split < target && split * 2 <= total_spp && total_spp % (split * 2) == 0) split *= 2;
+        if (total_spp % split != 0) throw std::runtime_error("MTSAMD_WAVEFRONT_SPLIT must divide the sample count");
+    }
+    const size_t launch_spp = samples_per_pass / split;            // samples per pixel one entry of a launch renders
     std::vector<std::vector<DBlock>> pass_blocks(1);
     uint64_t samples = 0;
     for (size_t pass = 0; pass < n_passes; ++pass)
@@ -186,9 +199,12 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             if (!spiral.next_block(b, id)) throw std::runtime_error("spiral exhausted early");
             if ((int) (id % (size_t) opts.shard_count) != opts.shard_index) continue;
             if (id >= ((uint64_t) 1 << 32)) throw std::runtime_error("block id overflow");
-            b.id = (uint32_t) id;
-            if (pass_blocks.back().size() >= MAX_BLOCKS_PER_LAUNCH) pass_blocks.emplace_back();
-            pass_blocks.back().push_back(b);
+            b.id = (uint32_t) id; b.sample_base = 0;
+            for (size_t sub = 0; sub < split; ++sub) {               // wavefront streams: `split` entries share a block's samples
+                b.sample_base = (uint32_t) (sub * launch_spp);
+                if (pass_blocks.back().size() >= MAX_BLOCKS_PER_LAUNCH) pass_blocks.emplace_back();
+                pass_blocks.back().push_back(b);
+            }
             samples += (uint64_t) b.sx * b.sy * samples_per_pass;
         }
     const size_t film_floats = (size_t) se.crop_w * se.crop_h * (size_t) hs.scene.film_channels;     // X, Y, Z, A, W (+ two AOV channels per spectral bin)
@@ -281,7 +297,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             int cu_count = 0;
             HIP_CHECK(hipDeviceGetAttribute(&cu_count, hipDeviceAttributeMultiprocessorCount, hs.device));
             const char *lpt = getenv("MTSAMD_LPT");                // 0: spiral order as it is
-            const uint32_t cal_spp = (uint32_t) std::min<size_t>(4, samples_per_pass / 128);
+            const uint32_t cal_spp = (uint32_t) std::min<size_t>(4, launch_spp / 128);
             const bool force = lpt && atoi(lpt) == 2;              // 2: calibrate whatever the block count (diagnostic, with MTSAMD_LPT_DEBUG)
             if (variant >= 10000 && (!lpt || atoi(lpt) != 0) && cal_spp > 0 && (force || pass_blocks[0].size() > (size_t) std::max(cu_count, 1)) && !should_stop()) {
                 std::vector<DBlock> cal(pass_blocks[0]);           // the distinct block positions of the first chunk
@@ -323,14 +339,14 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
                 HIP_CHECK(hipMemcpyAsync(d_counters + 15, &flag, sizeof(flag), hipMemcpyHostToDevice, stream));
                 HIP_CHECK(hipMemsetAsync(d_counters + N_COUNTERS, 0, blocks.size() * sizeof(unsigned long long), stream));
             }
-            launch(blocks, (uint32_t) samples_per_pass);
+            launch(blocks, (uint32_t) launch_spp);
             if (dbg) {
                 std::vector<unsigned long long> ticks(blocks.size());
                 HIP_CHECK(hipMemcpyAsync(ticks.data(), d_counters + N_COUNTERS, blocks.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
                 HIP_CHECK(hipStreamSynchronize(stream));
                 double sum = 0.0; unsigned long long lo = ~0ull, hi = 0;
                 for (unsigned long long t : ticks) { sum += (double) t; lo = std::min(lo, t); hi = std::max(hi, t); }
-                fprintf(stderr, "[mtsamd] launch of %zu blocks x %zu spp: workgroup residence min %.4g mean %.4g max %.4g ticks, max / mean %.3f\n", ticks.size(), samples_per_pass,
+                fprintf(stderr, "[mtsamd] launch of %zu blocks x %zu spp: workgroup residence min %.4g mean %.4g max %.4g ticks, max / mean %.3f\n", ticks.size(), launch_spp,
                         (double) lo, sum / (double) ticks.size(), (double) hi, (double) hi * (double) ticks.size() / sum);
             }
         }

@@ -105,6 +105,7 @@ struct DSensor {
     int32_t width, height, crop_x, crop_y, crop_w, crop_h;
     DRFilter rfilter;
     int32_t sample_count;
+    int32_t wavefront;             // 1: one TEA-seeded stream per (pixel, sample) as the reference's gpu_* variants (seed_wavefront_sample)
     uint64_t seed;
     const float *multi;            // mradiancemeter / mdistant: multi_count 4x4 matrices (device pointer)
     int32_t multi_count;
@@ -123,7 +124,7 @@ struct DVolumeSp { int32_t value_sp; int32_t spectral_grid; float lambda_min, la
 struct DIntegrator { int32_t type, max_depth, rr_depth, hide_emitters, use_spectral_mis, monochrome; };
 
 // One spiral block (librender/spiral.cpp:27-72) assigned to this launch
-struct DBlock { int32_t ox, oy, sx, sy; uint32_t id; };
+struct DBlock { int32_t ox, oy, sx, sy; uint32_t id; uint32_t sample_base; /* wavefront streams: first sample index this entry renders */ };
 
 struct DScene {
     const DVolume *volumes;

@@ -91,6 +91,16 @@ __device__ __forceinline__ bool stop_requested(const uint32_t *stop_flag) {
     return __builtin_amdgcn_ballot_w64(v != 0u) != 0ull;
 }
 
+// The stream of sample j (counted from blk.sample_base) of pixel (lx, ly) in the wavefront (gpu_*) variants: PCG32Sampler::seed seeds lane
+// L of the wavefront with (sample_tea_64(seed, L), sample_tea_64(L, seed)) in 64-bit arithmetic (librender/sampler.cpp:89-92), and
+// SamplingIntegrator::render lays the lanes out as L = pixel * spp + sample, pixel = y * width + x inside the crop window
+// (integrator.cpp:143-163)
+DEV void seed_wavefront_sample(Pcg32 &rng, const DSensor &se, const DBlock &blk, uint32_t lx, uint32_t ly, uint32_t j) {
+    const uint64_t pixel = (uint64_t) (uint32_t) (blk.oy + (int) ly - se.crop_y) * (uint64_t) (uint32_t) se.crop_w + (uint64_t) (uint32_t) (blk.ox + (int) lx - se.crop_x);
+    const uint64_t L = pixel * (uint64_t) (uint32_t) se.sample_count + (uint64_t) blk.sample_base + (uint64_t) j;
+    rng.seed(sample_tea_64_u64(se.seed, L), sample_tea_64_u64(L, se.seed));
+}
+
 // What survives of a SurfaceInteraction between loop iterations: the hit distance, the hit point
 // (computed from the ray that found it), and the primitive; normals / frames / wi are rebuilt on
 // demand by complete_surface() with the same arithmetic.

@@ -88,7 +88,9 @@ __device__ __forceinline__ void path_pixel_flat(const DScene &sc, Pcg32 &rng, co
     uint32_t bs_type = 0;
     bool valid_ray = false;
     int depth = 0;                                              // 0: the camera ray of a fresh sample has not been traced yet
+    uint32_t j = 0;
     auto begin_sample = [&]() {                                 // integrator.cpp:242-264, path.cpp:106-119
+        if (se.wavefront) seed_wavefront_sample(rng, se, blk, lx, ly, j);     // gpu_* streams: one per (pixel, sample)
         F2 u = rng.next_2d();
         position_sample.x = px + u.x; position_sample.y = py + u.y;
         F2 aperture_sample; aperture_sample.x = .5f; aperture_sample.y = .5f;
@@ -104,7 +106,6 @@ __device__ __forceinline__ void path_pixel_flat(const DScene &sc, Pcg32 &rng, co
         throughput = f3s(1.f); result = f3s(0.f); eta = 1.f; emission_weight = 1.f; depth = 0;
     };
     begin_sample();
-    uint32_t j = 0;
     for (uint32_t it = 0;; ++it) {
         if ((it & 1023u) == 1023u && stop_requested(stop_flag)) break;      // should_stop(), integrator.h:143-146
         const Hit si = ray_intersect(sc, ray);
@@ -223,6 +224,7 @@ __global__ void __launch_bounds__(256, (FLAT && INTEG != NI_PATH) ? 1 : (INTEG =
             // should_stop(), integrator.h:143-146: the reference looks at its flag once per sample; here one lane of the wave reads the
             // host-visible word every 64 samples
             if ((j & 63u) == 63u && stop_requested(stop_flag)) break;
+            if (sc.sensor.wavefront) seed_wavefront_sample(rng, sc.sensor, blk, lx, ly, j);       // gpu_* streams: one per (pixel, sample)
             render_sample<COUNT, INTEG>(sc, rng, blk, lx, ly, film, acc, cnt);
         }
 #if MTS_SPEC_N == 3

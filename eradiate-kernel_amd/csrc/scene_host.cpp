@@ -490,6 +490,9 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
     if (se.rfilter.radius > 16.f) throw std::runtime_error("reconstruction filter radius too large");
     if (s.sample_count <= 0) throw std::runtime_error("sampler: sample_count must be positive");
     se.sample_count = s.sample_count; se.seed = s.sampler_seed; se.medium = s.medium; se.shutter_open_time = s.shutter_open_time;
+    se.wavefront = s.sampler_wavefront != 0;
+    if (se.wavefront && d->integrator.samples_per_pass >= 0 && d->integrator.samples_per_pass != s.sample_count)
+        throw std::runtime_error("wavefront streams (mts_sensor.sampler_wavefront): samples_per_pass must cover the whole sample_count (one pass)");
     check_index(s.medium, d->medium_count, "sensor medium", true);
     if (s.type == MTS_SENSOR_PERSPECTIVE) {
         se.near_clip = s.near_clip; se.far_clip = s.far_clip;

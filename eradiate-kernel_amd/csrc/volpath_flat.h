@@ -336,6 +336,7 @@ struct VolpathMachine {
     template <class E> DEV void begin_sample(PathState &p, const E &e) const {      // integrator.cpp:242-264, volpath.cpp:48-71
         const DSensor &se = sc.sensor;
         const float px = (float) (e.lx + (uint32_t) e.blk.ox), py = (float) (e.ly + (uint32_t) e.blk.oy);
+        if (se.wavefront) seed_wavefront_sample(p.rng, se, e.blk, e.lx, e.ly, __float_as_uint(e.cold.f(C_SAMPLE)));   // gpu_* streams: one per (pixel, sample)
         F2 u = p.rng.next_2d();
         F2 position_sample; position_sample.x = px + u.x; position_sample.y = py + u.y;
         F2 aperture_sample; aperture_sample.x = .5f; aperture_sample.y = .5f;

@@ -822,6 +822,9 @@ class SceneBuilder:
             raise RuntimeError("Unknown / unsupported sampler plugin \"%s\" (parity target is 'independent')" % sp.type)
         s.sample_count = int(sp.get("sample_count", 4))
         s.sampler_seed = int(sp.get("seed", 0))
+        # Extension of this backend (the reference picks the seeding by variant): "wavefront": True gives the streams of the gpu_* variants --
+        # one TEA-seeded PCG32 per (pixel, sample), librender/sampler.cpp:89-92 -- instead of scalar_rgb's one stream per pixel
+        s.sampler_wavefront = int(bool(sp.get("wavefront", False)))
         sp.finish()
         shutter_open, shutter_close = float(p.get("shutter_open", 0.0)), float(p.get("shutter_close", 0.0))      # sensor.cpp:20-27
         if shutter_close < shutter_open:

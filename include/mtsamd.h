@@ -201,6 +201,13 @@ typedef struct mts_sensor {
        function the sample's wavelengths are drawn from (Texture::sample_spectrum of a uniform or discrete spectrum) instead of
        sample_wavelength().  1 + index into mts_scene_desc.spectra, 0 = none (a zeroed record has none).  Spectral variant only. */
     int32_t srf;
+    /* Random streams.  0: the scalar variants' -- one PCG32 stream per pixel, seeded from the spiral block id (integrator.cpp:198),
+       all samples of the pixel drawn from it in order: fixed-seed parity with scalar_rgb.  1: the wavefront (gpu_*) variants' --
+       one stream per (pixel, sample): lane L = pixel * sample_count + sample of the wavefront is seeded with
+       (sample_tea_64(seed, L), sample_tea_64(L, seed)) (librender/sampler.cpp:89-92, integrator.cpp:140-172; pixel = y * crop_width + x
+       inside the crop window).  Samples are then independent of each other, so small films are spread over the whole GPU (several
+       workgroups share a block's samples); needs samples_per_pass = all (one pass). */
+    int32_t sampler_wavefront;
 } mts_sensor;
 
 /* ---- Integrator (src/integrators/{path,volpath}.cpp, src/librender/integrator.cpp:23-39,302-315) */

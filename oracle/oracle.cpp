@@ -1716,7 +1716,18 @@ static void render_block(const Scene &sc, Sampler &sampler, ImageBlock &block, u
         uint32_t x, y; morton_decode(i, &x, &y);
         if (x >= (uint32_t) block.w || y >= (uint32_t) block.h) continue;
         float px = (float) (x + block.ox), py = (float) (y + block.oy);
-        for (size_t j = 0; j < sample_count; ++j) render_sample(sc, sampler, block, px, py, cnt);
+        for (size_t j = 0; j < sample_count; ++j) {
+            if (sc.sensor.wavefront) {
+                // The streams of the wavefront (gpu_*) variants: lane L = pixel * spp + sample is seeded with (sample_tea_64(seed, L),
+                // sample_tea_64(L, seed)) in 64-bit arithmetic (librender/sampler.cpp:89-92), pixel = y * width + x inside the crop
+                // window (integrator.cpp:143-163).  One stream per (pixel, sample) instead of one per pixel.
+                const uint64_t pixel = (uint64_t) (y + (uint32_t) block.oy - (uint32_t) sc.sensor.crop_y) * (uint64_t) sc.sensor.crop_w +
+                                       (uint64_t) (x + (uint32_t) block.ox - (uint32_t) sc.sensor.crop_x);
+                const uint64_t L = pixel * (uint64_t) sc.sensor.sample_count + (uint64_t) j;
+                sampler.rng.seed(sample_tea_64_u64(sampler.base_seed, L), sample_tea_64_u64(L, sampler.base_seed));
+            }
+            render_sample(sc, sampler, block, px, py, cnt);
+        }
     }
 }
 

@@ -416,7 +416,7 @@ struct Sensor {
     // film
     int width, height, crop_x, crop_y, crop_w, crop_h;
     RFilter rfilter;
-    int sample_count; uint64_t seed;
+    int sample_count; uint64_t seed; bool wavefront = false;      // wavefront: one TEA-seeded stream per (pixel, sample), the gpu_* variants' seeding
     std::vector<float> multi; int multi_count = 0;   // mradiancemeter / mdistant: m_transforms (mradiancemeter.cpp:95-113, mdistant.cpp:160-175)
     int srf = -1;                                    // spectral variant: index of the "srf" spectrum (perspective.cpp:113-116, radiancemeter.cpp:62-66)
 };
@@ -643,6 +643,9 @@ static inline Scene *make_scene(const mts_scene_desc *d) {
         if (se.width <= 0 || se.height <= 0 || se.crop_w <= 0 || se.crop_h <= 0) throw std::runtime_error("film: invalid size");
         se.rfilter = make_rfilter(s.rfilter_type, s.rfilter_radius, s.rfilter_stddev);
         se.sample_count = s.sample_count; se.seed = s.sampler_seed; se.medium = s.medium; se.shutter_open_time = s.shutter_open_time;
+        se.wavefront = s.sampler_wavefront != 0;
+        if (se.wavefront && d->integrator.samples_per_pass >= 0 && d->integrator.samples_per_pass != s.sample_count)
+            throw std::runtime_error("wavefront streams: samples_per_pass must cover the whole sample_count (one pass)");
         if ((s.type == MTS_SENSOR_DISTANT || s.type == MTS_SENSOR_DISTANTFLUX) && s.distant_origin_type != 0) {
             se.origin_is_shape = true;
             se.origin_shape = make_shape(s.distant_origin_shape);

@@ -112,6 +112,28 @@ def test_sharded_render_sums_to_full(gpu_rgb):
     assert np.all(full[..., 4] == 8)
 
 
+def test_expensive_blocks_first_gives_the_same_film(gpu_rgb, monkeypatch):
+    """A launch with more spiral blocks than the GPU has CUs renders a few calibration samples first and then starts its blocks by
+    descending cost (capi.cpp: longest processing time first).  The order of the blocks does not change which pixel receives which
+    samples: the film equals the spiral-order film and the oracle's, and the calibration samples are not part of it."""
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    side = 32 * (int(np.sqrt(cus)) + 1)                                    # (sqrt(CUs) + 1)^2 > CUs blocks
+    d = scenes.c4_atmosphere(side, side, 128, layers=8)
+    a, st = gpu_render(gpu_rgb, d, collect_counters=True)
+    assert st["kernel_launches"] == 2 and st["samples"] == side * side * 128           # calibration + the render; only the render's samples count
+    monkeypatch.setenv("MTSAMD_LPT", "0")
+    b, st0 = gpu_render(gpu_rgb, d, collect_counters=True)
+    assert st0["kernel_launches"] == 1
+    assert np.array_equal(a, b) and np.all(a[..., 4] == 128)
+    assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (st0["n_iter"], st0["n_lookup"], st0["n_nee_step"])
+    monkeypatch.delenv("MTSAMD_LPT")
+    crop = scenes.c4_atmosphere(side, side, 128, layers=8)                   # the oracle on one block of it (a full render takes minutes on the CPU)
+    crop["sensor"]["film"].update({"crop_offset_x": 64, "crop_offset_y": 32, "crop_width": 32, "crop_height": 32})
+    c, _ = gpu_render(gpu_rgb, crop)
+    assert_parity(c, ob.OracleScene(crop).render())
+
+
 def test_bench_strong_scaling_rehearsal(gpu_rgb, tmp_path):
     """bench.py's own N-rank path (strong scaling: passes of spp / N, block_id % N, film reduce, 1-rank film check, weak side
     figure) with two ranks on this one GPU through the gloo rehearsal switch -- the code the driver runs on 8 GPUs over RCCL."""
