@@ -31,7 +31,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
 CONFIG_SIZES = {"C1": (256, 256, 64), "C2": (512, 512, 256), "C3": (512, 512, 1024), "C4": (1024, 1024, 4096), "C5": (1024, 1024, 4096),
-                "C5S": (1024, 1024, 256), "C5SM": (1024, 1024, 256), "C5SB": (1024, 1024, 256), "C3M": (512, 512, 1024), "C1L": (512, 512, 256)}      # C5S: the same atmosphere in the spectral variant (gpu_spectral), 256 spp
+                "C5S": (1024, 1024, 256), "C5SM": (1024, 1024, 256), "C5SB": (1024, 1024, 256), "C3M": (512, 512, 1024), "C1L": (512, 512, 256), "C1W": (256, 256, 64)}      # C5S: the same atmosphere in the spectral variant (gpu_spectral), 256 spp
 C5_WAVELENGTHS = 16        # BASELINE.json configs[4]: the C4 atmosphere as a 16-wavelength batch
 
 
@@ -42,8 +42,10 @@ def c5_rayleigh_scale(k):
 
 
 def build_scene_dict(scenes, config, width, height, spp, samples_per_pass=-1, res=128, wavelength=0):
-    if config in ("C1", "C1L"):                                     # C1L: the same cornell box at a size that fills the chip
+    if config in ("C1", "C1L", "C1W"):                              # C1L: the same cornell box at a size that fills the chip
         d = scenes.c1_cornell(width, height, spp)
+        if config == "C1W":                                         # C1 with the streams of the reference's gpu_* variants: one per (pixel, sample)
+            d["sensor"]["sampler"]["wavefront"] = True
     elif config == "C2":
         d = scenes.c2_homogeneous_slab(width, height, spp)
     elif config == "C4":
@@ -190,7 +192,7 @@ def main():
     # cut into N passes.  Checked for the configurations at their BASELINE sizes (a rehearsal on a small film cannot meet it).
     blocks_total = -(-args.width // 32) * -(-args.height // 32) * (args.spp // spp_pass if n > 1 else 1)
     workgroups_per_rank = blocks_total // n
-    if (args.width, args.height, args.spp) == CONFIG_SIZES[args.config] and args.config not in ("C1",) and workgroups_per_rank < 256:
+    if (args.width, args.height, args.spp) == CONFIG_SIZES[args.config] and args.config not in ("C1", "C1W") and workgroups_per_rank < 256:
         raise SystemExit("bench.py: %d workgroups per rank (< 256 CUs) at --gpus %d" % (workgroups_per_rank, n))
     elapsed, kernel_ms, launches, samples_rank = timed(job, args.steps, args.warmup, barrier, all_max)
     value = job.samples_step * args.steps / elapsed / 1e6
@@ -302,7 +304,7 @@ def main():
                                                   % (args.width, args.height, cpu_spp, " (first wavelength)" if args.config == "C5" else "", tcpu, cores)}
 
     if rank == 0:
-        workload = {"C1": "C1 path cornell box", "C1L": "C1L = the C1 cornell box at 512x512x256 (262144 pixel streams: one per lane of the chip)", "C2": "C2 volpath homogeneous slab", "C4": "C4 volpath layered atmosphere, blend/tabulated phase, RPV ground",
+        workload = {"C1": "C1 path cornell box", "C1W": "C1W = C1 with wavefront (gpu_*) streams, one per (pixel, sample): the samples of a pixel spread over several workgroups", "C1L": "C1L = the C1 cornell box at 512x512x256 (262144 pixel streams: one per lane of the chip)", "C2": "C2 volpath homogeneous slab", "C4": "C4 volpath layered atmosphere, blend/tabulated phase, RPV ground",
                     "C5": "C5 = C4 as %d monochromatic wavelength batches (Rayleigh ~ lambda^-4), gpu_mono" % C5_WAVELENGTHS,
                     "C5S": "C5S = the C4 atmosphere in the spectral variant (gpu_spectral: 4 wavelengths per sample, gridvolume_spectral grids, global majorant)",
                     "C5SB": "C5SB = C5S inside nbins (16 wavelength bins over 360 .. 830 nm: 32 AOV channels behind X, Y, Z, A, W), regrouping kernel",

@@ -260,6 +260,10 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
         // volpath_flat.h); `path`, `volpathmis` and a discrete response function with repeated wavelengths stay per lane
         if ((hs.scene.bin_count > 0 || hs.scene.srf >= 0) &&
             !(variant >= 10000 && hs.integrator.type == MTS_INTEGRATOR_VOLPATH && hs.srf_lookup_by_wavelength)) variant = 0;
+        // Wavefront (gpu_*) streams carry their own PCG32 increment per (pixel, sample); the regrouping machines keep only the 64-bit state in
+        // LDS (their increment is the default stream's, a constant) and have no room for two more dwords per path, so these scenes run
+        // per lane, where the generator lives in registers: `volpath` as the flat state machine, the others nested
+        if (se.wavefront && variant >= 10000) variant = (hs.integrator.type == MTS_INTEGRATOR_VOLPATH && !hs.integrator.spectral) ? 1 : 0;
         int wg_threads = 0;                                         // MTSAMD_WG_THREADS: threads per workgroup of the wga kernels (<= paths; default = paths)
         if (const char *tv = getenv("MTSAMD_WG_THREADS")) wg_threads = atoi(tv);
         last_variant = variant;

@@ -112,6 +112,37 @@ def test_sharded_render_sums_to_full(gpu_rgb):
     assert np.all(full[..., 4] == 8)
 
 
+@pytest.mark.parametrize("case", ["cornell_path", "cornell_path_nested", "c3_volpath", "c3_volpath_nested", "c3_volpathmis", "c4_small"])
+def test_wavefront_streams_match_the_oracle(gpu_rgb, monkeypatch, case):
+    """The random streams of the reference's wavefront (gpu_*) variants -- one PCG32 per (pixel, sample), seeded with the 64-bit TEA of
+    librender/sampler.cpp:89-92 in the lane order of integrator.cpp:143-163 -- as a render mode (sampler "wavefront": True): every
+    kernel formulation gives the film of the oracle run with the same seeding.  With one workgroup entry per block (split 1) the sums
+    are taken in sample order: bit-identical.  Spread over several entries per block (the default on a small film) the partial sums
+    meet in the film by float atomics: equal to rounding."""
+    d = {"cornell_path": lambda: scenes.c1_cornell(48, 40, 16), "cornell_path_nested": lambda: scenes.c1_cornell(48, 40, 16),
+         "c3_volpath": lambda: scenes.c3_heterogeneous(64, 40, 16, res=16), "c3_volpath_nested": lambda: scenes.c3_heterogeneous(64, 40, 16, res=16),
+         "c3_volpathmis": lambda: scenes.c3_heterogeneous(64, 40, 16, res=16), "c4_small": lambda: scenes.c4_atmosphere(24, 24, 8, layers=8)}[case]()
+    if case == "c3_volpathmis":
+        d["integrator"]["type"] = "volpathmis"
+    if case.endswith("nested"):
+        monkeypatch.setenv("MTSAMD_KERNEL", "nested")
+    scalar = ob.OracleScene(d).render()
+    d["sensor"]["sampler"]["wavefront"] = True
+    o = ob.OracleScene(d); ref = o.render()
+    assert not np.array_equal(ref, scalar) and abs(ref[..., 1].sum() / scalar[..., 1].sum() - 1) < 0.2          # other streams, same image
+    monkeypatch.setenv("MTSAMD_WAVEFRONT_SPLIT", "1")
+    gpu, st = gpu_render(gpu_rgb, d, collect_counters=True)
+    assert np.array_equal(gpu, ref)
+    assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (o.last_stats["n_iter"], o.last_stats["n_lookup"], o.last_stats["n_nee_step"])
+    monkeypatch.delenv("MTSAMD_WAVEFRONT_SPLIT")
+    spread, st2 = gpu_render(gpu_rgb, d, collect_counters=True)                   # small film: several entries per block
+    assert np.array_equal(spread[..., 3:], ref[..., 3:]) and np.allclose(spread, ref, rtol=2e-5, atol=1e-7)
+    assert (st2["n_iter"], st2["n_lookup"], st2["n_nee_step"]) == (st["n_iter"], st["n_lookup"], st["n_nee_step"]) and st2["samples"] == st["samples"]
+    with pytest.raises(RuntimeError, match="one pass"):
+        d["integrator"]["samples_per_pass"] = d["sensor"]["sampler"]["sample_count"] // 2
+        gpu_rgb.load_dict(d)
+
+
 def test_expensive_blocks_first_gives_the_same_film(gpu_rgb, monkeypatch):
     """A launch with more spiral blocks than the GPU has CUs renders a few calibration samples first and then starts its blocks by
     descending cost (capi.cpp: longest processing time first).  The order of the blocks does not change which pixel receives which
@@ -125,7 +156,7 @@ def test_expensive_blocks_first_gives_the_same_film(gpu_rgb, monkeypatch):
     monkeypatch.setenv("MTSAMD_LPT", "0")
     b, st0 = gpu_render(gpu_rgb, d, collect_counters=True)
     assert st0["kernel_launches"] == 1
-    assert np.array_equal(a, b) and np.all(a[..., 4] == 128)
+    assert np.array_equal(a, b) and abs(float(a[..., 4].mean()) - 128.0) < 0.01      # (a sample at u = 0 can land on the neighbouring pixel)
     assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (st0["n_iter"], st0["n_lookup"], st0["n_nee_step"])
     monkeypatch.delenv("MTSAMD_LPT")
     crop = scenes.c4_atmosphere(side, side, 128, layers=8)                   # the oracle on one block of it (a full render takes minutes on the CPU)
