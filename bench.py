@@ -187,6 +187,7 @@ def main():
         spp_pass = max(1, args.spp // n)
         while args.spp % spp_pass:
             spp_pass -= 1
+    variant = {"C5": "gpu_mono", "C5S": "gpu_spectral", "C5SM": "gpu_spectral", "C5SB": "gpu_spectral"}.get(args.config, "gpu_rgb")
     job = Job(pkg, scenes, args, rank, n, local_rank, backend, args.spp, spp_pass if n > 1 else -1)
     # every rank should get at least one workgroup per CU (256) per launch, or the GPUs run partly empty: the reason the N-rank job is
     # cut into N passes.  Checked for the configurations at their BASELINE sizes (a rehearsal on a small film cannot meet it).
@@ -228,7 +229,9 @@ def main():
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
     integ_type = (job.dicts[0]["integrator"].get("integrator") or job.dicts[0]["integrator"])["type"]
     kv = os.environ.get("MTSAMD_KERNEL", "wga1024")
-    if integ_type == "path" or kv == "nested":
+    if integ_type == "path" and kv != "nested" and variant == "gpu_rgb":
+        kernel_name = "render_kernel<false, true, 0>"                # path_pixel_flat: one flat loop with regeneration
+    elif integ_type == "path" or kv == "nested":
         kernel_name = "render_kernel<false, false, %d>" % {"path": 0, "volpath": 1, "volpathmis": 2}.get(integ_type, 0)
     elif kv == "flat" and integ_type == "volpath":
         kernel_name = "render_kernel<false, true, 1>"
