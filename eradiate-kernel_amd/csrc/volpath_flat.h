@@ -986,20 +986,18 @@ static __device__ WG_BLOCK_ATTR int wg_block(const MTS_CONST_AS void *kernarg_, 
 //
 // Ring protocol.  q_ctl[2c] / q_ctl[2c + 1] are head / tail of ring c: two 32-bit counters that only ever grow (slot = counter mod
 // WG), each touched with 32-bit atomics only; "ring" B_DONE has no slots, its tail counts the finished paths; q_ctl[2 B_COUNT] is the
-// workgroup's stop word.  A slot holds 0xFFFF while it is empty, and every slot is touched with 16-bit atomics only.
-//   producer: release fence (state in LDS / HBM is written), tail++ -> index, wait until the slot is empty, store the id;
-//   consumer: head: h -> h + n by compare-and-swap (n <= tail - h of a snapshot: those indices are already handed out), wait until
-//             the slot holds an id, take it and store 0xFFFF AT ONCE, acquire fence.
-// The hand-over of a slot is a load followed by a store, not one atomic: it is exact as long as at most one producer and one consumer
-// work on a slot at a time, which holds unless a lane sits between its tail++ (or its claim) and its slot access for as long as the
-// workgroup needs to push WG further ids through the same ring -- a few instructions against thousands of cycles of block executions.
-// Should it ever happen an id is lost or taken twice; the former ends in the bounded idle wait below (diagnostic code 3), not in a hang.
-// A consumer can be ahead of its producer (index handed out, id not stored yet) and a producer ahead of the previous lap's consumer
-// (slot claimed, not yet emptied); with WG slots per ring and WG paths neither wait lasts.  The first look is inline; a lane that
-// has to wait does so in a wave-uniform loop whose body does the per-lane hand-over, so a lane's store never waits for another
-// lane's spin (a divergent `while` would place it after the reconvergence point), and the wait is BOUNDED: after
-// MTS_RING_SPIN_LIMIT polls it writes a diagnostic record (ring, index, head, tail) and stops the workgroup -- mts_render reports an
-// error instead of hanging.
+// workgroup's stop word.  The slots are 16 bit wide and touched with 16-bit loads / stores only; a slot holds (lap, id), lap = the
+// ring index's lap number modulo 2^(16 - log2 WG) (RingSlot below; round 3 -- rounds 1 and 2 marked a slot empty / full instead):
+//   producer: release fence (state in LDS / HBM is written), tail++ -> index, store (lap of index, id): no look at the slot, no wait;
+//   consumer: head: h -> h + n by compare-and-swap (n <= tail - h of a snapshot: those indices are already handed out), the n slots
+//             read together with it; a slot is accepted when it carries the lap of its index, acquire fence.  Nothing is written back.
+// A consumer can be ahead of its producer (index handed out, id not stored yet): the slot then still carries the previous lap, and
+// the lane waits in a wave-uniform loop (a divergent `while` would park the ready lanes behind the reconvergence point).  The wait is
+// BOUNDED: after MTS_RING_SPIN_LIMIT polls it writes a diagnostic record (ring, index, head, tail) and stops the workgroup --
+// mts_render reports an error instead of hanging.  A slot is overwritten one lap (WG pushes through this ring) after it was written,
+// while its consumer reads it within a few instructions of its claim; a lane that ever sat between claim and read for a whole lap
+// would find a newer lap, run into that bound and fail the render loudly.  A path that never comes back for any other reason leaves
+// the finished count short: the idle wait is bounded too (MTS_IDLE_LIMIT naps in a row with every ring empty: diagnostic code 3).
 // Stopping (Integrator::cancel / timeout, or a stall) adds no exit to the claim loop (a second exit measured 4.5 % slower): the
 // first lane to raise the stop word adds 2^31 to every head, which makes every ring look empty to every wave (a count above WG is no
 // count, see the snapshot) and every pending claim fail; a wave that finds every ring empty looks at the stop word before it naps.
@@ -1025,38 +1023,9 @@ DEV void wga_stall(uint32_t code, int ring, uint32_t index, uint32_t *q_ctl, uns
         }
     }
 }
-// Slow side of a slot hand-over, entered (wave-uniformly) when some lane's first look found its slot not ready.  TAKE: wait until
-// the slot holds an id, take it and empty the slot; otherwise wait until the slot is empty and store `id`.  Returns the id taken /
-// stored, 0xFFFF for a lane that gave up (workgroup stopping, or MTS_RING_SPIN_LIMIT polls: ring stall).
-template <int WG, bool TAKE>
-DEV uint32_t wga_slot_wait(bool pending, uint16_t *slot, uint32_t id, uint32_t *q_ctl, unsigned long long *counters, int ring, uint32_t index) {
-    uint32_t out = 0xFFFFu;
-#pragma nounroll
-    for (uint32_t spins = 0;; ++spins) {
-        if (pending) {
-            const uint32_t v = __atomic_load_n(slot, __ATOMIC_RELAXED);
-            if (TAKE ? v != 0xFFFFu : v == 0xFFFFu) {
-                __atomic_store_n(slot, (uint16_t) (TAKE ? 0xFFFFu : id), __ATOMIC_RELAXED);
-                out = TAKE ? v : id; pending = false;
-            }
-        }
-        if (!__builtin_amdgcn_ballot_w64(pending)) break;
-        if (spins > MTS_RING_SPIN_LIMIT) { if (pending) wga_stall<WG>(TAKE ? 1u : 2u, ring, index, q_ctl, counters); break; }
-        if (__atomic_load_n(&q_ctl[2 * B_COUNT], __ATOMIC_RELAXED) != STOP_NONE) break;
-    }
-    return out;
-}
-
-// Round 3: TAGGED slots.  A slot holds (lap << log2(WG)) | id, lap = (ring index / WG) mod 2^(16 - log2(WG)): the consumer of index i
-// accepts the slot only when it carries i's lap, so a slot need not be emptied after use and a producer need not look at it before it
-// stores -- the push is one atomic add and one store (no load, no wait), the claim reads its slots TOGETHER with the compare-and-swap
-// on the head instead of after it, and never writes them: two dependent LDS round trips less per block visit (claim + push were 28 %
-// of a wave's time).  A slot is overwritten one lap (WG pushes through this ring) after it was written; its consumer reads it within
-// a few instructions of its claim.  Should a lane ever sit between claim and read for a whole lap, it finds a newer lap in its slot,
-// waits out its bound and the render fails with the diagnostic -- the same outcome as any other lost hand-over.
-#ifndef MTS_RING_TAGGED
-#define MTS_RING_TAGGED 1
-#endif
+// Tagged slots: (lap << log2(WG)) | id.  Against the empty / full marking of rounds 1 and 2 (load, store on both sides, and a producer
+// that waits for the previous lap's consumer) this is two dependent LDS round trips less per block visit; measured C3 +-0, C4 +2 %
+// (profiles/r03_ab_experiments.log).
 template <int WG> struct RingSlot {
     static constexpr uint32_t IDBITS = WG == 1024 ? 10 : WG == 512 ? 9 : WG == 256 ? 8 : WG == 128 ? 7 : 6;
     static_assert((1u << IDBITS) == (uint32_t) WG, "paths per workgroup: 64 .. 1024, a power of two");
@@ -1084,28 +1053,13 @@ DEV uint32_t wga_tag_wait(bool pending, uint16_t *slot, uint32_t *q_ctl, unsigne
 }
 
 template <int WG>
-DEV void wga_push(int cls, uint32_t pid, bool valid, uint16_t (*q_ids)[WG], uint32_t *q_ctl, unsigned long long *counters) {
-#if MTS_RING_TAGGED
-    (void) counters;
-    uint32_t ti = 0;
-    if (valid) ti = atomicAdd(&q_ctl[2 * cls + 1], 1u);          // the value returned IS the lane's ring index
-    if (valid && cls != B_DONE) __atomic_store_n(&q_ids[cls][ti & (uint32_t) (WG - 1)], (uint16_t) RingSlot<WG>::make(ti, pid), __ATOMIC_RELAXED);
-#else
-    // One LDS atomic per lane: the tail value it returns IS the lane's slot; the LDS unit serialises the lanes that share a ring.
+DEV void wga_push(int cls, uint32_t pid, bool valid, uint16_t (*q_ids)[WG], uint32_t *q_ctl) {
+    // One LDS atomic per lane: the tail value it returns IS the lane's ring index; the LDS unit serialises the lanes that share a ring.
     // (Ranking the lanes first -- nine ballots, per-class counts, one atomic per class -- took 45 to 100 VALU instructions per push
     // and measured 1 to 3 % slower; the order of the ids inside a ring is immaterial.)
-    uint32_t idx = 0;
-    if (valid) idx = atomicAdd(&q_ctl[2 * cls + 1], 1u);
-    bool pending = valid && cls != B_DONE;
-    uint16_t *slot = &q_ids[pending ? cls : 0][idx & (uint32_t) (WG - 1)];
-    if (pending && __atomic_load_n(slot, __ATOMIC_RELAXED) == 0xFFFFu) {        // empty, as ever: hand the id over
-        __atomic_store_n(slot, (uint16_t) pid, __ATOMIC_RELAXED);
-        pending = false;
-    }
-    // the previous lap's consumer has not emptied the slot yet (rare).  The test is wave-uniform on purpose: every ready lane has
-    // stored its id by now, whatever order the compiler gives to divergent branches.
-    if (__builtin_amdgcn_ballot_w64(pending) != 0ull) (void) wga_slot_wait<WG, false>(pending, slot, pid, q_ctl, counters, cls, idx);
-#endif
+    uint32_t ti = 0;
+    if (valid) ti = atomicAdd(&q_ctl[2 * cls + 1], 1u);
+    if (valid && cls != B_DONE) __atomic_store_n(&q_ids[cls][ti & (uint32_t) (WG - 1)], (uint16_t) RingSlot<WG>::make(ti, pid), __ATOMIC_RELAXED);
 }
 
 // A stopped workgroup (Integrator::cancel(), the integrator's timeout, a stall) adds the accumulators of its unfinished pixels to the
@@ -1169,7 +1123,7 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         const int cls = vm.classify(p);
         hs.store(p, cls);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        wga_push<WG>(cls, pid0, true, q_ids, q_ctl, cload_k<WgArgs>(kernarg).counters);
+        wga_push<WG>(cls, pid0, true, q_ids, q_ctl);
     }
 #if defined(MTSAMD_BLOCKSTATS)
     long long bs_t0 = clock64(); unsigned long long bs_loc[45] = {};                      // laid out like g_blockstats
@@ -1228,10 +1182,8 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         n = best < 64u ? best : 64u;
         h = (uint32_t) __builtin_amdgcn_readlane((int) hd, sel);
         uint32_t won = 0;
-#if MTS_RING_TAGGED
         // the slots are read together with the compare-and-swap (both depend on the snapshot only); a lost claim discards them
         if (lane < n) spec_slot = __atomic_load_n(&q_ids[sel][(h + lane) & (uint32_t) (WG - 1)], __ATOMIC_RELAXED);
-#endif
         if (lane == 0) won = atomicCAS(&q_ctl[2 * sel], h, h + n) == h ? 1u : 0u;
 #if defined(MTSAMD_BLOCKSTATS)
         if (COUNT) { bs_loc[10] += 1ull; if (!__builtin_amdgcn_readfirstlane((int) won)) bs_loc[11] += 1ull; }      // claim attempts / lost compare-and-swaps
@@ -1241,7 +1193,6 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
       if (finished) break;
         uint32_t pid = 0xFFFFu;
         bool mine = lane < n;
-#if MTS_RING_TAGGED
         {
             uint16_t *slot = &q_ids[sel][(h + lane) & (uint32_t) (WG - 1)];
             const bool ready = mine && RingSlot<WG>::matches(spec_slot, h + lane);
@@ -1252,21 +1203,6 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
                 mine = mine && pid != 0xFFFFu;                // 0xFFFF: the workgroup is stopping, the lane drops out
             }
         }
-#else
-        {
-            uint16_t *slot = &q_ids[sel][(h + lane) & (uint32_t) (WG - 1)];     // relaxed atomics, not volatile: volatile accesses stay FLAT
-            if (mine) {
-                pid = __atomic_load_n(slot, __ATOMIC_RELAXED);
-                if (pid != 0xFFFFu) __atomic_store_n(slot, (uint16_t) 0xFFFFu, __ATOMIC_RELAXED);   // taken: empty the slot at once
-            }
-            // a lane ahead of its producer (rare); wave-uniform test, see wga_push
-            if (__builtin_amdgcn_ballot_w64(mine && pid == 0xFFFFu) != 0ull) {
-                const uint32_t got = wga_slot_wait<WG, true>(mine && pid == 0xFFFFu, slot, 0u, q_ctl, cload_k<WgArgs>(kernarg).counters, sel, h + lane);
-                if (pid == 0xFFFFu) pid = got;
-                mine = mine && pid != 0xFFFFu;                // 0xFFFF: the workgroup is stopping, the lane drops out
-            }
-        }
-#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #if defined(MTSAMD_BLOCKSTATS)
         if (COUNT) { bs_loc[sel] += 1ull; bs_loc[12 + sel] += (unsigned long long) n;
@@ -1296,7 +1232,7 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         if (COUNT) { long long t = clock64(); bs_loc[24 + sel] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
 #endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        wga_push<WG>(cls, pid, mine, q_ids, q_ctl, cload_k<WgArgs>(kernarg).counters);
+        wga_push<WG>(cls, pid, mine, q_ids, q_ctl);
 #if defined(MTSAMD_BLOCKSTATS)
         if (COUNT) { long long t = clock64(); bs_loc[43] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
 #endif

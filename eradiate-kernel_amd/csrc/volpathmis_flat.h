@@ -5,7 +5,7 @@
 // :330-445).  As in volpath_flat.h the three nested loops become one state machine -- a path is (mode, state) and advances one block
 // at a time: INTERSECT, MEDIUM step of the path, MEDIUM step of a walk, SCATTER (emitter sampling at a medium interaction), walk
 // SURFACE, path SURFACE + BSDF, PHASE, NEW sample -- and the workgroup regroups its paths by the block they wait for through the LDS
-// rings of volpath_flat.h (same protocol: wga_push, wga_slot_wait, wga_raise_stop).  The hot state is 67 dwords per path with the
+// rings of volpath_flat.h (same protocol: wga_push, wga_tag_wait, wga_raise_stop).  The hot state is 67 dwords per path with the
 // four 3 x 3 matrices (43 with `use_spectral_mis = false`), so a workgroup holds 512 paths (137 KB of LDS) served by 512 threads.
 // The spectral build (MTS_SPEC_N = 4: 4 x 4 matrices, volpathmis.cpp:66-69) carries 101 dwords per path with spectral MIS -- 256 paths
 // per workgroup (103 KB), one workgroup per CU -- and 53 without (256 paths, three workgroups per CU).
@@ -611,7 +611,7 @@ DEV void volpathmis_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &
         const int cls = vm.classify(p);
         hs.store(p, cls);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        wga_push<WG>(cls, pid0, true, q_ids, q_ctl, cload_k<WgArgs>(kernarg).counters);
+        wga_push<WG>(cls, pid0, true, q_ids, q_ctl);
     }
     uint32_t poll_ticks = (tid >> 6) * 2048u, idle_naps = 0;
 #pragma unroll 1
@@ -647,16 +647,13 @@ DEV void volpathmis_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &
         n = best < 64u ? best : 64u;
         h = (uint32_t) __builtin_amdgcn_readlane((int) hd, sel);
         uint32_t won = 0;
-#if MTS_RING_TAGGED
         if (lane < n) spec_slot = __atomic_load_n(&q_ids[sel][(h + lane) & (uint32_t) (WG - 1)], __ATOMIC_RELAXED);     // tagged slots: read with the claim (volpath_flat.h)
-#endif
         if (lane == 0) won = atomicCAS(&q_ctl[2 * sel], h, h + n) == h ? 1u : 0u;
         if (__builtin_amdgcn_readfirstlane((int) won)) break;
       }
       if (finished) break;
         uint32_t pid = 0xFFFFu;
         bool mine = lane < n;
-#if MTS_RING_TAGGED
         {
             uint16_t *slot = &q_ids[sel][(h + lane) & (uint32_t) (WG - 1)];
             const bool ready = mine && RingSlot<WG>::matches(spec_slot, h + lane);
@@ -667,20 +664,6 @@ DEV void volpathmis_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &
                 mine = mine && pid != 0xFFFFu;
             }
         }
-#else
-        {
-            uint16_t *slot = &q_ids[sel][(h + lane) & (uint32_t) (WG - 1)];
-            if (mine) {
-                pid = __atomic_load_n(slot, __ATOMIC_RELAXED);
-                if (pid != 0xFFFFu) __atomic_store_n(slot, (uint16_t) 0xFFFFu, __ATOMIC_RELAXED);
-            }
-            if (__builtin_amdgcn_ballot_w64(mine && pid == 0xFFFFu) != 0ull) {
-                const uint32_t got = wga_slot_wait<WG, true>(mine && pid == 0xFFFFu, slot, 0u, q_ctl, cload_k<WgArgs>(kernarg).counters, sel, h + lane);
-                if (pid == 0xFFFFu) pid = got;
-                mine = mine && pid != 0xFFFFu;
-            }
-        }
-#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         int cls = B_DONE;
         if (mine) {
@@ -701,7 +684,7 @@ DEV void volpathmis_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &
                 (void) wga_raise_stop<WG>(q_ctl, STOP_CANCEL);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        wga_push<WG>(cls, pid, mine, q_ids, q_ctl, cload_k<WgArgs>(kernarg).counters);
+        wga_push<WG>(cls, pid, mine, q_ids, q_ctl);
     }
     __syncthreads();                                          // stopped: the unfinished pixels' samples go to the film (volpath_flat.h)
     if (__atomic_load_n(&q_ctl[2 * B_COUNT], __ATOMIC_RELAXED) != STOP_NONE) wg_flush_unfinished<WG, NT>(kernarg, hot_lds, Hot::M_PACKED, wg_base);
