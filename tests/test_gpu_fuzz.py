@@ -97,6 +97,8 @@ def _scene(seed):
     else:
         d["lamp"] = {"type": str(rng.choice(["rectangle", "disk", "cube", "sphere"])), "to_world": T.translate([0.5, 0, 6]) @ T.rotate([1, 0, 0], 180) @ T.scale(1.5),
                      "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [4.0, 3.5, 3.0]}}}
+    if rng.random() < 0.2:                               # the streams of the gpu_* variants: one per (pixel, sample) (drawn last: the scenes of round 2 keep their layout)
+        d["sensor"]["sampler"]["wavefront"] = True
     return d
 
 
@@ -113,6 +115,8 @@ def test_random_scene(gpu_rgb, monkeypatch, seed, bvh):
     o = ob.OracleScene(d); ref = o.render(); so = o.last_stats
     if d["sensor"]["film"]["rfilter"]["type"] == "gaussian":          # neighbouring pixels are reached by atomics in arbitrary order
         assert np.allclose(gpu, ref, rtol=2e-4, atol=1e-6)
+    elif d["sensor"]["sampler"].get("wavefront"):                      # a small film's samples are spread over several workgroup entries: partial sums meet by atomics
+        assert np.allclose(gpu, ref, rtol=2e-5, atol=1e-7) and np.array_equal(gpu[..., 4], ref[..., 4])
     else:
         assert np.array_equal(gpu, ref), (seed, float(np.abs(gpu - ref).max()))
     assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
@@ -132,6 +136,7 @@ def test_random_scene_full_blocks(gpu_rgb, seed):
     d = _enlarge(_scene(100 + seed), 96, 72, 12)
     if d is None or d["integrator"]["type"] == "path":
         pytest.skip("sensor with a fixed film size / per-lane integrator")
+    d["sensor"]["sampler"].pop("wavefront", None)             # this test is about the regrouping machines (scalar streams)
     gpu, st = None, None
     scene = gpu_rgb.load_dict(d)
     sensor = scene.sensors()[0]
@@ -153,10 +158,7 @@ def _to_spectral(node, rng):
 
 def _scene_spectral(seed):
     rng = np.random.default_rng(1000 + seed)
-    d = _scene(seed)
-    if d["integrator"]["type"] == "volpathmis":
-        d["integrator"] = dict(d["integrator"], type="volpath")
-        d["integrator"].pop("use_spectral_mis", None)
+    d = _scene(seed)                                          # volpathmis stays volpathmis (round 3: 4 x 4 weight matrices in the spectral variant)
     d = _to_spectral(d, rng)
     med = d.get("slab", {}).get("interior")
     if med and med["type"] == "heterogeneous" and rng.random() < 0.6:        # spectral grids for extinction and / or albedo
@@ -182,8 +184,9 @@ def gpu_spectral(pkg):
 
 @pytest.mark.parametrize("seed", range(40))
 def test_random_scene_spectral(gpu_spectral, seed):
-    """The same random scenes in the spectral variant: `volpath` on the four-wide ring machine (or per lane without media), `path`
-    per lane, spectra on every colour parameter, spectral grids -- film and counters against liboracle_spectral.so."""
+    """The same random scenes in the spectral variant: `volpath` and `volpathmis` on the four-wide ring machines (or per lane without
+    media / with wavefront streams), `path` per lane, spectra on every colour parameter, spectral grids -- film and counters against
+    liboracle_spectral.so."""
     d = _scene_spectral(seed)
     scene = gpu_spectral.load_dict(d)
     sensor = scene.sensors()[0]
@@ -192,6 +195,8 @@ def test_random_scene_spectral(gpu_spectral, seed):
     o = ob.OracleScene(d, spectral=True); ref = o.render(); so = o.last_stats
     if d["sensor"]["film"]["rfilter"]["type"] == "gaussian":
         assert np.allclose(gpu, ref, rtol=2e-4, atol=1e-6)
+    elif d["sensor"]["sampler"].get("wavefront"):
+        assert np.allclose(gpu, ref, rtol=2e-5, atol=1e-7) and np.array_equal(gpu[..., 4], ref[..., 4])
     else:
         assert np.array_equal(gpu, ref), (seed, float(np.abs(gpu - ref).max()))
     assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
