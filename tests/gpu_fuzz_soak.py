@@ -1,0 +1,28 @@
+"""Diagnostic: the random scenes of tests/test_gpu_fuzz.py over a wider range of seeds (rgb and spectral).  usage: python tests/gpu_fuzz_soak.py FIRST LAST"""
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tests.oracle_binding as ob
+from tests.test_gpu_fuzz import _scene, _scene_spectral
+pkg = importlib.import_module("eradiate-kernel_amd")
+first, last = int(sys.argv[1]), int(sys.argv[2])
+bad = 0
+for spectral in (False, True):
+    pkg.set_variant("gpu_spectral" if spectral else "gpu_rgb")
+    for seed in range(first, last):
+        d = _scene_spectral(seed) if spectral else _scene(seed)
+        try:
+            scene = pkg.load_dict(d); sensor = scene.sensors()[0]
+            scene.integrator().render(scene, sensor, collect_counters=True)
+            gpu = np.array(sensor.film().bitmap(raw=True)); st = scene.integrator().last_stats
+            o = ob.OracleScene(d, spectral=spectral); ref = o.render(); so = o.last_stats
+        except Exception as e:
+            print("seed", seed, "spectral", spectral, "EXCEPTION", e); bad += 1; continue
+        loose = d["sensor"]["film"]["rfilter"]["type"] == "gaussian" or d["sensor"]["sampler"].get("wavefront")
+        ok = np.allclose(gpu, ref, rtol=2e-4, atol=1e-6) if loose else np.array_equal(gpu, ref)
+        ok = ok and (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
+        if not ok:
+            bad += 1
+            print("seed", seed, "spectral", spectral, "MISMATCH", d["integrator"], d["sensor"]["type"], float(np.abs(gpu - ref).max()), flush=True)
+print("soak seeds %d..%d: %d failures" % (first, last, bad))
+sys.exit(1 if bad else 0)
