@@ -146,6 +146,21 @@ def c4_atmosphere(width=1024, height=1024, spp=4096, layers=64, sigma_r0=0.012, 
     }
 
 
+def c4_three_species(width=1024, height=1024, spp=4096, layers=64, g_cloud=0.85, chain=False):
+    """The C4 atmosphere with a third species: blend(blend(rayleigh, tabulated aerosol; w_a), hg cloud droplets; w_c) -- a blendphase
+    inside a blendphase (src/phase/blendphase.cpp:42-66), every weight a grid over the layers.  chain=True nests three levels on the right."""
+    d = c4_atmosphere(width, height, spp, layers=layers)
+    ph = d["atmosphere"]["interior"]["phase"]
+    xf = ph["weight"]["to_world"]
+    wc = np.ascontiguousarray(np.broadcast_to((0.15 + 0.6 * np.exp(-np.arange(layers) / (layers / 4.0))).astype(np.float32)[:, None, None], (layers, 2, 2)))
+    tree = {"type": "blendphase", "phase_0": ph, "phase_1": {"type": "hg", "g": g_cloud}, "weight": {"type": "gridvolume", "data": wc, "to_world": xf}}
+    if chain:
+        tree = {"type": "blendphase", "phase_0": {"type": "isotropic"}, "phase_1": {"type": "blendphase", "phase_0": {"type": "hg", "g": -0.3}, "phase_1": tree, "weight": 0.7},
+                "weight": {"type": "gridvolume", "data": np.ascontiguousarray(1.0 - 0.5 * wc), "to_world": xf}}
+    d["atmosphere"]["interior"]["phase"] = tree
+    return d
+
+
 def c5_atmosphere_spectral(width=1024, height=1024, spp=4096, layers=64, nodes=17, samples_per_pass=-1):
     """C5 in the spectral variant (gpu_spectral): the C4 atmosphere with extinction and albedo as `gridvolume_spectral` grids whose
     `nodes` spectral nodes cover 0 .. 1600 nm (Rayleigh ~ lambda^-4 relative to 550 nm, aerosol grey), a D65 sun and an RPV ground with

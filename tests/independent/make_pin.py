@@ -17,6 +17,7 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 CASES = {   # name: (problem factory, width, height, walks per pixel, seed)
     "c3": (lambda: problems.c3(16, 16, res=16), 16, 16, 3000, 20261004),
     "c4": (lambda: problems.c4(16, 16), 16, 16, 1600, 20261005),
+    "c4x3": (lambda: problems.c4x3(16, 16), 16, 16, 1600, 20261006),          # three species: a blendphase nested in a blendphase (round 3)
 }
 STEPS, REFINE = 96, 16
 

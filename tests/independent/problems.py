@@ -39,3 +39,23 @@ def c4(width=16, height=16, layers=64, continuation="reference"):
     def sensor(rng, pix):
         return walk.distant_hemisphere_rays(rng, width, height, [-1.0, -1.0], [1.0, 1.0], top, 4.0e4, pix)
     return d, prob, sensor
+
+
+def c4x3(width=16, height=16, layers=64):
+    """The C4 atmosphere with a third species (scenes.c4_three_species: a blendphase nested in a blendphase).  Restated as a three-way
+    mixture: (1 - w_c) [(1 - w_a) Rayleigh + w_a tabulated] + w_c HG(g_cloud), the weights read from the scene's two weight grids."""
+    d = scenes.c4_three_species(width, height, 1, layers=layers)
+    med = d["atmosphere"]["interior"]
+    outer = med["phase"]; inner = outer["phase_0"]
+    sig = np.asarray(med["sigma_t"]["data"], np.float64)
+    alb = np.asarray(med["albedo"]["data"], np.float64)
+    tab = np.array([float(v) for v in inner["phase_1"]["values"].split()])
+    ext, top = 1.0e4, 50.0
+    sza = math.radians(30.0)
+    prob = walk.SlabProblem(box_min=[-ext, -ext, 0], box_max=[ext, ext, top], sigma_t_grid=sig, albedo=alb, phase=("mix3", tab, float(outer["phase_1"]["g"])),
+                            blend_weight_grid=np.asarray(inner["weight"]["data"], np.float64), ground_z=scenes.C4_GROUND_Z, ground_half=1.2 * ext,
+                            ground=("rpv", 0.1, 0.6, -0.2, 0.1, "reference"), sun_dir=[math.sin(sza), 0.0, -math.cos(sza)])
+    prob.wgrid3 = np.asarray(outer["weight"]["data"], np.float64)
+    def sensor(rng, pix):
+        return walk.distant_hemisphere_rays(rng, width, height, [-1.0, -1.0], [1.0, 1.0], top, 4.0e4, pix)
+    return d, prob, sensor

@@ -32,14 +32,15 @@ class SlabProblem:
         self.bmax = np.asarray(box_max, np.float64)
         self.sig = np.asarray(sigma_t_grid, np.float64) * float(sigma_scale)      # [z, y, x]
         self.albedo = albedo                                                     # scalar or grid [z, y, x]
-        self.phase = phase                                                       # ("hg", g) | ("blend", table_values)
+        self.phase = phase                                                       # ("hg", g) | ("blend", table_values) | ("mix3", table_values, g_third)
         self.wgrid = None if blend_weight_grid is None else np.asarray(blend_weight_grid, np.float64)
+        self.wgrid3 = None                                                       # "mix3": share of the third species (set by the caller)
         self.ground_z, self.ground_half = float(ground_z), float(ground_half)
         self.ground = ground                                                     # ("diffuse", rho) | ("rpv", rho0, k, g, rho_c, continuation)
         s = np.asarray(sun_dir, np.float64)
         self.sun = s / np.linalg.norm(s)                                         # direction of propagation of the sunlight
         self.E = float(irradiance)
-        if phase[0] == "blend":
+        if phase[0] in ("blend", "mix3"):
             tab = np.asarray(phase[1], np.float64)
             dx = 2.0 / (len(tab) - 1)
             self.tab = tab / (np.sum(0.5 * (tab[1:] + tab[:-1])) * dx)           # piecewise linear, unit integral over mu in [-1, 1]
@@ -83,7 +84,13 @@ class SlabProblem:
             return (1.0 - g * g) / (4.0 * math.pi * (1.0 + g * g - 2.0 * g * mu) ** 1.5)
         w = self._trilinear(self.wgrid, p)                                       # probability / weight of the tabulated lobe
         ray = 3.0 / (16.0 * math.pi) * (1.0 + mu * mu)
-        return (1.0 - w) * ray + w * self._tab_eval(mu)
+        two = (1.0 - w) * ray + w * self._tab_eval(mu)
+        if self.phase[0] == "blend":
+            return two
+        # "mix3": a third species (Henyey-Greenstein, asymmetry phase[2]) with local share w3 beside the two-species mixture
+        w3 = self._trilinear(self.wgrid3, p)
+        g = self.phase[2]
+        return (1.0 - w3) * two + w3 * (1.0 - g * g) / (4.0 * math.pi * (1.0 + g * g - 2.0 * g * mu) ** 1.5)
 
     def phase_sample(self, rng, d, p):
         """New direction of the walk and the weight phase / pdf."""
@@ -95,13 +102,19 @@ class SlabProblem:
             mu = (1.0 + g * g - s * s) / (2.0 * g)
             weight = np.ones(n)
         else:
-            # proposal: isotropic for the Rayleigh share, HG(0.7) for the tabulated share; weight = true phase / proposal pdf
+            # proposal: isotropic for the Rayleigh share, HG(0.7) for the tabulated share (and the third species' own HG for its share);
+            # weight = true phase / proposal pdf
             w = self._trilinear(self.wgrid, p)
+            w3 = self._trilinear(self.wgrid3, p) if self.phase[0] == "mix3" else np.zeros(n)
+            g3 = self.phase[2] if self.phase[0] == "mix3" else 0.5
+            pick3 = rng.random(n) < w3
             pick_tab = rng.random(n) < w
             g = 0.7
             s = (1.0 - g * g) / (1.0 - g + 2.0 * g * u1)
-            mu = np.where(pick_tab, (1.0 + g * g - s * s) / (2.0 * g), 1.0 - 2.0 * u1)
-            q = (1.0 - w) / (4.0 * math.pi) + w * (1.0 - g * g) / (4.0 * math.pi * (1.0 + g * g - 2.0 * g * mu) ** 1.5)
+            s3 = (1.0 - g3 * g3) / (1.0 - g3 + 2.0 * g3 * u1)
+            mu = np.where(pick3, (1.0 + g3 * g3 - s3 * s3) / (2.0 * g3), np.where(pick_tab, (1.0 + g * g - s * s) / (2.0 * g), 1.0 - 2.0 * u1))
+            q2 = (1.0 - w) / (4.0 * math.pi) + w * (1.0 - g * g) / (4.0 * math.pi * (1.0 + g * g - 2.0 * g * mu) ** 1.5)
+            q = (1.0 - w3) * q2 + w3 * (1.0 - g3 * g3) / (4.0 * math.pi * (1.0 + g3 * g3 - 2.0 * g3 * mu) ** 1.5)
             weight = self.phase_eval(mu, p) / q
         mu = np.clip(mu, -1.0, 1.0)
         return _rotate_about(d, mu, 2.0 * math.pi * u2), weight

@@ -43,19 +43,8 @@ def test_golden_fixtures(gpu_rgb, name):
 
 
 def three_species_atmosphere(width=24, height=24, spp=8, chain=False):
-    """The C4 miniature with a third species: blend(blend(rayleigh, tabulated aerosol; w_a), hg cloud droplets; w_c) -- a blendphase
-    inside a blendphase (blendphase.cpp:42-66), every weight a grid over the layers.  chain=True nests three levels on the right."""
-    d = scenes.c4_atmosphere(width, height, spp, layers=8)
-    ph = d["atmosphere"]["interior"]["phase"]
-    xf = ph["weight"]["to_world"]
-    layers = ph["weight"]["data"].shape[0]
-    wc = np.ascontiguousarray(np.broadcast_to((0.15 + 0.6 * np.exp(-np.arange(layers) / 2.0)).astype(np.float32)[:, None, None], (layers, 2, 2)))
-    tree = {"type": "blendphase", "phase_0": ph, "phase_1": {"type": "hg", "g": 0.85}, "weight": {"type": "gridvolume", "data": wc, "to_world": xf}}
-    if chain:
-        tree = {"type": "blendphase", "phase_0": {"type": "isotropic"}, "phase_1": {"type": "blendphase", "phase_0": {"type": "hg", "g": -0.3}, "phase_1": tree, "weight": 0.7},
-                "weight": {"type": "gridvolume", "data": np.ascontiguousarray(1.0 - 0.5 * wc), "to_world": xf}}
-    d["atmosphere"]["interior"]["phase"] = tree
-    return d
+    """scenes.c4_three_species in miniature: a blendphase inside a blendphase (chain=True: four levels)."""
+    return scenes.c4_three_species(width, height, spp, layers=8, chain=chain)
 
 
 CASES = {
@@ -718,7 +707,7 @@ def test_stopped_render_keeps_the_finished_samples(gpu_rgb, monkeypatch, integra
 
 
 @pytest.mark.parametrize("integrator", ["volpath", "volpathmis"])
-@pytest.mark.parametrize("name", ["c3", "c4"])
+@pytest.mark.parametrize("name", ["c3", "c4", "c4x3"])
 def test_hip_path_agrees_with_the_independent_estimator(gpu_rgb, name, integrator):
     """The HIP path itself (not via the oracle) against tests/golden/indep_pin_*.npz, the fixtures of the structurally
     different float64 estimator (tests/independent/walk.py): per-pixel Z-test with the Sidak correction of the reference's

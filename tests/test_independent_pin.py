@@ -90,7 +90,7 @@ def test_estimator_reproduces_the_single_scattering_closed_form():
         assert abs(val.mean() - expected) < 4 * se + 2e-4 * expected, (mu, val.mean(), expected, se)
 
 
-@pytest.mark.parametrize("name", ["c3", "c4"])
+@pytest.mark.parametrize("name", ["c3", "c4", "c4x3"])
 def test_fixture_comes_from_the_committed_estimator(name):
     """A short live run of the estimator agrees with its fixture (same code, other seed, 40 walks per pixel)."""
     mean, var, _ = load_pin(name)
@@ -106,10 +106,11 @@ def test_fixture_comes_from_the_committed_estimator(name):
 
 
 @pytest.mark.parametrize("integrator", ["volpath", "volpathmis"])
-@pytest.mark.parametrize("name", ["c3", "c4"])
+@pytest.mark.parametrize("name", ["c3", "c4", "c4x3"])
 def test_oracle_agrees_with_the_independent_estimator(name, integrator):
     """`volpath`, and `volpathmis` (src/integrators/volpathmis.cpp: another estimator of the same radiance, for which the reference
-    holds no vector either), against the same fixtures."""
+    holds no vector either), against the same fixtures.  c4x3 (round 3) = the atmosphere with a third species, i.e. a blendphase nested
+    in a blendphase (src/phase/blendphase.cpp:42-66, 92-108), restated by the estimator as a three-way mixture."""
     mean, var, _ = load_pin(name)
     d, _, _ = getattr(problems, name)()
     d["integrator"] = dict(d["integrator"], type=integrator)
