@@ -18,6 +18,10 @@ CASES = {   # name: (problem factory, width, height, walks per pixel, seed)
     "c3": (lambda: problems.c3(16, 16, res=16), 16, 16, 3000, 20261004),
     "c4": (lambda: problems.c4(16, 16), 16, 16, 1600, 20261005),
     "c4x3": (lambda: problems.c4x3(16, 16), 16, 16, 1600, 20261006),          # three species: a blendphase nested in a blendphase (round 3)
+    # a chromatic slab, one monochromatic run per colour channel (round 3): what spectral MIS is for
+    "chroma_r": (lambda: problems.c2_chroma(0), 16, 16, 2000, 20261007),
+    "chroma_g": (lambda: problems.c2_chroma(1), 16, 16, 2000, 20261008),
+    "chroma_b": (lambda: problems.c2_chroma(2), 16, 16, 2000, 20261009),
 }
 STEPS, REFINE = 96, 16
 

@@ -59,3 +59,21 @@ def c4x3(width=16, height=16, layers=64):
     def sensor(rng, pix):
         return walk.distant_hemisphere_rays(rng, width, height, [-1.0, -1.0], [1.0, 1.0], top, 4.0e4, pix)
     return d, prob, sensor
+
+
+# A chromatic medium: what spectral MIS (volpathmis) exists for.  The estimator is monochromatic, so it runs once per colour channel with
+# that channel's coefficients; the integrators follow one hero channel and reweight the others (volpath.cpp:113-117, volpathmis.cpp:447-466).
+CHROMA = {"sigma_t": [0.4, 1.0, 1.6], "albedo": [0.9, 0.7, 0.5], "ground": [0.2, 0.4, 0.6], "g": 0.3}
+
+
+def c2_chroma(channel, width=16, height=16):
+    d = scenes.c2_homogeneous_slab(width, height, 1, phase={"type": "hg", "g": CHROMA["g"]})
+    d["slab"]["interior"]["sigma_t"] = {"type": "rgb", "value": CHROMA["sigma_t"]}
+    d["slab"]["interior"]["albedo"] = {"type": "rgb", "value": CHROMA["albedo"]}
+    d["ground"]["bsdf"]["reflectance"] = {"type": "rgb", "value": CHROMA["ground"]}
+    prob = walk.SlabProblem(box_min=[-50, -50, 0], box_max=[50, 50, 2], sigma_t_grid=np.full((2, 2, 2), CHROMA["sigma_t"][channel]),
+                            albedo=CHROMA["albedo"][channel], phase=("hg", CHROMA["g"]), ground_z=-0.01, ground_half=60.0,
+                            ground=("diffuse", CHROMA["ground"][channel]), sun_dir=[0.5, 0.0, -0.866])
+    def sensor(rng, pix):
+        return walk.pinhole_rays(rng, width, height, 45.0, [0, 0, 20], [0, 0, -1], [0, 1, 0], pix)
+    return d, prob, sensor

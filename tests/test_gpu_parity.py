@@ -734,6 +734,20 @@ def test_hip_path_agrees_with_the_independent_estimator(gpu_rgb, name, integrato
     assert (p > alpha).mean() >= 0.9975
 
 
+def test_hip_path_on_a_chromatic_medium_agrees_with_the_independent_estimator(gpu_rgb):
+    """`volpathmis` with spectral MIS on the chromatic slab of tests/independent/problems.py, through the HIP path, per colour channel
+    against the per-channel fixtures of the independent estimator (tests/test_independent_pin.py has the oracle side and the reasoning)."""
+    from tests.test_independent_pin import chroma_estimate, check_chroma
+    def render(dicts):
+        out = []
+        for dd in dicts:
+            dd["integrator"].update(type="volpathmis", use_spectral_mis=True)
+            out.append(gpu_render(gpu_rgb, dd)[0])
+        return out
+    mean_rgb, var_rgb = chroma_estimate(render, seeds=16, spp=1024)
+    check_chroma(mean_rgb, var_rgb, "hip volpathmis", True)
+
+
 INGEST_XML = """<?xml version="1.0"?>
 <scene version="2.0.0">
     <default name="spp" value="8"/>

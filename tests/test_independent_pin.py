@@ -183,3 +183,62 @@ def test_spectral_oracle_agrees_with_the_independent_estimator(integrator):
     assert se < 6e-3 and abs(rel) < 4 * se and abs(rel) < 1.5e-2
     p, alpha, z = z_test(om, ov, mean, var)
     assert (p > alpha).mean() >= 0.9975
+
+
+XYZ_TO_RGB = np.array([[3.240479, -1.537150, -0.498535], [-0.969256, 1.875991, 0.041556], [0.055648, -0.204043, 1.057311]])   # core/spectrum.h:229-235
+
+
+def chroma_estimate(render, seeds=16, spp=256):
+    """Per-pixel mean and variance of the mean of the linear RGB radiance from `seeds` renders (render(dict) -> XYZAW film)."""
+    def one(seed):
+        dd, _, _ = problems.c2_chroma(0)
+        dd["sensor"]["sampler"]["sample_count"] = spp
+        dd["sensor"]["sampler"]["seed"] = seed
+        return dd
+    imgs = []
+    for film in render([one(s) for s in range(seeds)]):
+        imgs.append((film[..., :3] / film[..., 4:5]) @ XYZ_TO_RGB.T)
+    imgs = np.array(imgs, np.float64)
+    return imgs.mean(0), imgs.var(0, ddof=1) / seeds
+
+
+def check_chroma(mean_rgb, var_rgb, label, strict):
+    worst = 0.0
+    for c, ch in enumerate("rgb"):
+        mean, var, _ = load_pin("chroma_" + ch)
+        se = math.hypot(math.sqrt(var.sum()) / var.size / mean.mean(), math.sqrt(var_rgb[..., c].sum()) / var.size / mean_rgb[..., c].mean())
+        rel = mean_rgb[..., c].mean() / mean.mean() - 1.0
+        p, alpha, z = z_test(mean_rgb[..., c], var_rgb[..., c], mean, var)
+        print("%s channel %s: image mean %.6f, independent %.6f, difference %+.3f %% +- %.3f %%, pixels accepted %.4f, max |z| %.2f"
+              % (label, ch, mean_rgb[..., c].mean(), mean.mean(), 100 * rel, 100 * se, (p > alpha).mean(), z.max()))
+        worst = max(worst, abs(rel) / se)
+        if strict:
+            assert se < 4e-3 and abs(rel) < 4 * se and abs(rel) < 1e-2, (label, ch, rel, se)
+            assert (p > alpha).mean() >= 0.9975
+    return worst
+
+
+@pytest.mark.parametrize("integrator", ["volpathmis", "volpathmis_no_spectral_mis", "volpath"])
+def test_chromatic_medium_against_the_independent_estimator(integrator):
+    """A chromatic homogeneous slab (sigma_t 0.4 / 1.0 / 1.6, albedo 0.9 / 0.7 / 0.5 per channel) -- the case spectral MIS exists for.
+    The estimator runs once per channel with that channel's coefficients (fixtures indep_pin_chroma_{r,g,b}); the integrators follow a
+    hero channel and reweight the others.  `volpathmis` with spectral MIS must agree per channel like a grey scene does.  The
+    single-channel estimators (`volpath`, `volpathmis` without spectral MIS) are unbiased too, but their weights e^{(sigma_hero -
+    sigma_c) t} are heavy-tailed: the sample mean sits below the expectation with high probability and its empirical standard error
+    understates the spread (measured here: red, the thinnest channel, -1.1 % / -1.6 % at 16 x 256 spp; green and blue within 0.7 %) --
+    they are held to 3 % on the image mean, not to the Z-test."""
+    def render(dicts):
+        def one(dd):
+            dd["integrator"]["type"] = "volpath" if integrator == "volpath" else "volpathmis"
+            if integrator != "volpath":
+                dd["integrator"]["use_spectral_mis"] = integrator == "volpathmis"
+            return ob.OracleScene(dd).render(threads=1)
+        with ThreadPoolExecutor(min(8, os.cpu_count() or 1)) as ex:
+            return list(ex.map(one, dicts))
+    mean_rgb, var_rgb = chroma_estimate(render)
+    strict = integrator == "volpathmis"
+    check_chroma(mean_rgb, var_rgb, integrator, strict)
+    if not strict:
+        for c, ch in enumerate("rgb"):
+            mean, _, _ = load_pin("chroma_" + ch)
+            assert abs(mean_rgb[..., c].mean() / mean.mean() - 1.0) < 3e-2
