@@ -255,14 +255,22 @@ class Integrator:
         """SamplingIntegrator::aov_names (integrator.cpp:47-49; nbins.cpp:127-134, bins.cpp:112-119)."""
         return list(getattr(self._scene._keep, "aov_names", []))
 
-    def sample(self, scene, origins, directions, seed_offset=0):
-        """SamplingIntegrator.sample for a batch of rays (integrator_v.cpp:62-78): returns (rgb (n,3), valid (n,))."""
+    def sample(self, scene, origins, directions, seed_offset=0, wavelengths=None):
+        """SamplingIntegrator.sample for a batch of rays (integrator_v.cpp:62-78): returns (rgb (n,3), valid (n,)).  Scenes of the
+        spectral variant take the rays' `wavelengths` ((4,) for all rays or (n, 4), nm: Ray.wavelengths) and return the (n, 4)
+        spectrum at those wavelengths."""
         o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
         d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
         n = o.shape[0]
         cols = [np.ascontiguousarray(o[:, i]) for i in range(3)] + [np.ascontiguousarray(d[:, i]) for i in range(3)]
-        rgb = np.zeros((n, 3), dtype=np.float32)
         valid = np.zeros(n, dtype=np.uint8)
+        if wavelengths is not None:
+            w = np.ascontiguousarray(np.broadcast_to(np.asarray(wavelengths, dtype=np.float32).reshape(-1, 4), (n, 4)))
+            spec = np.zeros((n, 4), dtype=np.float32)
+            A.check(A.lib().mts_sample_spectral(scene._handle, n, seed_offset, *[c.ctypes.data_as(A.fp) for c in cols], w.ctypes.data_as(A.fp),
+                                                spec.ctypes.data_as(A.fp), valid.ctypes.data_as(C.POINTER(C.c_uint8))))
+            return spec, valid.astype(bool)
+        rgb = np.zeros((n, 3), dtype=np.float32)
         A.check(A.lib().mts_sample(scene._handle, n, seed_offset, *[c.ctypes.data_as(A.fp) for c in cols],
                                    rgb.ctypes.data_as(A.fp), valid.ctypes.data_as(C.POINTER(C.c_uint8))))
         return rgb, valid.astype(bool)

@@ -12,7 +12,7 @@ from . import _buildid
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MTSAMD_LIB") or os.path.join(HERE, "libmtsamd.so")
 
-MTS_ABI_VERSION = 7
+MTS_ABI_VERSION = 8
 
 # enums (include/mtsamd.h)
 VOLUME_CONST, VOLUME_GRID, VOLUME_GRID_SPECTRAL = 0, 1, 2
@@ -127,7 +127,7 @@ ABI_STRUCTS = {"mts_spectrum": Spectrum, "mts_transform": Transform, "mts_volume
 
 # every symbol include/mtsamd.h declares
 ABI_SYMBOLS = ["mts_abi_version", "mts_build_id", "mts_last_error", "mts_device_count", "mts_scene_create", "mts_scene_destroy",
-               "mts_render", "mts_cancel", "mts_sample", "mts_ray_intersect", "mts_abi_sizeof", "mts_sample_tea", "mts_wavefront_sampler"]
+               "mts_render", "mts_cancel", "mts_sample", "mts_sample_spectral", "mts_ray_intersect", "mts_abi_sizeof", "mts_sample_tea", "mts_wavefront_sampler"]
 
 _lib = None
 
@@ -154,6 +154,7 @@ def lib():
     L.mts_render.argtypes = [C.c_void_p, C.POINTER(RenderOpts), C.c_void_p, C.POINTER(Stats)]
     L.mts_cancel.argtypes = [C.c_void_p]
     L.mts_sample.argtypes = [C.c_void_p, i32, C.c_uint64] + [fp] * 6 + [fp, C.POINTER(C.c_uint8)]
+    L.mts_sample_spectral.argtypes = [C.c_void_p, i32, C.c_uint64] + [fp] * 7 + [fp, C.POINTER(C.c_uint8)]
     L.mts_ray_intersect.argtypes = [C.c_void_p, i32, fp, fp, fp, fp, fp, C.POINTER(i32), C.POINTER(i32), fp, fp]
     L.mts_sample_tea.argtypes = [C.c_int, i32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), i32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), fp]
     L.mts_wavefront_sampler.argtypes = [C.c_int, i32, C.c_uint64, i32, fp]

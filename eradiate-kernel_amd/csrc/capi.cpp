@@ -379,7 +379,7 @@ int mts_sample(mts_scene *scene, int32_t n, uint64_t seed_offset, const float *o
     if (!scene || n < 0) throw std::runtime_error("mts_sample: invalid argument");
     if (n == 0) return 0;
     HostScene &hs = *scene->hs;
-    if (hs.integrator.spectral) throw std::runtime_error("mts_sample: not available for scenes of the spectral variant");
+    if (hs.integrator.spectral) throw std::runtime_error("mts_sample: the scene was built for the spectral variant (use mts_sample_spectral: the rays carry wavelengths)");
     HIP_CHECK(hipSetDevice(hs.device));
     DeviceBuffer<float> d_rays((size_t) 6 * n), d_rgb((size_t) 3 * n);
     DeviceBuffer<uint8_t> d_valid((size_t) n);
@@ -387,6 +387,26 @@ int mts_sample(mts_scene *scene, int32_t n, uint64_t seed_offset, const float *o
     for (int r = 0; r < 6; ++r) HIP_CHECK(hipMemcpy(d_rays.p + (size_t) r * n, rows[r], (size_t) n * sizeof(float), hipMemcpyHostToDevice));
     HIP_CHECK(launch_sample(hs.scene, n, seed_offset, d_rays.p, d_rgb.p, d_valid.p, nullptr));
     HIP_CHECK(hipMemcpy(out_rgb, d_rgb.p, (size_t) 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(out_valid, d_valid.p, (size_t) n, hipMemcpyDeviceToHost));
+    API_CATCH
+}
+
+int mts_sample_spectral(mts_scene *scene, int32_t n, uint64_t seed_offset, const float *ox, const float *oy, const float *oz,
+                        const float *dx, const float *dy, const float *dz, const float *wavelengths, float *out_spec, uint8_t *out_valid) {
+    API_TRY
+    if (!scene || n < 0) throw std::runtime_error("mts_sample_spectral: invalid argument");
+    if (n == 0) return 0;
+    if (!ox || !oy || !oz || !dx || !dy || !dz || !wavelengths || !out_spec || !out_valid) throw std::runtime_error("mts_sample_spectral: null array");
+    HostScene &hs = *scene->hs;
+    if (!hs.integrator.spectral) throw std::runtime_error("mts_sample_spectral: the scene was built for an rgb / mono variant (use mts_sample)");
+    HIP_CHECK(hipSetDevice(hs.device));
+    DeviceBuffer<float> d_rays((size_t) 6 * n), d_wl((size_t) 4 * n), d_spec((size_t) 4 * n);
+    DeviceBuffer<uint8_t> d_valid((size_t) n);
+    const float *rows[6] = { ox, oy, oz, dx, dy, dz };
+    for (int r = 0; r < 6; ++r) HIP_CHECK(hipMemcpy(d_rays.p + (size_t) r * n, rows[r], (size_t) n * sizeof(float), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_wl.p, wavelengths, (size_t) 4 * n * sizeof(float), hipMemcpyHostToDevice));
+    HIP_CHECK(launch_sample_spectral(hs.scene, n, seed_offset, d_rays.p, d_wl.p, d_spec.p, d_valid.p, nullptr));
+    HIP_CHECK(hipMemcpy(out_spec, d_spec.p, (size_t) 4 * n * sizeof(float), hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(out_valid, d_valid.p, (size_t) n, hipMemcpyDeviceToHost));
     API_CATCH
 }

@@ -498,6 +498,30 @@ hipError_t launch_intersect(const DScene &sc, int32_t n, const float *o, const f
 }
 #endif // MTS_SPEC_N == 3
 
+#if MTS_SPEC_N != 3
+// SamplingIntegrator::sample in the spectral variant (librender/python/integrator_v.cpp:62-78): the caller's rays carry their wavelengths
+__global__ void __launch_bounds__(256) sample_spectral_kernel(DScene sc, int32_t n, uint64_t seed_offset, const float *__restrict__ rays /* 6 SoA rows */,
+                                                              const float *__restrict__ wavelengths /* 4 per ray */,
+                                                              float *__restrict__ out_spec, uint8_t *__restrict__ out_valid) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Pcg32 rng; rng.seed(sc.sensor.seed + seed_offset + (uint64_t) i, PCG32_DEFAULT_STREAM);
+    DRay ray = make_ray(f3(rays[i], rays[n + i], rays[2 * n + i]), f3(rays[3 * n + i], rays[4 * n + i], rays[5 * n + i]), MTS_RAY_EPSILON, pm_inf());
+    SpecCtx cx = make_ctx(sc);
+    cx.wl = spec4(wavelengths[4 * i], wavelengths[4 * i + 1], wavelengths[4 * i + 2], wavelengths[4 * i + 3]);
+    bool valid; Counters cnt;
+    const Spec L = integrator_sample<false>(sc, rng, ray, sc.sensor.medium, valid, cnt, cx);
+    out_spec[4 * i] = L.x; out_spec[4 * i + 1] = L.y; out_spec[4 * i + 2] = L.z; out_spec[4 * i + 3] = L.w; out_valid[i] = valid ? 1 : 0;
+}
+
+hipError_t launch_sample_spectral(const DScene &sc, int32_t n, uint64_t seed_offset, const float *d_rays, const float *d_wavelengths, float *d_spec, uint8_t *d_valid,
+                                  hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sample_spectral_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, sc, n, seed_offset, d_rays, d_wavelengths, d_spec, d_valid);
+    return hipGetLastError();
+}
+#endif
+
 } // namespace mtsamd
 
 #if defined(MTSAMD_BLOCKSTATS) && MTS_SPEC_N == 3

@@ -16,6 +16,9 @@ hipError_t launch_render_spectral(const DScene &sc, const DBlock *d_blocks, uint
                                   float *d_film, unsigned long long *d_counters, bool count, int variant, int wg_threads, float *d_workspace,
                                   const uint32_t *d_stop_flag, hipStream_t stream);
 hipError_t launch_sample(const DScene &sc, int32_t n, uint64_t seed_offset, const float *d_rays, float *d_rgb, uint8_t *d_valid, hipStream_t stream);
+// spectral variant (kernels_spectral.hip): per-ray wavelengths (4 n floats), four-wide result
+hipError_t launch_sample_spectral(const DScene &sc, int32_t n, uint64_t seed_offset, const float *d_rays, const float *d_wavelengths, float *d_spec, uint8_t *d_valid,
+                                  hipStream_t stream);
 hipError_t launch_intersect(const DScene &sc, int32_t n, const float *o, const float *d, const float *mint, const float *maxt,
                             float *t, int32_t *shape, int32_t *prim, float *p, float *nn, hipStream_t stream);
 

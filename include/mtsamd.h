@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MTS_ABI_VERSION 7
+#define MTS_ABI_VERSION 8
 
 /* Transform4f: row-major 4x4 matrix and its inverse transpose (transform.h:36-50). */
 typedef struct mts_transform {
@@ -306,6 +306,15 @@ int  mts_sample(mts_scene *scene, int32_t n, uint64_t seed_offset,
                 const float *ox, const float *oy, const float *oz,
                 const float *dx, const float *dy, const float *dz,
                 float *out_rgb /* 3*n */, uint8_t *out_valid /* n */);
+
+/* The same for a scene of the spectral variant: the rays carry their four wavelengths (Ray::wavelengths, include/mitsuba/core/ray.h;
+ * python: RayDifferential3f(..., wavelengths=...)), the result is the integrator's Spectrum at those wavelengths -- for `nbins` /
+ * `bins` the wrapped integrator's (nbins.cpp:127-134).  Nothing is converted to XYZ: that is render_sample's job (integrator.cpp:266). */
+int  mts_sample_spectral(mts_scene *scene, int32_t n, uint64_t seed_offset,
+                         const float *ox, const float *oy, const float *oz,
+                         const float *dx, const float *dy, const float *dz,
+                         const float *wavelengths /* 4*n, nm */,
+                         float *out_spec /* 4*n */, uint8_t *out_valid /* n */);
 
 /* Closest-hit query used by the traversal parity tests (Scene::ray_intersect, scene.cpp:117-125). */
 int  mts_ray_intersect(mts_scene *scene, int32_t n,

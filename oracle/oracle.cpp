@@ -1982,6 +1982,25 @@ int oracle_emitter_sample_direction(oracle_scene *s, const float *ref_p, float u
 int oracle_spec_n(void) { return MTS_SPEC_N; }
 #if MTS_SPEC_N != 3
 int oracle_set_wavelengths(const float *w) { tls_wavelengths = spec4(w[0], w[1], w[2], w[3]); return 0; }
+// SamplingIntegrator::sample for rays that carry their own wavelengths (Ray::wavelengths, core/ray.h:36); four-wide result
+int oracle_sample_spectral(oracle_scene *s, int32_t n, uint64_t seed_offset, const float *ox, const float *oy, const float *oz,
+                           const float *dx, const float *dy, const float *dz, const float *wavelengths, float *out_spec, uint8_t *out_valid) {
+    ORC_TRY
+    const Scene &sc = *((OracleScene *) s)->scene;
+    unsigned csr = _mm_getcsr(); _mm_setcsr(csr | 0x8040);
+    const Spec saved = tls_wavelengths;
+    for (int i = 0; i < n; ++i) {
+        Sampler sampler; sampler.base_seed = sc.sensor.seed; sampler.seed(seed_offset + (uint64_t) i);
+        Ray ray = make_ray(v3(ox[i], oy[i], oz[i]), v3(dx[i], dy[i], dz[i]), RayEpsilon, pm_inf());
+        tls_wavelengths = spec4(wavelengths[4 * i], wavelengths[4 * i + 1], wavelengths[4 * i + 2], wavelengths[4 * i + 3]);
+        bool valid;
+        Spec L = integrator_sample(sc, sampler, ray, sc.sensor.medium, &valid, nullptr);
+        out_spec[4 * i] = L.x; out_spec[4 * i + 1] = L.y; out_spec[4 * i + 2] = L.z; out_spec[4 * i + 3] = L.w; out_valid[i] = valid;
+    }
+    tls_wavelengths = saved;
+    _mm_setcsr(csr);
+    ORC_CATCH
+}
 int oracle_spectrum_eval(oracle_scene *s, int spectrum, const float *w, float *out) {
     ORC_TRY
     const Scene &sc = *((OracleScene *) s)->scene;

@@ -96,6 +96,7 @@ def lib_spectral():
         L.oracle_spectrum_to_xyz.argtypes = [fp, fp, fp]
         L.oracle_spectrum_sample.argtypes = [C.c_void_p, C.c_int, fp, C.c_int, fp, fp]
         L.oracle_set_wavelengths.argtypes = [fp]
+        L.oracle_sample_spectral.argtypes = [C.c_void_p, C.c_int32, C.c_uint64] + [fp] * 7 + [fp, C.POINTER(C.c_uint8)]
         L.oracle_bsdf_eval.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, fp]
         assert L.oracle_spec_n() == 4
         _lib_spectral = L
@@ -162,10 +163,16 @@ class OracleScene:
         _check(self.L.oracle_volume_eval_spectral(self.h, volume, _p(q), _p(w), _p(out)), self.L)
         return out
 
-    def sample(self, origins, directions, seed_offset=0):
+    def sample(self, origins, directions, seed_offset=0, wavelengths=None):
         o = _f(origins).reshape(-1, 3); d = _f(directions).reshape(-1, 3)
         n = o.shape[0]
         cols = [np.ascontiguousarray(o[:, i]) for i in range(3)] + [np.ascontiguousarray(d[:, i]) for i in range(3)]
+        if wavelengths is not None:                             # spectral build: the rays carry their wavelengths
+            w = np.ascontiguousarray(np.broadcast_to(_f(wavelengths).reshape(-1, 4), (n, 4)))
+            spec = np.zeros((n, 4), np.float32); valid = np.zeros(n, np.uint8)
+            _check(self.L.oracle_sample_spectral(self.h, n, seed_offset, *[_p(c) for c in cols], _p(w), _p(spec),
+                                                 valid.ctypes.data_as(C.POINTER(C.c_uint8))), self.L)
+            return spec, valid.astype(bool)
         rgb = np.zeros((n, 3), np.float32); valid = np.zeros(n, np.uint8)
         _check(lib().oracle_sample(self.h, n, seed_offset, *[_p(c) for c in cols], _p(rgb), valid.ctypes.data_as(C.POINTER(C.c_uint8))))
         return rgb, valid.astype(bool)

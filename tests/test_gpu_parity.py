@@ -929,6 +929,36 @@ def test_spectral_variant_against_oracle(gpu_spectral, monkeypatch, name, kernel
     assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (o.last_stats["n_iter"], o.last_stats["n_lookup"], o.last_stats["n_nee_step"])
 
 
+@pytest.mark.parametrize("integrator", ["volpath", "volpathmis", "path"])
+def test_integrator_sample_spectral(gpu_spectral, integrator):
+    """SamplingIntegrator::sample in the spectral variant (mts_sample_spectral): the caller's rays carry their wavelengths
+    (Ray::wavelengths, core/ray.h:36); the four-wide result equals the oracle's, and the rgb entry point refuses the scene."""
+    d = _spectral_cases()["cornell_path" if integrator == "path" else "slab_chromatic_medium"]
+    d["integrator"] = dict(d["integrator"], type=integrator)
+    scene = gpu_spectral.load_dict(d)
+    o = ob.OracleScene(d, spectral=True)
+    rng = np.random.default_rng(21)
+    n = 2000
+    if integrator == "path":                                    # from the camera's side of the box into it
+        orig = np.stack([rng.uniform(-1, 1, n), np.full(n, -14.0), rng.uniform(2.5, 4.5, n)], 1).astype(np.float32)
+        dirs = np.stack([rng.uniform(-0.15, 0.15, n), np.full(n, 1.0), rng.uniform(-0.15, 0.15, n)], 1).astype(np.float32)
+    else:
+        orig = np.stack([rng.uniform(-8, 8, n), rng.uniform(-8, 8, n), np.full(n, 20.0)], 1).astype(np.float32)
+        dirs = rng.normal(size=(n, 3)).astype(np.float32); dirs[:, 2] = -np.abs(dirs[:, 2]) - 1
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    wl = rng.uniform(360., 830., (n, 4)).astype(np.float32)
+    spec_g, valid_g = scene.integrator().sample(scene, orig, dirs, seed_offset=5, wavelengths=wl)
+    spec_o, valid_o = o.sample(orig, dirs, seed_offset=5, wavelengths=wl)
+    assert spec_g.shape == (n, 4) and valid_o.mean() > 0.5 and spec_o.max() > 0
+    assert np.array_equal(valid_g, valid_o) and np.array_equal(spec_g, spec_o)
+    if integrator != "path":                                    # chromatic extinction: the four wavelengths of a ray see different media
+        assert (np.ptp(spec_o, axis=1) > 0).mean() > 0.3
+    one = scene.integrator().sample(scene, orig[:64], dirs[:64], seed_offset=5, wavelengths=wl[0])      # one packet for all rays
+    assert np.array_equal(one[0], o.sample(orig[:64], dirs[:64], seed_offset=5, wavelengths=wl[0])[0])
+    with pytest.raises(Exception, match="mts_sample_spectral"):
+        scene.integrator().sample(scene, orig[:4], dirs[:4])
+
+
 @pytest.mark.parametrize("kernel", [None, "nested"])
 @pytest.mark.parametrize("use_spectral_mis", [True, False])
 @pytest.mark.parametrize("name", ["slab_regular_reflectance", "slab_chromatic_medium", "grid_spectral_d65_rpv", "cornell_path", "c4_atmosphere",

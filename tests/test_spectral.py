@@ -158,6 +158,32 @@ def test_spectral_render_closed_forms():
     assert abs(img[1] / img[4] - 1.0 / np.pi) < 0.01 / np.pi
 
 
+def test_integrator_sample_with_caller_supplied_wavelengths():
+    """SamplingIntegrator::sample in the spectral variant (oracle_sample_spectral; the C ABI's mts_sample_spectral is compared with
+    it on the GPU): the rays carry their wavelengths, and on the Lambertian square under a directional emitter at normal incidence the
+    result is the closed form E(lambda) rho(lambda) / pi per wavelength -- no Monte Carlo noise: the emitter is a delta."""
+    d = _lambert_scene(1, {"type": "regular", "lambda_min": 400., "lambda_max": 800., "values": [0.2, 0.8]},
+                       {"type": "uniform", "value": 2.0, "lambda_min": 450., "lambda_max": 700.})
+    o = ob.OracleScene(d, spectral=True)
+    rng = np.random.default_rng(8)
+    n = 500
+    orig = np.stack([rng.uniform(-0.4, 0.4, n), rng.uniform(-0.4, 0.4, n), np.full(n, 5.0)], 1)
+    dirs = np.stack([rng.uniform(-0.1, 0.1, n), rng.uniform(-0.1, 0.1, n), np.full(n, -1.0)], 1)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    wl = rng.uniform(360., 830., (n, 4)).astype(np.float32)
+    spec, valid = o.sample(orig, dirs, seed_offset=3, wavelengths=wl)
+    assert valid.all() and spec.shape == (n, 4)
+    lam = wl.astype(np.float64)
+    rho = (0.2 + 0.6 * (lam - 400.) / 400.) * ((lam >= 400.) & (lam <= 800.))
+    irr = 2.0 * ((lam >= 450.) & (lam <= 700.))
+    assert np.allclose(spec, irr * rho / np.pi, rtol=2e-5, atol=1e-7)
+    assert (spec > 0).mean() > 0.4 and (spec == 0).mean() > 0.2
+    one, _ = o.sample(orig, dirs, seed_offset=3, wavelengths=[500., 550., 600., 650.])          # one packet for every ray
+    assert np.allclose(one, (2.0 * (0.2 + 0.6 * (np.array([500., 550., 600., 650.]) - 400.) / 400.) / np.pi)[None, :], rtol=2e-5)
+    miss, valid = o.sample([[5., 5., 5.]], [[0., 0., 1.]], wavelengths=wl[0])
+    assert not valid.any() and (miss == 0).all()
+
+
 def test_spectral_volpath_matches_the_mono_render_per_wavelength():
     """volpath in the spectral variant with grey (wavelength-independent) media and surfaces, uniform irradiance: every wavelength
     carries the radiance the gpu_mono / scalar_mono semantics give, so film Y = L_mono * integral(ybar) up to Monte Carlo noise (the
