@@ -41,6 +41,22 @@ inline namespace MTS_VARIANT_NS {
 #else
 #define MTS_FILM_STRIDE(sc) ((size_t) (sc).film_channels)          // X, Y, Z, A, W (+ two AOV channels per spectral bin: nbins / bins)
 #endif
+// Blocks that run a path's NEXT block in the same visit (bit mask; wg_block).  A visit costs a ring push, a claim and an LDS round trip
+// of the state, but what runs in place runs on the lanes that want it only.  Measured one by one (round 3, profiles/r03_ab_experiments.log;
+// C3 512 x 512 x 256 / C4 1024 x 1024 x 64, Msamples/s against 547 / 267 without; all bit-identical):
+//   1  walk SURFACE twice: a walk that leaves through a boundary face with nothing behind it (queue_intersection: the new ray
+//      misses the scene's box, no INTERSECT visit) comes straight back to this class, only to end.  569 / 268: ON.
+//   2  ... and then the PHASE sample of the main path the ended walk hands back to: 567 / 258 together with 1.
+//   4  the walk's MEDIUM block runs the SURFACE step(s) of the lanes whose walk left the medium: 540 / 229 together with 1 and 2.
+//   8  the main path's MEDIUM block runs SCATTER (emitter sample, start of the walk) for its real collisions: 564 / 250 with 1.
+//  16  main-path SURFACE twice (a ray that leaves through a boundary face into nothing ends the sample): 564 / 267 with 1.
+// Only the first pays: its second round is a handful of instructions, every other candidate runs real work on a thinned wave.
+#ifndef MTS_CHAIN
+#define MTS_CHAIN 1
+#endif
+#ifndef MTS_REPEAT_MIN_W
+#define MTS_REPEAT_MIN_W 32        // MTS_REPEAT_MIN for the walks' class: 16 and 48 measured 539 / 265 and 536 / 265
+#endif
 #define MTS_REPEAT_MIN 32          // lanes that must stay in a MEDIUM class for the block to run again in place (wg_block)
 
 enum : uint32_t { S_TOP = 0, S_MED = 1, S_SURF = 2, S_PHASE = 3, S_BSDF = 4, S_DIRB = 5, S_NEW = 6, S_DONE = 7, S_SCATTER = 8,
@@ -893,6 +909,26 @@ struct HotStore {
 #endif
         unpack(u(H_PACKED), p);
     }
+    // the fields of M on top of a state that already holds the others (st / mode / flags / depth stay as the registers have them)
+    template <uint32_t M> DEV void load_add(PathState &p) const {
+        if (M & G_RNG) p.rng.state = (uint64_t) u(H_RNG) | ((uint64_t) u(H_RNG + 1) << 32);
+        if (M & G_O) p.ray.o = get3(H_O);
+        if (M & G_D) { p.ray.d = get3(H_D); p.ray.d_rcp = get3(H_DRCP); }
+        if (M & G_MINT) p.ray.mint = f(H_MINT);
+        if (M & G_MAXT) p.ray.maxt = f(H_MAXT);
+        if (M & G_SIT) p.si.t = f(H_SIT);
+        if (M & G_SIX) { p.si.p = get3(H_SIX); p.si.uv.x = f(H_SIX + 3); p.si.uv.y = f(H_SIX + 4); p.si.shape = (int) u(H_SIX + 5); p.si.prim = (int) u(H_SIX + 6); }
+        if (M & G_MED) p.medium = (int) u(H_MEDIUM);
+        if (M & G_THR) p.thr = get_spec(H_THR);
+        if (M & G_RES) p.res = get_spec(H_RES);
+        if (M & G_ETA) p.eta = f(H_ETA);
+        if (M & G_TRANS) p.trans = get_spec(H_TRANS);
+        if (M & G_WA) p.wa = f(H_WA);
+        if (M & G_WB) p.wb = f(H_WB);
+#if MTS_SPEC_N != 3
+        if (M & G_WL) p.wl = get_spec(H_WL);
+#endif
+    }
     DEV void store(const PathState &p, int cls) const { store_m<G_ALL>(p, cls); }
     DEV void load(PathState &p) const { load_m<G_ALL>(p); }
 };
@@ -962,10 +998,42 @@ static __device__ WG_BLOCK_ATTR int wg_block(const MTS_CONST_AS void *kernarg_, 
         }
         if (COUNT && C == B_MED) MTS_SEG(*cnt, 4);
         cls = vm.classify(p);
+        if ((MTS_CHAIN & 16) && C == B_SURF) {                 // the same for the main path (its second visit finds no hit: the sample ends)
+            if (cls != C || rounds >= 1) break;
+            continue;
+        }
+        if ((MTS_CHAIN & 1) && C == B_WSURF) {                 // a walk that left through a boundary face with nothing behind it (queue_intersection:
+            if (cls != C || rounds >= 1) break;                 // the ray misses the scene's box) comes straight back to this class to end
+            continue;
+        }
         if (!(C == B_MED || C == B_MEDW) || cls != C || rounds >= 16) break;
-        if (__popcll(__ballot(true)) < MTS_REPEAT_MIN) break;
+        if (__popcll(__ballot(true)) < (C == B_MEDW ? MTS_REPEAT_MIN_W : MTS_REPEAT_MIN)) break;
     }
-    hs.template store_m<CF::store>(p, cls);
+    bool chained = false;
+    if ((MTS_CHAIN & 4) && C == B_MEDW && cls == B_WSURF) {    // the walk left the medium: its surface step(s) run here, on the lanes that have one
+        hs.template load_add<G_ALL & ~CF::load>(p);
+#pragma nounroll
+        for (int r = 0; r < 2; ++r) {
+            vm.blk_wsurf(p, e);
+            vm.top(p, e);
+            cls = vm.classify(p);
+            if (cls != B_WSURF) break;
+        }
+        chained = true;
+    }
+    if ((MTS_CHAIN & 2) && (C == B_WSURF || chained) && cls == B_PHASE) {      // the walk has ended: the main path's phase sample (volpath.cpp:169-175)
+        vm.blk_phase(p, e);
+        vm.top(p, e);
+        cls = vm.classify(p);
+    }
+    if ((MTS_CHAIN & 8) && C == B_MED && cls == B_SCATTER) {   // a real collision: emitter sample and the start of its walk (volpath.cpp:162-167)
+        vm.blk_scatter(p, e);
+        vm.template top<true>(p, e);
+        cls = vm.classify(p);
+        hs.template store_m<CF::store | ClassFields<B_SCATTER>::store>(p, cls);
+    } else
+    if (chained) hs.template store_m<G_ALL>(p, cls);
+    else hs.template store_m<CF::store>(p, cls);
     if (COUNT && C == B_MED) MTS_SEG(*cnt, 5);
     if (CF::defer && (p.st == S_ENDNEE || p.st == S_ENDDIR0)) {     // rare tail on the full state
         PathState q;

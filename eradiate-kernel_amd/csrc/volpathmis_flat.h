@@ -550,6 +550,10 @@ static __device__ __forceinline__ int mis_block(const MTS_CONST_AS void *kernarg
         vm.template run<CF::defer>(p, e, C);
         vm.template top<CF::defer>(p, e);
         cls = vm.classify(p);
+        if ((MTS_CHAIN & 1) && C == B_WSURF) {                 // a walk that left the scene's box ends in the same visit (volpath_flat.h, MTS_CHAIN)
+            if (cls != C || rounds >= 1) break;
+            continue;
+        }
         if (!(C == B_MED || C == B_MEDW) || cls != C || rounds >= 16) break;
         if (__popcll(__ballot(true)) < MTS_REPEAT_MIN) break;
     }
