@@ -97,6 +97,9 @@ def test_default_kernel_resource_budget(tmp_path):
     # volpathmis on the rings: 512 paths x 68 state dwords, two waves per SIMD
     m = one("5v_rgb21render_kernel_wga_misILb0ELb1ELi512ELi512E")
     assert m["vgpr_count"] <= 256 and m["vgpr_spill_count"] == 0 and m["group_segment_fixed_size"] <= 160 * 1024, m
+    # `path` as a flat loop with regeneration: 128 VGPRs (4 waves per SIMD) with spills; 5 waves measured 40 % slower
+    pk = one("5v_rgb13render_kernelILb0ELb1ELi0EE")
+    assert pk["vgpr_count"] <= 128 and pk["vgpr_spill_count"] <= 100, pk
     # the spectral variant's volpath: 256 paths x 42 state dwords, three workgroups per CU
     sp = one("10v_spectral17render_kernel_wgaILb0ELi256ELi256ELi2E")
     assert sp["vgpr_count"] <= 168 and sp["vgpr_spill_count"] == 0 and 3 * sp["group_segment_fixed_size"] <= 160 * 1024, sp
