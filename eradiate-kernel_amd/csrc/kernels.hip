@@ -524,9 +524,13 @@ hipError_t launch_sample_spectral(const DScene &sc, int32_t n, uint64_t seed_off
 
 } // namespace mtsamd
 
-#if defined(MTSAMD_BLOCKSTATS) && MTS_SPEC_N == 3
-// diagnostic build only (python eradiate-kernel_amd/build.py with MTSAMD_EXTRA_FLAGS=-DMTSAMD_BLOCKSTATS)
+#if defined(MTSAMD_BLOCKSTATS)
+// diagnostic build only (python eradiate-kernel_amd/build.py with MTSAMD_EXTRA_FLAGS=-DMTSAMD_BLOCKSTATS); one copy per variant
+#if MTS_SPEC_N == 3
 extern "C" int mts_debug_blockstats(unsigned long long *out32, int reset) {
+#else
+extern "C" int mts_debug_blockstats_spectral(unsigned long long *out32, int reset) {
+#endif
     if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(mtsamd::g_blockstats), 48 * sizeof(unsigned long long)) != hipSuccess) return 1;
     if (reset) { unsigned long long z[48] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(mtsamd::g_blockstats), z, sizeof(z)) != hipSuccess) return 1; }
     return 0;

@@ -366,11 +366,17 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
                     dm.shared_grid = 2;
             }
             std::vector<float> pair;
-            if (dm.shared_grid && a.channels == 1 && b.channels == 1 && a.filter == MTS_FILTER_TRILINEAR && a.wrap == MTS_WRAP_CLAMP && a.nx >= 2) {
+            if (dm.shared_grid && a.channels == 1 && b.channels == 1 && a.filter == MTS_FILTER_TRILINEAR && a.wrap == MTS_WRAP_CLAMP) {
                 const std::vector<float> &ga = hs.grid_data[m.sigma_t_volume], &gb = hs.grid_data[m.albedo_volume];
-                const size_t n = (size_t) a.nx * a.ny * a.nz;
-                pair.assign(2 * (n + 1), 0.f);
-                for (size_t k = 0; k < n; ++k) { pair[2 * k] = ga[k]; pair[2 * k + 1] = gb[k]; }
+                // rows of at least two voxels (one 16-byte gather = both x-neighbours of both grids): a one-column grid -- the
+                // nz x 1 x 1 grids of 1-D atmospheres -- is stored with its column twice; both x-neighbours clamp to voxel 0 anyway
+                const size_t sx = a.nx < 2 ? 2 : (size_t) a.nx, rows = (size_t) a.ny * a.nz;
+                pair.assign(2 * (sx * rows + 1), 0.f);
+                for (size_t r = 0; r < rows; ++r)
+                    for (size_t x = 0; x < sx; ++x) {
+                        const size_t src = r * (size_t) a.nx + (x < (size_t) a.nx ? x : (size_t) a.nx - 1);
+                        pair[2 * (r * sx + x)] = ga[src]; pair[2 * (r * sx + x) + 1] = gb[src];
+                    }
                 memcpy(dm.pair_w2l, a.w2l, 64); dm.pair_nx = a.nx; dm.pair_ny = a.ny; dm.pair_nz = a.nz; dm.pair_affine = a.affine;
             }
             hs.pair_data.push_back(std::move(pair));

@@ -76,7 +76,7 @@ __device__ unsigned long long g_blockstats[48];    // class b < 12: [b] executio
 // textures/grid3d.cpp:259-341 split in two: cell coordinates / weights (shared by grids with the same
 // transform and resolution) and the 8 gathers + trilinear blend of one grid.
 struct GridCell { int32_t r00, r10, r01, r11, x0, x1; F3 w0, w1; };
-DEV GridCell grid_cell_clamp(const float *w2l, int affine, int nx, int ny, int nz, F3 p_world) {      // clamp mode (pair grids)
+DEV GridCell grid_cell_clamp(const float *w2l, int affine, int nx, int ny, int nz, int sx /* voxels per stored row */, F3 p_world) {      // clamp mode (pair grids)
     F3 p = affine ? mat_point_affine(w2l, p_world) : mat_point(w2l, p_world);
     p = f3(pm_fma(p.x, (float) nx, -.5f), pm_fma(p.y, (float) ny, -.5f), pm_fma(p.z, (float) nz, -.5f));
     int ix = (int) pm_floor(p.x), iy = (int) pm_floor(p.y), iz = (int) pm_floor(p.z);
@@ -84,7 +84,7 @@ DEV GridCell grid_cell_clamp(const float *w2l, int affine, int nx, int ny, int n
     c.w1 = p - f3((float) ix, (float) iy, (float) iz); c.w0 = f3(1.f - c.w1.x, 1.f - c.w1.y, 1.f - c.w1.z);
     c.x0 = min(max(ix, 0), nx - 1); c.x1 = min(max(ix + 1, 0), nx - 1);                                  // grid3d.cpp:234-250, clamp
     int y0 = min(max(iy, 0), ny - 1), y1 = min(max(iy + 1, 0), ny - 1), z0 = min(max(iz, 0), nz - 1), z1 = min(max(iz + 1, 0), nz - 1);
-    c.r00 = (z0 * ny + y0) * nx; c.r10 = (z0 * ny + y1) * nx; c.r01 = (z1 * ny + y0) * nx; c.r11 = (z1 * ny + y1) * nx;
+    c.r00 = (z0 * ny + y0) * sx; c.r10 = (z0 * ny + y1) * sx; c.r01 = (z1 * ny + y0) * sx; c.r11 = (z1 * ny + y1) * sx;
     return c;
 }
 DEV GridCell grid_cell(const DVolume &v, F3 p_world) {
@@ -109,6 +109,7 @@ DEV float grid_fetch1(const MTS_GLOBAL_AS float *__restrict__ D, const GridCell 
 
 // Both grids of a medium from the interleaved copy (DMedium::pair_grid): one 16-byte gather per (z, y) row covers the two
 // x-neighbours of sigma_t and albedo.  Clamp mode only: x1 is x0 + 1 except on the last column, where both are nx - 1.
+// `nx` here is the stored row length: a one-column grid (the 1-D atmospheres: nz x 1 x 1) is stored two voxels wide.
 typedef float mts_float4 __attribute__((ext_vector_type(4)));
 typedef mts_float4 __attribute__((aligned(8))) mts_float4_a8;
 DEV void grid_fetch_pair(const MTS_GLOBAL_AS float *__restrict__ P, const GridCell &c, int nx, float &sigma_t, float &albedo) {
@@ -149,9 +150,10 @@ DEV MedStep medium_step(const DScene &sc, const DMedium m, const DRay &ray, floa
     } else if (valid_mi) {
         if (COUNT) MTS_SEG(cnt, 1);
         if (m.pair_grid != nullptr) {                          // everything comes from the medium record and the interleaved grid
-            GridCell c = grid_cell_clamp(m.pair_w2l, m.pair_affine, m.pair_nx, m.pair_ny, m.pair_nz, mi.p);
+            const int sx = m.pair_nx < 2 ? 2 : m.pair_nx;
+            GridCell c = grid_cell_clamp(m.pair_w2l, m.pair_affine, m.pair_nx, m.pair_ny, m.pair_nz, sx, mi.p);
             float st_raw, al_raw;
-            grid_fetch_pair(as_global(m.pair_grid), c, m.pair_nx, st_raw, al_raw);
+            grid_fetch_pair(as_global(m.pair_grid), c, sx, st_raw, al_raw);
             float st = m.scale * st_raw;
             mi.sigma_t = spec_s(st);
             if (want_albedo) mi.sigma_s = spec_s(st * al_raw);

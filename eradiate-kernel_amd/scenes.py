@@ -102,7 +102,7 @@ C4_GROUND_Z = 0.05
 
 
 def c4_atmosphere(width=1024, height=1024, spp=4096, layers=64, sigma_r0=0.012, sigma_a0=0.1, sza_deg=30.0,
-                  rayleigh_scale=1.0, samples_per_pass=-1):
+                  rayleigh_scale=1.0, samples_per_pass=-1, columns=2):
     """C4: plane-parallel atmosphere, 50 km thick and 2*10^4 km wide: Rayleigh (scale height 8) + aerosol
     (scale height 2) extinction in `layers` homogeneous layers, blendphase(rayleigh, tabphase(HG 0.7)) weighted
     by the aerosol scattering fraction, RPV ground, directional sun, distant sensor over the hemisphere."""
@@ -115,9 +115,10 @@ def c4_atmosphere(width=1024, height=1024, spp=4096, layers=64, sigma_r0=0.012, 
     sigma_s = s_r * alb_r + s_a * alb_a
     albedo = (sigma_s / (s_r + s_a)).astype(np.float32)
     weight = (s_a * alb_a / sigma_s).astype(np.float32)
-    # (nz, ny, nx) = (layers, 2, 2): the reference requires >= 8 voxels (volume_data.h:70-73)
+    # (nz, ny, nx) = (layers, columns, columns); the reference requires >= 8 voxels in all (volume_data.h:67-72), so columns = 1 -- the
+    # nz x 1 x 1 grid of a 1-D atmosphere -- is a legal file from 8 layers on
     def grid(v):
-        return np.ascontiguousarray(np.broadcast_to(v[:, None, None], (layers, 2, 2)), dtype=np.float32)
+        return np.ascontiguousarray(np.broadcast_to(v[:, None, None], (layers, columns, columns)), dtype=np.float32)
     ext = 1.0e4
     grid_xf = T.translate([-ext, -ext, 0]) @ T.scale([2 * ext, 2 * ext, top])
     sun = [np.sin(np.radians(sza_deg)), 0.0, -np.cos(np.radians(sza_deg))]

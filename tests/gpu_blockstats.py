@@ -4,15 +4,16 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("eradiate-kernel_amd"); A = importlib.import_module("eradiate-kernel_amd._capi")
 scenes = importlib.import_module("eradiate-kernel_amd.scenes")
-pkg.set_variant("gpu_rgb")
 w, h, spp = [int(x) for x in sys.argv[1:4]]
 cfg = sys.argv[4] if len(sys.argv) > 4 else "C3"
-scene = pkg.load_dict({"C3": scenes.c3_heterogeneous, "C4": scenes.c4_atmosphere, "C2": scenes.c2_homogeneous_slab}[cfg](w, h, spp)); sensor = scene.sensors()[0]
+pkg.set_variant("gpu_spectral" if cfg == "C5S" else "gpu_rgb")
+scene = pkg.load_dict({"C3": scenes.c3_heterogeneous, "C4": scenes.c4_atmosphere, "C2": scenes.c2_homogeneous_slab, "C5S": scenes.c5_atmosphere_spectral}[cfg](w, h, spp)); sensor = scene.sensors()[0]
 out = (C.c_ulonglong * 48)()
-A.lib().mts_debug_blockstats(out, 1)
+read = A.lib().mts_debug_blockstats_spectral if cfg == "C5S" else A.lib().mts_debug_blockstats
+read(out, 1)
 scene.integrator().render(scene, sensor, collect_counters=True)
 st = scene.integrator().last_stats
-A.lib().mts_debug_blockstats(out, 0)
+read(out, 0)
 names = ["INT", "MED", "SCATTER", "WSURF", "SURF", "PHASE", "NEW", "MEDW"]
 waves = w * h / 64          # normalisation unit: one 64-pixel group (the launch may use fewer, fuller waves)
 print("samples/wave-lane", spp, "kernel ms", st["kernel_ms"])

@@ -17,7 +17,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     gpu = np.array(sensor.film().bitmap(raw=True)); o = ob.OracleScene(d); ref = o.render(); so = o.last_stats
     ok = np.array_equal(gpu, ref) and (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
     w, h, spp = [int(x) for x in sys.argv[2:5]]
-    big = {"C3": scenes.c3_heterogeneous, "C4": scenes.c4_atmosphere, "C2": scenes.c2_homogeneous_slab, "C1": scenes.c1_cornell}[os.environ.get("MTSAMD_AB_SCENE", "C3")]
+    big = {"C3": scenes.c3_heterogeneous, "C4": scenes.c4_atmosphere, "C4Z": lambda w, h, spp: scenes.c4_atmosphere(w, h, spp, columns=1), "C2": scenes.c2_homogeneous_slab, "C1": scenes.c1_cornell}[os.environ.get("MTSAMD_AB_SCENE", "C3")]
     scene = pkg.load_dict(with_integrator(big(w, h, spp))); sensor = scene.sensors()[0]
     for rep in range(2):
         scene.integrator().render(scene, sensor); st = scene.integrator().last_stats

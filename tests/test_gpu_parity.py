@@ -57,6 +57,7 @@ CASES = {
     "c2_rr_depth1": lambda: scenes.c2_homogeneous_slab(40, 40, 16, rr_depth=1),
     "c1_maxdepth2": lambda: scenes.c1_cornell(48, 48, 8, max_depth=2),
     "c4_small": lambda: scenes.c4_atmosphere(24, 24, 8, layers=8),
+    "c4_one_column_grids": lambda: scenes.c4_atmosphere(24, 24, 8, layers=12, columns=1),     # nz x 1 x 1: the grids of a 1-D atmosphere
     "furnace_het": lambda: tc.white_furnace(200, heterogeneous=True)[0],
     "absorbing": lambda: tc.absorbing_slab(2000)[0],
 }
