@@ -26,6 +26,8 @@ struct DVolume {
     int32_t nx, ny, nz, channels, filter, wrap;
     float max;
     int32_t has_max;
+    int32_t columns_equal;        // every (y, x) column holds the same values (a 1-D, plane-parallel profile stored as a 3-D grid): the eight
+                                  // corners of a cell are two distinct voxels (z0, z1) -- the lookups gather those two and run the same arithmetic
 };
 
 // Phase functions (phase/*.cpp); the tabulated distribution of tabphase (core/distr_1d.h:293-345)
@@ -56,7 +58,7 @@ struct DMedium {
     // ... together with a copy of what a lookup needs from the sigma_t volume record (one scalar load for the whole step
     // instead of the chain medium -> volume): world_to_local, resolution, affine flag.  Valid when pair_grid != NULL.
     float pair_w2l[16];
-    int32_t pair_nx, pair_ny, pair_nz, pair_affine;
+    int32_t pair_nx, pair_ny, pair_nz, pair_affine;      // pair_affine: bit 0 = affine, bit 1 = both grids have equal columns (DVolume::columns_equal)
 };
 
 struct DBsdf { int32_t type; float reflectance[3], rho_0[3], k[3], g[3], rho_c[3]; uint32_t flags; float transmittance[3]; };

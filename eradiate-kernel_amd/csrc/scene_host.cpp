@@ -282,6 +282,15 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
             float mx = -INFINITY;
             for (size_t k = 0; k < n; ++k) mx = std::max(mx, v.data[k]);
             dv.max = mx; dv.has_max = 1;
+            {   // a profile that only varies with z (bitwise comparison: the lookups then read column (0, 0) for every corner)
+                const size_t row = (size_t) v.nx * v.channels, col = (size_t) v.channels;
+                bool equal = true;
+                for (size_t z = 0; z < (size_t) v.nz && equal; ++z) {
+                    const float *base = v.data + z * (size_t) v.ny * row;
+                    for (size_t c = 1; c < (size_t) v.ny * v.nx && equal; ++c) equal = memcmp(base, base + c * col, col * sizeof(float)) == 0;
+                }
+                dv.columns_equal = equal ? 1 : 0;
+            }
             hs.grid_data.emplace_back(v.data, v.data + n);
             if (v.use_grid_bbox) {
                 F3 bmin = f3(v.file_bbox_min), bmax = f3(v.file_bbox_max);
@@ -377,7 +386,7 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
                         const size_t src = r * (size_t) a.nx + (x < (size_t) a.nx ? x : (size_t) a.nx - 1);
                         pair[2 * (r * sx + x)] = ga[src]; pair[2 * (r * sx + x) + 1] = gb[src];
                     }
-                memcpy(dm.pair_w2l, a.w2l, 64); dm.pair_nx = a.nx; dm.pair_ny = a.ny; dm.pair_nz = a.nz; dm.pair_affine = a.affine;
+                memcpy(dm.pair_w2l, a.w2l, 64); dm.pair_nx = a.nx; dm.pair_ny = a.ny; dm.pair_nz = a.nz; dm.pair_affine = (a.affine ? 1 : 0) | ((a.columns_equal && b.columns_equal) ? 2 : 0);
             }
             hs.pair_data.push_back(std::move(pair));
         }

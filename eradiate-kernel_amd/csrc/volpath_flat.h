@@ -112,11 +112,12 @@ DEV float grid_fetch1(const MTS_GLOBAL_AS float *__restrict__ D, const GridCell 
 // `nx` here is the stored row length: a one-column grid (the 1-D atmospheres: nz x 1 x 1) is stored two voxels wide.
 typedef float mts_float4 __attribute__((ext_vector_type(4)));
 typedef mts_float4 __attribute__((aligned(8))) mts_float4_a8;
-DEV void grid_fetch_pair(const MTS_GLOBAL_AS float *__restrict__ P, const GridCell &c, int nx, float &sigma_t, float &albedo) {
+// columns_equal (wave-uniform): a profile in z only -- the two rows of a z-level hold the same voxels, one gather serves both.
+DEV void grid_fetch_pair(const MTS_GLOBAL_AS float *__restrict__ P, const GridCell &c, int nx, bool columns_equal, float &sigma_t, float &albedo) {
     const int xb = min(c.x0, nx - 2);
     const bool hi0 = c.x0 != xb, hi1 = c.x1 != xb;           // take the second voxel of the pair
-    const mts_float4 q00 = *(const MTS_GLOBAL_AS mts_float4_a8 *) (P + 2 * (c.r00 + xb)), q10 = *(const MTS_GLOBAL_AS mts_float4_a8 *) (P + 2 * (c.r10 + xb)),
-                     q01 = *(const MTS_GLOBAL_AS mts_float4_a8 *) (P + 2 * (c.r01 + xb)), q11 = *(const MTS_GLOBAL_AS mts_float4_a8 *) (P + 2 * (c.r11 + xb));
+    mts_float4 q00 = *(const MTS_GLOBAL_AS mts_float4_a8 *) (P + 2 * (c.r00 + xb)), q01 = *(const MTS_GLOBAL_AS mts_float4_a8 *) (P + 2 * (c.r01 + xb)), q10 = q00, q11 = q01;
+    if (!columns_equal) { q10 = *(const MTS_GLOBAL_AS mts_float4_a8 *) (P + 2 * (c.r10 + xb)); q11 = *(const MTS_GLOBAL_AS mts_float4_a8 *) (P + 2 * (c.r11 + xb)); }
     sigma_t = trilerp(hi0 ? q00.z : q00.x, hi1 ? q00.z : q00.x, hi0 ? q10.z : q10.x, hi1 ? q10.z : q10.x,
                       hi0 ? q01.z : q01.x, hi1 ? q01.z : q01.x, hi0 ? q11.z : q11.x, hi1 ? q11.z : q11.x, c.w0, c.w1);
     albedo = trilerp(hi0 ? q00.w : q00.y, hi1 ? q00.w : q00.y, hi0 ? q10.w : q10.y, hi1 ? q10.w : q10.y,
@@ -151,9 +152,9 @@ DEV MedStep medium_step(const DScene &sc, const DMedium m, const DRay &ray, floa
         if (COUNT) MTS_SEG(cnt, 1);
         if (m.pair_grid != nullptr) {                          // everything comes from the medium record and the interleaved grid
             const int sx = m.pair_nx < 2 ? 2 : m.pair_nx;
-            GridCell c = grid_cell_clamp(m.pair_w2l, m.pair_affine, m.pair_nx, m.pair_ny, m.pair_nz, sx, mi.p);
+            GridCell c = grid_cell_clamp(m.pair_w2l, m.pair_affine & 1, m.pair_nx, m.pair_ny, m.pair_nz, sx, mi.p);
             float st_raw, al_raw;
-            grid_fetch_pair(as_global(m.pair_grid), c, sx, st_raw, al_raw);
+            grid_fetch_pair(as_global(m.pair_grid), c, sx, (m.pair_affine & 2) != 0, st_raw, al_raw);
             float st = m.scale * st_raw;
             mi.sigma_t = spec_s(st);
             if (want_albedo) mi.sigma_s = spec_s(st * al_raw);
@@ -171,7 +172,8 @@ DEV MedStep medium_step(const DScene &sc, const DMedium m, const DRay &ray, floa
                 GridRef g;
                 for (int k = 0; k < 16; ++k) g.w2l[k] = vs.w2l[k];
                 g.data = vs.data; g.nx = vs.nx; g.ny = vs.ny; g.nz = vs.nz;
-                g.channels_affine_filter_wrap = (uint32_t) vs.channels | ((uint32_t) (vs.affine != 0) << 8) | ((uint32_t) vs.filter << 16) | ((uint32_t) vs.wrap << 24);
+                g.channels_affine_filter_wrap = (uint32_t) vs.channels | ((uint32_t) (vs.affine != 0) << 8) | ((uint32_t) vs.filter << 16) | ((uint32_t) vs.wrap << 24) |
+                                                ((uint32_t) (vs.columns_equal != 0 && (!want_albedo || va.columns_equal != 0)) << 9);
                 const DVolumeSp sp = cload(cx.volume_sp + m.sigma_t);
                 if (want_albedo) {
                     const SpecPair r = volume_eval_grid_spectral_pair(g, va.data, mi.p, cx.wl, sp.lambda_min, sp.lambda_max);
