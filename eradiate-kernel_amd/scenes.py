@@ -162,12 +162,12 @@ def c4_three_species(width=1024, height=1024, spp=4096, layers=64, g_cloud=0.85,
     return d
 
 
-def c5_atmosphere_spectral(width=1024, height=1024, spp=4096, layers=64, nodes=17, samples_per_pass=-1):
+def c5_atmosphere_spectral(width=1024, height=1024, spp=4096, layers=64, nodes=17, samples_per_pass=-1, columns=2):
     """C5 in the spectral variant (gpu_spectral): the C4 atmosphere with extinction and albedo as `gridvolume_spectral` grids whose
     `nodes` spectral nodes cover 0 .. 1600 nm (Rayleigh ~ lambda^-4 relative to 550 nm, aerosol grey), a D65 sun and an RPV ground with
     a sloped rho_0.  lambda_min = 0 because of the mask gridvolume_spectral applies (tests/test_spectral.py::test_gridvolume_spectral_eval).
     The blend weight stays a plain grid (gridvolume_spectral has no eval_1, gridvolume_spectral.cpp:204-214): its 550 nm value."""
-    d = c4_atmosphere(width, height, spp, layers=layers, samples_per_pass=samples_per_pass)
+    d = c4_atmosphere(width, height, spp, layers=layers, samples_per_pass=samples_per_pass, columns=columns)
     top = 50.0
     z = (np.arange(layers, dtype=np.float64) + 0.5) * (top / layers)
     lam = np.linspace(0.0, 1600.0, nodes)
@@ -176,7 +176,7 @@ def c5_atmosphere_spectral(width=1024, height=1024, spp=4096, layers=64, nodes=1
     sigma_t = ray + aer
     albedo = (ray * 1.0 + aer * 0.92) / sigma_t
     def grid(v):
-        return np.ascontiguousarray(np.broadcast_to(v[:, None, None, :], (layers, 2, 2, nodes)), dtype=np.float32)
+        return np.ascontiguousarray(np.broadcast_to(v[:, None, None, :], (layers, columns, columns, nodes)), dtype=np.float32)
     med = d["atmosphere"]["interior"]
     xf = med["sigma_t"]["to_world"]
     med["sigma_t"] = {"type": "gridvolume_spectral", "data": grid(sigma_t), "lambda_min": 0.0, "lambda_max": 1600.0, "to_world": xf}

@@ -909,12 +909,17 @@ def _spectral_cases():
     d["sun"]["irradiance"] = {"type": "uniform", "value": 1.0}
     cases["c4_atmosphere"] = d
     cases["c5s_atmosphere"] = scenes.c5_atmosphere_spectral(40, 32, 4, layers=8, nodes=5)       # bench.py --config C5S in small
+    cases["c5s_one_column"] = scenes.c5_atmosphere_spectral(24, 24, 4, layers=9, nodes=4, columns=1)   # nz x 1 x 1 spectral grids
+    d = scenes.c5_atmosphere_spectral(24, 24, 4, layers=8, nodes=5)                               # one column differs: the eight-corner lookup
+    g = np.array(d["atmosphere"]["interior"]["sigma_t"]["data"]); g[3, 1, 0, 2] *= 1.5
+    d["atmosphere"]["interior"]["sigma_t"]["data"] = g
+    cases["c5s_columns_differ"] = d
     return cases
 
 
 @pytest.mark.parametrize("kernel", [None, "nested"])
 @pytest.mark.parametrize("name", ["slab_regular_reflectance", "slab_chromatic_medium", "grid_spectral_d65_rpv", "cornell_path", "c4_atmosphere",
-                                  "c5s_atmosphere"])
+                                  "c5s_atmosphere", "c5s_one_column", "c5s_columns_differ"])
 def test_spectral_variant_against_oracle(gpu_spectral, monkeypatch, name, kernel):
     """gpu_spectral (kernels_spectral.hip: Spectrum<Float, 4>, sample_wavelength, spectrum_to_xyz) against liboracle_spectral.so on the
     same seeded inputs: the films and the loop counters are identical -- `volpath` on the regrouping machine (four-wide state, 256-path
