@@ -1,5 +1,5 @@
 # Round-3 evidence run on the GPU box: bench lines of every configuration, rocprofv3 kernel stats (C3, C4, C1L), PMC traffic + issue +
-# latency / LDS counters for C3, issue counters for C4 and C1L.  Usage: gpurun -- 'bash profiles/collect_r03.sh [part]'   (part: a | b | c)
+# latency / LDS counters for C3, issue counters for C4 and C1L.  Usage: gpurun -- 'bash profiles/collect_r03.sh [part]'   (part: a | b | c | d)
 set -e
 PART=${1:-a}
 R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp
@@ -55,5 +55,17 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c5sm -o p -- pyt
 cd $R
 python3 tests/pmc_summary.py --json $O/pmc_summary_c1l.json --probe "bench.py --config C1L --steps 1 (512x512x256, path)" $O/c1l_SQ_INSTS_VALU $O/c1l_SQ_THREAD_CYCLES_VALU > /dev/null
 cat $O/pmc_summary_c1l.json | tail -10
+fi
+if [ $PART = d ]; then
+# C5S (the spectral variant on the C4 atmosphere): kernel stats and issue counters (128-spp probe)
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c5s -o p -- python3 $R/bench.py --config C5S --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_prof_c5s.log 2>&1
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" "SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_INSTS_SMEM"; do
+  tag=$(echo $grp | cut -d' ' -f1)
+  rocprofv3 --pmc $grp --output-format csv -d $O/c5s_$tag -o p -- python3 $R/bench.py --config C5S --spp 128 --steps 1 --warmup 0 --no-cpu-baseline > $O/c5s_$tag.log 2>&1
+done
+cd $R
+python3 tests/pmc_summary.py --json $O/pmc_summary_c5s.json --probe "bench.py --config C5S --spp 128 --steps 1 (1024x1024x128, gpu_spectral)" $O/c5s_FETCH_SIZE $O/c5s_WRITE_SIZE $O/c5s_SQ_INSTS_VALU $O/c5s_SQ_THREAD_CYCLES_VALU > /dev/null
+cat $O/pmc_summary_c5s.json | tail -12
 fi
 find $O -name "*kernel_stats*" | head
