@@ -442,7 +442,7 @@ DEV float trilerp(float d000, float d100, float d010, float d110, float d001, fl
 struct GridRef { float w2l[16]; const float *data; int32_t nx, ny, nz; uint32_t channels_affine_filter_wrap; };
 DEV_NOINLINE F3 volume_eval_grid(const GridRef g, F3 p_world);
 #if MTS_SPEC_N != 3
-DEV_NOINLINE Spec volume_eval_grid_spectral(const GridRef g, F3 p_world, Spec wl, float lambda_min, float lambda_max);
+DEV Spec volume_eval_grid_spectral(const GridRef g, F3 p_world, Spec wl, float lambda_min, float lambda_max);
 #endif
 DEV Spec volume_eval(const DVolume &v, F3 p_world, const SpecCtx &cx = SpecCtx(), int vid = 0) {
 #if MTS_SPEC_N == 3
@@ -517,18 +517,22 @@ DEV void volume_eval_grid_spectral_n(const GridRef &g, const float *data_b, F3 p
     }
     for (int gi = 0; gi < NG; ++gi) out_s[gi] = spec4(out[gi][0], out[gi][1], out[gi][2], out[gi][3]);
 }
-DEV_NOINLINE Spec volume_eval_grid_spectral(const GridRef g, F3 p_world, Spec wl, float lambda_min, float lambda_max) {
-    Spec o[1];
-    if ((g.channels_affine_filter_wrap >> 9) & 1u) volume_eval_grid_spectral_n<1, true>(g, nullptr, p_world, wl, lambda_min, lambda_max, o);
-    else volume_eval_grid_spectral_n<1, false>(g, nullptr, p_world, wl, lambda_min, lambda_max, o);
-    return o[0];
-}
-DEV_NOINLINE SpecPair volume_eval_grid_spectral_pair(const GridRef g, const float *data_b, F3 p_world, Spec wl, float lambda_min, float lambda_max) {
-    Spec o[2];
-    if ((g.channels_affine_filter_wrap >> 9) & 1u) volume_eval_grid_spectral_n<2, true>(g, data_b, p_world, wl, lambda_min, lambda_max, o);
-    else volume_eval_grid_spectral_n<2, false>(g, data_b, p_world, wl, lambda_min, lambda_max, o);
+// Four real functions (eight corners / z profile, one grid / two): their register need counts towards the kernel's, and with both
+// instantiations in one function the allocator took 180 VGPRs where the regrouping kernel has 168 (three 256-path workgroups per CU).
+template <int NG, bool COLUMNS_EQUAL>
+DEV_NOINLINE SpecPair volume_eval_grid_spectral_f(const GridRef g, const float *data_b, F3 p_world, Spec wl, float lambda_min, float lambda_max) {
+    Spec o[2]; o[1] = spec_s(0.f);
+    volume_eval_grid_spectral_n<NG, COLUMNS_EQUAL>(g, data_b, p_world, wl, lambda_min, lambda_max, o);
     SpecPair r; r.a = o[0]; r.b = o[1];
     return r;
+}
+DEV Spec volume_eval_grid_spectral(const GridRef g, F3 p_world, Spec wl, float lambda_min, float lambda_max) {
+    if ((g.channels_affine_filter_wrap >> 9) & 1u) return volume_eval_grid_spectral_f<1, true>(g, nullptr, p_world, wl, lambda_min, lambda_max).a;
+    return volume_eval_grid_spectral_f<1, false>(g, nullptr, p_world, wl, lambda_min, lambda_max).a;
+}
+DEV SpecPair volume_eval_grid_spectral_pair(const GridRef g, const float *data_b, F3 p_world, Spec wl, float lambda_min, float lambda_max) {
+    if ((g.channels_affine_filter_wrap >> 9) & 1u) return volume_eval_grid_spectral_f<2, true>(g, data_b, p_world, wl, lambda_min, lambda_max);
+    return volume_eval_grid_spectral_f<2, false>(g, data_b, p_world, wl, lambda_min, lambda_max);
 }
 #endif
 DEV_NOINLINE F3 volume_eval_grid(const GridRef g, F3 p_world) {
