@@ -518,8 +518,8 @@ struct VolpathMachine {
             if (is_nee) t = pm_min(remaining_dist, t);
             t = t - mi.mint;
             const bool surface_first = p.si.t < mi.t || mi.t > remaining_dist;
-            if (grey) {                                        // every channel carries the same value: one exp, one division
-                float tr = pm_exp(-t * mi.combined.x);
+            if (grey || !homogeneous) {                        // the combined extinction is one value for every channel (a grey medium, or a
+                float tr = pm_exp(-t * mi.combined.x);          // heterogeneous one: its majorant is a scalar, heterogeneous.cpp:29): one exp, one division
                 float tr_pdf = surface_first ? tr : tr * mi.combined.x;
                 weight = weight * (tr_pdf > 0.f ? tr * (1.0f / tr_pdf) : 0.f);     // spectrum / scalar = spectrum * (1 / scalar), dmath.h
             } else {

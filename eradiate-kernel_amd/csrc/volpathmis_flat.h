@@ -200,7 +200,8 @@ struct VolpathMisMachine {
         const Spec sigma_n = homogeneous ? spec_s(0.f) : mi.combined - mi.sigma_t;
         if (spectral) {
             float t = pm_min(mi.t, p.si.t) - mi.mint;                                  // medium.cpp:77-89
-            Spec tr = transmittance_exp(t, mi.combined);
+            // a heterogeneous medium's combined extinction is its scalar majorant (heterogeneous.cpp:29): one exponential for every channel
+            Spec tr = homogeneous ? transmittance_exp(t, mi.combined) : spec_s(pm_exp(-t * mi.combined.x));
             Spec free_flight_pdf = p.si.t < mi.t ? tr : tr * mi.combined;
             update_weights(p.pf, free_flight_pdf, tr, channel, true);
             update_weights(p.pn, free_flight_pdf, tr, channel, true);
@@ -276,7 +277,8 @@ struct VolpathMisMachine {
         const float remaining_dist = p.ray.maxt;
         if (spectral) {
             float t = pm_min(remaining_dist, pm_min(mi.t, p.si.t)) - mi.mint;
-            Spec tr = transmittance_exp(t, mi.combined);
+            // a heterogeneous medium's combined extinction is its scalar majorant (heterogeneous.cpp:29): one exponential for every channel
+            Spec tr = homogeneous ? transmittance_exp(t, mi.combined) : spec_s(pm_exp(-t * mi.combined.x));
             Spec free_flight_pdf = (p.si.t < mi.t || mi.t > remaining_dist) ? tr : tr * mi.combined;
             update_weights(p.wn, free_flight_pdf, tr, channel, true);
             update_weights(p.wu, free_flight_pdf, tr, channel, true);
