@@ -29,7 +29,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md ("HBM3E ... 8 TB/s"): the contract's `peak`.  The device's own
+                           # figure (memory clock x bus width from hipDeviceProp) rides along in the line as `peak_device_query`.
 CONFIG_SIZES = {"C1": (256, 256, 64), "C2": (512, 512, 256), "C3": (512, 512, 1024), "C4": (1024, 1024, 4096), "C5": (1024, 1024, 4096),
                 "C5S": (1024, 1024, 256), "C5SM": (1024, 1024, 256), "C5SB": (1024, 1024, 256), "C3M": (512, 512, 1024), "C1L": (512, 512, 256), "C1W": (256, 256, 64)}      # C5S: the same atmosphere in the spectral variant (gpu_spectral), 256 spp
 C5_WAVELENGTHS = 16        # BASELINE.json configs[4]: the C4 atmosphere as a 16-wavelength batch
@@ -110,14 +111,95 @@ def timed(job, steps, warmup, barrier, all_max):
         job.step()
     barrier()
     t0 = time.perf_counter()
-    kernel_ms, launches, samples_rank = 0.0, 0, 0
+    kernel_ms, launches, samples_rank, cal_ms = 0.0, 0, 0, 0.0
     for _ in range(steps):
         sts = job.step()
+        # kernel_ms / kernel_launches: the render launches only; the short block-cost calibration launch of scenes with more blocks than
+        # CUs is reported apart (mts_stats.calibration_ms) -- it is inside the timed region and in `value`, not in the roofline's launch time
         kernel_ms += sum(s["kernel_ms"] for s in sts); launches += sum(s["kernel_launches"] for s in sts)
+        cal_ms += sum(s["calibration_ms"] for s in sts)
         samples_rank = sum(s["samples"] for s in sts)
     barrier()
     elapsed = all_max(time.perf_counter() - t0)
-    return elapsed, kernel_ms, launches, samples_rank
+    return elapsed, kernel_ms, launches, samples_rank, cal_ms
+
+
+def device_hbm_peak_gbs(torch, device):
+    """Peak HBM bandwidth as the device reports it: 2 x memory clock x bus width (hipDeviceProp_t memoryClockRate / memoryBusWidth,
+    through torch's device properties); None when the runtime does not expose them.  Reported next to the guide's figure."""
+    try:
+        pr = torch.cuda.get_device_properties(device)
+        khz, bits = getattr(pr, "memory_clock_rate", None), getattr(pr, "memory_bus_width", None)
+        if not khz or not bits:
+            return None
+        return round(2.0 * khz * 1e3 * bits / 8 / 1e9, 1)
+    except Exception:
+        return None
+
+
+def spawn_ranks(n, argv=None, env=None, timeout=None):
+    """`python bench.py --gpus N` without a launcher: the parent -- BEFORE anything touches the GPU or imports torch -- starts N fresh
+    child processes of this script, one per GPU, with the environment torch.distributed.run would give them (RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR = 127.0.0.1, a free MASTER_PORT), lets rank 0 write the JSON line to our stdout, and returns non-zero
+    if any rank fails (the others are then ended: a rank that died leaves its peers waiting in a collective).  Never exec: children
+    only.  Returns the exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    argv = list(sys.argv[1:] if argv is None else argv)
+    base = dict(os.environ if env is None else env)
+    base.update({"WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC: what RCCL needs on this driver
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    t0 = time.monotonic()
+    code = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                pending.discard(r)
+                if rc != 0 and code == 0:
+                    code = rc if rc > 0 else 1
+                    print("bench.py: rank %d exited with status %d; ending the other ranks" % (r, rc), file=sys.stderr, flush=True)
+            if code != 0 or (timeout is not None and time.monotonic() - t0 > timeout):
+                if code == 0:
+                    code = 124
+                    print("bench.py: ranks still running after %.0f s; ending them" % timeout, file=sys.stderr, flush=True)
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:                                           # exactly the processes started here
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill(); p.wait()
+    return code
+
+
+def partition(width, height, spp, n, block=32):
+    """The strong-scaling cut of `bench.py --gpus n` as plain arithmetic (tests/test_distributed_cpu.py holds it against the oracle's
+    spiral): passes of the largest divisor of spp not above spp / n, (pass, block) pairs dealt block_id % n."""
+    spp_pass = spp
+    if n > 1:
+        spp_pass = max(1, spp // n)
+        while spp % spp_pass:
+            spp_pass -= 1
+    passes = spp // spp_pass if n > 1 else 1
+    blocks_total = -(-width // block) * -(-height // block) * passes
+    per_rank = [len(range(r, blocks_total, n)) for r in range(n)]
+    return {"spp_pass": spp_pass, "passes": passes, "blocks_total": blocks_total, "workgroups_per_rank": per_rank}
 
 
 def main():
@@ -137,6 +219,9 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU-baseline sample (0 = sized for ~15 s)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))                  # `python bench.py --gpus N`: start the N ranks ourselves
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -144,11 +229,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    selftest = os.environ.get("MTSAMD_BENCH_SELFTEST")
+    if selftest:
+        # tests/test_distributed_cpu.py: the launch plumbing of spawn_ranks on a box without GPUs -- rendezvous over gloo with the
+        # environment the parent made, one all-reduce, rank 0 prints the line; "fail" lets rank 1 die before the rendezvous
+        if selftest == "fail" and rank == 1:
+            raise SystemExit(3)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"selftest": True, "n_gpus": world, "sum_of_ranks_plus_one": int(t.item()), "local_rank": local_rank,
+                              "partition": partition(*CONFIG_SIZES[args.config], world)}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     n = args.gpus
     if world != n:
-        if world == 1 and n > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (n, n))
-        n = world
+        n = world                                                 # the launcher's world size wins over --gpus
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the gpu_rgb backend has no CPU fallback)")
     # Rehearsal switch: MTSAMD_BENCH_BACKEND=gloo runs the N-rank path with all ranks on ONE GPU and the film reduce on the
@@ -182,20 +280,16 @@ def main():
         return float(t.item())
 
     # ---- strong scaling: the fixed job, N passes of spp / N (the largest divisor of spp not above spp / N)
-    spp_pass = args.spp
-    if n > 1:
-        spp_pass = max(1, args.spp // n)
-        while args.spp % spp_pass:
-            spp_pass -= 1
+    part = partition(args.width, args.height, args.spp, n)
+    spp_pass = part["spp_pass"]
     variant = {"C5": "gpu_mono", "C5S": "gpu_spectral", "C5SM": "gpu_spectral", "C5SB": "gpu_spectral"}.get(args.config, "gpu_rgb")
     job = Job(pkg, scenes, args, rank, n, local_rank, backend, args.spp, spp_pass if n > 1 else -1)
     # every rank should get at least one workgroup per CU (256) per launch, or the GPUs run partly empty: the reason the N-rank job is
     # cut into N passes.  Checked for the configurations at their BASELINE sizes (a rehearsal on a small film cannot meet it).
-    blocks_total = -(-args.width // 32) * -(-args.height // 32) * (args.spp // spp_pass if n > 1 else 1)
-    workgroups_per_rank = blocks_total // n
+    workgroups_per_rank = min(part["workgroups_per_rank"])
     if (args.width, args.height, args.spp) == CONFIG_SIZES[args.config] and args.config not in ("C1", "C1W") and workgroups_per_rank < 256:
         raise SystemExit("bench.py: %d workgroups per rank (< 256 CUs) at --gpus %d" % (workgroups_per_rank, n))
-    elapsed, kernel_ms, launches, samples_rank = timed(job, args.steps, args.warmup, barrier, all_max)
+    elapsed, kernel_ms, launches, samples_rank, cal_ms = timed(job, args.steps, args.warmup, barrier, all_max)
     value = job.samples_step * args.steps / elapsed / 1e6
     # kernel time per step of every rank (HIP events around the launches): a SCALE record shows load imbalance directly
     per_rank_ms = [kernel_ms / args.steps]
@@ -252,7 +346,9 @@ def main():
     roofline = {"bound": "latency", "model_bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "achieved_is": "algorithmic bytes per launch / measured launch time (SURVEY.md 8(d)): a modelling figure, not a bandwidth measurement",
-                "kernel": kernel_name, "avg_launch_ms": round(avg_launch_ms, 3),
+                "kernel": kernel_name, "avg_launch_ms": round(avg_launch_ms, 3), "launches_per_step": round(launches / args.steps, 3),
+                "calibration_ms_per_step": round(cal_ms / args.steps, 3),
+                "peak_source": "MI355X_MICROARCH.md (HBM3E, 8 TB/s)", "peak_device_query": device_hbm_peak_gbs(torch, local_rank),
                 "bytes_per_sample": round(bytes_per_sample, 1),
                 "n_iter_per_sample": round(c_iter / c_samp, 3),
                 "n_lookup_per_sample": round(c_look / c_samp, 3),
@@ -281,7 +377,7 @@ def main():
         del job
         torch.cuda.empty_cache()
         wjob = Job(pkg, scenes, args, rank, n, local_rank, backend, args.spp * n, args.spp)
-        w_elapsed, _, _, _ = timed(wjob, args.steps, args.warmup, barrier, all_max)
+        w_elapsed = timed(wjob, args.steps, args.warmup, barrier, all_max)[0]
         weak = {"value": round(wjob.samples_step * args.steps / w_elapsed / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(w_elapsed / args.steps * 1e3, 2),
                 "workload": "%dx%dx%d spp total, passes of %d: one %dx%dx%d job per GPU" % (args.width, args.height, args.spp * n, args.spp, args.width, args.height, args.spp)}
         del wjob

@@ -16,7 +16,6 @@ Everything below the Python layer is libmtsamd.so (C ABI in include/mtsamd.h, HI
 Only the `gpu_rgb` variant exists: there is no CPU fallback in the product path.
 """
 import ctypes as C
-import signal
 import threading
 import types
 
@@ -206,9 +205,9 @@ class Integrator:
         """Integrator.render(scene, sensor) -> bool: `not m_stop` (integrator.cpp:178), i.e. False iff cancel() stopped it; a render
         cut short by the integrator's "timeout" returns True like the reference's (last_stats["timed_out"] tells).
 
-        The reference binding releases the GIL and turns SIGINT into cancel()
+        The reference binding releases the GIL and turns SIGINT into cancel() from a C signal handler
         (integrator_v.cpp:124-156); ctypes releases the GIL for the duration of mts_render, and the
-        SIGINT handler below calls mts_cancel.  Extra keyword arguments are extensions used by the
+        SIGINT scope of the C ABI (mts_sigint_scope_enter / _exit) does the same here.  Extra keyword arguments are extensions used by the
         multi-GPU path: `shard_*` selects the blocks this rank renders, `device_film` is a device
         pointer (e.g. torch tensor data_ptr) receiving the film instead of host memory: crop_height x crop_width x (5 + 2 x bins)
         floats -- X, Y, Z, A, W and, under `nbins` / `bins`, two AOV channels per spectral bin.  `device_film_floats` is the size of
@@ -224,28 +223,28 @@ class Integrator:
         opts.stream = stream
         opts.collect_counters = int(bool(collect_counters))
         stats = A.Stats()
-        old = None
-        if threading.current_thread() is threading.main_thread():
-            try:
-                old = signal.signal(signal.SIGINT, lambda *a: A.lib().mts_cancel(scene._handle))
-            except ValueError:
-                old = None
+        # SIGINT -> cancel() as the reference's binding does it (integrator_v.cpp:129-151): a C-level handler, because a Python-level
+        # one only runs between bytecodes, i.e. after mts_render has returned.  The handler cancels the render, puts the previous
+        # handler back and re-raises, so KeyboardInterrupt still reaches the caller -- once the render has wound down and its
+        # finished samples are on the film (which is why the film storage is attached BEFORE the call).
+        scoped = threading.current_thread() is threading.main_thread() and A.lib().mts_sigint_scope_enter(scene._handle) == 0
         try:
             if device_film is not None:
                 opts.film_on_device = 1
                 opts.film_capacity = int(device_film_floats) if device_film_floats is not None else h * w * 5
-                A.check(A.lib().mts_render(scene._handle, C.byref(opts), C.c_void_p(int(device_film)), C.byref(stats)))
                 sensor._film._storage = None
+                A.check(A.lib().mts_render(scene._handle, C.byref(opts), C.c_void_p(int(device_film)), C.byref(stats)))
             else:
                 out = np.zeros((h, w, 5 + 2 * scene._desc.integrator.bin_count), dtype=np.float32)    # X, Y, Z, A, W + aov_names()
                 opts.film_on_device = 0
                 opts.film_capacity = out.size
-                A.check(A.lib().mts_render(scene._handle, C.byref(opts), out.ctypes.data_as(C.c_void_p), C.byref(stats)))
                 sensor._film._storage = out
+                A.check(A.lib().mts_render(scene._handle, C.byref(opts), out.ctypes.data_as(C.c_void_p), C.byref(stats)))
         finally:
-            if old is not None:
-                signal.signal(signal.SIGINT, old)
-        self.last_stats = {k: getattr(stats, k) for k, _ in A.Stats._fields_}
+            # stats first: a KeyboardInterrupt re-raised by the handler surfaces at the next bytecode
+            self.last_stats = {k: getattr(stats, k) for k, _ in A.Stats._fields_ if k != "reserved_"}
+            if scoped:
+                A.lib().mts_sigint_scope_exit()
         return not bool(stats.cancelled)
 
     def cancel(self):

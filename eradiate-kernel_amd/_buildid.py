@@ -21,6 +21,40 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-mllvm", "-disable-machine-licm", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 
 
+def effective_flags(environ=None):
+    """The flag list of the build as the environment shapes it -- the ONE place build.py and the loader (_capi.lib) take it from, so a
+    library built with MTSAMD_EXTRA_FLAGS / MTSAMD_EXP_FASTDIV at the default path is recognised by the loader under the same
+    environment (and refused under another)."""
+    env = os.environ if environ is None else environ
+    flags = [("-fno-hip-fp32-correctly-rounded-divide-sqrt" if (env.get("MTSAMD_EXP_FASTDIV") and f == "-fhip-fp32-correctly-rounded-divide-sqrt") else f)
+             for f in FLAGS]                                 # MTSAMD_EXP_FASTDIV: measurement only, breaks parity
+    return flags + env.get("MTSAMD_EXTRA_FLAGS", "").split()
+
+
+TOOLCHAIN_MARKER = b"MTSAMD_TOOLCHAIN="
+
+
+def toolchain_id(hipcc):
+    """8 hex digits of `hipcc --version`: embedded next to the build id, so that build.py rebuilds after a compiler update.  Not part
+    of the build id itself -- the loader must be able to verify a library on a box without the compiler."""
+    import subprocess
+    try:
+        out = subprocess.run([hipcc, "--version"], capture_output=True, timeout=60).stdout
+    except (OSError, subprocess.SubprocessError):
+        out = b"unknown"
+    return hashlib.sha256(out).hexdigest()[:8]
+
+
+def binary_toolchain_id(lib_path):
+    try:
+        with open(lib_path, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    k = blob.find(TOOLCHAIN_MARKER)
+    return blob[k + len(TOOLCHAIN_MARKER):k + len(TOOLCHAIN_MARKER) + 8].decode("ascii", "replace") if k >= 0 else None
+
+
 def tree_build_id(flags=FLAGS, csrc=CSRC, include=None):
     """Hash of the sources as they are in the tree now, plus the compiler flags."""
     h = hashlib.sha256()

@@ -12,7 +12,7 @@ from . import _buildid
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MTSAMD_LIB") or os.path.join(HERE, "libmtsamd.so")
 
-MTS_ABI_VERSION = 8
+MTS_ABI_VERSION = 9
 
 # enums (include/mtsamd.h)
 VOLUME_CONST, VOLUME_GRID, VOLUME_GRID_SPECTRAL = 0, 1, 2
@@ -112,7 +112,8 @@ class SceneDesc(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("n_iter", C.c_uint64), ("n_lookup", C.c_uint64),
                 ("n_nee_step", C.c_uint64), ("kernel_ms", C.c_double), ("wall_ms", C.c_double),
-                ("kernel_launches", i32), ("cancelled", i32), ("timed_out", i32), ("kernel_variant", i32)]
+                ("kernel_launches", i32), ("cancelled", i32), ("timed_out", i32), ("kernel_variant", i32),
+                ("calibration_launches", i32), ("reserved_", i32), ("calibration_ms", C.c_double)]
 
 
 class RenderOpts(C.Structure):
@@ -127,7 +128,7 @@ ABI_STRUCTS = {"mts_spectrum": Spectrum, "mts_transform": Transform, "mts_volume
 
 # every symbol include/mtsamd.h declares
 ABI_SYMBOLS = ["mts_abi_version", "mts_build_id", "mts_last_error", "mts_device_count", "mts_scene_create", "mts_scene_destroy",
-               "mts_render", "mts_cancel", "mts_sample", "mts_sample_spectral", "mts_ray_intersect", "mts_abi_sizeof", "mts_sample_tea", "mts_wavefront_sampler"]
+               "mts_render", "mts_cancel", "mts_sigint_scope_enter", "mts_sigint_scope_exit", "mts_sample", "mts_sample_spectral", "mts_ray_intersect", "mts_abi_sizeof", "mts_sample_tea", "mts_wavefront_sampler"]
 
 _lib = None
 
@@ -153,6 +154,8 @@ def lib():
     L.mts_scene_destroy.argtypes = [C.c_void_p]
     L.mts_render.argtypes = [C.c_void_p, C.POINTER(RenderOpts), C.c_void_p, C.POINTER(Stats)]
     L.mts_cancel.argtypes = [C.c_void_p]
+    L.mts_sigint_scope_enter.argtypes = [C.c_void_p]
+    L.mts_sigint_scope_exit.argtypes = []
     L.mts_sample.argtypes = [C.c_void_p, i32, C.c_uint64] + [fp] * 6 + [fp, C.POINTER(C.c_uint8)]
     L.mts_sample_spectral.argtypes = [C.c_void_p, i32, C.c_uint64] + [fp] * 7 + [fp, C.POINTER(C.c_uint8)]
     L.mts_ray_intersect.argtypes = [C.c_void_p, i32, fp, fp, fp, fp, fp, C.POINTER(i32), C.POINTER(i32), fp, fp]
@@ -165,8 +168,11 @@ def lib():
     # the binary must be the one this tree builds (a stale or foreign library would render with other kernels); an explicit MTSAMD_LIB
     # (side-by-side measurement builds with extra flags) is taken as it is
     L.mts_build_id.restype = C.c_char_p
-    if not os.environ.get("MTSAMD_LIB"):
-        built, tree = L.mts_build_id().decode(), _buildid.tree_build_id()
+    if not os.environ.get("MTSAMD_LIB") and os.path.isdir(_buildid.CSRC):       # a deployed package without csrc/ has nothing to compare with
+        try:
+            built, tree = L.mts_build_id().decode(), _buildid.tree_build_id(_buildid.effective_flags())
+        except OSError as e:
+            raise BackendError("cannot read the sources of libmtsamd.so to verify the build (%s)" % e)
         if built != tree:
             raise BackendError("%s was built from other sources or flags (build id %s, this tree: %s) -- run `python eradiate-kernel_amd/build.py`"
                                % (LIB_PATH, built, tree))

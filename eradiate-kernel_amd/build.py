@@ -24,22 +24,33 @@ FLAGS = _buildid.FLAGS
 
 
 def build_backend(force=False, verbose=True, extra=()):
-    extra = list(extra) + os.environ.get("MTSAMD_EXTRA_FLAGS", "").split()
-    flags = [("-fno-hip-fp32-correctly-rounded-divide-sqrt" if (os.environ.get("MTSAMD_EXP_FASTDIV") and f == "-fhip-fp32-correctly-rounded-divide-sqrt") else f)
-             for f in FLAGS]                                 # MTSAMD_EXP_FASTDIV: measurement only, breaks parity
+    flags = _buildid.effective_flags()                       # FLAGS as MTSAMD_EXP_FASTDIV / MTSAMD_EXTRA_FLAGS shape them: the loader computes the same
+    extra = list(extra)
     # The binary says which sources it was built from (mts_build_id): rebuild iff that differs from the tree -- not by mtimes, which
-    # a checkout, a copy to another box or a reverted experiment all falsify.
+    # a checkout, a copy to another box or a reverted experiment all falsify -- or the compiler has changed.
     build_id = _buildid.tree_build_id(flags + extra)
-    if not force and _buildid.binary_build_id(LIB) == build_id:
+    toolchain = _buildid.toolchain_id(HIPCC)
+    if not force and _buildid.binary_build_id(LIB) == build_id and _buildid.binary_toolchain_id(LIB) == toolchain:
         return LIB
     # one hipcc per translation unit, side by side (the two kernel files take ~2.5 minutes each), then one link
+    import shutil
     import tempfile
     cflags = [f for f in flags if f != "-shared"]
     with tempfile.TemporaryDirectory(prefix="mtsamd_build_") as tmp:
+        # Compile a SNAPSHOT of the sources: hipcc reads a translation unit twice (host and device pass, minutes apart), so a file
+        # edited while the build runs would give a binary that matches neither tree -- and whose build id claims the old one.  The
+        # snapshot keeps the tree's relative layout (csrc includes "../../include/mtsamd.h") and is checked against the id.
+        snap_csrc = os.path.join(tmp, "pkg", "csrc")
+        os.makedirs(os.path.join(tmp, "include"))
+        shutil.copytree(CSRC, snap_csrc)
+        shutil.copy(os.path.join(ROOT, "include", "mtsamd.h"), os.path.join(tmp, "include", "mtsamd.h"))
+        if _buildid.tree_build_id(flags + extra, csrc=snap_csrc, include=os.path.join(tmp, "include")) != build_id:
+            raise RuntimeError("the sources changed while they were being copied; run the build again")
         jobs = []
         for f in SOURCES:
             obj = os.path.join(tmp, os.path.splitext(f)[0] + ".o")
-            cmd = [HIPCC] + cflags + list(extra) + ['-DMTSAMD_BUILD_ID="%s"' % build_id, "-x", "hip", "-c", os.path.join(CSRC, f), "-o", obj]
+            cmd = [HIPCC] + cflags + list(extra) + ['-DMTSAMD_BUILD_ID="%s"' % build_id, '-DMTSAMD_TOOLCHAIN_ID="%s"' % toolchain,
+                                                    "-x", "hip", "-c", os.path.join(snap_csrc, f), "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             jobs.append((cmd, obj, subprocess.Popen(cmd)))

@@ -1,5 +1,10 @@
 // capi.cpp -- the extern "C" entry points declared in include/mtsamd.h.
 //
+// -DMTSAMD_HOST_ONLY (tests/test_host_sanitizers.py: the host pass alone, built with AddressSanitizer + UndefinedBehaviorSanitizer):
+// everything that validates and flattens caller-owned records runs as in the product -- mts_scene_create up to the upload, mts_render
+// up to the first device call (options, passes, spiral, shard filter, film capacity) -- and every entry point that would touch the GPU
+// reports "host-only build" instead.
+//
 // mts_render mirrors SamplingIntegrator::render (/root/reference/src/librender/integrator.cpp:51-179):
 // pass / block bookkeeping on the host, one kernel launch per pass over every spiral block this shard
 // owns.  No exception crosses the boundary: errors become a non-zero status + mts_last_error().
@@ -12,6 +17,7 @@
 #include <mutex>
 #include <thread>
 #include <atomic>
+#include <signal.h>
 #include "scene_host.h"
 #include "launch.h"
 
@@ -101,6 +107,11 @@ int mts_abi_version(void) { return MTS_ABI_VERSION; }
 #define MTSAMD_BUILD_ID "unidentified...."
 #endif
 static const char g_build_id[] = "MTSAMD_BUILD_ID=" MTSAMD_BUILD_ID;   // also readable from the file without loading it (eradiate-kernel_amd/_buildid.py)
+#ifndef MTSAMD_TOOLCHAIN_ID
+#define MTSAMD_TOOLCHAIN_ID "unknown."
+#endif
+// the compiler that built it (hash of `hipcc --version`): build.py rebuilds when it changes; read from the file's bytes only
+__attribute__((used)) static const char g_toolchain_id[] = "MTSAMD_TOOLCHAIN=" MTSAMD_TOOLCHAIN_ID;
 const char *mts_build_id(void) { return g_build_id + 16; }
 const char *mts_last_error(void) { return g_error.c_str(); }
 
@@ -112,9 +123,17 @@ int mts_abi_sizeof(const char *name) {
     return -1;
 }
 
+#if defined(MTSAMD_HOST_ONLY)
+#define HOST_ONLY_STOP(what) throw std::runtime_error(std::string(what) + ": host-only build (validated, nothing launched)")
+#endif
+
 int mts_device_count(int *count) {
     API_TRY
+#if defined(MTSAMD_HOST_ONLY)
+    (void) count; HOST_ONLY_STOP("mts_device_count");
+#else
     HIP_CHECK(hipGetDeviceCount(count));
+#endif
     API_CATCH
 }
 
@@ -122,19 +141,29 @@ int mts_scene_create(const mts_scene_desc *desc, int device, mts_scene **out) {
     API_TRY
     if (!out) throw std::runtime_error("mts_scene_create: out is NULL");
     HostScene *hs = build_host_scene(desc);
+#if defined(MTSAMD_HOST_ONLY)
+    (void) device;
+    mts_scene *s = new mts_scene(); s->hs = hs;
+    s->stop_word = new uint32_t(0);
+#else
     try { upload_host_scene(*hs, device); } catch (...) { free_host_scene(hs); throw; }
     mts_scene *s = new mts_scene(); s->hs = hs;
     void *sw = nullptr;
     if (hipHostMalloc(&sw, 64, hipHostMallocDefault) != hipSuccess) { free_host_scene(hs); delete s; throw std::runtime_error("hipHostMalloc failed (stop word)"); }
     s->stop_word = (volatile uint32_t *) sw; *s->stop_word = 0;
+#endif
     *out = s;
     API_CATCH
 }
 
 int mts_scene_destroy(mts_scene *scene) {
     if (scene) {
+#if defined(MTSAMD_HOST_ONLY)
+        delete (uint32_t *) scene->stop_word;
+#else
         (void) hipSetDevice(scene->hs->device); scene->cache.release();
         if (scene->stop_word) (void) hipHostFree((void *) scene->stop_word);
+#endif
         free_host_scene(scene->hs); delete scene;
     }
     return 0;
@@ -144,6 +173,36 @@ int mts_cancel(mts_scene *scene) {
     if (!scene) { g_error = "mts_cancel: scene is NULL"; return 1; }
     scene->hs->stop.store(1);
     if (scene->stop_word) *scene->stop_word = 1;          // seen by the running kernels within a few microseconds
+    return 0;
+}
+
+// ---- the SIGINT scope (integrator_v.cpp:129-151).  The handler touches lock-free atomics, one word of pinned host memory,
+// sigaction and raise: all async-signal-safe.
+static std::atomic<mts_scene *> g_sigint_scene{nullptr};
+static struct sigaction g_sigint_prev;
+static_assert(std::atomic<int>::is_always_lock_free, "the stop flag is stored from a signal handler");
+static void mts_sigint_handler(int) {
+    mts_scene *s = g_sigint_scene.exchange(nullptr);
+    if (!s) return;
+    s->hs->stop.store(1);                                  // = mts_cancel
+    if (s->stop_word) *s->stop_word = 1;
+    (void) sigaction(SIGINT, &g_sigint_prev, nullptr);     // the previous handler sees the signal as well (Python: KeyboardInterrupt once
+    (void) raise(SIGINT);                                  // the interpreter runs again, i.e. after the render has wound down)
+}
+
+int mts_sigint_scope_enter(mts_scene *scene) {
+    if (!scene) { g_error = "mts_sigint_scope_enter: scene is NULL"; return 1; }
+    mts_scene *expected = nullptr;
+    if (!g_sigint_scene.compare_exchange_strong(expected, scene)) { g_error = "mts_sigint_scope_enter: another scope is open"; return 1; }
+    struct sigaction sa; memset(&sa, 0, sizeof(sa));
+    sa.sa_handler = mts_sigint_handler; sigemptyset(&sa.sa_mask);
+    if (sigaction(SIGINT, &sa, &g_sigint_prev) != 0) { g_sigint_scene.store(nullptr); g_error = "mts_sigint_scope_enter: sigaction failed"; return 1; }
+    return 0;
+}
+
+int mts_sigint_scope_exit(void) {
+    // a handler that ran has already put the previous one back (and emptied the slot); otherwise do it here
+    if (g_sigint_scene.exchange(nullptr)) (void) sigaction(SIGINT, &g_sigint_prev, nullptr);
     return 0;
 }
 
@@ -157,7 +216,9 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
     if (opts.shard_count < 1 || opts.shard_index < 0 || opts.shard_index >= opts.shard_count) throw std::runtime_error("mts_render: invalid shard specification");
     auto t0 = std::chrono::steady_clock::now();
     hs.stop.store(0);                                               // integrator.cpp:53
+#if !defined(MTSAMD_HOST_ONLY)
     HIP_CHECK(hipSetDevice(hs.device));
+#endif
     hipStream_t stream = (hipStream_t) opts.stream;
     const DSensor &se = hs.scene.sensor;
     // integrator.cpp:58-65
@@ -183,10 +244,16 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
     // sample_count / split samples of every pixel of the block (DBlock::sample_base); their sums meet in the film by atomics.
     size_t split = 1;
     if (se.wavefront) {
-        int cus = 0;
+        int cus = 256;
+#if !defined(MTSAMD_HOST_ONLY)
         HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, hs.device));
+#endif
         const size_t pixels = (size_t) se.crop_w * se.crop_h, target = (size_t) std::max(cus, 1) * 4096;      // four 1024-path workgroups' worth per CU
-        if (const char *sv = getenv("MTSAMD_WAVEFRONT_SPLIT")) split = (size_t) std::max(1, atoi(sv));
+        if (const char *sv = getenv("MTSAMD_WAVEFRONT_SPLIT")) {
+            char *end = nullptr; const long v = strtol(sv, &end, 10);
+            if (end == sv || *end != '\0' || v < 1) throw std::runtime_error("MTSAMD_WAVEFRONT_SPLIT must be a positive integer");
+            split = (size_t) v;
+        }
         else while (pixels * split < target && split * 2 <= total_spp && total_spp % (split * 2) == 0) split *= 2;
         if (total_spp % split != 0) throw std::runtime_error("MTSAMD_WAVEFRONT_SPLIT must divide the sample count");
     }
@@ -211,6 +278,10 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
     if (opts.film_capacity > 0 && (uint64_t) opts.film_capacity < (uint64_t) film_floats)
         throw std::runtime_error("mts_render: the film buffer holds " + std::to_string(opts.film_capacity) + " floats, this scene writes " + std::to_string(film_floats) +
                                  " (crop_width x crop_height x " + std::to_string(hs.scene.film_channels) + " channels: X, Y, Z, A, W + two per spectral bin)");
+#if defined(MTSAMD_HOST_ONLY)
+    (void) stream; (void) samples; (void) launch_spp; (void) t0; (void) stats;
+    HOST_ONLY_STOP("mts_render");
+#else
     RenderCache &rc = scene->cache;
     float *d_film = film;
     if (!opts.film_on_device) d_film = (float *) rc.get(0, film_floats * sizeof(float));
@@ -220,9 +291,13 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
     unsigned long long *d_counters = (unsigned long long *) rc.get(1, (N_COUNTERS + max_chunk) * sizeof(unsigned long long));   // [16 + b]: cost of block b of a calibration launch
     HIP_CHECK(hipMemsetAsync(d_film, 0, film_floats * sizeof(float), stream));               // hdrfilm.cpp:201-203 (storage cleared by prepare())
     HIP_CHECK(hipMemsetAsync(d_counters, 0, N_COUNTERS * sizeof(unsigned long long), stream));
+    if (const char *inj = getenv("MTSAMD_TEST_INJECT_LOST_PATH")) {   // test hook of the ring drivers' error path (volpath_flat.h, MTS_INJECT_SLOT): idle bound in ticks
+        const unsigned long long ticks = strtoull(inj, nullptr, 10);
+        if (ticks != 0ull && opts.collect_counters) HIP_CHECK(hipMemcpyAsync(d_counters + 14, &ticks, sizeof(ticks), hipMemcpyHostToDevice, stream));
+    }
     rc.events();
     hipEvent_t ev0 = rc.ev0, ev1 = rc.ev1;
-    double kernel_ms = 0.0; int launches = 0, last_variant = 0; bool timed_out = false;
+    double kernel_ms = 0.0, calibration_ms = 0.0; int launches = 0, calibration_launches = 0, last_variant = 0; bool timed_out = false;
     const float timeout = hs.integrator.timeout;
     *scene->stop_word = 0;
     if (hs.stop.load()) *scene->stop_word = 1;                      // cancel() raced the start of the render
@@ -230,6 +305,12 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
         if (hs.stop.load()) return true;
         if (timeout > 0.f && std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count() > timeout) { timed_out = true; return true; }
         return false;
+    };
+    auto throw_on_ring_stall = [](const unsigned long long *c) {    // counters[4..9]: a bounded ring wait gave up (volpath_flat.h): an error, never a hang
+        if (c[4] != 0)
+            throw std::runtime_error("render kernel: " + std::string(c[4] == 3 ? "lost path (nothing waiting, finished paths = tail" : c[4] == 1 ? "ring stall (consumer" : "ring stall (producer") + ", ring " + std::to_string(c[5]) +
+                                     ", index " + std::to_string(c[6]) + ", head " + std::to_string(c[7]) + ", tail " + std::to_string(c[8]) +
+                                     ", workgroup " + std::to_string(c[9]) + ")");
     };
     try {
         // ---- kernel variant: MTSAMD_KERNEL = nested | flat | wga256 | wga512 | wga1024 (default) | wgl1024
@@ -312,6 +393,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
                 HIP_CHECK(hipMemcpyAsync(d_counters + 15, &flag, sizeof(flag), hipMemcpyHostToDevice, stream));
                 HIP_CHECK(hipMemsetAsync(d_counters + N_COUNTERS, 0, cal.size() * sizeof(unsigned long long), stream));
                 launch(cal, cal_spp);
+                calibration_ms = kernel_ms; calibration_launches = launches; kernel_ms = 0.0; launches = 0;      // timed apart from the render (mts_stats)
                 std::vector<unsigned long long> ticks(cal.size());
                 HIP_CHECK(hipMemcpyAsync(ticks.data(), d_counters + N_COUNTERS, cal.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
                 HIP_CHECK(hipStreamSynchronize(stream));
@@ -323,8 +405,16 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
                     fprintf(stderr, "[mtsamd] block costs over %zu blocks (%u spp): min %.3g mean %.3g max %.3g ticks, max / mean %.3f\n", ticks.size(), cal_spp,
                             (double) lo, sum / (double) ticks.size(), (double) hi, (double) hi * (double) ticks.size() / sum);
                 }
-                HIP_CHECK(hipMemsetAsync(d_film, 0, film_floats * sizeof(float), stream));          // the calibration samples are not part of the image
-                HIP_CHECK(hipMemsetAsync(d_counters, 0, N_COUNTERS * sizeof(unsigned long long), stream));
+                unsigned long long diag[N_COUNTERS] = {};
+                HIP_CHECK(hipMemcpyAsync(diag, d_counters, sizeof(diag), hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));
+                throw_on_ring_stall(diag);                         // a bounded wait that gave up during calibration is an error like any other
+                // A cancel or the timeout that landed during calibration: the samples it rendered are the first of every pixel's stream --
+                // they stay as the (partial) film, as a stopped render keeps its finished samples; otherwise they are not part of the image
+                if (!should_stop()) {
+                    HIP_CHECK(hipMemsetAsync(d_film, 0, film_floats * sizeof(float), stream));
+                    HIP_CHECK(hipMemsetAsync(d_counters, 0, N_COUNTERS * sizeof(unsigned long long), stream));
+                }
             }
         }
         auto cost = [&](const DBlock &b) -> uint64_t {
@@ -358,18 +448,17 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
         unsigned long long h_counters[N_COUNTERS] = {};
         HIP_CHECK(hipMemcpyAsync(h_counters, d_counters, sizeof(h_counters), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
-        if (h_counters[4] != 0)                                      // a bounded ring wait gave up (volpath_flat.h): an error, never a hang
-            throw std::runtime_error("render kernel: " + std::string(h_counters[4] == 3 ? "lost path (lane-affine driver: nothing waiting, finished paths = tail" : h_counters[4] == 1 ? "ring stall (consumer" : "ring stall (producer") + ", ring " + std::to_string(h_counters[5]) +
-                                     ", index " + std::to_string(h_counters[6]) + ", head " + std::to_string(h_counters[7]) + ", tail " + std::to_string(h_counters[8]) +
-                                     ", workgroup " + std::to_string(h_counters[9]) + ")");
+        throw_on_ring_stall(h_counters);
         const bool cancelled = hs.stop.load() != 0;                  // render() returns !m_stop (integrator.cpp:178): a timeout alone is not a cancellation
         if (stats) {
             memset(stats, 0, sizeof(*stats));
             stats->samples = samples; stats->n_iter = h_counters[0]; stats->n_lookup = h_counters[1]; stats->n_nee_step = h_counters[2];
             stats->kernel_ms = kernel_ms; stats->kernel_launches = launches; stats->cancelled = cancelled ? 1 : 0; stats->timed_out = timed_out ? 1 : 0; stats->kernel_variant = last_variant;
+            stats->calibration_ms = calibration_ms; stats->calibration_launches = calibration_launches;
             stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
     } catch (...) { (void) hipStreamSynchronize(stream); throw; }     // nothing of this render may still be using the cached buffers
+#endif
     API_CATCH
 }
 
@@ -380,6 +469,9 @@ int mts_sample(mts_scene *scene, int32_t n, uint64_t seed_offset, const float *o
     if (n == 0) return 0;
     HostScene &hs = *scene->hs;
     if (hs.integrator.spectral) throw std::runtime_error("mts_sample: the scene was built for the spectral variant (use mts_sample_spectral: the rays carry wavelengths)");
+#if defined(MTSAMD_HOST_ONLY)
+    HOST_ONLY_STOP("mts_sample");
+#else
     HIP_CHECK(hipSetDevice(hs.device));
     DeviceBuffer<float> d_rays((size_t) 6 * n), d_rgb((size_t) 3 * n);
     DeviceBuffer<uint8_t> d_valid((size_t) n);
@@ -388,6 +480,7 @@ int mts_sample(mts_scene *scene, int32_t n, uint64_t seed_offset, const float *o
     HIP_CHECK(launch_sample(hs.scene, n, seed_offset, d_rays.p, d_rgb.p, d_valid.p, nullptr));
     HIP_CHECK(hipMemcpy(out_rgb, d_rgb.p, (size_t) 3 * n * sizeof(float), hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(out_valid, d_valid.p, (size_t) n, hipMemcpyDeviceToHost));
+#endif
     API_CATCH
 }
 
@@ -399,6 +492,9 @@ int mts_sample_spectral(mts_scene *scene, int32_t n, uint64_t seed_offset, const
     if (!ox || !oy || !oz || !dx || !dy || !dz || !wavelengths || !out_spec || !out_valid) throw std::runtime_error("mts_sample_spectral: null array");
     HostScene &hs = *scene->hs;
     if (!hs.integrator.spectral) throw std::runtime_error("mts_sample_spectral: the scene was built for an rgb / mono variant (use mts_sample)");
+#if defined(MTSAMD_HOST_ONLY)
+    HOST_ONLY_STOP("mts_sample_spectral");
+#else
     HIP_CHECK(hipSetDevice(hs.device));
     DeviceBuffer<float> d_rays((size_t) 6 * n), d_wl((size_t) 4 * n), d_spec((size_t) 4 * n);
     DeviceBuffer<uint8_t> d_valid((size_t) n);
@@ -408,6 +504,7 @@ int mts_sample_spectral(mts_scene *scene, int32_t n, uint64_t seed_offset, const
     HIP_CHECK(launch_sample_spectral(hs.scene, n, seed_offset, d_rays.p, d_wl.p, d_spec.p, d_valid.p, nullptr));
     HIP_CHECK(hipMemcpy(out_spec, d_spec.p, (size_t) 4 * n * sizeof(float), hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(out_valid, d_valid.p, (size_t) n, hipMemcpyDeviceToHost));
+#endif
     API_CATCH
 }
 
@@ -415,12 +512,16 @@ int mts_sample_tea(int device, int32_t n, const uint32_t *v0, const uint32_t *v1
     API_TRY
     if (n < 0 || !v0 || !v1 || !out32 || !out64 || !out_float32) throw std::runtime_error("mts_sample_tea: invalid argument");
     if (n == 0) return 0;
+#if defined(MTSAMD_HOST_ONLY)
+    HOST_ONLY_STOP("mts_sample_tea");
+#else
     HIP_CHECK(hipSetDevice(device));
     DeviceBuffer<uint32_t> d0(n), d1(n), o32(n); DeviceBuffer<uint64_t> o64(n); DeviceBuffer<float> of(n);
     HIP_CHECK(hipMemcpy(d0.p, v0, (size_t) n * 4, hipMemcpyHostToDevice)); HIP_CHECK(hipMemcpy(d1.p, v1, (size_t) n * 4, hipMemcpyHostToDevice));
     HIP_CHECK(launch_tea(n, d0.p, d1.p, rounds, o32.p, o64.p, of.p, nullptr));
     HIP_CHECK(hipMemcpy(out32, o32.p, (size_t) n * 4, hipMemcpyDeviceToHost)); HIP_CHECK(hipMemcpy(out64, o64.p, (size_t) n * 8, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(out_float32, of.p, (size_t) n * 4, hipMemcpyDeviceToHost));
+#endif
     API_CATCH
 }
 
@@ -428,10 +529,14 @@ int mts_wavefront_sampler(int device, int32_t lanes, uint64_t seed_value, int32_
     API_TRY
     if (lanes < 0 || count < 0 || !out) throw std::runtime_error("mts_wavefront_sampler: invalid argument");
     if (lanes == 0 || count == 0) return 0;
+#if defined(MTSAMD_HOST_ONLY)
+    HOST_ONLY_STOP("mts_wavefront_sampler");
+#else
     HIP_CHECK(hipSetDevice(device));
     DeviceBuffer<float> d((size_t) lanes * count);
     HIP_CHECK(launch_wavefront_sampler(lanes, seed_value, count, d.p, nullptr));
     HIP_CHECK(hipMemcpy(out, d.p, (size_t) lanes * count * 4, hipMemcpyDeviceToHost));
+#endif
     API_CATCH
 }
 
@@ -440,7 +545,10 @@ int mts_ray_intersect(mts_scene *scene, int32_t n, const float *o, const float *
     API_TRY
     if (!scene || n < 0) throw std::runtime_error("mts_ray_intersect: invalid argument");
     if (n == 0) return 0;
-    HostScene &hs = *scene->hs;
+    HostScene &hs = *scene->hs; (void) hs;
+#if defined(MTSAMD_HOST_ONLY)
+    HOST_ONLY_STOP("mts_ray_intersect");
+#else
     HIP_CHECK(hipSetDevice(hs.device));
     DeviceBuffer<float> d_o((size_t) 3 * n), d_d((size_t) 3 * n), d_mint(n), d_maxt(n), d_t(n), d_p((size_t) 3 * n), d_n((size_t) 3 * n);
     DeviceBuffer<int32_t> d_shape(n), d_prim(n);
@@ -450,6 +558,7 @@ int mts_ray_intersect(mts_scene *scene, int32_t n, const float *o, const float *
     HIP_CHECK(hipMemcpy(out_t, d_t.p, (size_t) n * 4, hipMemcpyDeviceToHost)); HIP_CHECK(hipMemcpy(out_shape, d_shape.p, (size_t) n * 4, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(out_prim, d_prim.p, (size_t) n * 4, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(out_p, d_p.p, (size_t) 3 * n * 4, hipMemcpyDeviceToHost)); HIP_CHECK(hipMemcpy(out_n, d_n.p, (size_t) 3 * n * 4, hipMemcpyDeviceToHost));
+#endif
     API_CATCH
 }
 

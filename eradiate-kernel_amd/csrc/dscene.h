@@ -50,6 +50,9 @@ struct DMedium {
     float scale;
     int32_t sample_emitters, has_spectral_extinction, is_homogeneous;
     float max_density;
+    // RN(1 / max_density) when the kernels may divide by the majorant through it (div_by_invariant, volpath_flat.h): 0 otherwise
+    // (homogeneous media, or a majorant whose reciprocal is not safely representable)
+    float inv_max_density;
     DBBox aabb;
     // MI355X layout: when sigma_t and albedo are single-channel trilinear clamp-mode grids sharing one transform, the host also
     // uploads them interleaved, voxel by voxel {sigma_t, albedo} (padded by one voxel): the two x-neighbours of both grids are

@@ -9,6 +9,9 @@
 // (MTS_SPEC_N = 4: the spectral variant: `volpath` on the regrouping machine with 512-path workgroups, `path` per lane; launchers carry
 // the suffix _spectral).
 #include <hip/hip_runtime.h>
+#if !defined(EXP_PM_TABLES_CONST)     // measurement only: the tables of pm_log / pm_exp read from the constant address space
+#define PM_TABLES_IN_LDS 1            // pmath.h: LDS copies of the two hot lookup tables; every kernel below fills them first
+#endif
 #include "integrator_dev.h"
 #include "volpath_flat.h"
 #include "volpathmis_flat.h"
@@ -194,6 +197,7 @@ __global__ void __launch_bounds__(256, (FLAT && INTEG != NI_PATH) ? 1 : (INTEG =
         const int staged = min(sc.bvh_node_count, MTS_BVH_LDS_NODES);
 #endif
         for (int k = (int) threadIdx.x; k < staged * 8; k += (int) blockDim.x) bvh_top[k] = sc.bvh_nodes[k];
+        pm_tables_to_lds(threadIdx.x);
         __syncthreads();
         sc.bvh_lds = bvh_top; sc.bvh_lds_count = staged;
     }
@@ -306,6 +310,8 @@ __global__ void __launch_bounds__(NT, MTS_SPEC_N == 3 ? 2 : (SPEC ? 1 : 2)) rend
 // SamplingIntegrator::sample for caller-supplied rays (librender/python/integrator_v.cpp:62-78)
 __global__ void __launch_bounds__(256) sample_kernel(DScene sc, int32_t n, uint64_t seed_offset, const float *__restrict__ rays /* 6 SoA rows */,
                                                      float *__restrict__ out_rgb, uint8_t *__restrict__ out_valid) {
+    pm_tables_to_lds(threadIdx.x);
+    __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Pcg32 rng; rng.seed(sc.sensor.seed + seed_offset + (uint64_t) i, PCG32_DEFAULT_STREAM);
@@ -320,6 +326,8 @@ __global__ void __launch_bounds__(256) intersect_kernel(DScene sc, int32_t n, co
                                                         const float *__restrict__ mint, const float *__restrict__ maxt,
                                                         float *__restrict__ out_t, int32_t *__restrict__ out_shape, int32_t *__restrict__ out_prim,
                                                         float *__restrict__ out_p, float *__restrict__ out_n) {
+    pm_tables_to_lds(threadIdx.x);
+    __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     DRay ray = make_ray(f3(o + 3 * i), f3(d + 3 * i), mint[i], maxt[i]);
@@ -503,6 +511,8 @@ hipError_t launch_intersect(const DScene &sc, int32_t n, const float *o, const f
 __global__ void __launch_bounds__(256) sample_spectral_kernel(DScene sc, int32_t n, uint64_t seed_offset, const float *__restrict__ rays /* 6 SoA rows */,
                                                               const float *__restrict__ wavelengths /* 4 per ray */,
                                                               float *__restrict__ out_spec, uint8_t *__restrict__ out_valid) {
+    pm_tables_to_lds(threadIdx.x);
+    __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Pcg32 rng; rng.seed(sc.sensor.seed + seed_offset + (uint64_t) i, PCG32_DEFAULT_STREAM);

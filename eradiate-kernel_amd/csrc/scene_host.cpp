@@ -361,6 +361,15 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
             const DVolume &st = hs.volumes[m.sigma_t_volume];
             if (!st.has_max) throw std::runtime_error("max() not implemented (constvolume sigma_t in heterogeneous medium)");
             dm.max_density = dm.scale * st.max;
+            {   // the kernels divide by the majorant two or three times per tracking step: with the correctly rounded reciprocal at hand an
+                // IEEE-exact quotient is five multiply-adds instead of the ~11-instruction division sequence (div_by_invariant,
+                // volpath_flat.h).  Usable when both are normal numbers well inside the exponent range and the significand of the
+                // divisor is not all ones (the one case Markstein's correction step does not cover).
+                const uint32_t b = pm_bits(dm.max_density), e = (b >> 23) & 0xffu;
+                const float rd = 1.0f / dm.max_density;
+                const uint32_t er = (pm_bits(rd) >> 23) & 0xffu;
+                dm.inv_max_density = (dm.max_density > 0.f && e >= 67u && e <= 187u && er >= 67u && er <= 187u && (b & 0x7fffffu) != 0x7fffffu) ? rd : 0.f;
+            }
             dm.aabb = st.bbox;
         } else if (m.type != MTS_MEDIUM_HOMOGENEOUS) throw std::runtime_error("unknown medium type");
         {   // kernel fast paths that do not change a single bit of the result
@@ -506,7 +515,8 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
     if (s.sample_count <= 0) throw std::runtime_error("sampler: sample_count must be positive");
     se.sample_count = s.sample_count; se.seed = s.sampler_seed; se.medium = s.medium; se.shutter_open_time = s.shutter_open_time;
     se.wavefront = s.sampler_wavefront != 0;
-    if (se.wavefront && d->integrator.samples_per_pass >= 0 && d->integrator.samples_per_pass != s.sample_count)
+    // (mts_render clamps samples_per_pass to sample_count as integrator.cpp:58-65 does: a larger value is one pass as well)
+    if (se.wavefront && d->integrator.samples_per_pass >= 0 && d->integrator.samples_per_pass < s.sample_count)
         throw std::runtime_error("wavefront streams (mts_sensor.sampler_wavefront): samples_per_pass must cover the whole sample_count (one pass)");
     check_index(s.medium, d->medium_count, "sensor medium", true);
     if (s.type == MTS_SENSOR_PERSPECTIVE) {

@@ -66,7 +66,31 @@ enum : uint32_t { FL_ALIVE = 1, FL_VALID_RAY = 2, FL_SPEC_CHAIN = 4, FL_NEEDS_IN
 
 // Result of one free-flight sample (librender/medium.cpp:34-75); sigma_n is derived by the caller
 // (heterogeneous.cpp:46: combined - sigma_t, homogeneous.cpp:44: 0).
-struct MedStep { float t, mint; F3 p; Spec sigma_t, sigma_s, combined; uint32_t info; };
+struct MedStep { float t, mint; F3 p; Spec sigma_t, sigma_s, combined; uint32_t info; float inv_combined /* DMedium::inv_max_density */; };
+
+// x / d for a divisor whose correctly rounded reciprocal rd = RN(1 / d) is at hand (the majorant of a heterogeneous medium: a constant
+// of the medium record): q = x rd, two Markstein corrections q += RN(x - q d) rd with the remainders exact by fma.  The first makes q
+// faithful, the second correctly rounded -- the IEEE quotient, bit for bit (the host excludes divisors with an all-ones significand
+// and exponents near the ends of the range, scene_host.cpp; checked against x / d on 4 * 10^10 quotients, tests/test_pmath.py has the
+// sampled version).  Five multiply-adds instead of v_div_scale x 2, v_rcp, six fma, v_div_fmas, v_div_fixup.  rd == 0: plain division.
+// The sign of a zero quotient is the dividend's (d > 0).
+DEV float div_by_invariant(float x, float d, float rd) {
+    if (rd == 0.f) return x / d;
+    float q = x * rd;
+    float r = pm_fma(-q, d, x);
+    q = pm_fma(r, rd, q);
+    r = pm_fma(-q, d, x);
+    q = pm_fma(r, rd, q);
+    return pm_from_bits(pm_bits(q) | (pm_bits(x) & 0x80000000u));
+}
+DEV Spec div_by_invariant(Spec x, Spec d, float rd) {          // every channel of d holds the same value when rd != 0
+    if (rd == 0.f) return x / d;
+#if MTS_SPEC_N == 3
+    return f3(div_by_invariant(x.x, d.x, rd), div_by_invariant(x.y, d.x, rd), div_by_invariant(x.z, d.x, rd));
+#else
+    return spec4(div_by_invariant(x.x, d.x, rd), div_by_invariant(x.y, d.x, rd), div_by_invariant(x.z, d.x, rd), div_by_invariant(x.w, d.x, rd));
+#endif
+}
 enum : uint32_t { MI_HOMOGENEOUS = 1, MI_SPECTRAL = 2, MI_SAMPLE_EMITTERS = 4, MI_GREY = 8, MI_PHASE_SHIFT = 8 + 8 };
 
 #if defined(MTSAMD_BLOCKSTATS)
@@ -138,7 +162,8 @@ DEV MedStep medium_step(const DScene &sc, const DMedium m, const DRay &ray, floa
     maxt = pm_min(ray.maxt, maxt);
     Spec combined = m.is_homogeneous ? volume_eval(cload(sc.volumes + m.sigma_t), ray.o MTS_CXI(m.sigma_t)) * m.scale : spec_s(m.max_density);
     float mext = pick(combined, channel);
-    float sampled_t = mint + (-pm_log(1.f - sample) / mext);
+    const float inv_mext = m.is_homogeneous ? 0.f : m.inv_max_density;
+    float sampled_t = mint + div_by_invariant(-pm_log(1.f - sample), mext, inv_mext);
     bool valid_mi = active && (sampled_t <= maxt);
     mi.t = valid_mi ? sampled_t : pm_inf();
     mi.p = ray_at(ray, sampled_t);
@@ -192,6 +217,7 @@ DEV MedStep medium_step(const DScene &sc, const DMedium m, const DRay &ray, floa
         if (COUNT) MTS_SEG(cnt, 2);
     }
     mi.combined = combined;
+    mi.inv_combined = inv_mext;
     mi.info = (m.is_homogeneous ? MI_HOMOGENEOUS : 0u) | (m.has_spectral_extinction ? MI_SPECTRAL : 0u) |
               (m.sample_emitters ? MI_SAMPLE_EMITTERS : 0u) | (m.grey ? MI_GREY : 0u) | ((uint32_t) m.phase << MI_PHASE_SHIFT);
     return mi;
@@ -541,15 +567,16 @@ struct VolpathMachine {
             p.st = S_SURF;
             return;
         }
-        const bool real_scatter = is_main && !(u2 >= (grey ? mi.sigma_t.x / mi.combined.x : pick(mi.sigma_t, channel) / pick(mi.combined, channel)));
+        const bool real_scatter = is_main && !(u2 >= (grey ? div_by_invariant(mi.sigma_t.x, mi.combined.x, mi.inv_combined)
+                                                                : div_by_invariant(pick(mi.sigma_t, channel), pick(mi.combined, channel), mi.inv_combined)));
         if (!real_scatter) {
             // null collision of the main path (volpath.cpp:128-131,140-144) or a step of a walk (:322-333, :411-420)
             if (grey) {
                 if (is_main) { if (spectral) weight = weight * ((sigma_n.x * mi.combined.x) * (1.0f / sigma_n.x)); }
-                else { if (spectral) weight = weight * sigma_n.x; else weight = weight * (sigma_n.x / mi.combined.x); }
+                else { if (spectral) weight = weight * sigma_n.x; else weight = weight * div_by_invariant(sigma_n.x, mi.combined.x, mi.inv_combined); }
             } else {
                 if (is_main) { if (spectral) weight = weight * (sigma_n * pick(mi.combined, channel) / pick(sigma_n, channel)); }
-                else { if (spectral) weight = weight * sigma_n; else weight = weight * (sigma_n / mi.combined); }
+                else { if (spectral) weight = weight * sigma_n; else weight = weight * div_by_invariant(sigma_n, mi.combined, mi.inv_combined); }
             }
             if (is_nee) p.wa += mi.t;
             p.ray.o = mi.p; p.ray.mint = 0.f; p.si.t = p.si.t - mi.t;
@@ -1069,14 +1096,27 @@ static __device__ WG_BLOCK_ATTR int wg_block(const MTS_CONST_AS void *kernarg_, 
 // mts_render reports an error instead of hanging.  A slot is overwritten one lap (WG pushes through this ring) after it was written,
 // while its consumer reads it within a few instructions of its claim; a lane that ever sat between claim and read for a whole lap
 // would find a newer lap, run into that bound and fail the render loudly.  A path that never comes back for any other reason leaves
-// the finished count short: the idle wait is bounded too (MTS_IDLE_LIMIT naps in a row with every ring empty: diagnostic code 3).
+// the finished count short: the idle wait is bounded too -- by ELAPSED TIME (round 4; a nap count measured the wave's own speed, and
+// a debugger, a profiler or a throttled clock stretches another wave's long block visit but not the naps): MTS_IDLE_TICKS of the
+// constant 100 MHz clock (s_memrealtime) in a row with every ring empty -> diagnostic code 3.
 // Stopping (Integrator::cancel / timeout, or a stall) adds no exit to the claim loop (a second exit measured 4.5 % slower): the
 // first lane to raise the stop word adds 2^31 to every head, which makes every ring look empty to every wave (a count above WG is no
 // count, see the snapshot) and every pending claim fail; a wave that finds every ring empty looks at the stop word before it naps.
 #define MTS_RING_SPIN_LIMIT (1u << 22)
-#define MTS_IDLE_LIMIT (1u << 22)      // naps in a row with nothing waiting anywhere before a wave reports a lost path (never seen; about a second)
+#define MTS_IDLE_TICKS 1000000000u     // ten seconds of the 100 MHz constant clock with nothing waiting anywhere before a wave reports a lost path (never seen)
+#define MTS_INJECT_SLOT 14         // counters[14] != 0 (set by mts_render from MTSAMD_TEST_INJECT_LOST_PATH, counting kernel variants only):
+                                   // the first wave of workgroup 0 drops one hand-over, and the idle bound is that many ticks -- the
+                                   // test of the error path (tests/test_gpu_parity.py::test_lost_path_is_reported)
 #define MTS_DIAG_BASE 4            // counters[MTS_DIAG_BASE + 0..5]: code (1 consumer / 2 producer), ring, index, head, tail, workgroup
 enum : uint32_t { STOP_NONE = 0, STOP_CANCEL = 1, STOP_STALL = 2 };
+
+// One nap of an idle wave: true once the rings have looked empty for `limit` ticks in a row.  The clock is read on the first nap of
+// an idle period and on every 1024th after it (32-bit differences: the checks are ~1 ms apart, the counter wraps after 43 s).
+DEV bool wga_idle_expired(uint32_t &idle_naps, uint32_t &idle_t0, uint32_t limit) {
+    if (idle_naps++ == 0u) { idle_t0 = (uint32_t) __builtin_amdgcn_s_memrealtime(); return false; }
+    if ((idle_naps & 1023u) != 0u) return false;
+    return (uint32_t) __builtin_amdgcn_s_memrealtime() - idle_t0 > limit;
+}
 
 template <int WG>
 DEV bool wga_raise_stop(uint32_t *q_ctl, uint32_t why) {
@@ -1168,6 +1208,7 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         for (uint32_t i = tid; i < (uint32_t) WG; i += NT) q_ids[c][i] = 0xFFFFu;      // runs once: not worth 300 unrolled instructions
     }
     if (tid < 2u * B_COUNT + 2u) q_ctl[tid] = 0;
+    pm_tables_to_lds(tid);
     __syncthreads();
 #pragma unroll 1
     for (uint32_t pid0 = tid; pid0 < (uint32_t) WG; pid0 += NT) {   // ---- initialise the paths (integrator.cpp:198) and queue them
@@ -1200,7 +1241,12 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
 #if defined(MTSAMD_BLOCKSTATS)
     long long bs_t0 = clock64(); unsigned long long bs_loc[45] = {};                      // laid out like g_blockstats
 #endif
-    uint32_t poll_ticks = (tid >> 6) * 2048u, idle_naps = 0; // per wave, staggered: paces the polls of the host's stop word
+    uint32_t poll_ticks = (tid >> 6) * 2048u, idle_naps = 0, idle_t0 = 0; // per wave, staggered: paces the polls of the host's stop word
+    uint32_t idle_limit = MTS_IDLE_TICKS; bool drop_one = false;
+    if (COUNT) {                                              // error-path test hook (MTS_INJECT_SLOT): never in the production instantiation
+        const uint32_t inj = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) cload_k<WgArgs>(kernarg).counters[MTS_INJECT_SLOT]);
+        if (inj != 0u) { idle_limit = inj; drop_one = blockIdx.x == 0u && tid < 64u; }
+    }
 #pragma unroll 1
     for (;;) {
       uint32_t n = 0, h = 0, spec_slot = 0xFFFFu; int sel = 0; bool finished = false;
@@ -1241,8 +1287,8 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
                     (void) wga_raise_stop<WG>(q_ctl, STOP_CANCEL);
             }
             // a path that never comes back (a lost hand-over, see the protocol notes) would leave the finished count short for ever:
-            // after MTS_IDLE_LIMIT naps in a row with every ring empty the wave reports it (diagnostic code 3) instead
-            if (++idle_naps > MTS_IDLE_LIMIT) wga_stall<WG>(3u, B_DONE, 0u, q_ctl, cload_k<WgArgs>(kernarg).counters);
+            // after MTS_IDLE_TICKS with every ring empty the wave reports it (diagnostic code 3) instead
+            if (wga_idle_expired(idle_naps, idle_t0, idle_limit)) wga_stall<WG>(3u, B_DONE, 0u, q_ctl, cload_k<WgArgs>(kernarg).counters);
             __builtin_amdgcn_s_sleep(2);
 #if defined(MTSAMD_BLOCKSTATS)
             if (COUNT) { long long t = clock64(); bs_loc[42] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
@@ -1304,6 +1350,7 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         if (COUNT) { long long t = clock64(); bs_loc[24 + sel] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
 #endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (COUNT && drop_one && cls != B_DONE) { mine = mine && lane != 0u; drop_one = false; }      // the injected lost hand-over (test hook)
         wga_push<WG>(cls, pid, mine, q_ids, q_ctl);
 #if defined(MTSAMD_BLOCKSTATS)
         if (COUNT) { long long t = clock64(); bs_loc[43] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
@@ -1351,6 +1398,7 @@ DEV void workgroup_lanes(const MTS_CONST_AS void *kernarg, Counters &cnt) {
     const uint32_t wg_base = blockIdx.x * WG;
     if (tid < 256u) (&q_mask[0][0])[tid] = 0u;
     if (tid < 4u) q_ctl[tid] = 0u;
+    pm_tables_to_lds(tid);
     __syncthreads();
 #pragma unroll 1
     for (uint32_t pid0 = tid; pid0 < (uint32_t) WG; pid0 += NT) {   // ---- initialise the paths (integrator.cpp:198) and queue them
@@ -1365,7 +1413,7 @@ DEV void workgroup_lanes(const MTS_CONST_AS void *kernarg, Counters &cnt) {
 #if defined(MTSAMD_BLOCKSTATS)
     long long bs_t0 = clock64(); unsigned long long bs_loc[45] = {};                      // laid out like g_blockstats
 #endif
-    uint32_t poll_ticks = (tid >> 6) * 2048u, idle_naps = 0;  // poll_ticks paces the reads of the host's stop word (see driver 2)
+    uint32_t poll_ticks = (tid >> 6) * 2048u, idle_naps = 0, idle_t0 = 0;  // poll_ticks paces the reads of the host's stop word (see driver 2)
 #pragma unroll 1
     for (;;) {
         int sel = 0; bool finished = false, mine = false; uint32_t j = 0;
@@ -1388,7 +1436,7 @@ DEV void workgroup_lanes(const MTS_CONST_AS void *kernarg, Counters &cnt) {
                     if (lane == 0 && __hip_atomic_load(cload_k<WgArgs>(kernarg).stop_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
                         atomicCAS(&q_ctl[1], (uint32_t) STOP_NONE, (uint32_t) STOP_CANCEL);
                 }
-                if (++idle_naps > MTS_IDLE_LIMIT) {           // a path was lost: report instead of waiting for ever
+                if (wga_idle_expired(idle_naps, idle_t0, MTS_IDLE_TICKS)) {   // a path was lost: report instead of waiting for ever
                     if (lane == 0 && atomicCAS(&q_ctl[1], (uint32_t) STOP_NONE, (uint32_t) STOP_STALL) == STOP_NONE) {
                         unsigned long long *counters = cload_k<WgArgs>(kernarg).counters;
                         if (atomicCAS(counters + MTS_DIAG_BASE, 0ull, 3ull) == 0ull) {

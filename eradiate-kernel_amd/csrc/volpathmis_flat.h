@@ -207,14 +207,14 @@ struct VolpathMisMachine {
             update_weights(p.pn, free_flight_pdf, tr, channel, true);
         }
         if (mi.t == pm_inf()) { p.st = S_SURF; return; }                               // escaped_medium: the surface part of this iteration
-        const bool null_scatter = p.rng.next_1d() >= pick(mi.sigma_t, channel) / pick(mi.combined, channel);
+        const bool null_scatter = p.rng.next_1d() >= div_by_invariant(pick(mi.sigma_t, channel), pick(mi.combined, channel), mi.inv_combined);
         if (null_scatter) {
             if (spectral) {
-                update_weights(p.pf, sigma_n / mi.combined, sigma_n, channel, true);
+                update_weights(p.pf, div_by_invariant(sigma_n, mi.combined, mi.inv_combined), sigma_n, channel, true);
                 update_weights(p.pn, 1.0f, sigma_n, channel, true);
             } else {
                 update_weights(p.pf, sigma_n, sigma_n, channel, true);
-                update_weights(p.pn, 1.0f, sigma_n / mi.combined, channel, true);
+                update_weights(p.pn, 1.0f, div_by_invariant(sigma_n, mi.combined, mi.inv_combined), channel, true);
             }
             p.ray.o = mi.p; p.ray.mint = 0.f; p.si.t = p.si.t - mi.t;
             p.st = S_TOP;
@@ -224,7 +224,7 @@ struct VolpathMisMachine {
         const bool sample_emitters = (mi.info & MI_SAMPLE_EMITTERS) != 0;
         if (!(p.depth < max_depth)) { p.flags &= ~FL_ALIVE; p.st = S_TOP; return; }    // :197-198: the path ends at the next loop head
         if (sample_emitters) p.flags &= ~FL_SPEC_CHAIN;                                // :199
-        if (spectral) update_weights(p.pf, mi.sigma_t / mi.combined, mi.sigma_s, channel, true);
+        if (spectral) update_weights(p.pf, div_by_invariant(mi.sigma_t, mi.combined, mi.inv_combined), mi.sigma_s, channel, true);
         else update_weights(p.pf, mi.sigma_t, mi.sigma_s, channel, true);
         p.flags |= FL_VALID_RAY;
         p.ray.o = mi.p;                                                                // scattering position; ray.d stays the incident direction
@@ -290,9 +290,9 @@ struct VolpathMisMachine {
         p.ray.o = mi.p; p.ray.mint = 0.f; p.si.t = p.si.t - mi.t;
         if (spectral) {
             update_weights(p.wn, 1.f, sigma_n, channel, true);
-            update_weights(p.wu, sigma_n / mi.combined, sigma_n, channel, true);
+            update_weights(p.wu, div_by_invariant(sigma_n, mi.combined, mi.inv_combined), sigma_n, channel, true);
         } else {
-            update_weights(p.wn, 1.f, sigma_n / mi.combined, channel, true);
+            update_weights(p.wn, 1.f, div_by_invariant(sigma_n, mi.combined, mi.inv_combined), channel, true);
             update_weights(p.wu, sigma_n, sigma_n, channel, true);
         }
         if (walk_goes_on(p)) p.st = S_TOP; else nee_done<DEFER>(p, e);
@@ -589,6 +589,7 @@ DEV void volpathmis_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &
         for (uint32_t i = tid; i < (uint32_t) WG; i += NT) q_ids[c][i] = 0xFFFFu;
     }
     if (tid < 2u * B_COUNT + 2u) q_ctl[tid] = 0;
+    pm_tables_to_lds(tid);
     __syncthreads();
 #pragma unroll 1
     for (uint32_t pid0 = tid; pid0 < (uint32_t) WG; pid0 += NT) {   // ---- initialise the paths (integrator.cpp:198) and queue them
@@ -619,7 +620,12 @@ DEV void volpathmis_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         wga_push<WG>(cls, pid0, true, q_ids, q_ctl);
     }
-    uint32_t poll_ticks = (tid >> 6) * 2048u, idle_naps = 0;
+    uint32_t poll_ticks = (tid >> 6) * 2048u, idle_naps = 0, idle_t0 = 0;
+    uint32_t idle_limit = MTS_IDLE_TICKS; bool drop_one = false;
+    if (COUNT) {                                              // error-path test hook (volpath_flat.h, MTS_INJECT_SLOT)
+        const uint32_t inj = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) cload_k<WgArgs>(kernarg).counters[MTS_INJECT_SLOT]);
+        if (inj != 0u) { idle_limit = inj; drop_one = blockIdx.x == 0u && tid < 64u; }
+    }
 #pragma unroll 1
     for (;;) {
       uint32_t n = 0, h = 0, spec_slot = 0xFFFFu; int sel = 0; bool finished = false;
@@ -645,7 +651,7 @@ DEV void volpathmis_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &
                 if (lane == 0 && __hip_atomic_load(cload_k<WgArgs>(kernarg).stop_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
                     (void) wga_raise_stop<WG>(q_ctl, STOP_CANCEL);
             }
-            if (++idle_naps > MTS_IDLE_LIMIT) wga_stall<WG>(3u, B_DONE, 0u, q_ctl, cload_k<WgArgs>(kernarg).counters);   // a lost path: report, do not hang
+            if (wga_idle_expired(idle_naps, idle_t0, idle_limit)) wga_stall<WG>(3u, B_DONE, 0u, q_ctl, cload_k<WgArgs>(kernarg).counters);   // a lost path: report, do not hang
             __builtin_amdgcn_s_sleep(2);
             continue;
         }
@@ -690,6 +696,7 @@ DEV void volpathmis_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &
                 (void) wga_raise_stop<WG>(q_ctl, STOP_CANCEL);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (COUNT && drop_one && cls != B_DONE) { mine = mine && lane != 0u; drop_one = false; }      // the injected lost hand-over (test hook)
         wga_push<WG>(cls, pid, mine, q_ids, q_ctl);
     }
     __syncthreads();                                          // stopped: the unfinished pixels' samples go to the film (volpath_flat.h)

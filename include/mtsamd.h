@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MTS_ABI_VERSION 8
+#define MTS_ABI_VERSION 9
 
 /* Transform4f: row-major 4x4 matrix and its inverse transpose (transform.h:36-50). */
 typedef struct mts_transform {
@@ -257,14 +257,18 @@ typedef struct mts_stats {
     uint64_t n_iter;          /* iterations of the main integrator loop (volpath.cpp:72)         */
     uint64_t n_lookup;        /* get_scattering_coefficients calls in heterogeneous media        */
     uint64_t n_nee_step;      /* iterations of the two NEE tracking loops (volpath.cpp:282,385)  */
-    double kernel_ms;         /* device time of the render kernel(s), HIP events on the stream   */
+    double kernel_ms;         /* device time of the render launches, HIP events on the stream (the calibration launch is not in it) */
     double wall_ms;           /* host wall time of the call                                      */
-    int32_t kernel_launches;
+    int32_t kernel_launches;  /* render launches behind kernel_ms                                */
     int32_t cancelled;        /* 1 if mts_cancel stopped the render (render() == false, integrator.cpp:178) */
     int32_t timed_out;        /* 1 if the "timeout" of the integrator stopped it (should_stop(), integrator.h:143-146;
                                  like the reference, render() still returns true then)            */
     int32_t kernel_variant;   /* kernel formulation of the last launch: 0 = nested per-lane loops, 1 = per-lane state machine,
                                  10000 + P = regrouping machine on LDS rings with P paths per workgroup, 20000 + P = lane-affine driver */
+    int32_t calibration_launches; /* 0 or 1: the short launch that measures the blocks' costs before a render with more blocks than CUs
+                                     (expensive blocks first; its samples are discarded)          */
+    int32_t reserved_;
+    double calibration_ms;    /* device time of that launch                                      */
 } mts_stats;
 
 typedef struct mts_render_opts {
@@ -299,6 +303,15 @@ int  mts_render(mts_scene *scene, const mts_render_opts *opts, float *film, mts_
 
 /* Integrator::cancel */
 int  mts_cancel(mts_scene *scene);
+
+/* The SIGINT scope of the reference's Python binding (src/librender/python/integrator_v.cpp:129-151): between enter and exit a
+ * SIGINT cancels `scene`'s running render from an async-signal-safe C handler (two stores: the stop flag and the word the kernels
+ * poll), puts the previous handler back and re-raises the signal for it -- so Ctrl-C winds the render down within milliseconds,
+ * the finished samples stay on the film, and the caller's own handler (Python: KeyboardInterrupt) still sees the signal.
+ * A binding calls enter before mts_render and exit after it, on the thread that owns signal handling (Python: the main thread).
+ * One scope per process at a time: enter fails while another scope is open. */
+int  mts_sigint_scope_enter(mts_scene *scene);
+int  mts_sigint_scope_exit(void);
 
 /* SamplingIntegrator::sample for n caller-supplied rays (python binding integrator_v.cpp:62-78):
  * lane i uses a PCG32 seeded as `sampler.seed(seed_offset + i)`; inputs/outputs are host SoA arrays. */

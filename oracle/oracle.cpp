@@ -2082,8 +2082,14 @@ int oracle_bbox_ops(int n_points, const float *points, int n_boxes, const float 
 }
 float oracle_math(int fn, float x, float y) {
     switch (fn) { case 0: return pm_log(x); case 1: return pm_exp(x); case 2: { float s, c; pm_sincos(x, &s, &c); return s; }
-                  case 3: { float s, c; pm_sincos(x, &s, &c); return c; } case 4: return pm_cbrt(x); case 5: return pm_pow(x, y); }
+                  case 3: { float s, c; pm_sincos(x, &s, &c); return c; } case 4: return pm_cbrt(x); case 5: return pm_pow(x, y);
+                  // the correctly rounded routines (pmath.h: -DPM_CORRECTLY_ROUNDED, and the |x| >= 120 tail of pm_sincos)
+                  case 6: return pm_log_cr(x); case 7: return pm_exp_cr(x); case 8: { float s, c; pm_sincos_cr(x, &s, &c); return s; }
+                  case 9: { float s, c; pm_sincos_cr(x, &s, &c); return c; } case 10: return pm_cbrt_cr(x); case 11: return pm_pow_cr(x, y); }
     return 0.f;
+}
+void oracle_math_n(int fn, int64_t n, const float *x, const float *y, float *out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = oracle_math(fn, x[i], y ? y[i] : 0.f);
 }
 
 } // extern "C"

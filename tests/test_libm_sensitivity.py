@@ -1,18 +1,22 @@
-"""How far is the oracle from a build on glibc's libm?  
+"""How far is the oracle from a build on glibc's libm?  (round 3, next #1.)
 
-The oracle and the HIP kernels share csrc/pmath.h so that GPU and CPU agree bit for bit; the reference's scalar_rgb calls
-libm (enoki's scalar fallbacks).  oracle/liboracle_libm.so is the same restatement with logf / expf / sinf / cosf / cbrtf /
-powf from glibc.  A 1-ulp difference matters only where it flips a comparison (sampled_t <= maxt, the roulette test, ...)
-and desynchronises the pixel's random stream from there on; everywhere else it moves the result by ~1e-7.  This test
-measures both effects per BASELINE configuration (miniatures, 64 spp) and keeps the numbers from drifting; DESIGN.md
-section 2 quotes them.  It is a sensitivity measurement, not a parity claim about the reference binary (whose libm,
-compiler and fma contraction are unknown)."""
+The reference's scalar_rgb calls libm (enoki's scalar fallbacks); the oracle and the HIP kernels share csrc/pmath.h so that GPU
+and CPU agree bit for bit.  oracle/liboracle_libm.so is the same restatement with logf / expf / sinf / cosf / cbrtf / powf from
+glibc.  A 1-ulp difference matters where it flips a comparison (sampled_t <= maxt, the roulette test, ...) and desynchronises the
+pixel's random stream from there on.  Rounds 1-3 measured that distance (pmath.h was a ~1.5-ulp implementation: at the metric's
+1024 spp only 99.6 % (C3) / 93 % (C4) of the pixels stayed within 1e-3 of the libm build).  Round 4 removed it: pmath.h restates
+glibc's own algorithms (tests/test_pmath.py: the same bits for every argument), so on glibc 2.28 .. 2.40 the two builds render THE
+SAME FILM, which is what this file now asserts.  On another libm the one-sided bounds of the correctly rounded routines apply
+(measured with -DPM_CORRECTLY_ROUNDED against glibc 2.35: 64-spp miniatures C1 0.951 / 1.0, C2 0.998 / 1.0, C3 0.916 / 1.0, C4
+0.688 / 0.9998 bit-identical / within 1e-3; at 1024 spp C3 0.817 / 1.0, C4 0.608 / 0.990).  Still not a claim about the reference
+BINARY, whose compiler and fma contraction are unknown."""
 import importlib
 
 import numpy as np
 import pytest
 
 import tests.oracle_binding as ob
+from tests.test_pmath import GLIBC
 
 scenes = importlib.import_module("eradiate-kernel_amd.scenes")
 
@@ -22,8 +26,10 @@ CASES = {
     "C3": lambda: scenes.c3_heterogeneous(64, 64, 64, res=32),
     "C4": lambda: scenes.c4_atmosphere(64, 64, 64),
 }
-# measured here (glibc 2.35, gcc 11, -mfma -ffp-contract=off): fraction of pixels bit-identical / within 1e-3 relative
-MEASURED = {"C1": (0.389, 1.0), "C2": (0.885, 1.0), "C3": (0.144, 0.9995), "C4": (0.111, 0.9958)}
+# Lower bounds (one-sided) on the fraction of pixels bit-identical / within 1e-3 relative for a libm whose float functions are not
+# the ones pmath.h restates (there the correctly rounded routines' numbers of the module docstring are the expectation).
+SAME_LIBM = GLIBC is not None and (2, 28) <= GLIBC <= (2, 40)
+AT_LEAST = {"C1": (0.90, 0.999), "C2": (0.98, 0.999), "C3": (0.85, 0.999), "C4": (0.60, 0.998)}
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
@@ -39,7 +45,10 @@ def test_libm_build_stays_within_the_tolerance_of_the_metric(name):
     print("%s: pixels bit-identical %.4f, within 1e-3 %.4f, image mean differs by %.1e" % (name, identical, within, mean_diff))
     assert within >= 0.99                       # BASELINE.json: per-pixel radiance within 1e-3 relative
     assert mean_diff < 2e-4                     # desynchronised pixels are independent estimates of the same quantity
-    assert abs(identical - MEASURED[name][0]) < 0.1 and within >= MEASURED[name][1] - 5e-3
+    if SAME_LIBM:
+        assert identical == 1.0 and (a == b).all()          # the same film, bit for bit
+    else:
+        assert identical >= AT_LEAST[name][0] and within >= AT_LEAST[name][1]
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -54,17 +63,17 @@ def _crop(d, x, y, n=32):
 
 FULL = {"C3": lambda spp: _crop(scenes.c3_heterogeneous(512, 512, spp), 240, 300),
         "C4": lambda spp: _crop(scenes.c4_atmosphere(1024, 1024, spp), 600, 420)}
-MEASURED_1024 = {"C3": {"identical": 0.049, 1e-3: 0.9961, 1e-2: 0.9990, 3e-2: 1.0, "max_z": 0.15},
-                 "C4": {"identical": 0.104, 1e-3: 0.9297, 1e-2: 0.9932, 3e-2: 1.0, "max_z": 0.80}}
+# one-sided bounds for another libm (the correctly rounded routines against glibc 2.35 reach 0.817 / 1.0 and 0.608 / 0.990)
+MEASURED_1024 = {"C3": {"identical": 0.70, 1e-3: 0.995, 1e-2: 0.999, 3e-2: 1.0, "max_z": 0.15},
+                 "C4": {"identical": 0.50, 1e-3: 0.98, 1e-2: 0.995, 3e-2: 1.0, "max_z": 0.80}}
 
 
 @pytest.mark.parametrize("name", sorted(FULL))
 def test_libm_build_at_the_sample_count_of_the_metric(name):
-    """What "per-pixel radiance within 1e-3 relative of scalar_rgb" (BASELINE.json) means for this backend at 1024 spp.  A pixel whose
-    arithmetic never flips a comparison differs from the libm build in the last bits (median 1.4e-7 of the differing pixels); one whose
-    stream desynchronises becomes an independent estimate of the same radiance and differs by its Monte Carlo noise (relative standard
-    error of a 1024-spp pixel: 5 % on C3, 2 % on C4).  Asserted as measured, not as a looser bound: C3 99.6 % of the pixels within
-    1e-3, C4 93 % within 1e-3 and 99.3 % within 1e-2, every pixel within 3e-2 and inside the Z-test with |z| < 1."""
+    """What "per-pixel radiance within 1e-3 relative of scalar_rgb" (BASELINE.json) means for this backend at 1024 spp: on glibc
+    2.28 .. 2.40 the build on libm and the build on pmath.h render the same film bit for bit (rounds 1-3: 99.6 % / 93 % of the
+    pixels within 1e-3).  On another libm: one-sided bounds, and every pixel inside the per-pixel Z-test of the reference's render
+    tests -- a pixel whose stream desynchronises is an independent estimate of the same radiance."""
     from scipy.stats import norm
     d = FULL[name](1024)
     a = ob.OracleScene(d).render()
@@ -74,10 +83,14 @@ def test_libm_build_at_the_sample_count_of_the_metric(name):
     rel = (np.abs(la - lb) / np.maximum(np.abs(la), 1e-6)).max(-1)
     m = MEASURED_1024[name]
     identical = float((a[..., :3] == b[..., :3]).all(-1).mean())
-    assert abs(identical - m["identical"]) < 0.03, identical
+    print("%s 1024 spp: identical %.4f, within 1e-3 %.4f, 1e-2 %.4f, 3e-2 %.4f" % (name, identical, float((rel < 1e-3).mean()), float((rel < 1e-2).mean()), float((rel < 3e-2).mean())))
+    if SAME_LIBM:
+        assert (a == b).all()
+        return
+    assert identical >= m["identical"], identical
     for tol in (1e-3, 1e-2, 3e-2):
         frac = float((rel < tol).mean())
-        assert abs(frac - m[tol]) < 0.015, (tol, frac)
+        assert frac >= m[tol], (tol, frac)
     assert abs(float(la.mean()) / float(lb.mean()) - 1.0) < 1e-4
     # per-pixel variance of a 1024-spp mean from 16 independent 64-spp renders (other seeds)
     imgs = []
