@@ -46,17 +46,46 @@ def build_backend(force=False, verbose=True, extra=()):
         shutil.copy(os.path.join(ROOT, "include", "mtsamd.h"), os.path.join(tmp, "include", "mtsamd.h"))
         if _buildid.tree_build_id(flags + extra, csrc=snap_csrc, include=os.path.join(tmp, "include")) != build_id:
             raise RuntimeError("the sources changed while they were being copied; run the build again")
+        # Object cache (build/obj, git-ignored): a translation unit is recompiled only when ITS inputs changed -- its own source, every
+        # header of csrc/ and include/ (any of them may be included), the flags and the compiler.  The build id goes into capi.cpp
+        # alone (mts_build_id), so an edit of the host side costs seconds, not the minutes of the two kernel files.
+        import hashlib
+        cache = os.path.join(ROOT, "build", "obj")
+        os.makedirs(cache, exist_ok=True)
+        hh = hashlib.sha256()
+        for name in sorted(HEADERS):
+            with open(os.path.join(snap_csrc, name), "rb") as fh:
+                hh.update(name.encode() + b"\0" + fh.read())
+        with open(os.path.join(tmp, "include", "mtsamd.h"), "rb") as fh:
+            hh.update(b"mtsamd.h\0" + fh.read())
+        hh.update(("\0".join(cflags + list(extra)) + "\0" + toolchain).encode())
         jobs = []
         for f in SOURCES:
-            obj = os.path.join(tmp, os.path.splitext(f)[0] + ".o")
-            cmd = [HIPCC] + cflags + list(extra) + ['-DMTSAMD_BUILD_ID="%s"' % build_id, '-DMTSAMD_TOOLCHAIN_ID="%s"' % toolchain,
-                                                    "-x", "hip", "-c", os.path.join(snap_csrc, f), "-o", obj]
+            ids = ['-DMTSAMD_BUILD_ID="%s"' % build_id, '-DMTSAMD_TOOLCHAIN_ID="%s"' % toolchain] if f == "capi.cpp" else []
+            h = hh.copy()
+            with open(os.path.join(snap_csrc, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+            h.update(" ".join(ids).encode())
+            obj = os.path.join(cache, "%s.%s.o" % (os.path.splitext(f)[0], h.hexdigest()[:20]))
+            if os.path.exists(obj) and not force:
+                jobs.append((None, obj, None))
+                continue
+            cmd = [HIPCC] + cflags + list(extra) + ids + ["-x", "hip", "-c", os.path.join(snap_csrc, f), "-o", obj + ".tmp"]
             if verbose:
                 print(" ".join(cmd), flush=True)
             jobs.append((cmd, obj, subprocess.Popen(cmd)))
-        failed = [cmd for cmd, _, proc in jobs if proc.wait() != 0]
+        failed = [cmd for cmd, _, proc in jobs if proc is not None and proc.wait() != 0]
         if failed:
             raise subprocess.CalledProcessError(1, failed[0])
+        for cmd, obj, proc in jobs:
+            if proc is not None:
+                os.replace(obj + ".tmp", obj)
+        # keep the cache small: the newest few objects per translation unit
+        for f in SOURCES:
+            stem = os.path.splitext(f)[0] + "."
+            old = sorted((os.path.join(cache, n) for n in os.listdir(cache) if n.startswith(stem) and n.endswith(".o")), key=os.path.getmtime)
+            for path in old[:-4]:
+                os.remove(path)
         link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + [obj for _, obj, _ in jobs] + ["-o", LIB]
         if verbose:
             print(" ".join(link), flush=True)

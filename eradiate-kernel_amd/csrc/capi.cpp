@@ -33,8 +33,8 @@ static thread_local std::string g_error;
 // renders of one scene (passes, sensors swept by the caller, benchmark steps) pays for hipMalloc / hipFree -- which synchronise
 // the device -- once.  Guarded by render_mutex.
 struct RenderCache {
-    void *ptr[4] = { nullptr, nullptr, nullptr, nullptr };         // 0: film (host-film renders), 1: counters, 2: blocks, 3: workspace
-    size_t cap[4] = { 0, 0, 0, 0 };
+    void *ptr[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };   // 0: film (host-film renders), 1: counters, 2: blocks, 3: workspace, 4: tile table
+    size_t cap[5] = { 0, 0, 0, 0, 0 };
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void *get(int k, size_t bytes) {
         bytes = std::max<size_t>(bytes, 16);
@@ -50,7 +50,7 @@ struct RenderCache {
         if (!ev0) { if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) throw std::runtime_error("hipEventCreate failed"); }
     }
     void release() {
-        for (int k = 0; k < 4; ++k) if (ptr[k]) { (void) hipFree(ptr[k]); ptr[k] = nullptr; cap[k] = 0; }
+        for (int k = 0; k < 5; ++k) if (ptr[k]) { (void) hipFree(ptr[k]); ptr[k] = nullptr; cap[k] = 0; }
         if (ev0) { (void) hipEventDestroy(ev0); ev0 = nullptr; }
         if (ev1) { (void) hipEventDestroy(ev1); ev1 = nullptr; }
     }
@@ -286,9 +286,8 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
     float *d_film = film;
     if (!opts.film_on_device) d_film = (float *) rc.get(0, film_floats * sizeof(float));
     constexpr int N_COUNTERS = 16;                                   // [0..2] loop counters, [4..9] ring-stall record (volpath_flat.h, MTS_DIAG_BASE), [15] cost-recording flag
-    size_t max_chunk = 0;
-    for (const auto &pb : pass_blocks) max_chunk = std::max(max_chunk, pb.size());
-    unsigned long long *d_counters = (unsigned long long *) rc.get(1, (N_COUNTERS + max_chunk) * sizeof(unsigned long long));   // [16 + b]: cost of block b of a calibration launch
+    // [16 + s]: cost of tile slot s of a calibration launch (16 pixels per tile: block_size^2 / 16 slots per block of the first chunk)
+    unsigned long long *d_counters = (unsigned long long *) rc.get(1, (N_COUNTERS + std::max<size_t>(1, pass_blocks[0].size()) * ((size_t) block_size * block_size / 16u + 1u)) * sizeof(unsigned long long));
     HIP_CHECK(hipMemsetAsync(d_film, 0, film_floats * sizeof(float), stream));               // hdrfilm.cpp:201-203 (storage cleared by prepare())
     HIP_CHECK(hipMemsetAsync(d_counters, 0, N_COUNTERS * sizeof(unsigned long long), stream));
     if (const char *inj = getenv("MTSAMD_TEST_INJECT_LOST_PATH")) {   // test hook of the ring drivers' error path (volpath_flat.h, MTS_INJECT_SLOT): idle bound in ticks
@@ -349,15 +348,23 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
         if (const char *tv = getenv("MTSAMD_WG_THREADS")) wg_threads = atoi(tv);
         last_variant = variant;
 
-        // one launch over `blocks` with `spp` samples per pixel, watched for cancel() / the timeout (which reach the kernel through the stop word)
-        auto launch = [&](const std::vector<DBlock> &blocks, uint32_t spp) {
+        // one launch over `blocks` with `spp` samples per pixel, watched for cancel() / the timeout (which reach the kernel through the stop word).
+        // `tiles`: the cost-sorted tile table of the regrouping kernels (volpath_flat.h, WgArgs::tiles), or empty: one workgroup per
+        // run of a block's Morton order.
+        auto launch = [&](const std::vector<DBlock> &blocks, uint32_t spp, const std::vector<uint32_t> &tiles) {
             DBlock *d_blocks = (DBlock *) rc.get(2, blocks.size() * sizeof(DBlock));
             HIP_CHECK(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(DBlock), hipMemcpyHostToDevice, stream));
+            uint32_t *d_tiles = nullptr;
+            if (!tiles.empty()) {
+                d_tiles = (uint32_t *) rc.get(4, tiles.size() * sizeof(uint32_t));
+                HIP_CHECK(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            }
+            const uint64_t paths = tiles.empty() ? (uint64_t) blocks.size() * block_size * block_size : (uint64_t) tiles.size() * 16u;
             HIP_CHECK(hipEventRecord(ev0, stream));
-            float *d_ws = (float *) rc.get(3, render_workspace_floats((uint32_t) blocks.size(), block_size, variant) * sizeof(float));
+            float *d_ws = (float *) rc.get(3, render_workspace_floats(paths, variant) * sizeof(float));
             HIP_CHECK((hs.integrator.spectral ? launch_render_spectral : launch_render)(
                           hs.scene, d_blocks, (uint32_t) blocks.size(), block_size, spp, d_film, d_counters,
-                          opts.collect_counters != 0, variant, wg_threads, d_ws, (const uint32_t *) scene->stop_word, stream));
+                          opts.collect_counters != 0, variant, wg_threads, d_ws, (const uint32_t *) scene->stop_word, d_tiles, (uint32_t) tiles.size(), stream));
             HIP_CHECK(hipEventRecord(ev1, stream));
             for (;;) {
                 hipError_t q = hipEventQuery(ev1);
@@ -370,45 +377,99 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             kernel_ms += ms; ++launches;
         };
 
-        // ---- Expensive blocks first.  A launch with more workgroups than the GPU holds at once runs them in rounds, in array order, and
-        // the blocks of a scene differ in cost (the horizon of an atmosphere costs a multiple of its zenith): in spiral order the tail of
-        // the launch waits for whichever expensive block happened to start last -- 27 % of the C4 render (measured: the same job cut
-        // into 8 passes, i.e. 8 x as many, shorter workgroups: 283 -> 361 Msamples/s).  So the regrouping kernels first render a few
-        // samples per pixel with the workgroups' residence times recorded (kernels.hip, record_block_cost; < 0.5 % of the job,
-        // results discarded -- the film is cleared again), and every launch then starts its blocks by descending cost (longest
-        // processing time first).  Which pixel receives which samples does not depend on the order of the blocks: same film.
-        std::vector<std::pair<uint64_t, uint64_t>> cost_of;      // (block position, ticks), sorted by position
+        // ---- Workgroups of equal-cost pixels, expensive ones first.
+        // (a) A launch with more workgroups than the GPU holds at once runs them in rounds, in array order, and the blocks of a scene
+        //     differ in cost (the horizon of an atmosphere costs a multiple of its zenith): in spiral order the tail of the launch waited
+        //     for whichever expensive block happened to start last (round 3: C4 278 -> 412 Msamples/s by starting expensive blocks first).
+        // (b) INSIDE a spatial block the costs differ as well -- steeply where they are highest -- and a path renders ONE pixel (that is
+        //     what makes the random streams those of scalar_rgb): the cheap pixels of a workgroup finish early, and for the rest of its
+        //     life the workgroup's 16 waves share a fraction of its 1024 paths (measured on C4: four fifths of the paths finished at the
+        //     snapshots of idle waves; waves idle 21 % of their time at 256 and at 2048 spp alike -- profiles/r04_ab_experiments.log).
+        // So the regrouping kernels first render a few samples per pixel with every path adding the time at which it finished to the
+        // cost of its TILE (16 Morton-consecutive pixels: a 4 x 4 square; < 0.5 % of the job, results discarded -- the film is cleared
+        // again); the tiles of every launch are then sorted by descending cost and cut into workgroups: a workgroup holds pixels of
+        // equal cost, whose paths finish together, and the expensive workgroups start first (longest processing time first).  Which
+        // pixel receives which samples does not depend on where its path runs (the stream is seeded by block id and Morton index): same film.
+        const uint32_t ppb = block_size * block_size, tiles_per_block = ppb / 16u;
+        int lpt_mode = -1;
+        std::vector<std::pair<uint64_t, uint32_t>> cost_index;   // (block position, index of its first tile in `tile_cost`), sorted by position
+        std::vector<uint64_t> tile_cost;
+        auto pos = [](const DBlock &b) { return ((uint64_t) (uint32_t) b.ox << 32) | (uint32_t) b.oy; };
         {
             int cu_count = 0;
             HIP_CHECK(hipDeviceGetAttribute(&cu_count, hipDeviceAttributeMultiprocessorCount, hs.device));
-            const char *lpt = getenv("MTSAMD_LPT");                // 0: spiral order as it is
+            const char *lpt = getenv("MTSAMD_LPT");                // 0: spiral order, one workgroup per run of a block's Morton order
+            lpt_mode = lpt ? atoi(lpt) : -1;
             const uint32_t cal_spp = (uint32_t) std::min<size_t>(4, launch_spp / 128);
-            const bool force = lpt && atoi(lpt) == 2;              // 2: calibrate whatever the block count (diagnostic, with MTSAMD_LPT_DEBUG)
-            if (variant >= 10000 && (!lpt || atoi(lpt) != 0) && cal_spp > 0 && (force || pass_blocks[0].size() > (size_t) std::max(cu_count, 1)) && !should_stop()) {
+            const bool force = lpt && (atoi(lpt) == 2 || atoi(lpt) == 3);   // 2, 3: calibrate whatever the block count (tests, diagnostics with MTSAMD_LPT_DEBUG)
+            if (variant >= 10000 && variant < 20000 && block_size <= 256 && (!lpt || atoi(lpt) != 0) && cal_spp > 0 &&
+                (force || pass_blocks[0].size() > (size_t) std::max(cu_count, 1)) && !should_stop()) {
                 std::vector<DBlock> cal(pass_blocks[0]);           // the distinct block positions of the first chunk
-                auto pos = [](const DBlock &b) { return ((uint64_t) (uint32_t) b.ox << 32) | (uint32_t) b.oy; };
                 std::sort(cal.begin(), cal.end(), [&](const DBlock &x, const DBlock &y) { return pos(x) < pos(y); });
                 cal.erase(std::unique(cal.begin(), cal.end(), [&](const DBlock &x, const DBlock &y) { return pos(x) == pos(y); }), cal.end());
+                const size_t n_cost = cal.size() * tiles_per_block;
+                HIP_CHECK(hipMemsetAsync(d_counters + N_COUNTERS, 0, n_cost * sizeof(unsigned long long), stream));
                 const unsigned long long flag = 1ull;
                 HIP_CHECK(hipMemcpyAsync(d_counters + 15, &flag, sizeof(flag), hipMemcpyHostToDevice, stream));
-                HIP_CHECK(hipMemsetAsync(d_counters + N_COUNTERS, 0, cal.size() * sizeof(unsigned long long), stream));
-                launch(cal, cal_spp);
+                launch(cal, cal_spp, {});                          // identity tiles: tile slot = block index * tiles_per_block + tile
                 calibration_ms = kernel_ms; calibration_launches = launches; kernel_ms = 0.0; launches = 0;      // timed apart from the render (mts_stats)
-                std::vector<unsigned long long> ticks(cal.size());
-                HIP_CHECK(hipMemcpyAsync(ticks.data(), d_counters + N_COUNTERS, cal.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-                HIP_CHECK(hipStreamSynchronize(stream));
-                for (size_t k = 0; k < cal.size(); ++k) cost_of.emplace_back(((uint64_t) (uint32_t) cal[k].ox << 32) | (uint32_t) cal[k].oy, ticks[k]);
-                std::sort(cost_of.begin(), cost_of.end());
-                if (getenv("MTSAMD_LPT_DEBUG")) {                  // spread of the block costs: what a static one-block-per-CU launch loses to its slowest block
-                    double sum = 0.0; unsigned long long lo = ~0ull, hi = 0;
-                    for (unsigned long long t : ticks) { sum += (double) t; lo = std::min(lo, t); hi = std::max(hi, t); }
-                    fprintf(stderr, "[mtsamd] block costs over %zu blocks (%u spp): min %.3g mean %.3g max %.3g ticks, max / mean %.3f\n", ticks.size(), cal_spp,
-                            (double) lo, sum / (double) ticks.size(), (double) hi, (double) hi * (double) ticks.size() / sum);
-                }
+                tile_cost.resize(n_cost);
+                HIP_CHECK(hipMemcpyAsync(tile_cost.data(), d_counters + N_COUNTERS, n_cost * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
                 unsigned long long diag[N_COUNTERS] = {};
                 HIP_CHECK(hipMemcpyAsync(diag, d_counters, sizeof(diag), hipMemcpyDeviceToHost, stream));
                 HIP_CHECK(hipStreamSynchronize(stream));
                 throw_on_ring_stall(diag);                         // a bounded wait that gave up during calibration is an error like any other
+                for (size_t k = 0; k < cal.size(); ++k) cost_index.emplace_back(pos(cal[k]), (uint32_t) (k * tiles_per_block));
+                // A tile's measurement is 16 pixels x 1-4 samples of a heavy-tailed quantity: too noisy to sort by (a workgroup of tiles
+                // with "equal" measurements would still spread by tens of per cent).  The cost of a pixel varies smoothly over the film, so
+                // every tile takes the mean over the 7 x 7 tiles around it (28 x 28 pixels), on the film-wide grid of 4 x 4-pixel tiles.
+                {
+                    const int gw = (se.crop_w + 3) / 4, gh = (se.crop_h + 3) / 4;
+                    std::vector<double> grid((size_t) gw * gh, -1.0);
+                    std::vector<uint32_t> where(tile_cost.size(), 0xFFFFFFFFu);      // tile slot -> grid cell
+                    for (size_t k = 0; k < cal.size(); ++k)
+                        for (uint32_t t = 0; t < tiles_per_block; ++t) {
+                            uint32_t x0 = 0, y0 = 0;
+                            for (uint32_t bit = 0; bit < 16; ++bit) { x0 |= (((16u * t) >> (2 * bit)) & 1u) << bit; y0 |= (((16u * t) >> (2 * bit + 1)) & 1u) << bit; }
+                            if ((int) x0 >= cal[k].sx || (int) y0 >= cal[k].sy) continue;
+                            const int gx = (cal[k].ox - se.crop_x + (int) x0) / 4, gy = (cal[k].oy - se.crop_y + (int) y0) / 4;
+                            if (gx < 0 || gy < 0 || gx >= gw || gy >= gh) continue;
+                            grid[(size_t) gy * gw + gx] = (double) tile_cost[k * tiles_per_block + t];
+                            where[k * tiles_per_block + t] = (uint32_t) ((size_t) gy * gw + gx);
+                        }
+                    // summed-area table over the cells that hold a measurement
+                    std::vector<double> sat((size_t) (gw + 1) * (gh + 1), 0.0), cnt((size_t) (gw + 1) * (gh + 1), 0.0);
+                    for (int y = 0; y < gh; ++y)
+                        for (int x = 0; x < gw; ++x) {
+                            const double v = grid[(size_t) y * gw + x];
+                            const size_t i = (size_t) (y + 1) * (gw + 1) + (x + 1);
+                            sat[i] = (v >= 0.0 ? v : 0.0) + sat[i - 1] + sat[i - (gw + 1)] - sat[i - (gw + 1) - 1];
+                            cnt[i] = (v >= 0.0 ? 1.0 : 0.0) + cnt[i - 1] + cnt[i - (gw + 1)] - cnt[i - (gw + 1) - 1];
+                        }
+                    const int R = 3;
+                    for (size_t sl = 0; sl < tile_cost.size(); ++sl) {
+                        if (where[sl] == 0xFFFFFFFFu) continue;
+                        const int x = (int) (where[sl] % (uint32_t) gw), y = (int) (where[sl] / (uint32_t) gw);
+                        const int x0 = std::max(0, x - R), x1 = std::min(gw, x + R + 1), y0 = std::max(0, y - R), y1 = std::min(gh, y + R + 1);
+                        auto box = [&](const std::vector<double> &a) { return a[(size_t) y1 * (gw + 1) + x1] - a[(size_t) y0 * (gw + 1) + x1] - a[(size_t) y1 * (gw + 1) + x0] + a[(size_t) y0 * (gw + 1) + x0]; };
+                        const double n = box(cnt);
+                        if (n > 0.0) tile_cost[sl] = (uint64_t) (box(sat) / n);
+                    }
+                }
+                if (getenv("MTSAMD_LPT_DEBUG")) {                  // spread of the costs: between blocks, and between the tiles of a block
+                    double sum = 0.0, worst_ratio = 1.0; uint64_t lo = ~0ull, hi = 0;
+                    for (size_t k = 0; k < cal.size(); ++k) {
+                        uint64_t bsum = 0, tlo = ~0ull, thi = 0;
+                        for (uint32_t t = 0; t < tiles_per_block; ++t) { const uint64_t c = tile_cost[k * tiles_per_block + t]; bsum += c; if (c) { tlo = std::min(tlo, c); thi = std::max(thi, c); } }
+                        sum += (double) bsum; lo = std::min(lo, bsum); hi = std::max(hi, bsum);
+                        if (thi && tlo != ~0ull) worst_ratio = std::max(worst_ratio, (double) thi / (double) tlo);
+                    }
+                    size_t odd = 0;
+                    for (size_t k = 0; k < tile_cost.size(); ++k) if (tile_cost[k] >> 62) { if (odd < 8) fprintf(stderr, "[mtsamd] odd tile cost %llx at tile slot %zu\n", (unsigned long long) tile_cost[k], k); ++odd; }
+                    fprintf(stderr, "[mtsamd] %zu of %zu tile costs have their top bits set\n", odd, tile_cost.size());
+                    fprintf(stderr, "[mtsamd] tile costs over %zu blocks x %u tiles (%u spp): block sums min %.3g mean %.3g max %.3g, max / mean %.3f; largest max / min tile cost inside one block %.2f\n",
+                            cal.size(), tiles_per_block, cal_spp, (double) lo, sum / (double) cal.size(), (double) hi, (double) hi * (double) cal.size() / sum, worst_ratio);
+                }
                 // A cancel or the timeout that landed during calibration: the samples it rendered are the first of every pixel's stream --
                 // they stay as the (partial) film, as a stopped render keeps its finished samples; otherwise they are not part of the image
                 if (!should_stop()) {
@@ -417,32 +478,52 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
                 }
             }
         }
-        auto cost = [&](const DBlock &b) -> uint64_t {
-            const uint64_t key = ((uint64_t) (uint32_t) b.ox << 32) | (uint32_t) b.oy;
-            auto it = std::lower_bound(cost_of.begin(), cost_of.end(), std::make_pair(key, (uint64_t) 0));
-            return it != cost_of.end() && it->first == key ? it->second : 0;
-        };
+        // Which of the two the measured costs are used for (profiles/r04_ab_experiments.log): the kernels that run few waves per CU -- the
+        // spectral variant (12 or 8) and volpathmis (8) -- gain from workgroups of equal-cost pixels (C5S +7 %, C5SM +47 %); the rgb
+        // volpath kernel (16 waves per CU) does not (C4 -1.4 %: its idle waves cost nothing it could use) and keeps one workgroup per
+        // spatial block, whose block record is a scalar load.  MTSAMD_LPT: 0 none, 1 whole blocks by cost, 3 tiles by cost, 2 = the
+        // default policy with the calibration forced.
+        const bool use_tiles = lpt_mode == 3 || (lpt_mode != 1 && (hs.integrator.spectral || hs.integrator.type == MTS_INTEGRATOR_VOLPATHMIS));
         for (size_t pass = 0; pass < pass_blocks.size(); ++pass) {
             if (should_stop()) break;
             std::vector<DBlock> &blocks = pass_blocks[pass];
             if (blocks.empty()) continue;
-            if (!cost_of.empty()) std::stable_sort(blocks.begin(), blocks.end(), [&](const DBlock &x, const DBlock &y) { return cost(x) > cost(y); });
-            const bool dbg = getenv("MTSAMD_LPT_DEBUG") != nullptr && variant >= 10000;      // diagnostic: residence times of the workgroups of the launch itself
-            if (dbg) {
-                const unsigned long long flag = 1ull;
-                HIP_CHECK(hipMemcpyAsync(d_counters + 15, &flag, sizeof(flag), hipMemcpyHostToDevice, stream));
-                HIP_CHECK(hipMemsetAsync(d_counters + N_COUNTERS, 0, blocks.size() * sizeof(unsigned long long), stream));
+            std::vector<uint32_t> tiles;
+            if (!cost_index.empty()) {
+                // every tile of this chunk that holds a pixel, by descending cost (ties: spiral order), cut into workgroups of `wg` paths
+                std::vector<std::pair<uint64_t, uint32_t>> order;
+                order.reserve(blocks.size() * tiles_per_block);
+                std::vector<uint64_t> bsum(blocks.size(), 0);
+                for (size_t bi = 0; bi < blocks.size(); ++bi) {
+                    const DBlock &bk = blocks[bi];
+                    auto it = std::lower_bound(cost_index.begin(), cost_index.end(), std::make_pair(pos(bk), (uint32_t) 0));
+                    const bool known = it != cost_index.end() && it->first == pos(bk);
+                    for (uint32_t t = 0; t < tiles_per_block; ++t) {
+                        // the tile's first pixel: Morton index 16 t -> (x, y) by de-interleaving the bits (the other fifteen lie right of / below it)
+                        uint32_t x0 = 0, y0 = 0;
+                        for (uint32_t bit = 0; bit < 16; ++bit) { x0 |= (((16u * t) >> (2 * bit)) & 1u) << bit; y0 |= (((16u * t) >> (2 * bit + 1)) & 1u) << bit; }
+                        if ((int) x0 >= bk.sx || (int) y0 >= bk.sy) continue;                      // a partial block at the image border
+                        const uint64_t c = known ? tile_cost[it->second + t] : 0ull;
+                        bsum[bi] += c;
+                        if (use_tiles) order.emplace_back(c, (uint32_t) ((bi << 12) | t));
+                    }
+                }
+                if (use_tiles && blocks.size() < ((size_t) 1 << 20)) {                             // 20 bits of block index
+                    std::stable_sort(order.begin(), order.end(), [](const auto &x, const auto &y) { return x.first > y.first; });
+                    const size_t wg_tiles = (size_t) (variant % 10000) / 16u;
+                    tiles.reserve((order.size() + wg_tiles - 1) / wg_tiles * wg_tiles);
+                    for (const auto &o : order) tiles.push_back(o.second);
+                    while (tiles.size() % wg_tiles) tiles.push_back(0xFFFFFFFFu);
+                } else {                                                                          // whole blocks, the expensive ones first
+                    std::vector<size_t> idx(blocks.size());
+                    for (size_t k = 0; k < idx.size(); ++k) idx[k] = k;
+                    std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return bsum[x] > bsum[y]; });
+                    std::vector<DBlock> sorted(blocks.size());
+                    for (size_t k = 0; k < idx.size(); ++k) sorted[k] = blocks[idx[k]];
+                    blocks.swap(sorted);
+                }
             }
-            launch(blocks, (uint32_t) launch_spp);
-            if (dbg) {
-                std::vector<unsigned long long> ticks(blocks.size());
-                HIP_CHECK(hipMemcpyAsync(ticks.data(), d_counters + N_COUNTERS, blocks.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-                HIP_CHECK(hipStreamSynchronize(stream));
-                double sum = 0.0; unsigned long long lo = ~0ull, hi = 0;
-                for (unsigned long long t : ticks) { sum += (double) t; lo = std::min(lo, t); hi = std::max(hi, t); }
-                fprintf(stderr, "[mtsamd] launch of %zu blocks x %zu spp: workgroup residence min %.4g mean %.4g max %.4g ticks, max / mean %.3f\n", ticks.size(), launch_spp,
-                        (double) lo, sum / (double) ticks.size(), (double) hi, (double) hi * (double) ticks.size() / sum);
-            }
+            launch(blocks, (uint32_t) launch_spp, tiles);
         }
         if (!opts.film_on_device) HIP_CHECK(hipMemcpyAsync(film, d_film, film_floats * sizeof(float), hipMemcpyDeviceToHost, stream));
         unsigned long long h_counters[N_COUNTERS] = {};

@@ -246,26 +246,16 @@ __global__ void __launch_bounds__(256, (FLAT && INTEG != NI_PATH) ? 1 : (INTEG =
     }
 }
 
-// Cost of a spiral block as the hardware sees it: the shader-clock ticks its workgroup(s) stayed resident, recorded when the host asks
-// for it (counters[MTS_COST_FLAG] != 0: the short calibration launch of mts_render, which then starts the expensive blocks first).
-#define MTS_COST_FLAG 15
-#define MTS_COST_BASE 16
-__device__ __forceinline__ void record_block_cost(unsigned long long *counters, uint32_t first_path, uint32_t block_size, long long t0) {
-    if ((threadIdx.x & 63u) == 0u && counters[MTS_COST_FLAG] != 0ull)
-        atomicMax(counters + MTS_COST_BASE + first_path / (block_size * block_size), (unsigned long long) (clock64() - t0));
-}
-
 // Asynchronous-regrouping variant of the volpath render kernel (volpath_flat.h, driver 2).  The parameter list must stay in
 // sync with WgArgs: the block functions re-read it from the kernarg segment with scalar loads.  WG paths are served by NT threads;
 // WPE = waves per SIMD the register budget is sized for (512 / WPE VGPRs).
 template <bool COUNT, int WG, int NT, int WPE>
 __global__ void __launch_bounds__(NT, WPE) render_kernel_wga(DScene sc, const DBlock *blocks, uint32_t n_blocks, uint32_t block_size,
                                                            uint32_t sample_count, float *film, float *cold_g, uint32_t cold_stride,
-                                                           unsigned long long *counters, const uint32_t *stop_flag) {
+                                                           unsigned long long *counters, const uint32_t *stop_flag,
+                                                           const uint32_t *tiles, uint32_t n_tiles) {
     Counters cnt = {};
-    const long long t0 = clock64();
     volpath_workgroup_async<COUNT, WG, NT>((const MTS_CONST_AS void *) __builtin_amdgcn_kernarg_segment_ptr(), cnt);
-    record_block_cost(counters, blockIdx.x * WG, block_size, t0);
     if (COUNT) {
         atomicAdd(counters + 0, (unsigned long long) cnt.n_iter);
         atomicAdd(counters + 1, (unsigned long long) cnt.n_lookup);
@@ -278,11 +268,10 @@ static_assert(sizeof(WgArgs) % 4 == 0, "WgArgs mirrors the kernel parameters");
 template <bool COUNT, int WG, int NT, int WPE>
 __global__ void __launch_bounds__(NT, WPE) render_kernel_wgl(DScene sc, const DBlock *blocks, uint32_t n_blocks, uint32_t block_size,
                                                            uint32_t sample_count, float *film, float *cold_g, uint32_t cold_stride,
-                                                           unsigned long long *counters, const uint32_t *stop_flag) {
+                                                           unsigned long long *counters, const uint32_t *stop_flag,
+                                                           const uint32_t *tiles, uint32_t n_tiles) {
     Counters cnt = {};
-    const long long t0 = clock64();
     workgroup_lanes<COUNT, WG, NT, VolpathLanes<COUNT, WG>>((const MTS_CONST_AS void *) __builtin_amdgcn_kernarg_segment_ptr(), cnt);
-    record_block_cost(counters, blockIdx.x * WG, block_size, t0);
     if (COUNT) {
         atomicAdd(counters + 0, (unsigned long long) cnt.n_iter);
         atomicAdd(counters + 1, (unsigned long long) cnt.n_lookup);
@@ -294,11 +283,10 @@ __global__ void __launch_bounds__(NT, WPE) render_kernel_wgl(DScene sc, const DB
 template <bool COUNT, bool SPEC, int WG, int NT>
 __global__ void __launch_bounds__(NT, MTS_SPEC_N == 3 ? 2 : (SPEC ? 1 : 2)) render_kernel_wga_mis(DScene sc, const DBlock *blocks, uint32_t n_blocks, uint32_t block_size,
                                                                uint32_t sample_count, float *film, float *cold_g, uint32_t cold_stride,
-                                                               unsigned long long *counters, const uint32_t *stop_flag) {
+                                                               unsigned long long *counters, const uint32_t *stop_flag,
+                                                               const uint32_t *tiles, uint32_t n_tiles) {
     Counters cnt = {};
-    const long long t0 = clock64();
     volpathmis_workgroup_async<COUNT, SPEC, WG, NT>((const MTS_CONST_AS void *) __builtin_amdgcn_kernarg_segment_ptr(), cnt);
-    record_block_cost(counters, blockIdx.x * WG, block_size, t0);
     if (COUNT) {
         atomicAdd(counters + 0, (unsigned long long) cnt.n_iter);
         atomicAdd(counters + 1, (unsigned long long) cnt.n_lookup);
@@ -376,11 +364,10 @@ hipError_t launch_wavefront_sampler(int32_t lanes, uint64_t seed_value, int32_t 
     return hipGetLastError();
 }
 
-size_t render_workspace_floats(uint32_t n_blocks, uint32_t block_size, int variant) {
+size_t render_workspace_floats(uint64_t threads, int variant) {
     if (variant < 256) return 0;
     if (variant >= 20000) variant -= 20000;
     if (variant >= 10000) variant -= 10000;
-    const uint64_t threads = (uint64_t) n_blocks * block_size * block_size;
     const uint64_t padded = (threads + variant - 1) / variant * variant;
     return (size_t) padded * (variant >= 256 && variant <= 4096 ? MTS_COLD_RECORD : C_COUNT) + 32;      // workgroup drivers: one 128-byte record per path
 }
@@ -389,9 +376,11 @@ size_t render_workspace_floats(uint32_t n_blocks, uint32_t block_size, int varia
 
 hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,
                          float *d_film, unsigned long long *d_counters, bool count, int variant, int wg_threads, float *d_workspace,
-                         const uint32_t *d_stop_flag, hipStream_t stream) {
+                         const uint32_t *d_stop_flag, const uint32_t *d_tiles, uint32_t n_tiles, hipStream_t stream) {
     if (n_blocks == 0) return hipSuccess;
-    const uint64_t threads = (uint64_t) n_blocks * block_size * block_size;
+    // cost-sorted tiles (regrouping kernels only): the launch covers n_tiles slots of 16 paths instead of the blocks' concatenated Morton orders
+    const uint64_t threads = d_tiles != nullptr ? (uint64_t) n_tiles * MTS_TILE_PIXELS : (uint64_t) n_blocks * block_size * block_size;
+    if (d_tiles != nullptr && variant < 10000) return hipErrorInvalidConfiguration;
     if (threads + 1024 >= ((uint64_t) 1 << 32)) return hipErrorInvalidValue;      // thread and path indices are 32 bit (mts_render launches in chunks)
 #if MTS_SPEC_N == 3
     if (variant >= 20000 && sc.integrator.type == MTS_INTEGRATOR_VOLPATH) {        // lane-affine regrouping, variant = 20000 + paths per workgroup
@@ -399,8 +388,8 @@ hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks,
         const uint32_t grid = (uint32_t) ((threads + wg - 1) / wg);
         const uint32_t stride = grid * wg;
         const int nt = wg_threads > 0 ? wg_threads : (int) wg;
-#define LAUNCH_WGL(W, T, E) do { if (count) hipLaunchKernelGGL((render_kernel_wgl<true, W, T, E>), dim3(grid), dim3(T), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag); \
-                                 else hipLaunchKernelGGL((render_kernel_wgl<false, W, T, E>), dim3(grid), dim3(T), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag); } while (0)
+#define LAUNCH_WGL(W, T, E) do { if (count) hipLaunchKernelGGL((render_kernel_wgl<true, W, T, E>), dim3(grid), dim3(T), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles); \
+                                 else hipLaunchKernelGGL((render_kernel_wgl<false, W, T, E>), dim3(grid), dim3(T), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles); } while (0)
         if (wg == 1024 && nt == 1024) LAUNCH_WGL(1024, 1024, 4);
         else return hipErrorInvalidConfiguration;
 #undef LAUNCH_WGL
@@ -411,8 +400,8 @@ hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks,
         const uint32_t grid = (uint32_t) ((threads + wg - 1) / wg);
         const uint32_t stride = grid * wg;
         const int nt = wg_threads > 0 ? wg_threads : (int) wg;
-#define LAUNCH_WGA(W, T, E) do { if (count) hipLaunchKernelGGL((render_kernel_wga<true, W, T, E>), dim3(grid), dim3(T), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag); \
-                                 else hipLaunchKernelGGL((render_kernel_wga<false, W, T, E>), dim3(grid), dim3(T), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag); } while (0)
+#define LAUNCH_WGA(W, T, E) do { if (count) hipLaunchKernelGGL((render_kernel_wga<true, W, T, E>), dim3(grid), dim3(T), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles); \
+                                 else hipLaunchKernelGGL((render_kernel_wga<false, W, T, E>), dim3(grid), dim3(T), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles); } while (0)
         if (wg == 256 && nt == 256) LAUNCH_WGA(256, 256, 4);
         else if (wg == 512 && nt == 512) LAUNCH_WGA(512, 512, 4);
         else if (wg == 512 && nt == 256) LAUNCH_WGA(512, 256, 2);
@@ -428,7 +417,7 @@ hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks,
         const uint32_t grid = (uint32_t) ((threads + wg - 1) / wg);
         const uint32_t stride = grid * wg;
         const bool spec = sc.integrator.use_spectral_mis != 0;
-#define LAUNCH_MIS(C, S, W) hipLaunchKernelGGL((render_kernel_wga_mis<C, S, W, W>), dim3(grid), dim3(W), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag)
+#define LAUNCH_MIS(C, S, W) hipLaunchKernelGGL((render_kernel_wga_mis<C, S, W, W>), dim3(grid), dim3(W), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles)
 #define LAUNCH_MIS_W(W) do { if (count) { if (spec) LAUNCH_MIS(true, true, W); else LAUNCH_MIS(true, false, W); } \
                              else { if (spec) LAUNCH_MIS(false, true, W); else LAUNCH_MIS(false, false, W); } } while (0)
         if (wg == 512) LAUNCH_MIS_W(512);
@@ -444,8 +433,8 @@ hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks,
         const uint32_t wg = (uint32_t) (variant - 10000);
         const uint32_t grid = (uint32_t) ((threads + wg - 1) / wg);
         const uint32_t stride = grid * wg;
-#define LAUNCH_WGA(W) do { if (count) hipLaunchKernelGGL((render_kernel_wga<true, W, W, 2>), dim3(grid), dim3(W), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag); \
-                           else hipLaunchKernelGGL((render_kernel_wga<false, W, W, 2>), dim3(grid), dim3(W), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag); } while (0)
+#define LAUNCH_WGA(W) do { if (count) hipLaunchKernelGGL((render_kernel_wga<true, W, W, 2>), dim3(grid), dim3(W), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles); \
+                           else hipLaunchKernelGGL((render_kernel_wga<false, W, W, 2>), dim3(grid), dim3(W), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles); } while (0)
         if (wg == 512) LAUNCH_WGA(512);
         else if (wg == 256) LAUNCH_WGA(256);
         else return hipErrorInvalidConfiguration;
@@ -458,13 +447,20 @@ hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks,
         const uint32_t stride = grid * wg;
         const bool spec = sc.integrator.use_spectral_mis != 0;
         if (wg != 256) return hipErrorInvalidConfiguration;
-#define LAUNCH_MIS(C, S) hipLaunchKernelGGL((render_kernel_wga_mis<C, S, 256, 256>), dim3(grid), dim3(256), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag)
+#define LAUNCH_MIS(C, S) hipLaunchKernelGGL((render_kernel_wga_mis<C, S, 256, 256>), dim3(grid), dim3(256), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles)
+        // spectral MIS: 101 hot dwords per path leave room for ONE 256-path workgroup per CU; served by 256 threads that is one wave per SIMD and
+        // every stall is an idle SIMD.  Default since round 4: the same 256 paths served by 512 threads (two waves per SIMD at 256 VGPRs, claims
+        // of <= 32 ids on average): C5SM 38.7 -> 42.3 Msamples/s (profiles/r04_ab_experiments.log); MTSAMD_WG_THREADS=256 gives the old launch
+        if (spec && wg_threads != 256) {
+            if (count) hipLaunchKernelGGL((render_kernel_wga_mis<true, true, 256, 512>), dim3(grid), dim3(512), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles);
+            else hipLaunchKernelGGL((render_kernel_wga_mis<false, true, 256, 512>), dim3(grid), dim3(512), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles);
+        } else
         if (count) { if (spec) LAUNCH_MIS(true, true); else LAUNCH_MIS(true, false); }
         else { if (spec) LAUNCH_MIS(false, true); else LAUNCH_MIS(false, false); }
 #undef LAUNCH_MIS
         return hipGetLastError();
     }
-    const bool flat = false; (void) wg_threads; (void) d_workspace;               // path: the per-lane kernel
+    const bool flat = false; (void) d_workspace;                                  // path: the per-lane kernel
 #endif
     const uint32_t grid = (uint32_t) ((threads + 255) / 256);
     const bool use_flat = flat && sc.integrator.type == MTS_INTEGRATOR_VOLPATH;

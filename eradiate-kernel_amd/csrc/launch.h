@@ -7,14 +7,16 @@ namespace mtsamd {
 
 // variant: 0 = nested formulation, 1 = flat per-lane state machine, 256 / 512 / 1024 = workgroup-regrouping kernel with
 // that workgroup size (needs a workspace of render_workspace_floats() floats for the cold path state)
-size_t render_workspace_floats(uint32_t n_blocks, uint32_t block_size, int variant);
+size_t render_workspace_floats(uint64_t paths, int variant);
 hipError_t launch_render(const DScene &sc, const DBlock *d_blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,
                          float *d_film, unsigned long long *d_counters, bool count, int variant, int wg_threads /* 0 = one thread per path */, float *d_workspace,
-                         const uint32_t *d_stop_flag /* host-visible word polled by the kernels: non-zero = stop */, hipStream_t stream);
+                         const uint32_t *d_stop_flag /* host-visible word polled by the kernels: non-zero = stop */,
+                         const uint32_t *d_tiles /* cost-sorted tiles of the regrouping kernels (volpath_flat.h, WgArgs::tiles) or NULL */, uint32_t n_tiles,
+                         hipStream_t stream);
 // the same for a scene of the spectral variant (kernels_spectral.hip)
 hipError_t launch_render_spectral(const DScene &sc, const DBlock *d_blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,
                                   float *d_film, unsigned long long *d_counters, bool count, int variant, int wg_threads, float *d_workspace,
-                                  const uint32_t *d_stop_flag, hipStream_t stream);
+                                  const uint32_t *d_stop_flag, const uint32_t *d_tiles, uint32_t n_tiles, hipStream_t stream);
 hipError_t launch_sample(const DScene &sc, int32_t n, uint64_t seed_offset, const float *d_rays, float *d_rgb, uint8_t *d_valid, hipStream_t stream);
 // spectral variant (kernels_spectral.hip): per-ray wavelengths (4 n floats), four-wide result
 hipError_t launch_sample_spectral(const DScene &sc, int32_t n, uint64_t seed_offset, const float *d_rays, const float *d_wavelengths, float *d_spec, uint8_t *d_valid,

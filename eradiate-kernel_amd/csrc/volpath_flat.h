@@ -140,8 +140,14 @@ typedef mts_float4 __attribute__((aligned(8))) mts_float4_a8;
 DEV void grid_fetch_pair(const MTS_GLOBAL_AS float *__restrict__ P, const GridCell &c, int nx, bool columns_equal, float &sigma_t, float &albedo) {
     const int xb = min(c.x0, nx - 2);
     const bool hi0 = c.x0 != xb, hi1 = c.x1 != xb;           // take the second voxel of the pair
+#if defined(EXP_GATHER_LOCAL)                                // measurement only (breaks parity): every gather inside the first 4 KiB of the grid, i.e.
+#define MTS_GL(i) ((i) & 511)                                // L1-resident -- how much of a tracking step is the L2 latency of its lookups?
+    mts_float4 q00 = *(const MTS_GLOBAL_AS mts_float4_a8 *) (P + 2 * MTS_GL(c.r00 + xb)), q01 = *(const MTS_GLOBAL_AS mts_float4_a8 *) (P + 2 * MTS_GL(c.r01 + xb)), q10 = q00, q11 = q01;
+    if (!columns_equal) { q10 = *(const MTS_GLOBAL_AS mts_float4_a8 *) (P + 2 * MTS_GL(c.r10 + xb)); q11 = *(const MTS_GLOBAL_AS mts_float4_a8 *) (P + 2 * MTS_GL(c.r11 + xb)); }
+#else
     mts_float4 q00 = *(const MTS_GLOBAL_AS mts_float4_a8 *) (P + 2 * (c.r00 + xb)), q01 = *(const MTS_GLOBAL_AS mts_float4_a8 *) (P + 2 * (c.r01 + xb)), q10 = q00, q11 = q01;
     if (!columns_equal) { q10 = *(const MTS_GLOBAL_AS mts_float4_a8 *) (P + 2 * (c.r10 + xb)); q11 = *(const MTS_GLOBAL_AS mts_float4_a8 *) (P + 2 * (c.r11 + xb)); }
+#endif
     sigma_t = trilerp(hi0 ? q00.z : q00.x, hi1 ? q00.z : q00.x, hi0 ? q10.z : q10.x, hi1 ? q10.z : q10.x,
                       hi0 ? q01.z : q01.x, hi1 ? q01.z : q01.x, hi0 ? q11.z : q11.x, hi1 ? q11.z : q11.x, c.w0, c.w1);
     albedo = trilerp(hi0 ? q00.w : q00.y, hi1 ? q00.w : q00.y, hi0 ? q10.w : q10.y, hi1 ? q10.w : q10.y,
@@ -354,6 +360,7 @@ typedef ColdStoreT<MTS_GLOBAL_AS float *, true> ColdStoreHbm;
 template <class Cold>
 struct PathEnvT {
     DBlock blk; uint32_t lx, ly, sample_count; MTS_GLOBAL_AS float *film; Cold cold;
+    uint32_t index;                // the pixel's Morton index inside its spiral block (seeds its stream, integrator.cpp:198)
 };
 // Scheduling classes: the block a path is waiting for
 enum { B_INT = 0, B_MED /* free-flight step of the main path */, B_SCATTER, B_WSURF, B_SURF, B_PHASE, B_NEW,
@@ -969,15 +976,19 @@ struct WgArgs {
     DScene sc; const DBlock *blocks; uint32_t n_blocks, block_size, sample_count; float *film; float *cold_g; uint32_t cold_stride;
     unsigned long long *counters;            // [0..2] loop counters, [MTS_DIAG_BASE ..] ring-stall record
     const uint32_t *stop_flag;               // host-visible word: non-zero = Integrator::cancel() / timeout (integrator.h:143-146)
+    // Cost-sorted tiles (round 4).  NULL: workgroup w renders paths w WG .. w WG + WG - 1 of the blocks' concatenated Morton orders (a
+    // workgroup sits in ONE spiral block).  Otherwise slot s = (w WG + pid) / 16 holds (block index << 12) | tile: sixteen
+    // Morton-consecutive pixels (a 4 x 4 square) of that block; 0xFFFFFFFF = padding.  mts_render sorts the tiles of a launch by the
+    // cost its calibration launch measured, so that a workgroup holds pixels of EQUAL cost and its paths finish together -- in a
+    // spatial block of an atmosphere seen by a distant sensor the costs differ by a multiple near the horizon, the cheap pixels
+    // finished early and four fifths of the paths of such a workgroup were done while the rest kept it (and its 16 waves) resident.
+    const uint32_t *tiles; uint32_t n_tiles;
 };
+#define MTS_TILE_PIXELS 16u
 
 template <int WG>
 DEV bool wg_env(const WgArgs &a, uint32_t wg_base, uint32_t pid, PathEnvT<ColdStoreHbm> &e) {     // pixel owned by path `pid`; false: outside the block
-    const uint32_t ppb = a.block_size * a.block_size;       // a multiple of WG (checked by the launcher): the workgroup sits in ONE block
-    // block_size is a power of two (mts_render rounds it up, as integrator.cpp:91-97 does): shift and mask instead of the ~30
-    // instructions of a 32-bit division, on every block visit
-    const uint32_t b = wg_base >> (uint32_t) __builtin_ctz(ppb);   // uniform
-    const uint32_t i = (wg_base & (ppb - 1u)) + pid;
+    const uint32_t ppb = a.block_size * a.block_size;       // a multiple of WG (checked by the launcher)
     e.sample_count = a.sample_count; e.film = as_global(a.film);
 #if defined(EXP_COLD_SOA)
     e.cold.base = as_global(a.cold_g) + wg_base + pid; e.cold.stride = a.cold_stride;
@@ -985,10 +996,24 @@ DEV bool wg_env(const WgArgs &a, uint32_t wg_base, uint32_t pid, PathEnvT<ColdSt
     e.cold.base = as_global(a.cold_g) + (size_t) (wg_base + pid) * MTS_COLD_RECORD; e.cold.stride = 1;
     __builtin_assume(((uintptr_t) e.cold.base & 127u) == 0);       // hipMalloc'ed base, 128-byte records: lets neighbouring fields share one wide access
 #endif
-    e.lx = e.ly = 0;
-    if (b >= a.n_blocks) return false;
-    e.blk = cload(a.blocks + b);
-    e.lx = compact_bits(i); e.ly = compact_bits(i >> 1);      // morton_decode, integrator.cpp:200
+    e.lx = e.ly = 0; e.index = 0;
+    if (a.tiles != nullptr) {                               // cost-sorted tiles: the block is per lane (vector loads; only NEW and the start need them)
+        const uint32_t slot = (wg_base + pid) / MTS_TILE_PIXELS;
+        if (slot >= a.n_tiles) return false;
+        const uint32_t ent = as_global(a.tiles)[slot];
+        if (ent == 0xFFFFFFFFu) return false;
+        const MTS_GLOBAL_AS int32_t *bp = (const MTS_GLOBAL_AS int32_t *) as_global(a.blocks + (ent >> 12));
+        e.blk.ox = bp[0]; e.blk.oy = bp[1]; e.blk.sx = bp[2]; e.blk.sy = bp[3]; e.blk.id = (uint32_t) bp[4]; e.blk.sample_base = (uint32_t) bp[5];
+        e.index = ((ent & 4095u) * MTS_TILE_PIXELS) | (pid & (MTS_TILE_PIXELS - 1u));
+    } else {
+        // one spiral block per workgroup.  block_size is a power of two (mts_render rounds it up, as integrator.cpp:91-97 does): shift
+        // and mask instead of the ~30 instructions of a 32-bit division, on every block visit
+        const uint32_t b = wg_base >> (uint32_t) __builtin_ctz(ppb);   // uniform
+        e.index = (wg_base & (ppb - 1u)) + pid;
+        if (b >= a.n_blocks) return false;
+        e.blk = cload(a.blocks + b);
+    }
+    e.lx = compact_bits(e.index); e.ly = compact_bits(e.index >> 1);      // morton_decode, integrator.cpp:200
     return e.lx < (uint32_t) e.blk.sx && e.ly < (uint32_t) e.blk.sy;
 }
 
@@ -1104,6 +1129,8 @@ static __device__ WG_BLOCK_ATTR int wg_block(const MTS_CONST_AS void *kernarg_, 
 // count, see the snapshot) and every pending claim fail; a wave that finds every ring empty looks at the stop word before it naps.
 #define MTS_RING_SPIN_LIMIT (1u << 22)
 #define MTS_IDLE_TICKS 1000000000u     // ten seconds of the 100 MHz constant clock with nothing waiting anywhere before a wave reports a lost path (never seen)
+#define MTS_COST_FLAG 15           // counters[15] != 0: a calibration launch; counters[MTS_COST_BASE + slot]: summed finish times of the paths of tile `slot`
+#define MTS_COST_BASE 16
 #define MTS_INJECT_SLOT 14         // counters[14] != 0 (set by mts_render from MTSAMD_TEST_INJECT_LOST_PATH, counting kernel variants only):
                                    // the first wave of workgroup 0 drops one hand-over, and the idle bound is that many ticks -- the
                                    // test of the error path (tests/test_gpu_parity.py::test_lost_path_is_reported)
@@ -1226,8 +1253,7 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         p.st = S_DONE;
         if (ok) {
             const uint32_t ppb = a.block_size * a.block_size;
-            const uint32_t i = (wg_base % ppb) + pid0;
-            p.rng.seed(a.sc.sensor.seed + (uint64_t) e.blk.id * ppb + i, PCG32_DEFAULT_STREAM);     // sampler.cpp:83-96
+            p.rng.seed(a.sc.sensor.seed + (uint64_t) e.blk.id * ppb + e.index, PCG32_DEFAULT_STREAM);     // sampler.cpp:83-96
             for (int k = 0; k < 5; ++k) e.cold.f(C_ACC + k) = 0.f;
             e.cold.f(C_SAMPLE) = __uint_as_float(0u);
             vm.begin_sample(p, e);
@@ -1239,7 +1265,7 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         wga_push<WG>(cls, pid0, true, q_ids, q_ctl);
     }
 #if defined(MTSAMD_BLOCKSTATS)
-    long long bs_t0 = clock64(); unsigned long long bs_loc[45] = {};                      // laid out like g_blockstats
+    long long bs_t0 = clock64(); unsigned long long bs_loc[48] = {};                      // laid out like g_blockstats
 #endif
     uint32_t poll_ticks = (tid >> 6) * 2048u, idle_naps = 0, idle_t0 = 0; // per wave, staggered: paces the polls of the host's stop word
     uint32_t idle_limit = MTS_IDLE_TICKS; bool drop_one = false;
@@ -1247,6 +1273,9 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         const uint32_t inj = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) cload_k<WgArgs>(kernarg).counters[MTS_INJECT_SLOT]);
         if (inj != 0u) { idle_limit = inj; drop_one = blockIdx.x == 0u && tid < 64u; }
     }
+    // calibration launch of mts_render (counters[MTS_COST_FLAG] != 0): every path adds the time at which it finished its pixel to its tile's cost
+    const bool record_cost = __builtin_amdgcn_readfirstlane((int) (uint32_t) cload_k<WgArgs>(kernarg).counters[MTS_COST_FLAG]) != 0;
+    const long long cost_t0 = record_cost ? clock64() : 0ll;
 #pragma unroll 1
     for (;;) {
       uint32_t n = 0, h = 0, spec_slot = 0xFFFFu; int sel = 0; bool finished = false;
@@ -1274,6 +1303,13 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         key = max(key, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) key, 0x114 /* row_shr:4 */, 0xf, 0xf, true));
         const uint32_t top_key = (uint32_t) __builtin_amdgcn_readlane((int) key, 7);
         const uint32_t best = top_key >> 4; sel = 15 - (int) (top_key & 15u);
+#if defined(MTSAMD_BLOCKSTATS)
+        if (COUNT) {      // population at snapshot time: finished paths [45], paths waiting in the rings [46], snapshots [47]
+            uint32_t waiting = 0;
+            for (int c = 0; c < NQ; ++c) waiting += (uint32_t) __builtin_amdgcn_readlane((int) avail, c);
+            bs_loc[45] += (uint32_t) __builtin_amdgcn_readlane((int) avail, B_DONE); bs_loc[46] += waiting; bs_loc[47] += 1ull;
+        }
+#endif
         if (best == 0) {
             // every path of the workgroup has finished, or the workgroup was stopped (then every ring looks empty for good)
             if ((uint32_t) __builtin_amdgcn_readlane((int) avail, B_DONE) == (uint32_t) WG || __atomic_load_n(&q_ctl[2 * B_COUNT], __ATOMIC_RELAXED) != STOP_NONE) { finished = true; break; }
@@ -1351,6 +1387,8 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
 #endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (COUNT && drop_one && cls != B_DONE) { mine = mine && lane != 0u; drop_one = false; }      // the injected lost hand-over (test hook)
+        if (record_cost && mine && cls == B_DONE)             // once per path: calibration launches only
+            atomicAdd(cload_k<WgArgs>(kernarg).counters + MTS_COST_BASE + (wg_base + pid) / MTS_TILE_PIXELS, (unsigned long long) (clock64() - cost_t0));
         wga_push<WG>(cls, pid, mine, q_ids, q_ctl);
 #if defined(MTSAMD_BLOCKSTATS)
         if (COUNT) { long long t = clock64(); bs_loc[43] += (unsigned long long) (t - bs_t0); bs_t0 = t; }
@@ -1360,7 +1398,7 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
     if (COUNT) {
         long long t = clock64(); bs_loc[44] += (unsigned long long) (t - bs_t0);
         for (int k = 0; k < 6; ++k) bs_loc[36 + k] = cnt.seg[k];
-        if (lane == 0) for (int k = 0; k < 45; ++k) atomicAdd(&g_blockstats[k], bs_loc[k]);
+        if (lane == 0) for (int k = 0; k < 48; ++k) atomicAdd(&g_blockstats[k], bs_loc[k]);
     }
 #endif
     __syncthreads();                                          // every wave has left the loop: the path state is final
@@ -1530,8 +1568,7 @@ struct VolpathLanes {
         p.st = S_DONE;
         if (ok) {
             const uint32_t ppb = a.block_size * a.block_size;
-            const uint32_t i = (wg_base % ppb) + pid0;
-            p.rng.seed(a.sc.sensor.seed + (uint64_t) e.blk.id * ppb + i, PCG32_DEFAULT_STREAM);     // sampler.cpp:83-96
+            p.rng.seed(a.sc.sensor.seed + (uint64_t) e.blk.id * ppb + e.index, PCG32_DEFAULT_STREAM);     // sampler.cpp:83-96
             for (int k = 0; k < 5; ++k) e.cold.f(C_ACC + k) = 0.f;
             e.cold.f(C_SAMPLE) = __uint_as_float(0u);
             vm.begin_sample(p, e);

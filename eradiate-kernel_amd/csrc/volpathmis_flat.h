@@ -577,7 +577,7 @@ template <bool COUNT, bool SPEC, int WG /* paths */, int NT /* threads */>
 DEV void volpathmis_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt) {
     constexpr int NQ = B_DONE;
     typedef MisHotStore<WG, SPEC> Hot;
-    static_assert((WG & (WG - 1)) == 0 && NT % 64 == 0 && WG % 64 == 0 && NT <= WG, "whole waves, power-of-two rings");
+    static_assert((WG & (WG - 1)) == 0 && NT % 64 == 0 && WG % 64 == 0 && NT <= 2 * WG, "whole waves, power-of-two rings");
     __shared__ uint32_t hot_lds[Hot::M_COUNT * WG];
     __shared__ uint16_t q_ids[NQ][WG];
     __shared__ __attribute__((aligned(8))) uint32_t q_ctl[2 * B_COUNT + 2];
@@ -608,8 +608,7 @@ DEV void volpathmis_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &
         p.st = S_DONE;
         if (ok) {
             const uint32_t ppb = a.block_size * a.block_size;
-            const uint32_t i = (wg_base % ppb) + pid0;
-            p.rng.seed(a.sc.sensor.seed + (uint64_t) e.blk.id * ppb + i, PCG32_DEFAULT_STREAM);
+            p.rng.seed(a.sc.sensor.seed + (uint64_t) e.blk.id * ppb + e.index, PCG32_DEFAULT_STREAM);
             for (int k = 0; k < 5; ++k) e.cold.f(C_ACC + k) = 0.f;
             e.cold.f(C_SAMPLE) = __uint_as_float(0u);
             vm.begin_sample(p, e);
@@ -626,6 +625,8 @@ DEV void volpathmis_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &
         const uint32_t inj = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) cload_k<WgArgs>(kernarg).counters[MTS_INJECT_SLOT]);
         if (inj != 0u) { idle_limit = inj; drop_one = blockIdx.x == 0u && tid < 64u; }
     }
+    const bool record_cost = __builtin_amdgcn_readfirstlane((int) (uint32_t) cload_k<WgArgs>(kernarg).counters[MTS_COST_FLAG]) != 0;   // calibration launch (volpath_flat.h)
+    const long long cost_t0 = record_cost ? clock64() : 0ll;
 #pragma unroll 1
     for (;;) {
       uint32_t n = 0, h = 0, spec_slot = 0xFFFFu; int sel = 0; bool finished = false;
@@ -697,6 +698,8 @@ DEV void volpathmis_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (COUNT && drop_one && cls != B_DONE) { mine = mine && lane != 0u; drop_one = false; }      // the injected lost hand-over (test hook)
+        if (record_cost && mine && cls == B_DONE)
+            atomicAdd(cload_k<WgArgs>(kernarg).counters + MTS_COST_BASE + (wg_base + pid) / MTS_TILE_PIXELS, (unsigned long long) (clock64() - cost_t0));
         wga_push<WG>(cls, pid, mine, q_ids, q_ctl);
     }
     __syncthreads();                                          // stopped: the unfinished pixels' samples go to the film (volpath_flat.h)

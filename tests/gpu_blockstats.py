@@ -27,3 +27,5 @@ print("claim / vote %5.1f %%   idle %5.1f %%   push %5.1f %%   total cycles/wave
 print("claim attempts %d, lost compare-and-swaps %d (%.1f %%)" % (out[10], out[11], 100.0 * out[11] / max(out[10], 1)))
 seg = ["lds load", "rng+free-flight sample", "grid lookup", "transmittance/decide", "top", "lds store"]
 print("MED segments (cycles / execution):", ", ".join("%s %.0f" % (n, out[36 + i] / max(out[1], 1)) for i, n in enumerate(seg)))
+if out[47]:
+    print("population at the claims' snapshots: finished paths %.1f, waiting in the rings %.1f of the workgroup's paths (%d snapshots)" % (out[45] / out[47], out[46] / out[47], out[47]))
