@@ -361,7 +361,9 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             }
             const uint64_t paths = tiles.empty() ? (uint64_t) blocks.size() * block_size * block_size : (uint64_t) tiles.size() * 16u;
             HIP_CHECK(hipEventRecord(ev0, stream));
-            float *d_ws = (float *) rc.get(3, render_workspace_floats(paths, variant) * sizeof(float));
+            // one 128-byte cold record per path in flight; volpathmis parks the path's two weight matrices in a second one (volpathmis_flat.h)
+            const size_t ws_records = hs.integrator.type == MTS_INTEGRATOR_VOLPATHMIS ? 2 : 1;
+            float *d_ws = (float *) rc.get(3, render_workspace_floats(paths, variant) * ws_records * sizeof(float));
             HIP_CHECK((hs.integrator.spectral ? launch_render_spectral : launch_render)(
                           hs.scene, d_blocks, (uint32_t) blocks.size(), block_size, spp, d_film, d_counters,
                           opts.collect_counters != 0, variant, wg_threads, d_ws, (const uint32_t *) scene->stop_word, d_tiles, (uint32_t) tiles.size(), stream));

@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(NT, WPE) render_kernel_wgl(DScene sc, const DB
 
 // The same driver for volpathmis (volpathmis_flat.h): four weight matrices per path, 512 paths per workgroup, two waves per SIMD.
 template <bool COUNT, bool SPEC, int WG, int NT>
-__global__ void __launch_bounds__(NT, MTS_SPEC_N == 3 ? 2 : (SPEC ? 1 : 2)) render_kernel_wga_mis(DScene sc, const DBlock *blocks, uint32_t n_blocks, uint32_t block_size,
+__global__ void __launch_bounds__(NT, NT <= 256 ? 2 : 1) render_kernel_wga_mis(DScene sc, const DBlock *blocks, uint32_t n_blocks, uint32_t block_size,
                                                                uint32_t sample_count, float *film, float *cold_g, uint32_t cold_stride,
                                                                unsigned long long *counters, const uint32_t *stop_flag,
                                                                const uint32_t *tiles, uint32_t n_tiles) {
@@ -448,10 +448,10 @@ hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks,
         const bool spec = sc.integrator.use_spectral_mis != 0;
         if (wg != 256) return hipErrorInvalidConfiguration;
 #define LAUNCH_MIS(C, S) hipLaunchKernelGGL((render_kernel_wga_mis<C, S, 256, 256>), dim3(grid), dim3(256), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles)
-        // spectral MIS: 101 hot dwords per path leave room for ONE 256-path workgroup per CU; served by 256 threads that is one wave per SIMD and
-        // every stall is an idle SIMD.  Default since round 4: the same 256 paths served by 512 threads (two waves per SIMD at 256 VGPRs, claims
-        // of <= 32 ids on average): C5SM 38.7 -> 42.3 Msamples/s (profiles/r04_ab_experiments.log); MTSAMD_WG_THREADS=256 gives the old launch
-        if (spec && wg_threads != 256) {
+        // 69 hot dwords per path with spectral MIS (round 4: the path's matrices are parked during walks): two 256-path workgroups per CU,
+        // 8 waves at <= 256 VGPRs.  (Before: 101 dwords, ONE workgroup per CU -- 256 threads: 38.7 Msamples/s on C5SM, 512 threads: 42.3;
+        // MTSAMD_WG_THREADS=512 still gives the latter launch.)
+        if (spec && wg_threads == 512) {
             if (count) hipLaunchKernelGGL((render_kernel_wga_mis<true, true, 256, 512>), dim3(grid), dim3(512), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles);
             else hipLaunchKernelGGL((render_kernel_wga_mis<false, true, 256, 512>), dim3(grid), dim3(512), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles);
         } else

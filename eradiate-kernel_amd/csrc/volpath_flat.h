@@ -360,6 +360,7 @@ typedef ColdStoreT<MTS_GLOBAL_AS float *, true> ColdStoreHbm;
 template <class Cold>
 struct PathEnvT {
     DBlock blk; uint32_t lx, ly, sample_count; MTS_GLOBAL_AS float *film; Cold cold;
+    MTS_GLOBAL_AS float *park;     // volpathmis: a second 128-byte record per path -- p_over_f / p_over_f_nee while an emitter-sampling walk runs (volpathmis_flat.h)
     uint32_t index;                // the pixel's Morton index inside its spiral block (seeds its stream, integrator.cpp:198)
 };
 // Scheduling classes: the block a path is waiting for
@@ -996,6 +997,7 @@ DEV bool wg_env(const WgArgs &a, uint32_t wg_base, uint32_t pid, PathEnvT<ColdSt
     e.cold.base = as_global(a.cold_g) + (size_t) (wg_base + pid) * MTS_COLD_RECORD; e.cold.stride = 1;
     __builtin_assume(((uintptr_t) e.cold.base & 127u) == 0);       // hipMalloc'ed base, 128-byte records: lets neighbouring fields share one wide access
 #endif
+    e.park = as_global(a.cold_g) + ((size_t) a.cold_stride + wg_base + pid) * MTS_COLD_RECORD;      // behind the cold records (volpathmis launches allocate it)
     e.lx = e.ly = 0; e.index = 0;
     if (a.tiles != nullptr) {                               // cost-sorted tiles: the block is per lane (vector loads; only NEW and the start need them)
         const uint32_t slot = (wg_base + pid) / MTS_TILE_PIXELS;

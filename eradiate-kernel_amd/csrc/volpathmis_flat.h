@@ -5,10 +5,13 @@
 // :330-445).  As in volpath_flat.h the three nested loops become one state machine -- a path is (mode, state) and advances one block
 // at a time: INTERSECT, MEDIUM step of the path, MEDIUM step of a walk, SCATTER (emitter sampling at a medium interaction), walk
 // SURFACE, path SURFACE + BSDF, PHASE, NEW sample -- and the workgroup regroups its paths by the block they wait for through the LDS
-// rings of volpath_flat.h (same protocol: wga_push, wga_tag_wait, wga_raise_stop).  The hot state is 67 dwords per path with the
-// four 3 x 3 matrices (43 with `use_spectral_mis = false`), so a workgroup holds 512 paths (137 KB of LDS) served by 512 threads.
-// The spectral build (MTS_SPEC_N = 4: 4 x 4 matrices, volpathmis.cpp:66-69) carries 101 dwords per path with spectral MIS -- 256 paths
-// per workgroup (103 KB), one workgroup per CU -- and 53 without (256 paths, three workgroups per CU).
+// rings of volpath_flat.h (same protocol: wga_push, wga_tag_wait, wga_raise_stop).
+// Hot state (round 4): TWO matrix slots per path, not four.  The path's pair (p_over_f, p_over_f_nee) is only read and written
+// outside a walk, the walk's pair (p_over_f_uni, p_over_f_nee of sample_emitter) only inside one, and a walk starts from a copy of
+// p_over_f (:345-346): start_walk PARKS the path's pair in a second 128-byte cold record (PathEnvT::park, HBM), the two slots then
+// hold the walk's pair, and end_nee fetches the path's pair back.  49 hot dwords per path with the 3 x 3 matrices (67 before), 69 with
+// the 4 x 4 matrices of the spectral build (MTS_SPEC_N = 4, volpathmis.cpp:66-69; 101 before): two 256-path workgroups per CU
+// instead of one, i.e. twice the paths behind the same eight waves.
 // The draws happen in the order of the nested formulation (integrator_dev.h, volpathmis_sample) -- results are bit-identical to it
 // and to the CPU restatement.  Citations are relative to /root/reference.
 #pragma once
@@ -59,6 +62,27 @@ struct VolpathMisMachine {
         p.si.t = pm_inf();
         if (pm_max(p.ray.mint, bmint) <= bmaxt) p.flags |= FL_NEEDS_INT; else p.flags &= ~FL_NEEDS_INT;
     }
+    // the parked pair: one 128-byte record per path behind the cold records, written and read by one lane as whole lines
+    template <class E> DEV static void park_put(const E &e, const W &a, const W &b) {
+        constexpr int NR = SPEC ? MTS_SPEC_N : 1;
+        for (int i = 0; i < NR; ++i) {
+            MTS_GLOBAL_AS float *pa = e.park + MTS_SPEC_N * i, *pb = e.park + MTS_SPEC_N * (NR + i);
+            pa[0] = a.r[i].x; pa[1] = a.r[i].y; pa[2] = a.r[i].z; pb[0] = b.r[i].x; pb[1] = b.r[i].y; pb[2] = b.r[i].z;
+#if MTS_SPEC_N != 3
+            pa[3] = a.r[i].w; pb[3] = b.r[i].w;
+#endif
+        }
+    }
+    template <class E> DEV static void park_get(const E &e, W &a, W &b) {
+        constexpr int NR = SPEC ? MTS_SPEC_N : 1;
+        for (int i = 0; i < NR; ++i) {
+            const MTS_GLOBAL_AS float *pa = e.park + MTS_SPEC_N * i, *pb = e.park + MTS_SPEC_N * (NR + i);
+            a.r[i].x = pa[0]; a.r[i].y = pa[1]; a.r[i].z = pa[2]; b.r[i].x = pb[0]; b.r[i].y = pb[1]; b.r[i].z = pb[2];
+#if MTS_SPEC_N != 3
+            a.r[i].w = pa[3]; b.r[i].w = pb[3];
+#endif
+        }
+    }
     DEV bool walk_goes_on(const P &p) const {                  // volpathmis.cpp:438-441
         if (SPEC) return any_nonzero(mis_weight_w(p.wu));
         return any_nonzero(p.wu.r[0]) || any_nonzero(p.wn.r[0]);
@@ -106,6 +130,7 @@ struct VolpathMisMachine {
         update_weights(p.wn, 1.0f, fval, p.channel, true);
         update_weights(p.wu, pdfv, fval, p.channel, true);
         p.res = p.res + mis_weight_w(p.wn, p.wu) * emitted;
+        park_get(e, p.pf, p.pn);                               // ... and comes back
         p.mode = M_MAIN; p.medium = __float_as_int(e.cold.f(C_SMED));
         F3 d = e.cold.get3(C_SD);
         p.ray.d = d; p.ray.d_rcp = vrcp(d);
@@ -232,6 +257,7 @@ struct VolpathMisMachine {
     }
     // ================================================================= SCATTER: emitter sampling at a medium interaction (:228-237 -> :330-356)
     template <bool DEFER, class E> DEV void start_walk(P &p, const E &e, F3 ref_p, const DirSample &ds, Spec emitter_sample_weight, Spec fval, float pdfv, bool from_medium) const {
+        park_put(e, p.pf, p.pn);                               // the path's pair leaves the hot state for the duration of the walk
         p.wn = p.pf; p.wu = p.pf;
         Spec emitter_val = emitter_sample_weight * ds.pdf;
         if (ds.pdf == 0.f) emitter_val = spec_s(0.f);
@@ -450,7 +476,7 @@ template <> struct MisClassFields<B_MEDW> {      // a walk: its two matrices and
                               store = K_RNG | K_O | K_MINT | K_MAXT | K_SIT | K_WN | K_WU | K_WA;
     static constexpr bool defer = true; };
 template <> struct MisClassFields<B_SCATTER> {
-    static constexpr uint32_t load = K_RNG | K_O | K_D | K_MINT | K_MAXT | K_SIT | K_MED | K_PF | K_WA | K_WB | K_WL,
+    static constexpr uint32_t load = K_RNG | K_O | K_D | K_MINT | K_MAXT | K_SIT | K_MED | K_PF | K_PN /* parked by start_walk */ | K_WA | K_WB | K_WL,
                               store = K_RNG | K_O | K_D | K_MINT | K_MAXT | K_SIT | K_WN | K_WU | K_WA | K_WB;
     static constexpr bool defer = true; };
 template <> struct MisClassFields<B_PHASE> {
@@ -468,7 +494,7 @@ struct MisHotStore {
 #else
            M_WL = M_SIX + 7, M_W = M_WL + 4,                    // 37
 #endif
-           M_COUNT = M_W + 4 * NW };
+           M_COUNT = M_W + 2 * NW };            // two matrix slots: A = p_over_f or the walk's p_over_f_uni, B = p_over_f_nee of the path or of the walk
     uint32_t *base;
     DEV uint32_t &u(int k) const { return base[k * WG]; }
     DEV float f(int k) const { return __uint_as_float(base[k * WG]); }
@@ -502,10 +528,10 @@ struct MisHotStore {
 #if MTS_SPEC_N != 3
         if (M & K_WL) put_spec(M_WL, p.wl);
 #endif
-        if (M & K_PF) putw(M_W, p.pf);
-        if (M & K_PN) putw(M_W + NW, p.pn);
-        if (M & K_WN) putw(M_W + 2 * NW, p.wn);
-        if (M & K_WU) putw(M_W + 3 * NW, p.wu);
+        // slot A / slot B: the path's pair outside a walk, the walk's pair inside one (a block that can hold either -- K_ALL -- picks by mode)
+        constexpr bool path_a = (M & K_PF) != 0, walk_a = (M & K_WU) != 0, path_b = (M & K_PN) != 0, walk_b = (M & K_WN) != 0;
+        if (path_a && walk_a) putw(M_W, p.mode == M_MAIN ? p.pf : p.wu); else if (path_a) putw(M_W, p.pf); else if (walk_a) putw(M_W, p.wu);
+        if (path_b && walk_b) putw(M_W + NW, p.mode == M_MAIN ? p.pn : p.wn); else if (path_b) putw(M_W + NW, p.pn); else if (walk_b) putw(M_W + NW, p.wn);
     }
     template <uint32_t M> DEV void load_m(MisPathState<SPEC> &p) const {
         p.rng.state = 0; p.rng.inc = (PCG32_DEFAULT_STREAM << 1u) | 1u;
@@ -524,8 +550,9 @@ struct MisHotStore {
 #if MTS_SPEC_N != 3
         p.wl = (M & K_WL) ? get_spec(M_WL) : spec_s(0.f);
 #endif
-        p.pf = (M & K_PF) ? getw(M_W) : mw_full<SPEC>(1.f); p.pn = (M & K_PN) ? getw(M_W + NW) : mw_full<SPEC>(1.f);
-        p.wn = (M & K_WN) ? getw(M_W + 2 * NW) : mw_full<SPEC>(1.f); p.wu = (M & K_WU) ? getw(M_W + 3 * NW) : mw_full<SPEC>(1.f);
+        // a block that may meet either pair (K_ALL) reads the two slots once; which pair they are follows from the mode, the other is never read
+        const MisWeights<SPEC> slot_a = (M & (K_PF | K_WU)) ? getw(M_W) : mw_full<SPEC>(1.f), slot_b = (M & (K_PN | K_WN)) ? getw(M_W + NW) : mw_full<SPEC>(1.f);
+        p.pf = slot_a; p.wu = slot_a; p.pn = slot_b; p.wn = slot_b;
     }
     DEV void store(const MisPathState<SPEC> &p, int cls) const { store_m<K_ALL>(p, cls); }
     DEV void load(MisPathState<SPEC> &p) const { load_m<K_ALL>(p); }
