@@ -336,14 +336,17 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             variant = (block_size * block_size) % (uint32_t) wg != 0 ? 1 : family * 10000 + wg;
         }
         if (hs.integrator.spectral && variant == 1) variant = 0;                                      // no per-lane flat kernel in the spectral build
-        // AOV channels (nbins / bins) and a sensor response function: `volpath` carries them on the regrouping machine (NEW block of
-        // volpath_flat.h); `path`, `volpathmis` and a discrete response function with repeated wavelengths stay per lane
+        // AOV channels (nbins / bins) and a sensor response function: `volpath` and (round 4) `volpathmis` carry them on the regrouping
+        // machines (their NEW blocks); `path` and a discrete response function with repeated wavelengths stay per lane
         if ((hs.scene.bin_count > 0 || hs.scene.srf >= 0) &&
-            !(variant >= 10000 && hs.integrator.type == MTS_INTEGRATOR_VOLPATH && hs.srf_lookup_by_wavelength)) variant = 0;
-        // Wavefront (gpu_*) streams carry their own PCG32 increment per (pixel, sample); the regrouping machines keep only the 64-bit state in
-        // LDS (their increment is the default stream's, a constant) and have no room for two more dwords per path, so these scenes run
-        // per lane, where the generator lives in registers: `volpath` as the flat state machine, the others nested
-        if (se.wavefront && variant >= 10000) variant = (hs.integrator.type == MTS_INTEGRATOR_VOLPATH && !hs.integrator.spectral) ? 1 : 0;
+            !(variant >= 10000 && hs.integrator.type != MTS_INTEGRATOR_PATH && hs.srf_lookup_by_wavelength)) variant = 0;
+        // Wavefront (gpu_*) streams carry their own PCG32 increment per (pixel, sample).  The regrouping machine of rgb / mono `volpath` keeps
+        // only the generator's 64-bit state in LDS and recomputes the increment on every load (round 4: wg_block's WF instantiation, 1024-path
+        // workgroups); everything else runs per lane, where the generator lives in registers: `volpath` as the flat state machine, the
+        // others nested
+        if (se.wavefront && variant >= 10000 &&
+            !(variant == 11024 && hs.integrator.type == MTS_INTEGRATOR_VOLPATH && !hs.integrator.spectral && !getenv("MTSAMD_WG_THREADS")))
+            variant = (hs.integrator.type == MTS_INTEGRATOR_VOLPATH && !hs.integrator.spectral) ? 1 : 0;
         int wg_threads = 0;                                         // MTSAMD_WG_THREADS: threads per workgroup of the wga kernels (<= paths; default = paths)
         if (const char *tv = getenv("MTSAMD_WG_THREADS")) wg_threads = atoi(tv);
         last_variant = variant;

@@ -101,6 +101,13 @@ DEV void seed_wavefront_sample(Pcg32 &rng, const DSensor &se, const DBlock &blk,
     rng.seed(sample_tea_64_u64(se.seed, L), sample_tea_64_u64(L, se.seed));
 }
 
+// the increment of that generator alone (Pcg32::seed: inc = (initseq << 1) | 1): what the regrouping kernels recompute on every load
+DEV uint64_t wavefront_increment(const DSensor &se, const DBlock &blk, uint32_t lx, uint32_t ly, uint32_t j) {
+    const uint64_t pixel = (uint64_t) (uint32_t) (blk.oy + (int) ly - se.crop_y) * (uint64_t) (uint32_t) se.crop_w + (uint64_t) (uint32_t) (blk.ox + (int) lx - se.crop_x);
+    const uint64_t L = pixel * (uint64_t) (uint32_t) se.sample_count + (uint64_t) blk.sample_base + (uint64_t) j;
+    return (sample_tea_64_u64(L, se.seed) << 1u) | 1u;
+}
+
 // What survives of a SurfaceInteraction between loop iterations: the hit distance, the hit point
 // (computed from the ray that found it), and the primitive; normals / frames / wi are rebuilt on
 // demand by complete_surface() with the same arithmetic.

@@ -249,13 +249,13 @@ __global__ void __launch_bounds__(256, (FLAT && INTEG != NI_PATH) ? 1 : (INTEG =
 // Asynchronous-regrouping variant of the volpath render kernel (volpath_flat.h, driver 2).  The parameter list must stay in
 // sync with WgArgs: the block functions re-read it from the kernarg segment with scalar loads.  WG paths are served by NT threads;
 // WPE = waves per SIMD the register budget is sized for (512 / WPE VGPRs).
-template <bool COUNT, int WG, int NT, int WPE>
+template <bool COUNT, int WG, int NT, int WPE, bool WF = false>
 __global__ void __launch_bounds__(NT, WPE) render_kernel_wga(DScene sc, const DBlock *blocks, uint32_t n_blocks, uint32_t block_size,
                                                            uint32_t sample_count, float *film, float *cold_g, uint32_t cold_stride,
                                                            unsigned long long *counters, const uint32_t *stop_flag,
                                                            const uint32_t *tiles, uint32_t n_tiles) {
     Counters cnt = {};
-    volpath_workgroup_async<COUNT, WG, NT>((const MTS_CONST_AS void *) __builtin_amdgcn_kernarg_segment_ptr(), cnt);
+    volpath_workgroup_async<COUNT, WG, NT, WF>((const MTS_CONST_AS void *) __builtin_amdgcn_kernarg_segment_ptr(), cnt);
     if (COUNT) {
         atomicAdd(counters + 0, (unsigned long long) cnt.n_iter);
         atomicAdd(counters + 1, (unsigned long long) cnt.n_lookup);
@@ -402,6 +402,11 @@ hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks,
         const int nt = wg_threads > 0 ? wg_threads : (int) wg;
 #define LAUNCH_WGA(W, T, E) do { if (count) hipLaunchKernelGGL((render_kernel_wga<true, W, T, E>), dim3(grid), dim3(T), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles); \
                                  else hipLaunchKernelGGL((render_kernel_wga<false, W, T, E>), dim3(grid), dim3(T), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles); } while (0)
+        if (sc.sensor.wavefront) {                              // gpu_* streams: the instantiation that recomputes the generator's increment (wg_block, WF)
+            if (wg != 1024 || nt != 1024) return hipErrorInvalidConfiguration;
+            if (count) hipLaunchKernelGGL((render_kernel_wga<true, 1024, 1024, 4, true>), dim3(grid), dim3(1024), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles);
+            else hipLaunchKernelGGL((render_kernel_wga<false, 1024, 1024, 4, true>), dim3(grid), dim3(1024), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles);
+        } else
         if (wg == 256 && nt == 256) LAUNCH_WGA(256, 256, 4);
         else if (wg == 512 && nt == 512) LAUNCH_WGA(512, 512, 4);
         else if (wg == 512 && nt == 256) LAUNCH_WGA(512, 256, 2);

@@ -1020,7 +1020,11 @@ DEV bool wg_env(const WgArgs &a, uint32_t wg_base, uint32_t pid, PathEnvT<ColdSt
 }
 
 // One block of class C for the path `pid`: load, run (repeat while the path stays in class C and enough lanes do), store.
-template <bool COUNT, int WG, int C>
+// WF: wavefront (gpu_*) streams -- one PCG32 per (pixel, sample), seeded with TEA (sampler.cpp:89-92).  The hot state holds only the
+// generator's 64-bit state; its increment, which for the scalar variants' streams is the default stream's constant, is recomputed here
+// from (pixel, sample index) on every load: a 64-bit TEA of four rounds, ~60 instructions, and one dword of the cold record -- in an
+// instantiation of its own, so that the kernels of the scalar streams do not change by an instruction.
+template <bool COUNT, int WG, int C, bool WF = false>
 #ifndef WG_BLOCK_ATTR
 #define WG_BLOCK_ATTR __forceinline__   // a real call costs 48 callee-saved VGPR spills + reloads per block visit (measured: 5 TB of scratch writes per render)
 #endif
@@ -1039,6 +1043,7 @@ static __device__ WG_BLOCK_ATTR int wg_block(const MTS_CONST_AS void *kernarg_, 
     PathState p;
     if (COUNT && C == B_MED) MTS_SEG_BEGIN(*cnt);
     hs.template load_m<CF::load>(p);
+    if (WF && C != B_INT) p.rng.inc = wavefront_increment(a.sc.sensor, e.blk, e.lx, e.ly, __float_as_uint(e.cold.f(C_SAMPLE)));
     if (COUNT && C == B_MED) MTS_SEG(*cnt, 0);
     int cls;
     // A tracking step is most often followed by another one (null collisions): while at least half of the wave's lanes stay in this
@@ -1096,6 +1101,7 @@ static __device__ WG_BLOCK_ATTR int wg_block(const MTS_CONST_AS void *kernarg_, 
     if (CF::defer && (p.st == S_ENDNEE || p.st == S_ENDDIR0)) {     // rare tail on the full state
         PathState q;
         hs.template load_m<G_ALL>(q);
+        if (WF) q.rng.inc = wavefront_increment(a.sc.sensor, e.blk, e.lx, e.ly, __float_as_uint(e.cold.f(C_SAMPLE)));     // top() draws the roulette sample
         vm.finish(q, e);
         vm.top(q, e);
         cls = vm.classify(q);
@@ -1221,7 +1227,7 @@ DEV void wg_flush_unfinished(const MTS_CONST_AS void *kernarg, const uint32_t *h
     }
 }
 
-template <bool COUNT, int WG /* paths */, int NT /* threads: fewer threads than paths keeps the rings fuller */>
+template <bool COUNT, int WG /* paths */, int NT /* threads: fewer threads than paths keeps the rings fuller */, bool WF = false /* wavefront streams, wg_block */>
 DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt) {
     constexpr int NQ = B_DONE;
     static_assert((WG & (WG - 1)) == 0 && WG <= 32768, "ring indices wrap with a mask and ids are 16 bit");
@@ -1367,14 +1373,14 @@ DEV void volpath_workgroup_async(const MTS_CONST_AS void *kernarg, Counters &cnt
         int cls = B_DONE;
         if (mine) {
             switch (sel) {
-                case B_INT: cls = wg_block<COUNT, WG, B_INT>(kernarg, hot_lds, wg_base, pid, &cnt); break;
-                case B_MED: cls = wg_block<COUNT, WG, B_MED>(kernarg, hot_lds, wg_base, pid, &cnt); break;
-                case B_MEDW: cls = wg_block<COUNT, WG, B_MEDW>(kernarg, hot_lds, wg_base, pid, &cnt); break;
-                case B_SCATTER: cls = wg_block<COUNT, WG, B_SCATTER>(kernarg, hot_lds, wg_base, pid, &cnt); break;
-                case B_WSURF: cls = wg_block<COUNT, WG, B_WSURF>(kernarg, hot_lds, wg_base, pid, &cnt); break;
-                case B_SURF: cls = wg_block<COUNT, WG, B_SURF>(kernarg, hot_lds, wg_base, pid, &cnt); break;
-                case B_PHASE: cls = wg_block<COUNT, WG, B_PHASE>(kernarg, hot_lds, wg_base, pid, &cnt); break;
-                default: cls = wg_block<COUNT, WG, B_NEW>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                case B_INT: cls = wg_block<COUNT, WG, B_INT, WF>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                case B_MED: cls = wg_block<COUNT, WG, B_MED, WF>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                case B_MEDW: cls = wg_block<COUNT, WG, B_MEDW, WF>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                case B_SCATTER: cls = wg_block<COUNT, WG, B_SCATTER, WF>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                case B_WSURF: cls = wg_block<COUNT, WG, B_WSURF, WF>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                case B_SURF: cls = wg_block<COUNT, WG, B_SURF, WF>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                case B_PHASE: cls = wg_block<COUNT, WG, B_PHASE, WF>(kernarg, hot_lds, wg_base, pid, &cnt); break;
+                default: cls = wg_block<COUNT, WG, B_NEW, WF>(kernarg, hot_lds, wg_base, pid, &cnt); break;
             }
         }
         // should_stop() for a busy wave: see the nap above.  Here, in the wake of the NEW block's film atomics, the vector load is cheap; at

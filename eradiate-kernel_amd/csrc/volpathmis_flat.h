@@ -99,8 +99,11 @@ struct VolpathMisMachine {
 #if MTS_SPEC_N == 3
         (void) p.rng.next_1d();                                // wavelength sample, unused in rgb
 #else
-        float wav_weight;                                      // constant (sample_uniform_spectrum); blk_new recomputes it
-        p.wl = sample_wavelengths(p.rng.next_1d(), wav_weight);
+        {                                                      // integrator.cpp:252 -> perspective.cpp:169-182, distant.cpp:311-313; blk_new recomputes the weights
+            const float wavelength_sample = p.rng.next_1d();
+            float wav_weight; Spec srf_weight;
+            p.wl = sc.srf >= 0 ? sample_wavelengths_srf(sc, wavelength_sample, srf_weight) : sample_wavelengths(wavelength_sample, wav_weight);
+        }
 #endif
         F2 adjusted;
         adjusted.x = (position_sample.x - (float) se.crop_x) / (float) se.crop_w;
@@ -186,16 +189,18 @@ struct VolpathMisMachine {
 #else
         {
             float wav_weight; (void) sample_wavelengths(0.f, wav_weight);
-            const Spec L = (wav_weight * e.cold.f(C_RAYW)) * p.res;     // ray_weight = wav_weight (x the sensor's grey weight), integrator.cpp:265
+            const Spec ww = sc.srf >= 0 ? srf_weights_of(sc, p.wl) : spec_s(wav_weight);      // a sensor response function: weights recovered from the wavelengths (volpath_flat.h)
+            const Spec L = (ww * e.cold.f(C_RAYW)) * p.res;             // ray_weight = wav_weight (x the sensor's grey weight), integrator.cpp:265
             float xyz[3];
             spectrum_to_xyz(sc.cie, L, p.wl, xyz);                      // integrator.cpp:266-269
             const float v[5] = { xyz[0], xyz[1], xyz[2], (p.flags & FL_VALID_RAY) != 0 ? 1.f : 0.f, 1.f };
-            splat_values_t<false>(sc, e.blk, e.lx, e.ly, position_sample, v, e.film, acc);
+            if (sc.bin_count == 0) splat_values_t<false>(sc, e.blk, e.lx, e.ly, position_sample, v, e.film, acc);
+            else splat_values_bins(sc, e.blk, e.lx, e.ly, position_sample, v, p.res, p.wl, e.film, acc);      // nbins / bins around volpathmis (round 4)
         }
 #endif
         const uint32_t sample_idx = __float_as_uint(e.cold.f(C_SAMPLE)) + 1u;
         if (sample_idx == e.sample_count) {
-            float *own = (float *) (e.film + 5 * ((size_t) (e.blk.oy + (int) e.ly - se.crop_y) * se.crop_w + (e.blk.ox + (int) e.lx - se.crop_x)));
+            float *own = (float *) (e.film + MTS_FILM_STRIDE(sc) * ((size_t) (e.blk.oy + (int) e.ly - se.crop_y) * se.crop_w + (e.blk.ox + (int) e.lx - se.crop_x)));
             for (int k = 0; k < 5; ++k) atomicAdd(own + k, acc[k]);
             p.st = S_DONE;
         } else {

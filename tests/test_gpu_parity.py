@@ -123,6 +123,8 @@ def test_wavefront_streams_match_the_oracle(gpu_rgb, monkeypatch, case):
     monkeypatch.setenv("MTSAMD_WAVEFRONT_SPLIT", "1")
     gpu, st = gpu_render(gpu_rgb, d, collect_counters=True)
     assert np.array_equal(gpu, ref)
+    # round 4: `volpath` with these streams runs on the regrouping machine (the generator's increment is recomputed on every load)
+    assert st["kernel_variant"] == (11024 if case in ("c3_volpath", "c4_small") else 1 if case == "cornell_path" else 0), st["kernel_variant"]
     assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (o.last_stats["n_iter"], o.last_stats["n_lookup"], o.last_stats["n_nee_step"])
     monkeypatch.delenv("MTSAMD_WAVEFRONT_SPLIT")
     spread, st2 = gpu_render(gpu_rgb, d, collect_counters=True)                   # small film: several entries per block
@@ -1159,22 +1161,23 @@ def test_spectral_volpathmis_against_oracle(gpu_spectral, monkeypatch, name, use
     assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (o.last_stats["n_iter"], o.last_stats["n_lookup"], o.last_stats["n_nee_step"])
 
 
+@pytest.mark.parametrize("inner", ["volpath", "volpathmis"])
 @pytest.mark.parametrize("kernel", [None, "nested"])
 @pytest.mark.parametrize("wrap", ["nbins", "bins_discrete_srf"])
-def test_bins_on_the_regrouping_machine(gpu_spectral, monkeypatch, wrap, kernel):
-    """nbins / bins around `volpath` and a sensor response function run on v_spectral::render_kernel_wga (AOV values splatted by the NEW
-    block, response-function weights recovered from the sampled wavelengths) and give the film and AOV channels of the oracle -- as does
-    the per-lane kernel they ran on before (MTSAMD_KERNEL=nested)."""
+def test_bins_on_the_regrouping_machine(gpu_spectral, monkeypatch, wrap, kernel, inner):
+    """nbins / bins around `volpath` and -- round 4 -- `volpathmis`, and a sensor response function, run on the regrouping kernels
+    (v_spectral::render_kernel_wga / _wga_mis: AOV values splatted by the NEW block, response-function weights recovered from the sampled
+    wavelengths) and give the film and AOV channels of the oracle -- as does the per-lane kernel they ran on before (MTSAMD_KERNEL=nested)."""
     if kernel:
         monkeypatch.setenv("MTSAMD_KERNEL", kernel)
     if wrap == "nbins":
         d = _spectral_cases()["c5s_atmosphere"]                                          # distant sensor, gridvolume_spectral, 40 x 32 (partial blocks)
-        d["integrator"] = {"type": "nbins", "wavelengths": "400, 480, 560, 640, 720, 800", "tolerance": 30.0, "integrator": dict(d["integrator"])}
+        d["integrator"] = {"type": "nbins", "wavelengths": "400, 480, 560, 640, 720, 800", "tolerance": 30.0, "integrator": dict(d["integrator"], type=inner)}
         channels = 5 + 2 * 6
     else:
         d = _spectral_cases()["grid_spectral_d65_rpv"]                                   # perspective camera: the sensors that take an srf
         d["sensor"]["srf"] = {"type": "discrete", "wavelengths": "450, 550, 650, 750", "values": "0.5, 1.0, 0.75, 0.25"}
-        d["integrator"] = {"type": "bins", "bins": "a:400:500, b:500:600, c:600:800", "integrator": dict(d["integrator"])}
+        d["integrator"] = {"type": "bins", "bins": "a:400:500, b:500:600, c:600:800", "integrator": dict(d["integrator"], type=inner)}
         channels = 5 + 2 * 3
     scene = gpu_spectral.load_dict(d)
     sensor = scene.sensors()[0]
