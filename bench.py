@@ -125,14 +125,23 @@ def timed(job, steps, warmup, barrier, all_max):
 
 
 def device_hbm_peak_gbs(torch, device):
-    """Peak HBM bandwidth as the device reports it: 2 x memory clock x bus width (hipDeviceProp_t memoryClockRate / memoryBusWidth,
-    through torch's device properties); None when the runtime does not expose them.  Reported next to the guide's figure."""
+    """Peak HBM bandwidth as the device reports it: 2 x memory clock x bus width (hipDeviceGetAttribute: MemoryClockRate in kHz,
+    MemoryBusWidth in bits -- torch does not expose them, so the HIP runtime torch has already loaded is asked directly; the enum
+    values are those of /opt/rocm/include/hip/hip_runtime_api.h and are cross-checked on MultiprocessorCount).  None when that
+    fails.  Reported next to the guide's figure, which stays the contract's `peak`."""
     try:
-        pr = torch.cuda.get_device_properties(device)
-        khz, bits = getattr(pr, "memory_clock_rate", None), getattr(pr, "memory_bus_width", None)
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        def attr(a):
+            v = ctypes.c_int(0)
+            return v.value if hip.hipDeviceGetAttribute(ctypes.byref(v), a, int(device)) == 0 else None
+        BUS_WIDTH, CLOCK_RATE, CU_COUNT = 59, 60, 63
+        if attr(CU_COUNT) != torch.cuda.get_device_properties(device).multi_processor_count:
+            return None
+        khz, bits = attr(CLOCK_RATE), attr(BUS_WIDTH)
         if not khz or not bits:
             return None
-        return round(2.0 * khz * 1e3 * bits / 8 / 1e9, 1)
+        return {"memory_clock_khz": khz, "bus_width_bits": bits, "ddr_peak_gbs": round(2.0 * khz * 1e3 * bits / 8 / 1e9, 1)}
     except Exception:
         return None
 
@@ -332,10 +341,10 @@ def main():
     elif integ_type == "volpathmis":
         kernel_name = "v_spectral::render_kernel_wga_mis<false, true, 256, 256>" if args.config == "C5SM" else "render_kernel_wga_mis<false, true, 512, 512>"
     elif args.config in ("C5S", "C5SB"):
-        kernel_name = "v_spectral::render_kernel_wga<false, 256, 256, 2>"
+        kernel_name = "v_spectral::render_kernel_wga<false, 256, 256, 2, false>"
     else:
         paths = int(kv[3:]); nt = int(os.environ.get("MTSAMD_WG_THREADS", str(paths)))
-        kernel_name = "render_kernel_%s<false, %d, %d, %d>" % (kv[:3], paths, nt, {1: 4, 0.75: 3, 0.5: 2}[nt / paths])
+        kernel_name = "render_kernel_%s<false, %d, %d, %d%s>" % (kv[:3], paths, nt, {1: 4, 0.75: 3, 0.5: 2}[nt / paths], ", false" if kv[:3] == "wga" else "")
     # `achieved` / `frac` follow the contract: ALGORITHMIC bytes (a wavefront formulation's state round trips) over
     # the kernel's measured time.  This kernel keeps path state in LDS, so its real HBM traffic is several times lower and its
     # bound is latency at 4 waves per SIMD; `traffic*` and `valu_pipe_busy` (rocprofv3 --pmc, profiles/) say so whenever this run
