@@ -1042,6 +1042,15 @@ static __device__ WG_BLOCK_ATTR int wg_block(const MTS_CONST_AS void *kernarg_, 
     typedef ClassFields<C> CF;
     PathState p;
     if (COUNT && C == B_MED) MTS_SEG_BEGIN(*cnt);
+#if defined(EXP_COLD_TOUCH)
+    // A walk's step may end the walk, and the end reads the path's cold record (parked at the start of the walk, ~10^5 cycles ago: by now in
+    // the Infinity Cache or in HBM) in a tail that the whole wave waits for.  One dword of the record is requested here, a block's worth of
+    // work before it is needed, so that the tail's loads find the line in the cache.  Hand-issued: the compiler would sink a plain load to
+    // its use.  The register is only read behind the s_waitcnt below.
+    uint32_t cold_touch = 0;
+    if (C == B_MEDW || C == B_WSURF)
+        asm volatile("global_load_dword %0, %1, off" : "=v"(cold_touch) : "v"((const MTS_GLOBAL_AS float *) (e.cold.base + C_SD)) : "memory");
+#endif
     hs.template load_m<CF::load>(p);
     if (WF && C != B_INT) p.rng.inc = wavefront_increment(a.sc.sensor, e.blk, e.lx, e.ly, __float_as_uint(e.cold.f(C_SAMPLE)));
     if (COUNT && C == B_MED) MTS_SEG(*cnt, 0);
@@ -1072,6 +1081,9 @@ static __device__ WG_BLOCK_ATTR int wg_block(const MTS_CONST_AS void *kernarg_, 
         if (!(C == B_MED || C == B_MEDW) || cls != C || rounds >= 16) break;
         if (__popcll(__ballot(true)) < (C == B_MEDW ? MTS_REPEAT_MIN_W : MTS_REPEAT_MIN)) break;
     }
+#if defined(EXP_COLD_TOUCH)
+    if (C == B_MEDW || C == B_WSURF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); asm volatile("" :: "v"(cold_touch)); }
+#endif
     bool chained = false;
     if ((MTS_CHAIN & 4) && C == B_MEDW && cls == B_WSURF) {    // the walk left the medium: its surface step(s) run here, on the lanes that have one
         hs.template load_add<G_ALL & ~CF::load>(p);
