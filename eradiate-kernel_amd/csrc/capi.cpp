@@ -405,8 +405,8 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             HIP_CHECK(hipDeviceGetAttribute(&cu_count, hipDeviceAttributeMultiprocessorCount, hs.device));
             const char *lpt = getenv("MTSAMD_LPT");                // 0: spiral order, one workgroup per run of a block's Morton order
             lpt_mode = lpt ? atoi(lpt) : -1;
-            const uint32_t cal_spp = (uint32_t) std::min<size_t>(4, launch_spp / 128);
             const bool force = lpt && (atoi(lpt) == 2 || atoi(lpt) == 3);   // 2, 3: calibrate whatever the block count (tests, diagnostics with MTSAMD_LPT_DEBUG)
+            const uint32_t cal_spp = (uint32_t) std::max<size_t>(std::min<size_t>(4, launch_spp / 128), force && launch_spp >= 2 ? 1 : 0);
             if (variant >= 10000 && variant < 20000 && block_size <= 256 && (!lpt || atoi(lpt) != 0) && cal_spp > 0 &&
                 (force || pass_blocks[0].size() > (size_t) std::max(cu_count, 1)) && !should_stop()) {
                 std::vector<DBlock> cal(pass_blocks[0]);           // the distinct block positions of the first chunk

@@ -274,13 +274,13 @@ PM_HD float pm_log(float x) {
     return pm_log_cr(x);
 #endif
     uint32_t ix = pm_bits(x);
-    if (ix == 0x3f800000u) return 0.0f;
-    if (ix >= 0x7f800000u) {            // negative, inf or NaN
+    if (__builtin_expect(ix - 0x00800000u >= 0x7f000000u, 0)) {   // everything but a positive normal number: ONE test on the common path
         if (ix == 0x7f800000u) return x;                  // +inf
-        if ((ix << 1) == 0u) return -pm_inf();            // -0
+        if ((ix << 1) == 0u) return -pm_inf();            // +-0
+        if (ix < 0x00800000u) return -pm_inf();           // denormals (DAZ)
         return pm_nan();                                  // negative or NaN
     }
-    if (ix < 0x00800000u) return -pm_inf();               // +0 and denormals (DAZ)
+    // (glibc tests x == 1 first; the arithmetic below returns +0 for it by itself: r = 0, y0 = 0)
     uint32_t tmp = ix - 0x3f330000u;
     uint32_t i = (tmp >> 19) & 15u;
     int k = (int32_t) tmp >> 23;
@@ -318,9 +318,11 @@ PM_HD float pm_exp(float x) {
 #if defined(PM_CORRECTLY_ROUNDED)
     return pm_exp_cr(x);
 #endif
-    if (!(x == x)) return x;
-    if (x > 88.7228317f) return pm_inf();                 // 0x1.62e42ep6f, e_expf.c's overflow bound
-    if (x < -87.3365402f) return 0.0f;                    // glibc returns a denormal here: zero under flush-to-zero
+    if (__builtin_expect((pm_bits(x) & 0x7fffffffu) > 0x42aeac4fu, 0)) {     // |x| > 87.3365402 or NaN: ONE test on the common path
+        if (!(x == x)) return x;
+        if (x > 88.7228317f) return pm_inf();             // 0x1.62e42ep6f, e_expf.c's overflow bound
+        if (x < 0.0f) return 0.0f;                        // below ln(FLT_MIN): glibc returns a denormal here, zero under flush-to-zero
+    }
     double xd = (double) x;
     double z = 0x1.71547652b82fep+5 * xd;
     double kd = z + 0x1.8p+52;
