@@ -238,6 +238,46 @@ def test_bench_strong_scaling_rehearsal(gpu_rgb, tmp_path):
     assert np.allclose(parts[0][0] + parts[1][0], full, rtol=1e-6, atol=0)
 
 
+def test_c_abi_from_cpp_with_an_rccl_film_reduce(gpu_rgb, tmp_path):
+    """The drop-in boundary without Python: integration/render_sharded.cpp builds a scene from plain C records, renders its shard into
+    a device film on its own HIP stream through libmtsamd.so and merges the films with ONE ncclReduce over RCCL (INTEGRATION.md
+    section 3: the multi-GPU pattern as a program).  Compiled and run here with one rank (RCCL refuses two ranks on one device): the
+    reduce is then the identity, and the film equals what the Python binding renders of the twin scene bit for bit."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    exe = str(tmp_path / "render_sharded")
+    libdir = os.path.join(root, "eradiate-kernel_amd")
+    subprocess.check_call([hipcc, "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "integration", "render_sharded.cpp"),
+                           "-L", libdir, "-lmtsamd", "-lrccl", "-Wl,-rpath," + libdir, "-o", exe])
+    out = str(tmp_path / "film.f32")
+    for spp_pass, passes in ((-1, 1), (8, 4)):
+        r = subprocess.run([exe, "0", "1", str(tmp_path / ("id%d" % passes)), out, str(spp_pass)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+        cpp = np.fromfile(out, dtype=np.float32).reshape(48, 64, 5)
+        d = {"type": "scene",
+             "integrator": {"type": "volpath", "max_depth": -1, "rr_depth": 5, "block_size": 32, "samples_per_pass": spp_pass},
+             "sensor": {"type": "perspective", "to_world": T(), "fov": 45.0, "near_clip": 0.1, "far_clip": 100.0,
+                        "film": {"type": "hdrfilm", "width": 64, "height": 48, "rfilter": {"type": "box"}},
+                        "sampler": {"type": "independent", "sample_count": 32, "seed": 0}},
+             "a_wall": {"type": "rectangle", "to_world": T.translate([0, 0, 10]) @ T.scale(8.0), "flip_normals": True,
+                        "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.5, 0.5, 0.5]}}},
+             "b_slab": {"type": "cube", "to_world": T.translate([0, 0, 8]) @ T.scale([4, 4, 1]), "bsdf": {"type": "null"},
+                        "interior": {"type": "homogeneous", "sigma_t": 0.5, "albedo": 0.75}},
+             "sun": {"type": "directional", "to_world": T(), "irradiance": 1.0}}
+        py, st = gpu_render(gpu_rgb, d)
+        assert st["samples"] == 64 * 48 * 32 and np.all(py[..., 4] == 32)
+        if passes == 1:
+            assert np.array_equal(cpp, py), float(np.abs(cpp - py).max())
+        else:       # several passes of a block add into one film entry by float atomics: equal up to the order of those additions
+            assert np.array_equal(cpp[..., 3:], py[..., 3:]) and np.allclose(cpp, py, rtol=1e-6, atol=0)
+        assert cpp[..., 1].max() > 0 and "rank 0 of 1" in r.stdout
+
+
 def test_device_film_pointer(gpu_rgb):
     import torch
     d = scenes.c3_heterogeneous(64, 32, 4, res=8)
