@@ -1352,7 +1352,7 @@ DEV float mw_nan0(float x) { return x != x ? 0.f : x; }
 #if MTS_SPEC_N == 3
 DEV Spec spec_map_fin(Spec a) { return f3(mw_fin(a.x), mw_fin(a.y), mw_fin(a.z)); }
 DEV Spec spec_map_nan0(Spec a) { return f3(mw_nan0(a.x), mw_nan0(a.y), mw_nan0(a.z)); }
-DEV Spec spec_div_s(Spec p, float f) { return f3(p.x / f, p.y / f, p.z / f); }              // true divisions (spectrum / coefficient, :456)
+DEV Spec spec_div_s(Spec p, float f) { float r = 1.0f / f; return f3(p.x * r, p.y * r, p.z * r); } // spectrum / coefficient (:456): reciprocal, then multiply (enoki array / scalar)
 DEV Spec spec_s_div(float p, Spec f) { return f3(p / f.x, p / f.y, p / f.z); }
 DEV Spec spec_of(float a, float b, float c, float) { return f3(a, b, c); }
 DEV float spec_hsum(Spec a) { return (a.x + a.y) + a.z; }
@@ -1360,7 +1360,7 @@ DEV float spec_hmin_abs(Spec a) { return pm_min(pm_min(pm_abs(a.x), pm_abs(a.y))
 #else
 DEV Spec spec_map_fin(Spec a) { return spec4(mw_fin(a.x), mw_fin(a.y), mw_fin(a.z), mw_fin(a.w)); }
 DEV Spec spec_map_nan0(Spec a) { return spec4(mw_nan0(a.x), mw_nan0(a.y), mw_nan0(a.z), mw_nan0(a.w)); }
-DEV Spec spec_div_s(Spec p, float f) { return spec4(p.x / f, p.y / f, p.z / f, p.w / f); }
+DEV Spec spec_div_s(Spec p, float f) { float r = 1.0f / f; return spec4(p.x * r, p.y * r, p.z * r, p.w * r); }
 DEV Spec spec_s_div(float p, Spec f) { return spec4(p / f.x, p / f.y, p / f.z, p / f.w); }
 DEV Spec spec_of(float a, float b, float c, float d) { return spec4(a, b, c, d); }
 DEV float spec_hsum(Spec a) { return (a.x + a.y) + (a.z + a.w); }                             // hsum of a 4-array: pairwise, as spec_hmean (dmath.h)

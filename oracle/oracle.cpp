@@ -1074,9 +1074,9 @@ template <bool SPEC>
 static inline void update_weights(MisWeights<SPEC> &w, Spec p, Spec f, uint32_t channel, bool active) {
     if (SPEC) {
         for (int i = 0; i < MTS_SPEC_N; ++i) {
-            float fi = sget(f, i);
+            float rfi = 1.0f / sget(f, i);                       // :456 spectrum / coefficient: enoki multiplies by the reciprocal (oracle_math.h)
             Spec ratio;
-            for (int j = 0; j < MTS_SPEC_N; ++j) { float r = sget(p, j) / fi; sset(ratio, j, finite3(r) ? r : 0.f); }
+            for (int j = 0; j < MTS_SPEC_N; ++j) { float r = sget(p, j) * rfi; sset(ratio, j, finite3(r) ? r : 0.f); }
             ratio = ratio * w.r[i];
             if (active) for (int j = 0; j < MTS_SPEC_N; ++j) { float r = sget(ratio, j); sset(w.r[i], j, r != r ? 0.f : r); }
         }
