@@ -1383,6 +1383,18 @@ DEV void update_weights(MisWeights<SPEC> &w, Spec p, Spec f, uint32_t channel, b
         if (active) w.r[0] = spec_map_fin(ratio);
     }
 }
+// update_weights(w, spec_s(p), spec_s(f)) when both operands carry one value in every channel (the majorant's transmittance, a grey medium):
+// every entry of the ratio matrix is the same number, so it is formed once -- the same products, entry by entry, as the general form above.
+template <bool SPEC>
+DEV void update_weights_uniform(MisWeights<SPEC> &w, float p, float f) {
+    if (SPEC) {
+        const float ratio = mw_fin(p * (1.0f / f));
+#pragma unroll
+        for (int i = 0; i < MTS_SPEC_N; ++i) w.r[i] = spec_map_nan0(spec_s(ratio) * w.r[i]);
+    } else {
+        w.r[0] = spec_map_fin(w.r[0] * spec_s(p / f));
+    }
+}
 template <bool SPEC> DEV void update_weights(MisWeights<SPEC> &w, float p, Spec f, uint32_t c, bool a) { update_weights(w, spec_s(p), f, c, a); }
 template <bool SPEC> DEV void update_weights(MisWeights<SPEC> &w, Spec p, float f, uint32_t c, bool a) { update_weights(w, p, spec_s(f), c, a); }
 template <bool SPEC> DEV void update_weights(MisWeights<SPEC> &w, float p, float f, uint32_t c, bool a) { update_weights(w, spec_s(p), spec_s(f), c, a); }

@@ -226,20 +226,29 @@ struct VolpathMisMachine {
             mi = medium_step<COUNT>(sc, cload(sc.media + mu), p.ray, u, channel, true, cnt MTS_CX);
         WATERFALL_END
         if (p.si.t < mi.t) mi.t = pm_inf();
-        const bool spectral = (mi.info & MI_SPECTRAL) != 0, homogeneous = (mi.info & MI_HOMOGENEOUS) != 0;
+        const bool spectral = (mi.info & MI_SPECTRAL) != 0, homogeneous = (mi.info & MI_HOMOGENEOUS) != 0, grey = (mi.info & MI_GREY) != 0;
         const Spec sigma_n = homogeneous ? spec_s(0.f) : mi.combined - mi.sigma_t;
         if (spectral) {
             float t = pm_min(mi.t, p.si.t) - mi.mint;                                  // medium.cpp:77-89
             // a heterogeneous medium's combined extinction is its scalar majorant (heterogeneous.cpp:29): one exponential for every channel
-            Spec tr = homogeneous ? transmittance_exp(t, mi.combined) : spec_s(pm_exp(-t * mi.combined.x));
-            Spec free_flight_pdf = p.si.t < mi.t ? tr : tr * mi.combined;
-            update_weights(p.pf, free_flight_pdf, tr, channel, true);
-            update_weights(p.pn, free_flight_pdf, tr, channel, true);
+            if (homogeneous) {
+                Spec tr = transmittance_exp(t, mi.combined);
+                Spec free_flight_pdf = p.si.t < mi.t ? tr : tr * mi.combined;
+                update_weights(p.pf, free_flight_pdf, tr, channel, true);
+                update_weights(p.pn, free_flight_pdf, tr, channel, true);
+            } else {
+                const float tr = pm_exp(-t * mi.combined.x), free_flight_pdf = p.si.t < mi.t ? tr : tr * mi.combined.x;
+                update_weights_uniform(p.pf, free_flight_pdf, tr);
+                update_weights_uniform(p.pn, free_flight_pdf, tr);
+            }
         }
         if (mi.t == pm_inf()) { p.st = S_SURF; return; }                               // escaped_medium: the surface part of this iteration
         const bool null_scatter = p.rng.next_1d() >= div_by_invariant(pick(mi.sigma_t, channel), pick(mi.combined, channel), mi.inv_combined);
         if (null_scatter) {
-            if (spectral) {
+            if (spectral && grey) {
+                update_weights_uniform(p.pf, div_by_invariant(sigma_n.x, mi.combined.x, mi.inv_combined), sigma_n.x);
+                update_weights_uniform(p.pn, 1.0f, sigma_n.x);
+            } else if (spectral) {
                 update_weights(p.pf, div_by_invariant(sigma_n, mi.combined, mi.inv_combined), sigma_n, channel, true);
                 update_weights(p.pn, 1.0f, sigma_n, channel, true);
             } else {
@@ -254,7 +263,8 @@ struct VolpathMisMachine {
         const bool sample_emitters = (mi.info & MI_SAMPLE_EMITTERS) != 0;
         if (!(p.depth < max_depth)) { p.flags &= ~FL_ALIVE; p.st = S_TOP; return; }    // :197-198: the path ends at the next loop head
         if (sample_emitters) p.flags &= ~FL_SPEC_CHAIN;                                // :199
-        if (spectral) update_weights(p.pf, div_by_invariant(mi.sigma_t, mi.combined, mi.inv_combined), mi.sigma_s, channel, true);
+        if (spectral && grey) update_weights_uniform(p.pf, div_by_invariant(mi.sigma_t.x, mi.combined.x, mi.inv_combined), mi.sigma_s.x);
+        else if (spectral) update_weights(p.pf, div_by_invariant(mi.sigma_t, mi.combined, mi.inv_combined), mi.sigma_s, channel, true);
         else update_weights(p.pf, mi.sigma_t, mi.sigma_s, channel, true);
         p.flags |= FL_VALID_RAY;
         p.ray.o = mi.p;                                                                // scattering position; ray.d stays the incident direction
@@ -303,23 +313,33 @@ struct VolpathMisMachine {
             mi = medium_step<COUNT>(sc, cload(sc.media + mu), p.ray, u, channel, false, cnt MTS_CX);
         WATERFALL_END
         if (p.si.t < mi.t) mi.t = pm_inf();
-        const bool spectral = (mi.info & MI_SPECTRAL) != 0, homogeneous = (mi.info & MI_HOMOGENEOUS) != 0;
+        const bool spectral = (mi.info & MI_SPECTRAL) != 0, homogeneous = (mi.info & MI_HOMOGENEOUS) != 0, grey = (mi.info & MI_GREY) != 0;
         const Spec sigma_n = homogeneous ? spec_s(0.f) : mi.combined - mi.sigma_t;
         const float remaining_dist = p.ray.maxt;
         if (spectral) {
             float t = pm_min(remaining_dist, pm_min(mi.t, p.si.t)) - mi.mint;
             // a heterogeneous medium's combined extinction is its scalar majorant (heterogeneous.cpp:29): one exponential for every channel
-            Spec tr = homogeneous ? transmittance_exp(t, mi.combined) : spec_s(pm_exp(-t * mi.combined.x));
-            Spec free_flight_pdf = (p.si.t < mi.t || mi.t > remaining_dist) ? tr : tr * mi.combined;
-            update_weights(p.wn, free_flight_pdf, tr, channel, true);
-            update_weights(p.wu, free_flight_pdf, tr, channel, true);
+            const bool no_event = p.si.t < mi.t || mi.t > remaining_dist;
+            if (homogeneous) {
+                Spec tr = transmittance_exp(t, mi.combined);
+                Spec free_flight_pdf = no_event ? tr : tr * mi.combined;
+                update_weights(p.wn, free_flight_pdf, tr, channel, true);
+                update_weights(p.wu, free_flight_pdf, tr, channel, true);
+            } else {
+                const float tr = pm_exp(-t * mi.combined.x), free_flight_pdf = no_event ? tr : tr * mi.combined.x;
+                update_weights_uniform(p.wn, free_flight_pdf, tr);
+                update_weights_uniform(p.wu, free_flight_pdf, tr);
+            }
         }
         if (mi.t > remaining_dist && mi.t != pm_inf()) p.wa = p.wb;
         if (mi.t > remaining_dist) mi.t = pm_inf();
         if (mi.t == pm_inf()) { p.st = S_SURF; return; }                               // escaped_medium
         p.wa += mi.t;
         p.ray.o = mi.p; p.ray.mint = 0.f; p.si.t = p.si.t - mi.t;
-        if (spectral) {
+        if (spectral && grey) {
+            update_weights_uniform(p.wn, 1.f, sigma_n.x);
+            update_weights_uniform(p.wu, div_by_invariant(sigma_n.x, mi.combined.x, mi.inv_combined), sigma_n.x);
+        } else if (spectral) {
             update_weights(p.wn, 1.f, sigma_n, channel, true);
             update_weights(p.wu, div_by_invariant(sigma_n, mi.combined, mi.inv_combined), sigma_n, channel, true);
         } else {
