@@ -32,7 +32,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md ("HBM3E ... 8 TB/s"): the contract's `peak`.  The device's own
                            # figure (memory clock x bus width from hipDeviceProp) rides along in the line as `peak_device_query`.
 CONFIG_SIZES = {"C1": (256, 256, 64), "C2": (512, 512, 256), "C3": (512, 512, 1024), "C4": (1024, 1024, 4096), "C5": (1024, 1024, 4096),
-                "C5S": (1024, 1024, 256), "C5SM": (1024, 1024, 256), "C5SB": (1024, 1024, 256), "C3M": (512, 512, 1024), "C1L": (512, 512, 256), "C1W": (256, 256, 64)}      # C5S: the same atmosphere in the spectral variant (gpu_spectral), 256 spp
+                "C5S": (1024, 1024, 256), "C5SM": (1024, 1024, 256), "C5SB": (1024, 1024, 256), "C3M": (512, 512, 1024), "C1L": (512, 512, 256), "C1W": (256, 256, 64), "C1S": (512, 512, 256)}      # C5S: the same atmosphere in the spectral variant (gpu_spectral), 256 spp
 C5_WAVELENGTHS = 16        # BASELINE.json configs[4]: the C4 atmosphere as a 16-wavelength batch
 
 
@@ -43,8 +43,14 @@ def c5_rayleigh_scale(k):
 
 
 def build_scene_dict(scenes, config, width, height, spp, samples_per_pass=-1, res=128, wavelength=0):
-    if config in ("C1", "C1L", "C1W"):                              # C1L: the same cornell box at a size that fills the chip
+    if config in ("C1", "C1L", "C1W", "C1S"):                       # C1L: the same cornell box at a size that fills the chip
         d = scenes.c1_cornell(width, height, spp)
+        if config == "C1S":                                         # C1L in the spectral variant: reflectances as regular spectra, a D65 light
+            for v in d.values():
+                if isinstance(v, dict) and "bsdf" in v:
+                    rgb = v["bsdf"]["reflectance"]["value"]
+                    v["bsdf"]["reflectance"] = {"type": "regular", "lambda_min": 400., "lambda_max": 700., "values": [rgb[2], rgb[1], rgb[0]]}
+            d["light"]["emitter"]["radiance"] = {"type": "d65", "scale": 3.0}
         if config == "C1W":                                         # C1 with the streams of the reference's gpu_* variants: one per (pixel, sample)
             d["sensor"]["sampler"]["wavefront"] = True
     elif config == "C2":
@@ -64,7 +70,7 @@ def build_scene_dict(scenes, config, width, height, spp, samples_per_pass=-1, re
         d = scenes.c3_heterogeneous(width, height, spp, res=res)
         if config == "C3M":                                         # the metric scene under volpathmis (side measurement)
             d["integrator"]["type"] = "volpathmis"
-    (d["integrator"].get("integrator") or d["integrator"])["samples_per_pass"] = samples_per_pass      # nbins / bins wrap the sampling integrator
+    d["integrator"]["samples_per_pass"] = samples_per_pass             # nbins / bins: the wrapper is the integrator that renders (its own property)
     return d
 
 
@@ -75,7 +81,7 @@ class Job:
         import torch
         self.torch, self.rank, self.n, self.backend = torch, rank, n, backend
         # C5: monochromatic batches (scalar_mono semantics), one per wavelength; C5S: the spectral variant
-        variant = {"C5": "gpu_mono", "C5S": "gpu_spectral", "C5SM": "gpu_spectral", "C5SB": "gpu_spectral"}.get(args.config, "gpu_rgb")
+        variant = {"C5": "gpu_mono", "C5S": "gpu_spectral", "C5SM": "gpu_spectral", "C5SB": "gpu_spectral", "C1S": "gpu_spectral"}.get(args.config, "gpu_rgb")
         pkg.set_variant(variant)
         self.dicts = [build_scene_dict(scenes, args.config, args.width, args.height, spp_total, samples_per_pass, args.res, k)
                       for k in range(C5_WAVELENGTHS if args.config == "C5" else 1)]
@@ -291,7 +297,7 @@ def main():
     # ---- strong scaling: the fixed job, N passes of spp / N (the largest divisor of spp not above spp / N)
     part = partition(args.width, args.height, args.spp, n)
     spp_pass = part["spp_pass"]
-    variant = {"C5": "gpu_mono", "C5S": "gpu_spectral", "C5SM": "gpu_spectral", "C5SB": "gpu_spectral"}.get(args.config, "gpu_rgb")
+    variant = {"C5": "gpu_mono", "C5S": "gpu_spectral", "C5SM": "gpu_spectral", "C5SB": "gpu_spectral", "C1S": "gpu_spectral"}.get(args.config, "gpu_rgb")
     job = Job(pkg, scenes, args, rank, n, local_rank, backend, args.spp, spp_pass if n > 1 else -1)
     # every rank should get at least one workgroup per CU (256) per launch, or the GPUs run partly empty: the reason the N-rank job is
     # cut into N passes.  Checked for the configurations at their BASELINE sizes (a rehearsal on a small film cannot meet it).
@@ -332,8 +338,8 @@ def main():
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
     integ_type = (job.dicts[0]["integrator"].get("integrator") or job.dicts[0]["integrator"])["type"]
     kv = os.environ.get("MTSAMD_KERNEL", "wga1024")
-    if integ_type == "path" and kv != "nested" and variant == "gpu_rgb":
-        kernel_name = "render_kernel<false, true, 0>"                # path_pixel_flat: one flat loop with regeneration
+    if integ_type == "path" and kv != "nested":
+        kernel_name = ("v_spectral::" if variant == "gpu_spectral" else "") + "render_kernel<false, true, 0>"      # path_pixel_flat: one flat loop with regeneration
     elif integ_type == "path" or kv == "nested":
         kernel_name = "render_kernel<false, false, %d>" % {"path": 0, "volpath": 1, "volpathmis": 2}.get(integ_type, 0)
     elif kv == "flat" and integ_type == "volpath":
@@ -398,7 +404,7 @@ def main():
         cores = os.cpu_count() or 1
         def cpu_render(spp):
             osc = ob.OracleScene(build_scene_dict(scenes, args.config, args.width, args.height, spp, -1, args.res, 0), mono=args.config == "C5",
-                                 spectral=args.config in ("C5S", "C5SM", "C5SB"))
+                                 spectral=args.config in ("C5S", "C5SM", "C5SB", "C1S"))
             tc0 = time.perf_counter()
             osc.render(threads=cores)
             return time.perf_counter() - tc0
@@ -413,6 +419,7 @@ def main():
 
     if rank == 0:
         workload = {"C1": "C1 path cornell box", "C1W": "C1W = C1 with wavefront (gpu_*) streams, one per (pixel, sample): the samples of a pixel spread over several workgroups", "C1L": "C1L = the C1 cornell box at 512x512x256 (262144 pixel streams: one per lane of the chip)", "C2": "C2 volpath homogeneous slab", "C4": "C4 volpath layered atmosphere, blend/tabulated phase, RPV ground",
+                    "C1S": "C1S = C1L in the spectral variant (gpu_spectral: regular reflectance spectra, D65 light), `path` as the flat loop with regeneration",
                     "C5": "C5 = C4 as %d monochromatic wavelength batches (Rayleigh ~ lambda^-4), gpu_mono" % C5_WAVELENGTHS,
                     "C5S": "C5S = the C4 atmosphere in the spectral variant (gpu_spectral: 4 wavelengths per sample, gridvolume_spectral grids, global majorant)",
                     "C5SB": "C5SB = C5S inside nbins (16 wavelength bins over 360 .. 830 nm: 32 AOV channels behind X, Y, Z, A, W), regrouping kernel",

@@ -64,7 +64,12 @@ def build_backend(force=False, verbose=True, extra=()):
             ids = ['-DMTSAMD_BUILD_ID="%s"' % build_id, '-DMTSAMD_TOOLCHAIN_ID="%s"' % toolchain] if f == "capi.cpp" else []
             h = hh.copy()
             with open(os.path.join(snap_csrc, f), "rb") as fh:
-                h.update(f.encode() + b"\0" + fh.read())
+                text = fh.read()
+            h.update(f.encode() + b"\0" + text)
+            for other in SOURCES:                               # a translation unit that includes another one (kernels_spectral.hip -> kernels.hip)
+                if other != f and ('#include "%s"' % other).encode() in text:
+                    with open(os.path.join(snap_csrc, other), "rb") as fh:
+                        h.update(other.encode() + b"\0" + fh.read())
             h.update(" ".join(ids).encode())
             obj = os.path.join(cache, "%s.%s.o" % (os.path.splitext(f)[0], h.hexdigest()[:20]))
             if os.path.exists(obj) and not force:

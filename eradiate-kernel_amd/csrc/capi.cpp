@@ -33,8 +33,8 @@ static thread_local std::string g_error;
 // renders of one scene (passes, sensors swept by the caller, benchmark steps) pays for hipMalloc / hipFree -- which synchronise
 // the device -- once.  Guarded by render_mutex.
 struct RenderCache {
-    void *ptr[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };   // 0: film (host-film renders), 1: counters, 2: blocks, 3: workspace, 4: tile table
-    size_t cap[5] = { 0, 0, 0, 0, 0 };
+    void *ptr[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };   // 0: film (host-film renders), 1: counters, 2: blocks, 3: workspace, 4: tile table, 5: film slots of the passes
+    size_t cap[6] = { 0, 0, 0, 0, 0, 0 };
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void *get(int k, size_t bytes) {
         bytes = std::max<size_t>(bytes, 16);
@@ -50,7 +50,7 @@ struct RenderCache {
         if (!ev0) { if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) throw std::runtime_error("hipEventCreate failed"); }
     }
     void release() {
-        for (int k = 0; k < 5; ++k) if (ptr[k]) { (void) hipFree(ptr[k]); ptr[k] = nullptr; cap[k] = 0; }
+        for (int k = 0; k < 6; ++k) if (ptr[k]) { (void) hipFree(ptr[k]); ptr[k] = nullptr; cap[k] = 0; }
         if (ev0) { (void) hipEventDestroy(ev0); ev0 = nullptr; }
         if (ev1) { (void) hipEventDestroy(ev1); ev1 = nullptr; }
     }
@@ -80,7 +80,7 @@ struct Spiral {
         block_id = block_counter + (remaining_passes - 1) * block_count;
         int offx = pos_x * block_size, offy = pos_y * block_size;
         b.sx = std::min(block_size, size_x - offx); b.sy = std::min(block_size, size_y - offy);
-        b.ox = offx + off_x; b.oy = offy + off_y;
+        b.ox = offx + off_x; b.oy = offy + off_y; b.film_off_lo = b.film_off_hi = 0;
         ++block_counter;
         if (block_counter != block_count) {
             do {
@@ -258,6 +258,14 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
         if (total_spp % split != 0) throw std::runtime_error("MTSAMD_WAVEFRONT_SPLIT must divide the sample count");
     }
     const size_t launch_spp = samples_per_pass / split;            // samples per pixel one entry of a launch renders
+    const size_t film_floats = (size_t) se.crop_w * se.crop_h * (size_t) hs.scene.film_channels;     // X, Y, Z, A, W (+ two AOV channels per spectral bin)
+    // The reference renders pass after pass and Film::put adds every finished block to the film (integrator.cpp:98-107,
+    // imageblock.cpp:59-77): film = ((pass 1 + pass 2) + pass 3) + ...  Here the (pass, block) pairs of a shard run concurrently, so every
+    // pass adds into a film-sized SLOT of its own (DBlock::film_off_*) and the slots are summed in pass order at the end
+    // (launch_film_sum_slots): the same additions in the same order -- for the AOV channels of nbins / bins too, whose samples go
+    // straight to the film by atomics.  Slots beyond 2 GiB are not allocated: the passes then meet in the one film in launch order.
+    bool pass_slots = n_passes > 1 && (uint64_t) n_passes * film_floats * sizeof(float) <= ((uint64_t) 2 << 30);
+    if (const char *ps = getenv("MTSAMD_PASS_SLOTS")) if (atoi(ps) == 0) pass_slots = false;
     std::vector<std::vector<DBlock>> pass_blocks(1);
     uint64_t samples = 0;
     for (size_t pass = 0; pass < n_passes; ++pass)
@@ -267,6 +275,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             if ((int) (id % (size_t) opts.shard_count) != opts.shard_index) continue;
             if (id >= ((uint64_t) 1 << 32)) throw std::runtime_error("block id overflow");
             b.id = (uint32_t) id; b.sample_base = 0;
+            { const uint64_t off = pass_slots ? (uint64_t) pass * film_floats : 0; b.film_off_lo = (uint32_t) off; b.film_off_hi = (uint32_t) (off >> 32); }
             for (size_t sub = 0; sub < split; ++sub) {               // wavefront streams: `split` entries share a block's samples
                 b.sample_base = (uint32_t) (sub * launch_spp);
                 if (pass_blocks.back().size() >= MAX_BLOCKS_PER_LAUNCH) pass_blocks.emplace_back();
@@ -274,12 +283,11 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             }
             samples += (uint64_t) b.sx * b.sy * samples_per_pass;
         }
-    const size_t film_floats = (size_t) se.crop_w * se.crop_h * (size_t) hs.scene.film_channels;     // X, Y, Z, A, W (+ two AOV channels per spectral bin)
     if (opts.film_capacity > 0 && (uint64_t) opts.film_capacity < (uint64_t) film_floats)
         throw std::runtime_error("mts_render: the film buffer holds " + std::to_string(opts.film_capacity) + " floats, this scene writes " + std::to_string(film_floats) +
                                  " (crop_width x crop_height x " + std::to_string(hs.scene.film_channels) + " channels: X, Y, Z, A, W + two per spectral bin)");
 #if defined(MTSAMD_HOST_ONLY)
-    (void) stream; (void) samples; (void) launch_spp; (void) t0; (void) stats;
+    (void) stream; (void) samples; (void) launch_spp; (void) t0; (void) stats; (void) pass_slots;
     HOST_ONLY_STOP("mts_render");
 #else
     RenderCache &rc = scene->cache;
@@ -289,6 +297,11 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
     // [16 + s]: cost of tile slot s of a calibration launch (16 pixels per tile: block_size^2 / 16 slots per block of the first chunk)
     unsigned long long *d_counters = (unsigned long long *) rc.get(1, (N_COUNTERS + std::max<size_t>(1, pass_blocks[0].size()) * ((size_t) block_size * block_size / 16u + 1u)) * sizeof(unsigned long long));
     HIP_CHECK(hipMemsetAsync(d_film, 0, film_floats * sizeof(float), stream));               // hdrfilm.cpp:201-203 (storage cleared by prepare())
+    float *d_target = d_film;                                        // what the kernels add to: the film, or the slots of the passes
+    if (pass_slots) {
+        d_target = (float *) rc.get(5, n_passes * film_floats * sizeof(float));
+        HIP_CHECK(hipMemsetAsync(d_target, 0, n_passes * film_floats * sizeof(float), stream));
+    }
     HIP_CHECK(hipMemsetAsync(d_counters, 0, N_COUNTERS * sizeof(unsigned long long), stream));
     if (const char *inj = getenv("MTSAMD_TEST_INJECT_LOST_PATH")) {   // test hook of the ring drivers' error path (volpath_flat.h, MTS_INJECT_SLOT): idle bound in ticks
         const unsigned long long ticks = strtoull(inj, nullptr, 10);
@@ -323,7 +336,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
         // without media there are no tracking walks to regroup: the per-lane kernels win (cornell box 512 x 512 x 256, volpath: rings 992,
         // per lane 1242 Msamples/s; `path` per lane: 2342, as one flat loop with regeneration 2910)
         if (!getenv("MTSAMD_KERNEL") && hs.media.empty() && hs.integrator.type != MTS_INTEGRATOR_PATH) variant = 0;
-        if (hs.integrator.type == MTS_INTEGRATOR_PATH) variant = (variant != 0 && !hs.integrator.spectral) ? 1 : 0;   // per lane: flat loop with regeneration (rgb / mono), or nested
+        if (hs.integrator.type == MTS_INTEGRATOR_PATH) variant = variant != 0 ? 1 : 0;   // per lane: flat loop with regeneration (every variant), or nested (MTSAMD_KERNEL=nested)
         // variant = family * 10000 + paths per workgroup (family 1: ring driver, 2: lane-affine driver)
         if (variant >= 10000) {
             int family = variant / 10000, wg = variant % 10000;
@@ -335,10 +348,11 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             if (wg != 1024) family = 1;                           // the lane-affine driver is built for 1024 paths only
             variant = (block_size * block_size) % (uint32_t) wg != 0 ? 1 : family * 10000 + wg;
         }
-        if (hs.integrator.spectral && variant == 1) variant = 0;                                      // no per-lane flat kernel in the spectral build
+        if (hs.integrator.spectral && variant == 1 && hs.integrator.type != MTS_INTEGRATOR_PATH) variant = 0;   // the spectral build's per-lane flat kernel is `path`'s
         // AOV channels (nbins / bins) and a sensor response function: `volpath` and (round 4) `volpathmis` carry them on the regrouping
-        // machines (their NEW blocks); `path` and a discrete response function with repeated wavelengths stay per lane
-        if ((hs.scene.bin_count > 0 || hs.scene.srf >= 0) &&
+        // machines (their NEW blocks) and `path` in its flat loop (kernels.hip: path_pixel_flat); a discrete response function with repeated
+        // wavelengths keeps the volumetric integrators per lane
+        if ((hs.scene.bin_count > 0 || hs.scene.srf >= 0) && !(variant == 1 && hs.integrator.type == MTS_INTEGRATOR_PATH) &&
             !(variant >= 10000 && hs.integrator.type != MTS_INTEGRATOR_PATH && hs.srf_lookup_by_wavelength)) variant = 0;
         // Wavefront (gpu_*) streams carry their own PCG32 increment per (pixel, sample).  The regrouping machine of rgb / mono `volpath` keeps
         // only the generator's 64-bit state in LDS and recomputes the increment on every load (round 4: wg_block's WF instantiation, 1024-path
@@ -368,7 +382,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             const size_t ws_records = hs.integrator.type == MTS_INTEGRATOR_VOLPATHMIS ? 2 : 1;
             float *d_ws = (float *) rc.get(3, render_workspace_floats(paths, variant) * ws_records * sizeof(float));
             HIP_CHECK((hs.integrator.spectral ? launch_render_spectral : launch_render)(
-                          hs.scene, d_blocks, (uint32_t) blocks.size(), block_size, spp, d_film, d_counters,
+                          hs.scene, d_blocks, (uint32_t) blocks.size(), block_size, spp, d_target, d_counters,
                           opts.collect_counters != 0, variant, wg_threads, d_ws, (const uint32_t *) scene->stop_word, d_tiles, (uint32_t) tiles.size(), stream));
             HIP_CHECK(hipEventRecord(ev1, stream));
             for (;;) {
@@ -412,6 +426,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
                 std::vector<DBlock> cal(pass_blocks[0]);           // the distinct block positions of the first chunk
                 std::sort(cal.begin(), cal.end(), [&](const DBlock &x, const DBlock &y) { return pos(x) < pos(y); });
                 cal.erase(std::unique(cal.begin(), cal.end(), [&](const DBlock &x, const DBlock &y) { return pos(x) == pos(y); }), cal.end());
+                for (DBlock &c : cal) c.film_off_lo = c.film_off_hi = 0;      // the calibration samples land in the first slot
                 const size_t n_cost = cal.size() * tiles_per_block;
                 HIP_CHECK(hipMemsetAsync(d_counters + N_COUNTERS, 0, n_cost * sizeof(unsigned long long), stream));
                 const unsigned long long flag = 1ull;
@@ -478,7 +493,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
                 // A cancel or the timeout that landed during calibration: the samples it rendered are the first of every pixel's stream --
                 // they stay as the (partial) film, as a stopped render keeps its finished samples; otherwise they are not part of the image
                 if (!should_stop()) {
-                    HIP_CHECK(hipMemsetAsync(d_film, 0, film_floats * sizeof(float), stream));
+                    HIP_CHECK(hipMemsetAsync(d_target, 0, film_floats * sizeof(float), stream));
                     HIP_CHECK(hipMemsetAsync(d_counters, 0, N_COUNTERS * sizeof(unsigned long long), stream));
                 }
             }
@@ -530,6 +545,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             }
             launch(blocks, (uint32_t) launch_spp, tiles);
         }
+        if (pass_slots) HIP_CHECK(launch_film_sum_slots(d_film, d_target, film_floats, (uint32_t) n_passes, stream));
         if (!opts.film_on_device) HIP_CHECK(hipMemcpyAsync(film, d_film, film_floats * sizeof(float), hipMemcpyDeviceToHost, stream));
         unsigned long long h_counters[N_COUNTERS] = {};
         HIP_CHECK(hipMemcpyAsync(h_counters, d_counters, sizeof(h_counters), hipMemcpyDeviceToHost, stream));

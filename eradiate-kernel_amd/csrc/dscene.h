@@ -129,7 +129,9 @@ struct DVolumeSp { int32_t value_sp; int32_t spectral_grid; float lambda_min, la
 struct DIntegrator { int32_t type, max_depth, rr_depth, hide_emitters, use_spectral_mis, monochrome; };
 
 // One spiral block (librender/spiral.cpp:27-72) assigned to this launch
-struct DBlock { int32_t ox, oy, sx, sy; uint32_t id; uint32_t sample_base; /* wavefront streams: first sample index this entry renders */ };
+struct DBlock { int32_t ox, oy, sx, sy; uint32_t id; uint32_t sample_base; /* wavefront streams: first sample index this entry renders */
+                uint32_t film_off_lo, film_off_hi; /* floats from the launch's film pointer to the film this entry adds to: the slot of its pass (capi.cpp) */ };
+static_assert(sizeof(DBlock) == 32, "DBlock is read as eight dwords (volpath_flat.h: wg_env)");
 
 struct DScene {
     const DVolume *volumes;

@@ -72,12 +72,13 @@ __device__ __forceinline__ void render_sample(const DScene &sc, Pcg32 &rng, cons
 #endif
 }
 
-#if MTS_SPEC_N == 3
 // `path` (integrators/path.cpp:100-211) for one pixel as ONE flat loop over path segments with regeneration: a lane whose path has ended
 // splats its sample and starts the pixel's next one at once, instead of idling until the longest path of the wave's 64 pixels has ended
 // (path lengths under Russian roulette are roughly geometric: the longest of 64 is several times the mean).  One ray_intersect site
 // serves camera rays and BSDF-sampled rays alike.  The lane draws exactly the numbers path_sample (integrator_dev.h) draws, in the
 // same order, and sums its samples in the same order: bit-identical to the nested formulation and to the CPU restatement.
+// Written over the variant's spectrum type: in the spectral build a sample also draws its four wavelengths (from the sensor's response
+// function when there is one), carries the bins' AOV values and reaches the film through spectrum_to_xyz, as render_sample above.
 template <bool COUNT>
 __device__ __forceinline__ void path_pixel_flat(const DScene &sc, Pcg32 &rng, const DBlock &blk, uint32_t lx, uint32_t ly, uint32_t sample_count,
                                                 float *__restrict__ film, float acc[5], Counters &cnt, const uint32_t *stop_flag) {
@@ -86,12 +87,17 @@ __device__ __forceinline__ void path_pixel_flat(const DScene &sc, Pcg32 &rng, co
     const float px = (float) (lx + (uint32_t) blk.ox), py = (float) (ly + (uint32_t) blk.oy);
     F2 position_sample; float ray_weight = 1.f;
     DRay ray;
-    F3 throughput = f3s(1.f), result = f3s(0.f), ref_p = f3s(0.f);
+    Spec throughput = spec_s(1.f), result = spec_s(0.f);
+    F3 ref_p = f3s(0.f);
     float eta = 1.f, emission_weight = 1.f, bs_pdf = 0.f;
     uint32_t bs_type = 0;
     bool valid_ray = false;
     int depth = 0;                                              // 0: the camera ray of a fresh sample has not been traced yet
     uint32_t j = 0;
+#if MTS_SPEC_N != 3
+    SpecCtx cx = make_ctx(sc);
+    Spec wav_weight = spec_s(0.f);
+#endif
     auto begin_sample = [&]() {                                 // integrator.cpp:242-264, path.cpp:106-119
         if (se.wavefront) seed_wavefront_sample(rng, se, blk, lx, ly, j);     // gpu_* streams: one per (pixel, sample)
         F2 u = rng.next_2d();
@@ -99,14 +105,22 @@ __device__ __forceinline__ void path_pixel_flat(const DScene &sc, Pcg32 &rng, co
         F2 aperture_sample; aperture_sample.x = .5f; aperture_sample.y = .5f;
         if (se.needs_aperture_sample) aperture_sample = rng.next_2d();
         if (se.shutter_open_time > 0.f) (void) rng.next_1d();
+#if MTS_SPEC_N == 3
         (void) rng.next_1d();                                   // wavelength sample, unused in rgb
+#else
+        {
+            const float wavelength_sample = rng.next_1d();      // integrator.cpp:252 -> Sensor::sample_ray: perspective.cpp:169-182, distant.cpp:311-313
+            if (sc.srf >= 0) cx.wl = sample_wavelengths_srf(sc, wavelength_sample, wav_weight);
+            else { float w; cx.wl = sample_wavelengths(wavelength_sample, w); wav_weight = spec_s(w); }
+        }
+#endif
         F2 adjusted;
         adjusted.x = (position_sample.x - (float) se.crop_x) / (float) se.crop_w;
         adjusted.y = (position_sample.y - (float) se.crop_y) / (float) se.crop_h;
         F3 rw;
         ray = sensor_sample_ray(sc, adjusted, aperture_sample, rw);
         ray_weight = rw.x;
-        throughput = f3s(1.f); result = f3s(0.f); eta = 1.f; emission_weight = 1.f; depth = 0;
+        throughput = spec_s(1.f); result = spec_s(0.f); eta = 1.f; emission_weight = 1.f; depth = 0;
     };
     begin_sample();
     for (uint32_t it = 0;; ++it) {
@@ -129,7 +143,7 @@ __device__ __forceinline__ void path_pixel_flat(const DScene &sc, Pcg32 &rng, co
         if (COUNT) cnt.n_iter++;
         Surf sf; sf.wi = -ray.d;
         if (hit_valid(si)) complete_surface(sc, si, ray.d, sf);
-        if (emitter >= 0) result = result + emission_weight * throughput * emitter_eval(sc, emitter, sf.wi.z);
+        if (emitter >= 0) result = result + emission_weight * throughput * emitter_eval(sc, emitter, sf.wi.z MTS_CX);
         bool active = hit_valid(si);
         if (depth > rr_depth) {
             float q = pm_min(hmax(throughput) * (eta * eta), .95f);
@@ -142,18 +156,18 @@ __device__ __forceinline__ void path_pixel_flat(const DScene &sc, Pcg32 &rng, co
             const DBsdf &bsdf = sc.bsdfs[bsdf_id];
             bool active_e = (bsdf.flags & F_Smooth) != 0;
             if (active_e) {
-                F3 emitter_val;
-                DirSample ds = sample_emitter_direction(sc, si.p, rng.next_2d(), true, emitter_val);
+                Spec emitter_val;
+                DirSample ds = sample_emitter_direction(sc, si.p, rng.next_2d(), true, emitter_val MTS_CX);
                 active_e = active_e && ds.pdf != 0.f;
                 F3 wo = to_local(sf.sh, ds.d);
-                F3 bsdf_val = bsdf_eval(bsdf, sf.wi, wo);
-                float bpdf = bsdf_pdf(bsdf, sf.wi, wo);
+                Spec bsdf_val = bsdf_eval(bsdf, sf.wi, wo MTS_CXI(bsdf_id));
+                float bpdf = bsdf_pdf(bsdf, sf.wi, wo MTS_CXI(bsdf_id));
                 float mis = ds.delta ? 1.f : mis_weight(ds.pdf, bpdf);
                 if (active_e) result = result + mis * throughput * bsdf_val * emitter_val;
             }
             float s1 = rng.next_1d(); F2 s2 = rng.next_2d();
             BSDFSample bs;
-            F3 bsdf_val = bsdf_sample(bsdf, sf.wi, s1, s2, bs);
+            Spec bsdf_val = bsdf_sample(bsdf, sf.wi, s1, s2, bs MTS_CXI(bsdf_id));
             throughput = throughput * bsdf_val;
             ended = !any_nonzero(throughput);
             if (!ended) {
@@ -163,13 +177,22 @@ __device__ __forceinline__ void path_pixel_flat(const DScene &sc, Pcg32 &rng, co
             }
         }
         if (ended) {                                             // integrator.cpp:265-288: splat, next sample of this pixel
+#if MTS_SPEC_N == 3
             splat_sample_t<false>(sc, blk, lx, ly, position_sample, f3s(ray_weight) * result, valid_ray, as_global(film), acc);
+#else
+            float aov[2 * 64]; const int na = 2 * sc.bin_count;  // nbins / bins: the wrapped integrator's own result, before the ray weight
+            for (int i = 0; i < sc.bin_count; ++i) bin_aovs(sc, result, cx.wl, i, aov[2 * i], aov[2 * i + 1]);
+            const Spec L = (wav_weight * ray_weight) * result;   // integrator.cpp:265
+            float xyz[3];
+            spectrum_to_xyz(sc.cie, L, cx.wl, xyz);              // integrator.cpp:266-269
+            const float v[5] = { xyz[0], xyz[1], xyz[2], valid_ray ? 1.f : 0.f, 1.f };
+            splat_values_t<false>(sc, blk, lx, ly, position_sample, v, as_global(film), acc, aov, na);
+#endif
             if (++j == sample_count) break;
             begin_sample();
         }
     }
 }
-#endif
 
 // librender/integrator.cpp:181-209 (scalar branch) for every block of this launch at once.
 // FLAT = true: volpath as the flat state machine of volpath_flat.h (the production kernel of the metric);
@@ -186,7 +209,7 @@ __device__ __forceinline__ void path_pixel_flat(const DScene &sc, Pcg32 &rng, co
 #endif
 template <bool COUNT, bool FLAT, int INTEG>
 __global__ void __launch_bounds__(256, (FLAT && INTEG != NI_PATH) ? 1 : (INTEG == NI_PATH ? MTS_PATH_WAVES : MTS_NESTED_WAVES)) render_kernel(DScene sc, const DBlock *__restrict__ blocks, uint32_t n_blocks, uint32_t block_size,
-                                                     uint32_t sample_count, float *__restrict__ film, unsigned long long *__restrict__ counters,
+                                                     uint32_t sample_count, float *__restrict__ film_base, unsigned long long *__restrict__ counters,
                                                      const uint32_t *__restrict__ stop_flag) {
     // LDS-staged BVH top: the breadth-first top levels of the host-built BVH (dscene.h), shared by the workgroup's traversals
     __shared__ float bvh_top[MTS_BVH_LDS_NODES * 8];
@@ -206,6 +229,7 @@ __global__ void __launch_bounds__(256, (FLAT && INTEG != NI_PATH) ? 1 : (INTEG =
     const uint32_t b = gid / ppb, i = gid - b * ppb;
     if (b >= n_blocks) return;
     const DBlock blk = blocks[b];
+    float *__restrict__ film = film_base + (((size_t) blk.film_off_hi << 32) | blk.film_off_lo);      // the film slot of the entry's pass (mts_render)
     const uint32_t lx = compact_bits(i), ly = compact_bits(i >> 1);                           // morton_decode, integrator.cpp:200
     if (lx >= (uint32_t) blk.sx || ly >= (uint32_t) blk.sy) return;
     Pcg32 rng;
@@ -220,10 +244,8 @@ __global__ void __launch_bounds__(256, (FLAT && INTEG != NI_PATH) ? 1 : (INTEG =
 #endif
     {
         float acc[5] = { 0.f, 0.f, 0.f, 0.f, 0.f };
-#if MTS_SPEC_N == 3
         if (INTEG == NI_PATH && FLAT) path_pixel_flat<COUNT>(sc, rng, blk, lx, ly, sample_count, film, acc, cnt, stop_flag);
         else
-#endif
         for (uint32_t j = 0; j < sample_count; ++j) {
             // should_stop(), integrator.h:143-146: the reference looks at its flag once per sample; here one lane of the wave reads the
             // host-visible word every 64 samples
@@ -364,6 +386,21 @@ hipError_t launch_wavefront_sampler(int32_t lanes, uint64_t seed_value, int32_t 
     return hipGetLastError();
 }
 
+// film[i] = ((slot 0 [i] + slot 1 [i]) + slot 2 [i]) + ... : the passes of a render added in pass order, as Film::put(block) adds the
+// blocks of pass after pass (integrator.cpp:98-107 -> hdrfilm.cpp:205-217 -> imageblock.cpp:59-77)
+__global__ void __launch_bounds__(256) film_sum_slots_kernel(float *__restrict__ film, const float *__restrict__ slots, size_t n, uint32_t count) {
+    const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = slots[i];
+    for (uint32_t k = 1; k < count; ++k) v += slots[(size_t) k * n + i];
+    film[i] = v;
+}
+hipError_t launch_film_sum_slots(float *d_film, const float *d_slots, size_t film_floats, uint32_t count, hipStream_t stream) {
+    if (film_floats == 0 || count == 0) return hipSuccess;
+    hipLaunchKernelGGL(film_sum_slots_kernel, dim3((unsigned) ((film_floats + 255) / 256)), dim3(256), 0, stream, d_film, d_slots, film_floats, count);
+    return hipGetLastError();
+}
+
 size_t render_workspace_floats(uint64_t threads, int variant) {
     if (variant < 256) return 0;
     if (variant >= 20000) variant -= 20000;
@@ -465,7 +502,7 @@ hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks,
 #undef LAUNCH_MIS
         return hipGetLastError();
     }
-    const bool flat = false; (void) d_workspace;                                  // path: the per-lane kernel
+    const bool flat = variant != 0; (void) d_workspace;                           // path: the per-lane kernels
 #endif
     const uint32_t grid = (uint32_t) ((threads + 255) / 256);
     const bool use_flat = flat && sc.integrator.type == MTS_INTEGRATOR_VOLPATH;
@@ -476,11 +513,8 @@ hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks,
     else
 #endif
     if (sc.integrator.type == MTS_INTEGRATOR_PATH) {
-#if MTS_SPEC_N == 3
         if (flat) LAUNCH_C(true, NI_PATH);                         // one flat loop over path segments with regeneration (path_pixel_flat)
-        else
-#endif
-        LAUNCH_C(false, NI_PATH);
+        else LAUNCH_C(false, NI_PATH);
     }
     else if (sc.integrator.type == MTS_INTEGRATOR_VOLPATH) LAUNCH_C(false, NI_VOLPATH);
     else if (sc.integrator.use_spectral_mis) LAUNCH_C(false, NI_VOLPATHMIS);

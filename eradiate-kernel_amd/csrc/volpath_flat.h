@@ -1006,6 +1006,7 @@ DEV bool wg_env(const WgArgs &a, uint32_t wg_base, uint32_t pid, PathEnvT<ColdSt
         if (ent == 0xFFFFFFFFu) return false;
         const MTS_GLOBAL_AS int32_t *bp = (const MTS_GLOBAL_AS int32_t *) as_global(a.blocks + (ent >> 12));
         e.blk.ox = bp[0]; e.blk.oy = bp[1]; e.blk.sx = bp[2]; e.blk.sy = bp[3]; e.blk.id = (uint32_t) bp[4]; e.blk.sample_base = (uint32_t) bp[5];
+        e.blk.film_off_lo = (uint32_t) bp[6]; e.blk.film_off_hi = (uint32_t) bp[7];
         e.index = ((ent & 4095u) * MTS_TILE_PIXELS) | (pid & (MTS_TILE_PIXELS - 1u));
     } else {
         // one spiral block per workgroup.  block_size is a power of two (mts_render rounds it up, as integrator.cpp:91-97 does): shift
@@ -1015,6 +1016,7 @@ DEV bool wg_env(const WgArgs &a, uint32_t wg_base, uint32_t pid, PathEnvT<ColdSt
         if (b >= a.n_blocks) return false;
         e.blk = cload(a.blocks + b);
     }
+    e.film += ((size_t) e.blk.film_off_hi << 32) | e.blk.film_off_lo;     // the film slot of the entry's pass (mts_render; 0 with a single pass)
     e.lx = compact_bits(e.index); e.ly = compact_bits(e.index >> 1);      // morton_decode, integrator.cpp:200
     return e.lx < (uint32_t) e.blk.sx && e.ly < (uint32_t) e.blk.sy;
 }

@@ -1042,9 +1042,13 @@ class SceneBuilder:
                     names += [item[0], item[0] + "_weights"]
                 mode = 2
             p.get(nested[0][0])
+            # the wrapper is the SamplingIntegrator that renders (nbins.cpp / bins.cpp: Base(props)): ITS block_size, samples_per_pass and
+            # timeout drive the render loop (integrator.cpp:29-48); of the nested integrator only sample() is used
+            outer = (int(p.get("block_size", 0)), int(p.get("samples_per_pass", -1)), float(p.get("timeout", -1.0)))
             p.finish()
             self.set_integrator(nested[0][1], where + "." + nested[0][0])
             it = self.integrator
+            it.block_size, it.samples_per_pass, it.timeout = outer
             if len(lo) > 64:
                 raise RuntimeError("this backend supports at most 64 spectral bins")
             it.bin_mode, it.bin_count = mode, len(lo)

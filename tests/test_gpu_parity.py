@@ -271,10 +271,8 @@ def test_c_abi_from_cpp_with_an_rccl_film_reduce(gpu_rgb, tmp_path):
              "sun": {"type": "directional", "to_world": T(), "irradiance": 1.0}}
         py, st = gpu_render(gpu_rgb, d)
         assert st["samples"] == 64 * 48 * 32 and np.all(py[..., 4] == 32)
-        if passes == 1:
-            assert np.array_equal(cpp, py), float(np.abs(cpp - py).max())
-        else:       # several passes of a block add into one film entry by float atomics: equal up to the order of those additions
-            assert np.array_equal(cpp[..., 3:], py[..., 3:]) and np.allclose(cpp, py, rtol=1e-6, atol=0)
+        # several passes: every pass adds into a film slot of its own and the slots are summed in pass order (capi.cpp) -- deterministic
+        assert np.array_equal(cpp, py), float(np.abs(cpp - py).max())
         assert cpp[..., 1].max() > 0 and "rank 0 of 1" in r.stdout
 
 
@@ -1080,6 +1078,27 @@ def test_tea_and_wavefront_sampler_on_device(gpu_rgb):
     assert np.array_equal(streams, ref) and len(np.unique(streams[:, 0])) > 290
 
 
+@pytest.mark.parametrize("case", ["volpath", "volpath_nested", "volpathmis", "path"])
+def test_passes_add_up_in_pass_order(gpu_rgb, monkeypatch, case):
+    """samples_per_pass: the reference renders pass after pass and Film::put adds each finished block to the film (integrator.cpp:98-107,
+    imageblock.cpp:59-77), i.e. film = ((pass 1 + pass 2) + pass 3) + ...  mts_render runs the (pass, block) pairs of a shard concurrently;
+    every pass adds into a film slot of its own and the slots are summed in pass order, so four passes give the oracle's film bit for
+    bit, where passes meeting in one film by atomics were equal only up to the order of the additions (MTSAMD_PASS_SLOTS=0 is that mode).  The reference's own order
+    is that of its worker threads' completions (one tbb::parallel_for over all pass x block pairs); with one thread it is pass after pass."""
+    if case == "volpath_nested":
+        monkeypatch.setenv("MTSAMD_KERNEL", "nested")
+    if case == "path":
+        d = scenes.c1_cornell(48, 40, 16)
+        d["integrator"]["samples_per_pass"] = 4
+    else:
+        d = scenes.c3_heterogeneous(72, 40, 16, res=16, samples_per_pass=4)
+        d["integrator"]["type"] = "volpathmis" if case == "volpathmis" else "volpath"
+    gpu, st = gpu_render(gpu_rgb, d)
+    ref = ob.OracleScene(d).render(threads=1)          # one thread: the blocks reach the film in spiral order, pass after pass
+    assert ref[..., :3].max() > 0
+    assert_parity(gpu, ref)
+
+
 # ---------------------------------------------------------------- spectral variant (SURVEY.md 8(f1))
 @pytest.fixture(scope="module")
 def gpu_spectral(pkg):
@@ -1138,11 +1157,14 @@ def _spectral_cases():
 def test_spectral_variant_against_oracle(gpu_spectral, monkeypatch, name, kernel):
     """gpu_spectral (kernels_spectral.hip: Spectrum<Float, 4>, sample_wavelength, spectrum_to_xyz) against liboracle_spectral.so on the
     same seeded inputs: the films and the loop counters are identical -- `volpath` on the regrouping machine (four-wide state, 256-path
-    workgroups; the default) and in the nested per-lane formulation (MTSAMD_KERNEL=nested), `path` per lane."""
+    workgroups; the default) and in the nested per-lane formulation (MTSAMD_KERNEL=nested), `path` per lane: as one flat loop with
+    regeneration (round 4: path_pixel_flat is written over the variant's spectrum type) or nested."""
     if kernel:
         monkeypatch.setenv("MTSAMD_KERNEL", kernel)
     d = _spectral_cases()[name]
     gpu, st = gpu_render(gpu_spectral, d, collect_counters=True)
+    if name == "cornell_path":
+        assert st["kernel_variant"] == (0 if kernel else 1)
     o = ob.OracleScene(d, spectral=True)
     ref = o.render()
     assert ref[..., :3].max() > 0
@@ -1198,6 +1220,55 @@ def test_spectral_volpathmis_against_oracle(gpu_spectral, monkeypatch, name, use
     ref = o.render()
     assert ref[..., :3].max() > 0
     assert_parity(gpu, ref)
+    assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (o.last_stats["n_iter"], o.last_stats["n_lookup"], o.last_stats["n_nee_step"])
+
+
+def test_passes_add_up_in_pass_order_with_aov_channels(gpu_spectral):
+    """The AOV channels of nbins reach the film by atomics, sample by sample; with a film slot per pass (test_passes_add_up_in_pass_order)
+    they too are the oracle's after four passes."""
+    d = _spectral_cases()["c5s_atmosphere"]
+    d["sensor"]["sampler"]["sample_count"] = 16
+    d["integrator"] = {"type": "nbins", "wavelengths": "400, 480, 560, 640, 720, 800", "tolerance": 30.0, "samples_per_pass": 4,
+                       "integrator": dict(d["integrator"])}
+    scene = gpu_spectral.load_dict(d)
+    sensor = scene.sensors()[0]
+    assert scene.integrator().render(scene, sensor)
+    raw = np.array(sensor.film().bitmap(raw=True))
+    ref = ob.OracleScene(d, spectral=True).render(threads=1)
+    assert raw.shape[2] == 17 and ref[..., 5:].max() > 0
+    assert_parity(raw, ref)
+
+
+@pytest.mark.parametrize("kernel", [None, "nested"])
+@pytest.mark.parametrize("wrap", ["nbins", "bins_discrete_srf", "srf_uniform"])
+def test_spectral_path_flat_loop_with_bins_and_srf(gpu_spectral, monkeypatch, wrap, kernel):
+    """`path` in the spectral variant runs as the flat loop with regeneration (kernels.hip: path_pixel_flat, kernel_variant 1) also inside
+    nbins / bins and under a sensor response function -- wavelengths from the response function, AOV values splatted with the sample --
+    and gives the film and AOV channels of the oracle, as the nested kernel does (MTSAMD_KERNEL=nested)."""
+    if kernel:
+        monkeypatch.setenv("MTSAMD_KERNEL", kernel)
+    d = _spectral_cases()["cornell_path"]
+    d["sensor"]["film"] = dict(d["sensor"]["film"], width=40, height=24)                 # partial blocks
+    channels = 5
+    if wrap == "nbins":
+        d["integrator"] = {"type": "nbins", "wavelengths": "400, 480, 560, 640, 720, 800", "tolerance": 30.0, "integrator": dict(d["integrator"])}
+        channels = 5 + 2 * 6
+    elif wrap == "bins_discrete_srf":
+        d["sensor"]["srf"] = {"type": "discrete", "wavelengths": "450, 550, 550, 750", "values": "0.5, 1.0, 0.75, 0.25"}      # a repeated wavelength too
+        d["integrator"] = {"type": "bins", "bins": "a:400:500, b:500:600, c:600:800", "integrator": dict(d["integrator"])}
+        channels = 5 + 2 * 3
+    else:
+        d["sensor"]["srf"] = {"type": "uniform", "lambda_min": 500.0, "lambda_max": 700.0, "value": 0.5}
+    d["integrator"]["samples_per_pass"] = 4                                              # 8 spp: two passes
+    scene = gpu_spectral.load_dict(d)
+    sensor = scene.sensors()[0]
+    assert scene.integrator().render(scene, sensor, collect_counters=True)
+    raw = np.array(sensor.film().bitmap(raw=True))
+    st = scene.integrator().last_stats
+    assert st["kernel_variant"] == (0 if kernel else 1)
+    o = ob.OracleScene(d, spectral=True); ref = o.render(threads=1)
+    assert raw.shape[2] == channels and ref[..., :3].max() > 0 and (channels == 5 or ref[..., 5:].max() > 0)
+    assert_parity(raw, ref)
     assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (o.last_stats["n_iter"], o.last_stats["n_lookup"], o.last_stats["n_nee_step"])
 
 
