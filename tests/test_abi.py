@@ -109,6 +109,9 @@ def test_default_kernel_resource_budget(tmp_path):
     # `path` as a flat loop with regeneration: 128 VGPRs (4 waves per SIMD) with spills; 5 waves measured 40 % slower
     pk = one("5v_rgb13render_kernelILb0ELb1ELi0EE")
     assert pk["vgpr_count"] <= 128 and pk["vgpr_spill_count"] <= 100, pk
+    # ... and over four-wide spectra (round 4): three waves per SIMD (168 VGPRs), fewer spills than the nested loop it replaces (51)
+    pks = one("10v_spectral13render_kernelILb0ELb1ELi0EE")
+    assert pks["vgpr_count"] <= 168 and pks["vgpr_spill_count"] <= 48, pks
     # the spectral variant's volpath: 256 paths x 42 state dwords, three workgroups per CU
     sp = one("10v_spectral17render_kernel_wgaILb0ELi256ELi256ELi2ELb0E")
     assert sp["vgpr_count"] <= 168 and sp["vgpr_spill_count"] == 0 and 3 * sp["group_segment_fixed_size"] <= 160 * 1024, sp

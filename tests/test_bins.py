@@ -45,6 +45,18 @@ def test_construct_nbins():
         integrator_only({"type": "nbins", "wavelengths": "400, 500, 600, 700"})
 
 
+def test_the_wrapper_is_the_integrator_that_renders():
+    """nbins / bins derive from SamplingIntegrator (nbins.cpp: Base(props)): block_size, samples_per_pass and timeout of the WRAPPER drive
+    the render loop (integrator.cpp:29-48); the nested integrator only lends its sample(), its own render-loop properties are unused."""
+    b = integrator_only({"type": "nbins", "wavelengths": "400, 500", "samples_per_pass": 4, "block_size": 16, "timeout": 2.5,
+                         "integrator": {"type": "volpath", "samples_per_pass": 8, "block_size": 64, "max_depth": 7, "rr_depth": 3}})
+    it = b.integrator
+    assert (it.samples_per_pass, it.block_size, it.timeout) == (4, 16, 2.5)
+    assert (it.max_depth, it.rr_depth, it.bin_count) == (7, 3, 2)                                   # what sample() needs stays the nested integrator's
+    it = integrator_only({"type": "bins", "bins": "a:400:500", "integrator": {"type": "path", "samples_per_pass": 8, "block_size": 64}}).integrator
+    assert (it.samples_per_pass, it.block_size, it.timeout) == (-1, 0, -1.0)
+
+
 def test_construct_bins():
     b = integrator_only({"type": "bins", "bins": "01:400:500, 02:500:600, 03:600:700, 04:700:800", "integrator": {"type": "path"}})
     names = ["01", "01_weights", "02", "02_weights", "03", "03_weights", "04", "04_weights"]
