@@ -264,7 +264,10 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
     // pass adds into a film-sized SLOT of its own (DBlock::film_off_*) and the slots are summed in pass order at the end
     // (launch_film_sum_slots): the same additions in the same order -- for the AOV channels of nbins / bins too, whose samples go
     // straight to the film by atomics.  Slots beyond 2 GiB are not allocated: the passes then meet in the one film in launch order.
-    bool pass_slots = n_passes > 1 && (uint64_t) n_passes * film_floats * sizeof(float) <= ((uint64_t) 2 << 30);
+    // The `split` entries of a block under wavefront streams (above) get slots of their own as well: their partial sums are added in
+    // sample order instead of in the order their atomics happen to land -- the same film run after run.
+    const size_t n_slots = n_passes * split;
+    bool pass_slots = n_slots > 1 && (uint64_t) n_slots * film_floats * sizeof(float) <= ((uint64_t) 2 << 30);
     if (const char *ps = getenv("MTSAMD_PASS_SLOTS")) if (atoi(ps) == 0) pass_slots = false;
     std::vector<std::vector<DBlock>> pass_blocks(1);
     uint64_t samples = 0;
@@ -275,9 +278,9 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             if ((int) (id % (size_t) opts.shard_count) != opts.shard_index) continue;
             if (id >= ((uint64_t) 1 << 32)) throw std::runtime_error("block id overflow");
             b.id = (uint32_t) id; b.sample_base = 0;
-            { const uint64_t off = pass_slots ? (uint64_t) pass * film_floats : 0; b.film_off_lo = (uint32_t) off; b.film_off_hi = (uint32_t) (off >> 32); }
             for (size_t sub = 0; sub < split; ++sub) {               // wavefront streams: `split` entries share a block's samples
                 b.sample_base = (uint32_t) (sub * launch_spp);
+                { const uint64_t off = pass_slots ? (uint64_t) (pass * split + sub) * film_floats : 0; b.film_off_lo = (uint32_t) off; b.film_off_hi = (uint32_t) (off >> 32); }
                 if (pass_blocks.back().size() >= MAX_BLOCKS_PER_LAUNCH) pass_blocks.emplace_back();
                 pass_blocks.back().push_back(b);
             }
@@ -287,7 +290,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
         throw std::runtime_error("mts_render: the film buffer holds " + std::to_string(opts.film_capacity) + " floats, this scene writes " + std::to_string(film_floats) +
                                  " (crop_width x crop_height x " + std::to_string(hs.scene.film_channels) + " channels: X, Y, Z, A, W + two per spectral bin)");
 #if defined(MTSAMD_HOST_ONLY)
-    (void) stream; (void) samples; (void) launch_spp; (void) t0; (void) stats; (void) pass_slots;
+    (void) stream; (void) samples; (void) launch_spp; (void) t0; (void) stats; (void) pass_slots; (void) n_slots;
     HOST_ONLY_STOP("mts_render");
 #else
     RenderCache &rc = scene->cache;
@@ -299,8 +302,8 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
     HIP_CHECK(hipMemsetAsync(d_film, 0, film_floats * sizeof(float), stream));               // hdrfilm.cpp:201-203 (storage cleared by prepare())
     float *d_target = d_film;                                        // what the kernels add to: the film, or the slots of the passes
     if (pass_slots) {
-        d_target = (float *) rc.get(5, n_passes * film_floats * sizeof(float));
-        HIP_CHECK(hipMemsetAsync(d_target, 0, n_passes * film_floats * sizeof(float), stream));
+        d_target = (float *) rc.get(5, n_slots * film_floats * sizeof(float));
+        HIP_CHECK(hipMemsetAsync(d_target, 0, n_slots * film_floats * sizeof(float), stream));
     }
     HIP_CHECK(hipMemsetAsync(d_counters, 0, N_COUNTERS * sizeof(unsigned long long), stream));
     if (const char *inj = getenv("MTSAMD_TEST_INJECT_LOST_PATH")) {   // test hook of the ring drivers' error path (volpath_flat.h, MTS_INJECT_SLOT): idle bound in ticks
@@ -545,7 +548,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             }
             launch(blocks, (uint32_t) launch_spp, tiles);
         }
-        if (pass_slots) HIP_CHECK(launch_film_sum_slots(d_film, d_target, film_floats, (uint32_t) n_passes, stream));
+        if (pass_slots) HIP_CHECK(launch_film_sum_slots(d_film, d_target, film_floats, (uint32_t) n_slots, stream));
         if (!opts.film_on_device) HIP_CHECK(hipMemcpyAsync(film, d_film, film_floats * sizeof(float), hipMemcpyDeviceToHost, stream));
         unsigned long long h_counters[N_COUNTERS] = {};
         HIP_CHECK(hipMemcpyAsync(h_counters, d_counters, sizeof(h_counters), hipMemcpyDeviceToHost, stream));

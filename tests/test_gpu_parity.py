@@ -107,8 +107,9 @@ def test_wavefront_streams_match_the_oracle(gpu_rgb, monkeypatch, case):
     """The random streams of the reference's wavefront (gpu_*) variants -- one PCG32 per (pixel, sample), seeded with the 64-bit TEA of
     librender/sampler.cpp:89-92 in the lane order of integrator.cpp:143-163 -- as a render mode (sampler "wavefront": True): every
     kernel formulation gives the film of the oracle run with the same seeding.  With one workgroup entry per block (split 1) the sums
-    are taken in sample order: bit-identical.  Spread over several entries per block (the default on a small film) the partial sums
-    meet in the film by float atomics: equal to rounding."""
+    are taken in sample order: bit-identical.  Spread over several entries per block (the default on a small film) every entry sums
+    its share of a pixel's samples into a film slot of its own and the slots are added in sample order (capi.cpp): equal to the
+    oracle's one running sum up to rounding, and the same film run after run."""
     d = {"cornell_path": lambda: scenes.c1_cornell(48, 40, 16), "cornell_path_nested": lambda: scenes.c1_cornell(48, 40, 16),
          "c3_volpath": lambda: scenes.c3_heterogeneous(64, 40, 16, res=16), "c3_volpath_nested": lambda: scenes.c3_heterogeneous(64, 40, 16, res=16),
          "c3_volpathmis": lambda: scenes.c3_heterogeneous(64, 40, 16, res=16), "c4_small": lambda: scenes.c4_atmosphere(24, 24, 8, layers=8)}[case]()
@@ -130,6 +131,8 @@ def test_wavefront_streams_match_the_oracle(gpu_rgb, monkeypatch, case):
     spread, st2 = gpu_render(gpu_rgb, d, collect_counters=True)                   # small film: several entries per block
     assert np.array_equal(spread[..., 3:], ref[..., 3:]) and np.allclose(spread, ref, rtol=2e-5, atol=1e-7)
     assert (st2["n_iter"], st2["n_lookup"], st2["n_nee_step"]) == (st["n_iter"], st["n_lookup"], st["n_nee_step"]) and st2["samples"] == st["samples"]
+    again, _ = gpu_render(gpu_rgb, d)
+    assert np.array_equal(again, spread)
     with pytest.raises(RuntimeError, match="one pass"):
         d["integrator"]["samples_per_pass"] = d["sensor"]["sampler"]["sample_count"] // 2
         gpu_rgb.load_dict(d)
