@@ -27,7 +27,7 @@ DM_HD F3 operator-(F3 a) { return f3(-a.x, -a.y, -a.z); }
 DM_HD F3 operator*(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
 DM_HD F3 operator*(float s, F3 a) { return f3(a.x * s, a.y * s, a.z * s); }
 DM_HD F3 operator*(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
-DM_HD F3 operator/(F3 a, float s) { const float r = 1.0f / s; return f3(a.x * r, a.y * r, a.z * r); }   // enoki: array / scalar = reciprocal, then multiply
+DM_HD F3 operator/(F3 a, float s) { const float r = pm_rcp(s); return f3(a.x * r, a.y * r, a.z * r); }   // enoki: array / scalar = reciprocal, then multiply
 DM_HD F3 operator/(F3 a, F3 b) { return f3(a.x / b.x, a.y / b.y, a.z / b.z); }
 DM_HD float dot(F3 a, F3 b) { return pm_fma(a.z, b.z, pm_fma(a.y, b.y, a.x * b.x)); }
 DM_HD float squared_norm(F3 a) { return dot(a, a); }
@@ -41,7 +41,7 @@ DM_HD F3 fnmadd(F3 a, float s, F3 c) { return f3(pm_fma(-a.x, s, c.x), pm_fma(-a
 DM_HD float hmax(F3 a) { return pm_max(pm_max(a.x, a.y), a.z); }
 DM_HD float hmin(F3 a) { return pm_min(pm_min(a.x, a.y), a.z); }
 DM_HD float hmax_abs(F3 a) { return pm_max(pm_max(pm_abs(a.x), pm_abs(a.y)), pm_abs(a.z)); }
-DM_HD F3 vrcp(F3 a) { return f3(1.0f / a.x, 1.0f / a.y, 1.0f / a.z); }
+DM_HD F3 vrcp(F3 a) { return f3(pm_rcp(a.x), pm_rcp(a.y), pm_rcp(a.z)); }
 DM_HD float pick(F3 a, uint32_t i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 DM_HD bool any_nonzero(F3 a) { return a.x != 0.f || a.y != 0.f || a.z != 0.f; }
 
@@ -68,7 +68,7 @@ DM_HD Spec operator-(Spec a, Spec b) { return spec4(a.x - b.x, a.y - b.y, a.z - 
 DM_HD Spec operator*(Spec a, float s) { return spec4(a.x * s, a.y * s, a.z * s, a.w * s); }
 DM_HD Spec operator*(float s, Spec a) { return spec4(a.x * s, a.y * s, a.z * s, a.w * s); }
 DM_HD Spec operator*(Spec a, Spec b) { return spec4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
-DM_HD Spec operator/(Spec a, float s) { const float r = 1.0f / s; return spec4(a.x * r, a.y * r, a.z * r, a.w * r); }   // as for F3: reciprocal, then multiply
+DM_HD Spec operator/(Spec a, float s) { const float r = pm_rcp(s); return spec4(a.x * r, a.y * r, a.z * r, a.w * r); }   // as for F3: reciprocal, then multiply
 DM_HD Spec operator/(Spec a, Spec b) { return spec4(a.x / b.x, a.y / b.y, a.z / b.z, a.w / b.w); }
 DM_HD float hmax(Spec a) { return pm_max(pm_max(a.x, a.y), pm_max(a.z, a.w)); }
 DM_HD float pick(Spec a, uint32_t) { return a.x; }                       // index_spectrum, volpath.cpp:26-36

@@ -133,7 +133,7 @@ DEV bool bbox_ray_intersect(const DBBox &b, const DRay &ray, float &mint, float 
 // shapes/rectangle.cpp:139-155
 DEV float rectangle_intersect(const float *to_object /* rows 0..2 suffice */, const DRay &ray, F2 &uv) {
     F3 o = mat_point_affine(to_object, ray.o), d = mat_vector(to_object, ray.d);
-    float t = -o.z * (1.0f / d.z);
+    float t = -o.z * pm_rcp(d.z);
     float lx = pm_fma(d.x, t, o.x), ly = pm_fma(d.y, t, o.y);
     bool active = t >= ray.mint && t <= ray.maxt && pm_abs(lx) <= 1.f && pm_abs(ly) <= 1.f;
     uv.x = lx; uv.y = ly;
@@ -142,7 +142,7 @@ DEV float rectangle_intersect(const float *to_object /* rows 0..2 suffice */, co
 // shapes/disk.cpp:136-153
 DEV float disk_intersect(const float *to_object, const DRay &ray, F2 &uv) {
     F3 o = mat_point_affine(to_object, ray.o), d = mat_vector(to_object, ray.d);
-    float t = -o.z * (1.0f / d.z);
+    float t = -o.z * pm_rcp(d.z);
     float lx = pm_fma(d.x, t, o.x), ly = pm_fma(d.y, t, o.y);
     bool active = t >= ray.mint && t <= ray.maxt && lx * lx + ly * ly <= 1.f;
     uv.x = lx; uv.y = ly;
@@ -489,7 +489,7 @@ DEV void volume_eval_grid_spectral_n(const GridRef &g, const float *data_b, F3 p
     int x0 = wrap_coord(wrap, ix, nx), x1 = wrap_coord(wrap, ix + 1, nx), y0 = wrap_coord(wrap, iy, ny), y1 = wrap_coord(wrap, iy + 1, ny),
         z0 = wrap_coord(wrap, iz, nz), z1 = wrap_coord(wrap, iz + 1, nz);
     int r00 = ((z0 * ny + y0) * nx), r10 = ((z0 * ny + y1) * nx), r01 = ((z1 * ny + y0) * nx), r11 = ((z1 * ny + y1) * nx);
-    const float inv_dlambda = 1.0f / (lambda_max - lambda_min), lambda_scale = (float) (ch - 1);          // array / scalar = array * (1 / scalar)
+    const float inv_dlambda = pm_rcp(lambda_max - lambda_min), lambda_scale = (float) (ch - 1);          // array / scalar = array * (1 / scalar)
     float out[NG][4]; const float lam[4] = { wl.x, wl.y, wl.z, wl.w };
     const int corner[8] = { (r00 + x0) * ch, (r00 + x1) * ch, (r10 + x0) * ch, (r10 + x1) * ch, (r01 + x0) * ch, (r01 + x1) * ch, (r11 + x0) * ch, (r11 + x1) * ch };
     for (int k = 0; k < 4; ++k) {
@@ -1026,7 +1026,7 @@ DEV DirSample sample_emitter_direction(const DScene &sc, F3 ref_p, F2 sample, bo
     if (sc.emitter_count == 0) { spec = spec_s(0.f); return ds; }
     if (sc.emitter_count == 1) ds = emitter_sample_direction<true>(sc, 0, ref_p, sample, spec, cx);
     else {
-        float n = (float) sc.emitter_count, emitter_pdf = 1.f / n;
+        float n = (float) sc.emitter_count, emitter_pdf = pm_rcp(n);
         uint32_t index = min((uint32_t) (sample.x * n), (uint32_t) sc.emitter_count - 1);
         sample.x = (sample.x - index * emitter_pdf) * n;
         ds = emitter_sample_direction(sc, (int) index, ref_p, sample, spec, cx);
@@ -1047,7 +1047,7 @@ DEV float pdf_emitter_direction(const DScene &sc, F3 ref_p, const DirSample &ds)
     else if (e.type == MTS_EMITTER_CONSTANT) value = MTS_INV_FOUR_PI;
     else { float dp = dot(ds.d, ds.n); value = dp < 0.f ? shape_pdf_direction(sc.shapes[e.shape], ref_p, ds) : 0.f; }
     if (sc.emitter_count == 1) return value;
-    return value * (1.f / sc.emitter_count);
+    return value * pm_rcp((float) sc.emitter_count);
 }
 // si.emitter(scene), render/scene.h:243-253 ; emitter->eval: area.cpp:63-71, constant.cpp:41-44, directional.cpp:75-78
 DEV int hit_emitter(const DScene &sc, const Hit &h) { return hit_valid(h) ? sc.shapes[h.shape].emitter : sc.environment; }
@@ -1352,16 +1352,18 @@ DEV float mw_nan0(float x) { return x != x ? 0.f : x; }
 #if MTS_SPEC_N == 3
 DEV Spec spec_map_fin(Spec a) { return f3(mw_fin(a.x), mw_fin(a.y), mw_fin(a.z)); }
 DEV Spec spec_map_nan0(Spec a) { return f3(mw_nan0(a.x), mw_nan0(a.y), mw_nan0(a.z)); }
-DEV Spec spec_div_s(Spec p, float f) { float r = 1.0f / f; return f3(p.x * r, p.y * r, p.z * r); } // spectrum / coefficient (:456): reciprocal, then multiply (enoki array / scalar)
+DEV Spec spec_div_s(Spec p, float f) { float r = pm_rcp(f); return f3(p.x * r, p.y * r, p.z * r); } // spectrum / coefficient (:456): reciprocal, then multiply (enoki array / scalar)
 DEV Spec spec_s_div(float p, Spec f) { return f3(p / f.x, p / f.y, p / f.z); }
+DEV Spec spec_rcp(Spec f) { return f3(pm_rcp(f.x), pm_rcp(f.y), pm_rcp(f.z)); }                  // 1.f / spectrum: the quotients, through pm_rcp
 DEV Spec spec_of(float a, float b, float c, float) { return f3(a, b, c); }
 DEV float spec_hsum(Spec a) { return (a.x + a.y) + a.z; }
 DEV float spec_hmin_abs(Spec a) { return pm_min(pm_min(pm_abs(a.x), pm_abs(a.y)), pm_abs(a.z)); }
 #else
 DEV Spec spec_map_fin(Spec a) { return spec4(mw_fin(a.x), mw_fin(a.y), mw_fin(a.z), mw_fin(a.w)); }
 DEV Spec spec_map_nan0(Spec a) { return spec4(mw_nan0(a.x), mw_nan0(a.y), mw_nan0(a.z), mw_nan0(a.w)); }
-DEV Spec spec_div_s(Spec p, float f) { float r = 1.0f / f; return spec4(p.x * r, p.y * r, p.z * r, p.w * r); }
+DEV Spec spec_div_s(Spec p, float f) { float r = pm_rcp(f); return spec4(p.x * r, p.y * r, p.z * r, p.w * r); }
 DEV Spec spec_s_div(float p, Spec f) { return spec4(p / f.x, p / f.y, p / f.z, p / f.w); }
+DEV Spec spec_rcp(Spec f) { return spec4(pm_rcp(f.x), pm_rcp(f.y), pm_rcp(f.z), pm_rcp(f.w)); }
 DEV Spec spec_of(float a, float b, float c, float d) { return spec4(a, b, c, d); }
 DEV float spec_hsum(Spec a) { return (a.x + a.y) + (a.z + a.w); }                             // hsum of a 4-array: pairwise, as spec_hmean (dmath.h)
 DEV float spec_hmin_abs(Spec a) { return pm_min(pm_min(pm_abs(a.x), pm_abs(a.y)), pm_min(pm_abs(a.z), pm_abs(a.w))); }
@@ -1388,7 +1390,7 @@ DEV void update_weights(MisWeights<SPEC> &w, Spec p, Spec f, uint32_t channel, b
 template <bool SPEC>
 DEV void update_weights_uniform(MisWeights<SPEC> &w, float p, float f) {
     if (SPEC) {
-        const float ratio = mw_fin(p * (1.0f / f));
+        const float ratio = mw_fin(p * pm_rcp(f));
 #pragma unroll
         for (int i = 0; i < MTS_SPEC_N; ++i) w.r[i] = spec_map_nan0(spec_s(ratio) * w.r[i]);
     } else {
@@ -1407,7 +1409,7 @@ DEV Spec mis_weight_w(const MisWeights<SPEC> &w) {                              
         return spec_of(o[0], o[1], o[2], o[3]);
     }
     Spec a = w.r[0];
-    return spec_hmin_abs(a) == 0.f ? spec_s(0.f) : spec_s_div(1.f, a);
+    return spec_hmin_abs(a) == 0.f ? spec_s(0.f) : spec_rcp(a);
 }
 template <bool SPEC>
 DEV Spec mis_weight_w(const MisWeights<SPEC> &a, const MisWeights<SPEC> &b) {                    // volpathmis.cpp:484-498
@@ -1418,7 +1420,7 @@ DEV Spec mis_weight_w(const MisWeights<SPEC> &a, const MisWeights<SPEC> &b) {   
         return spec_of(o[0], o[1], o[2], o[3]);
     }
     Spec sum = a.r[0] + b.r[0];
-    return spec_hmin_abs(sum) == 0.f ? spec_s(0.f) : spec_s_div(1.f, sum);
+    return spec_hmin_abs(sum) == 0.f ? spec_s(0.f) : spec_rcp(sum);
 }
 
 // volpathmis.cpp:330-445
@@ -1974,7 +1976,7 @@ DEV DRay sensor_sample_ray(const DScene &sc, F2 position_sample, F2 aperture_sam
             F3 tp, n; float pdf;
             shape_sample_position(mesh_tables(sc), se.target_shape, aperture_sample, tp, n, pdf);
             o = tp - 2.f * d * se.bsphere_radius;
-            w = 1.f / (pdf * se.target_area);
+            w = pm_rcp(pdf * se.target_area);
         } else {
             F2 offset = square_to_uniform_disk_concentric(aperture_sample);
             F3 perp_offset = mat_vector(m, f3(offset.x, offset.y, 0.f));
@@ -1991,7 +1993,7 @@ DEV DRay sensor_sample_ray(const DScene &sc, F2 position_sample, F2 aperture_sam
         if (se.target_type == MTS_DISTANT_TARGET_SHAPE) {
             F3 n; float pdf;
             shape_sample_position(mesh_tables(sc), se.target_shape, aperture_sample, ray_target, n, pdf);
-            w *= 1.f / (pdf * se.target_area);
+            w *= pm_rcp(pdf * se.target_area);
         } else if (se.target_type == MTS_DISTANT_TARGET_NONE) {
             F2 offset = square_to_uniform_disk_concentric(aperture_sample);
             F3 perp_offset = mat_vector(se.to_world.m, f3(offset.x, offset.y, 0.f));
@@ -2013,12 +2015,12 @@ DEV DRay sensor_sample_ray(const DScene &sc, F2 position_sample, F2 aperture_sam
     if (se.target_type == MTS_DISTANT_TARGET_SHAPE) {
         F3 n; float pdf;
         shape_sample_position(mesh_tables(sc), se.target_shape, aperture_sample, ray_target, n, pdf);
-        w = (1.f / pdf) * (1.f / se.target_area);                                                 // Spectrum / Float / Float: each a reciprocal-multiply
+        w = pm_rcp(pdf) * pm_rcp(se.target_area);                                                 // Spectrum / Float / Float: each a reciprocal-multiply
     } else if (se.target_type == MTS_DISTANT_TARGET_NONE) {
         F2 offset = square_to_uniform_disk_concentric(aperture_sample);
         F3 perp_offset = mat_vector(se.to_world.m, f3(offset.x, offset.y, 0.f));
         ray_target = f3(se.bsphere_center) + perp_offset * se.bsphere_radius;
-        w = 1.f / dot(-d, f3(0.f, 0.f, 1.f));
+        w = pm_rcp(dot(-d, f3(0.f, 0.f, 1.f)));
     }
     if (se.origin_type != 0) {                                                                    // distant.cpp:368-375
         if (!shape_hit_point(sc, se.origin_shape, make_ray(ray_target, -d, MTS_RAY_EPSILON, pm_inf()), o)) { o = f3s(pm_nan()); w = 0.f; }

@@ -555,7 +555,7 @@ struct VolpathMachine {
             if (grey || !homogeneous) {                        // the combined extinction is one value for every channel (a grey medium, or a
                 float tr = pm_exp(-t * mi.combined.x);          // heterogeneous one: its majorant is a scalar, heterogeneous.cpp:29): one exp, one division
                 float tr_pdf = surface_first ? tr : tr * mi.combined.x;
-                weight = weight * (tr_pdf > 0.f ? tr * (1.0f / tr_pdf) : 0.f);     // spectrum / scalar = spectrum * (1 / scalar), dmath.h
+                weight = weight * (tr_pdf > 0.f ? tr * pm_rcp(tr_pdf) : 0.f);     // spectrum / scalar = spectrum * (1 / scalar), dmath.h
             } else {
                 Spec tr = transmittance_exp(t, mi.combined);
                 Spec free_flight_pdf = surface_first ? tr : tr * mi.combined;
@@ -580,7 +580,7 @@ struct VolpathMachine {
         if (!real_scatter) {
             // null collision of the main path (volpath.cpp:128-131,140-144) or a step of a walk (:322-333, :411-420)
             if (grey) {
-                if (is_main) { if (spectral) weight = weight * ((sigma_n.x * mi.combined.x) * (1.0f / sigma_n.x)); }
+                if (is_main) { if (spectral) weight = weight * ((sigma_n.x * mi.combined.x) * pm_rcp(sigma_n.x)); }
                 else { if (spectral) weight = weight * sigma_n.x; else weight = weight * div_by_invariant(sigma_n.x, mi.combined.x, mi.inv_combined); }
             } else {
                 if (is_main) { if (spectral) weight = weight * (sigma_n * pick(mi.combined, channel) / pick(sigma_n, channel)); }
@@ -603,7 +603,7 @@ struct VolpathMachine {
         p.depth += 1;
         if (!(p.depth < max_depth)) { p.thr = weight; p.flags &= ~FL_ALIVE; p.st = S_TOP; return; }
         if (grey) {
-            if (spectral) weight = weight * ((mi.sigma_s.x * mi.combined.x) * (1.0f / mi.sigma_t.x));
+            if (spectral) weight = weight * ((mi.sigma_s.x * mi.combined.x) * pm_rcp(mi.sigma_t.x));
             else weight = weight * (mi.sigma_s.x / mi.sigma_t.x);
         } else {
             if (spectral) weight = weight * (mi.sigma_s * pick(mi.combined, channel) / pick(mi.sigma_t, channel));

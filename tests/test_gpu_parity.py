@@ -241,6 +241,26 @@ def test_bench_strong_scaling_rehearsal(gpu_rgb, tmp_path):
     assert np.allclose(parts[0][0] + parts[1][0], full, rtol=1e-6, atol=0)
 
 
+def test_pm_rcp_is_the_division_for_every_argument(gpu_rgb, tmp_path):
+    """csrc/pmath.h: on the device pm_rcp is one Newton step on v_rcp_f32 plus v_div_fixup_f32 (4 instructions, 35 cycles) instead of the
+    compiler's expansion of 1.0f / x (92 cycles with its two denormal-mode switches).  tests/micro/rcp_exhaustive.hip, built with the
+    product's own flags, compares the two on all 2^32 arguments on the GPU: no difference, so host (1.0f / x) and device stay bit-identical."""
+    import importlib
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    flags = [f for f in importlib.import_module("eradiate-kernel_amd._buildid").FLAGS if f not in ("-fPIC", "-Wall", "-shared")]
+    assert "-fgpu-flush-denormals-to-zero" in flags and "-fhip-fp32-correctly-rounded-divide-sqrt" in flags
+    exe = str(tmp_path / "rcp_exhaustive")
+    subprocess.check_call([hipcc] + flags + ["-w", os.path.join(root, "tests", "micro", "rcp_exhaustive.hip"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "2^32 arguments: 0 differences" in r.stdout, (r.stdout[-2000:], r.stderr[-1000:])
+
+
 def test_c_abi_from_cpp_with_an_rccl_film_reduce(gpu_rgb, tmp_path):
     """The drop-in boundary without Python: integration/render_sharded.cpp builds a scene from plain C records, renders its shard into
     a device film on its own HIP stream through libmtsamd.so and merges the films with ONE ncclReduce over RCCL (INTEGRATION.md
