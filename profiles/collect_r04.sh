@@ -42,7 +42,7 @@ python3 tests/pmc_summary.py --json $O/pmc_summary_c4.json --probe "bench.py --c
 cat $O/pmc_summary_c4.json | tail -12
 fi
 if [ $PART = c ]; then
-for c in C1 C1L C2 C3M C5S C5SM C5SB; do python bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_$c.log 2>&1; tail -1 $O/bench_$c.log | cut -c1-160; done
+for c in C1 C1L C1S C2 C3M C5S C5SM C5SB; do python bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_$c.log 2>&1; tail -1 $O/bench_$c.log | cut -c1-160; done
 # C5 = 16 wavelength batches of the C4 atmosphere: 256 spp per batch here (the full 4096 spp take minutes per step)
 python bench.py --config C5 --spp 256 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_C5.log 2>&1; tail -1 $O/bench_C5.log | cut -c1-160
 cd /tmp

@@ -17,7 +17,7 @@ def last_json(path):
 
 
 for log, name in [("bench.log", "bench_line"), ("bench_prof_c3.log", "bench_line_under_rocprof"), ("bench_c4.log", "bench_line_c4")] + \
-                 [("bench_%s.log" % c, "bench_line_%s" % c.lower()) for c in ("C1", "C1L", "C2", "C3M", "C5", "C5S", "C5SM", "C5SB")]:
+                 [("bench_%s.log" % c, "bench_line_%s" % c.lower()) for c in ("C1", "C1L", "C1S", "C2", "C3M", "C5", "C5S", "C5SM", "C5SB")]:
     j = last_json(os.path.join(src, log))
     if j:
         json.dump(j, open(os.path.join(P, "%s_%s.json" % (tag, name)), "w"), indent=1)
