@@ -1120,6 +1120,10 @@ def test_passes_add_up_in_pass_order(gpu_rgb, monkeypatch, case):
     ref = ob.OracleScene(d).render(threads=1)          # one thread: the blocks reach the film in spiral order, pass after pass
     assert ref[..., :3].max() > 0
     assert_parity(gpu, ref)
+    if case == "volpath":                              # the passes meeting in the one film by atomics: the same samples, another order of additions
+        monkeypatch.setenv("MTSAMD_PASS_SLOTS", "0")
+        direct, st2 = gpu_render(gpu_rgb, d)
+        assert st2["samples"] == st["samples"] and np.array_equal(direct[..., 3:], gpu[..., 3:]) and np.allclose(direct, gpu, rtol=1e-5, atol=1e-7)
 
 
 # ---------------------------------------------------------------- spectral variant
