@@ -69,3 +69,11 @@ python3 tests/pmc_summary.py --json $O/pmc_summary_c5s.json --probe "bench.py --
 cat $O/pmc_summary_c5s.json | tail -12
 fi
 find $O -name "*kernel_stats*" | head
+if [ $PART = e ]; then
+# kernel stats of the kernels that changed late in the round: volpathmis on the metric scene, `path` in the spectral variant
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3m -o p -- python3 $R/bench.py --config C3M --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_prof_c3m.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c1s -o p -- python3 $R/bench.py --config C1S --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_prof_c1s.log 2>&1
+cd $R
+tail -1 $O/bench_prof_c3m.log | cut -c1-160; tail -1 $O/bench_prof_c1s.log | cut -c1-160
+fi

@@ -22,7 +22,7 @@ for log, name in [("bench.log", "bench_line"), ("bench_prof_c3.log", "bench_line
     if j:
         json.dump(j, open(os.path.join(P, "%s_%s.json" % (tag, name)), "w"), indent=1)
         print(name, j["value"], j["roofline"]["frac"], j["roofline"]["avg_launch_ms"])
-for d, name in [("prof_c3", "bench_c3"), ("prof_c4", "bench_c4"), ("prof_c1l", "bench_c1l"), ("prof_c5s", "bench_c5s"), ("prof_c5sm", "bench_c5sm")]:
+for d, name in [("prof_c3", "bench_c3"), ("prof_c4", "bench_c4"), ("prof_c1l", "bench_c1l"), ("prof_c5s", "bench_c5s"), ("prof_c5sm", "bench_c5sm"), ("prof_c3m", "bench_c3m"), ("prof_c1s", "bench_c1s")]:
     hits = glob.glob(os.path.join(src, d, "**", "*kernel_stats.csv"), recursive=True)
     if hits:
         shutil.copy(hits[0], os.path.join(P, "%s_%s_kernel_stats.csv" % (tag, name)))
