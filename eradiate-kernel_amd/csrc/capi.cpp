@@ -366,7 +366,24 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             variant = (hs.integrator.type == MTS_INTEGRATOR_VOLPATH && !hs.integrator.spectral) ? 1 : 0;
         int wg_threads = 0;                                         // MTSAMD_WG_THREADS: threads per workgroup of the wga kernels (<= paths; default = paths)
         if (const char *tv = getenv("MTSAMD_WG_THREADS")) wg_threads = atoi(tv);
-        last_variant = variant;
+        // Lean kernels (kernels_lean_a.hip / _b.hip: the regrouping machines of rgb / mono `volpath` and `volpathmis` compiled WITHOUT what
+        // this scene cannot contain, integrator_dev.h: MTS_TRAITS): the leanest unit whose promises the scene keeps.  MTSAMD_LEAN=0: never.
+        // mts_stats.kernel_variant reports it as + 100000 (a) / + 200000 (b).
+        int lean = 0;
+#if !defined(MTSAMD_BLOCKSTATS)
+        {
+            const char *lv = getenv("MTSAMD_LEAN");
+            const bool machine = (variant == 11024 && hs.integrator.type == MTS_INTEGRATOR_VOLPATH) ||
+                                 (variant == 10512 && hs.integrator.type == MTS_INTEGRATOR_VOLPATHMIS && hs.integrator.use_spectral_mis);
+            if (!(lv && atoi(lv) == 0) && machine && !hs.integrator.spectral && !se.wavefront && wg_threads == 0) {
+                const int promises_a = 127, promises_b = 1 | 2 | 4 | 16 | 32;       // kernels_lean_a.hip: every trait; _b: rpv and grids behind volume_eval() allowed
+                if ((hs.traits & promises_a) == promises_a) lean = 1;
+                else if ((hs.traits & promises_b) == promises_b) lean = 2;
+                if (lv && atoi(lv) == 2 && lean == 1) lean = 2;                     // diagnostics: the b unit on a scene that qualifies for a
+            }
+        }
+#endif
+        last_variant = variant + 100000 * lean;
 
         // one launch over `blocks` with `spp` samples per pixel, watched for cancel() / the timeout (which reach the kernel through the stop word).
         // `tiles`: the cost-sorted tile table of the regrouping kernels (volpath_flat.h, WgArgs::tiles), or empty: one workgroup per
@@ -384,7 +401,11 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             // one 128-byte cold record per path in flight; volpathmis parks the path's two weight matrices in a second one (volpathmis_flat.h)
             const size_t ws_records = hs.integrator.type == MTS_INTEGRATOR_VOLPATHMIS ? 2 : 1;
             float *d_ws = (float *) rc.get(3, render_workspace_floats(paths, variant) * ws_records * sizeof(float));
-            HIP_CHECK((hs.integrator.spectral ? launch_render_spectral : launch_render)(
+            auto launcher = hs.integrator.spectral ? launch_render_spectral : launch_render;
+#if !defined(MTSAMD_BLOCKSTATS)
+            if (lean == 1) launcher = launch_render_lean_a; else if (lean == 2) launcher = launch_render_lean_b;
+#endif
+            HIP_CHECK(launcher(
                           hs.scene, d_blocks, (uint32_t) blocks.size(), block_size, spp, d_target, d_counters,
                           opts.collect_counters != 0, variant, wg_threads, d_ws, (const uint32_t *) scene->stop_word, d_tiles, (uint32_t) tiles.size(), stream));
             HIP_CHECK(hipEventRecord(ev1, stream));

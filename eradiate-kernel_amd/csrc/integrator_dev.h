@@ -11,8 +11,27 @@
 #include "dmath.h"
 #include "../../include/mtsamd.h"
 
+// Scene traits (round 4).  The render kernels are written for every scene the loader accepts; what a given scene cannot contain still
+// costs it: the out-of-line functions behind rarely-used features (a BVH, spheres, mesh emitters, nested blendphase trees, RPV, generic
+// grid lookups) impose the calling convention on the whole kernel -- values that live across a call site sit in callee-saved registers or
+// in scratch -- and every per-medium case distinction is a chain of scalar branches in the tracking step.  A translation unit compiled
+// with MTS_TRAITS != 0 (kernels_lean_*.hip) PROMISES the properties below; the host checks them per scene (scene_host.cpp:
+// scene_traits) and mts_render picks the leanest kernel whose promises the scene keeps.  Same source, same arithmetic: the promised-away
+// branches are simply never compiled (C3 562 -> 629, C4 397 -> 469 Msamples/s on the 256-spp probes, profiles/r04_ab_experiments.log).
+#define MT_MEDIA 1              // every medium: heterogeneous, grey, on a pair grid (DMedium::pair_grid), with spectral extinction
+#define MT_NO_BVH 2             // the primitive list is walked (no BVH)
+#define MT_NO_SPHERE 4          // no sphere shapes
+#define MT_NO_GRID_EVAL 8       // no grid volume is evaluated through volume_eval() (media go through their pair grids; no grid as a blend weight ...)
+#define MT_NO_SHAPE_EMITTER 16  // no area emitters (shape_sample_direction)
+#define MT_NO_PHASE_TREE 32     // no nested blendphase
+#define MT_NO_RPV 64            // no rpv BSDF
+#ifndef MTS_TRAITS
+#define MTS_TRAITS 0
+#endif
 #if MTS_SPEC_N == 3
+#if !defined(MTS_VARIANT_NS)
 #define MTS_VARIANT_NS v_rgb
+#endif
 #else
 #define MTS_VARIANT_NS v_spectral
 #endif
@@ -172,7 +191,11 @@ DEV float triangle_intersect(const TriRec &T, const DRay &ray, F2 &uv) {
 // shapes/sphere.cpp:272-306 in double precision (the reference's CPU path, sphere.cpp:276) + core/math.h:371-411
 // (a real function: double-precision code that only scenes with spheres execute)
 DEV_NOINLINE float sphere_intersect_v(float cx, float cy, float cz, float radius, const DRay ray);
+#if MTS_TRAITS & MT_NO_SPHERE
+DEV float sphere_intersect(const float *, float, const DRay &) { return pm_inf(); }
+#else
 DEV float sphere_intersect(const float *center, float radius, const DRay &ray) { return sphere_intersect_v(center[0], center[1], center[2], radius, ray); }
+#endif
 DEV_NOINLINE float sphere_intersect_v(float cx, float cy, float cz, float radius, const DRay ray) {
     const float center[3] = { cx, cy, cz };
     double mint = ray.mint, maxt = ray.maxt;
@@ -274,10 +297,12 @@ DEV Hit ray_intersect_preliminary(const DScene &sc, DRay ray) {
     bbox_ray_intersect(sc.bbox, ray, bmint, bmaxt);
     float mint = pm_max(ray.mint, bmint), maxt = pm_min(ray.maxt, bmaxt);
     if (!(mint <= maxt)) return h;
+#if !(MTS_TRAITS & MT_NO_BVH)
     if (sc.bvh_node_count > 0) {
         BvhArgs a; a.nodes = sc.bvh_nodes; a.leaf_prims = sc.bvh_prims; a.node_count = sc.bvh_node_count; a.walk = sc.walk; a.lds_nodes = sc.bvh_lds; a.lds_count = sc.bvh_lds_count;
         return bvh_intersect<ShadowRay>(a, ray);
     }
+#endif
     for (int i = 0; i < sc.prim_count; ++i) {
         const DWalkPrim w = cload(sc.walk + i);               // one 64-byte scalar load per primitive (fetching one ahead measured slower)
         F2 uv; uv.x = uv.y = 0.f; float t;
@@ -461,7 +486,9 @@ DEV Spec volume_eval(const DVolume &v, F3 p_world, const SpecCtx &cx = SpecCtx()
     for (int k = 0; k < 16; ++k) g.w2l[k] = v.w2l[k];
     g.data = v.data; g.nx = v.nx; g.ny = v.ny; g.nz = v.nz;
     g.channels_affine_filter_wrap = (uint32_t) v.channels | ((uint32_t) (v.affine != 0) << 8) | ((uint32_t) (v.columns_equal != 0) << 9) | ((uint32_t) v.filter << 16) | ((uint32_t) v.wrap << 24);
-#if MTS_SPEC_N == 3
+#if MTS_TRAITS & MT_NO_GRID_EVAL
+    return spec_s(0.f);
+#elif MTS_SPEC_N == 3
     return volume_eval_grid(g, p_world);
 #else
     const DVolumeSp vs = cx.volume_sp[vid];
@@ -717,7 +744,9 @@ template <bool U = false>
 DEV float phase_eval(const DScene &sc, int phase, F3 wi, F3 p, F3 wo, const SpecCtx &cx = SpecCtx()) {
     const DPhase ph = rload<U>(sc.phases, phase);
     if (ph.type != MTS_PHASE_BLEND) return phase_eval_leaf(ph, wi, wo);
+#if !(MTS_TRAITS & MT_NO_PHASE_TREE)
     if (ph.size > 1) return phase_eval_tree(sc.phases, sc.volumes, phase, wi, p, wo, cx);
+#endif
     float w = volume_eval_1(rload<U>(sc.volumes, ph.weight_volume), p, cx, ph.weight_volume);  // blendphase.cpp:113-139
     float weight = pm_min(pm_max(w, 0.f), 1.f);
     return phase_eval_leaf(rload<U>(sc.phases, ph.child[0]), wi, wo) * (1 - weight) + phase_eval_leaf(rload<U>(sc.phases, ph.child[1]), wi, wo) * weight;
@@ -746,7 +775,9 @@ template <bool U = false>
 DEV F3 phase_sample(const DScene &sc, int phase, const Frame3 &frame, F3 p, float sample1, F2 sample2, const SpecCtx &cx = SpecCtx()) {
     const DPhase ph = rload<U>(sc.phases, phase);
     if (ph.type != MTS_PHASE_BLEND) return phase_sample_leaf(ph, frame, sample2);
+#if !(MTS_TRAITS & MT_NO_PHASE_TREE)
     if (ph.size > 1) return phase_sample_leaf(sc.phases[phase_pick_leaf(sc.phases, sc.volumes, phase, p, sample1, cx)], frame, sample2);
+#endif
     float w = volume_eval_1(rload<U>(sc.volumes, ph.weight_volume), p, cx, ph.weight_volume);  // blendphase.cpp:68-111
     float weight = pm_min(pm_max(w, 0.f), 1.f);
     if (sample1 > weight) return phase_sample_leaf(rload<U>(sc.phases, ph.child[0]), frame, sample2);
@@ -782,7 +813,9 @@ DEV F3 phase_sample_leaf_pdf(const DPhase &ph, const Frame3 &frame, F2 sample2, 
 DEV F3 phase_sample_pdf(const DScene &sc, int phase, const Frame3 &frame, F3 p, float sample1, F2 sample2, float &pdf, const SpecCtx &cx = SpecCtx()) {
     const DPhase &ph = sc.phases[phase];
     if (ph.type != MTS_PHASE_BLEND) return phase_sample_leaf_pdf(ph, frame, sample2, pdf);
+#if !(MTS_TRAITS & MT_NO_PHASE_TREE)
     if (ph.size > 1) return phase_sample_leaf_pdf(sc.phases[phase_pick_leaf(sc.phases, sc.volumes, phase, p, sample1, cx)], frame, sample2, pdf);
+#endif
     float w = volume_eval_1(sc.volumes[ph.weight_volume], p, cx, ph.weight_volume);
     float weight = pm_min(pm_max(w, 0.f), 1.f);
     if (sample1 > weight) return phase_sample_leaf_pdf(sc.phases[ph.child[0]], frame, sample2, pdf);
@@ -837,7 +870,11 @@ DEV Spec eval_rpv(const DBsdf &b, F3 wi, F3 wo, const SpecCtx &cx = SpecCtx(), i
     q.rho_0[0] = r0.x; q.rho_0[1] = r0.y; q.rho_0[2] = r0.z; q.rho_0[3] = r0.w; q.k[0] = k.x; q.k[1] = k.y; q.k[2] = k.z; q.k[3] = k.w;
     q.g[0] = g.x; q.g[1] = g.y; q.g[2] = g.z; q.g[3] = g.w; q.rho_c[0] = rc.x; q.rho_c[1] = rc.y; q.rho_c[2] = rc.z; q.rho_c[3] = rc.w;
 #endif
+#if MTS_TRAITS & MT_NO_RPV
+    return spec_s(0.f);
+#else
     return eval_rpv_p(q, wi, wo);
+#endif
 }
 // bsdfs/bilambertian.cpp:62-190
 DEV float bilambertian_reflection_weight(const DBsdf &b, const SpecCtx &cx = SpecCtx(), int id = 0) {
@@ -1013,7 +1050,11 @@ DEV DirSample emitter_sample_direction(const DScene &sc, int ei, F3 ref_p, F2 sa
         ds.d = ds.d * inv_dist;
         spec = EMITTER_COLOR(e, cx, ei) * (inv_dist * inv_dist);
     } else {
+#if !(MTS_TRAITS & MT_NO_SHAPE_EMITTER)
         ds = shape_sample_direction(mesh_tables(sc), sc.shapes[e.shape], ref_p, sample);
+#else
+        ds = DirSample();
+#endif
         bool active = dot(ds.d, ds.n) < 0.f && ds.pdf != 0.f;
         spec = active ? EMITTER_COLOR(e, cx, ei) / ds.pdf : spec_s(0.f);
     }

@@ -15,7 +15,11 @@
 #include "integrator_dev.h"
 #include "volpath_flat.h"
 #include "volpathmis_flat.h"
-#if MTS_SPEC_N == 3
+#if defined(MTS_LEAN)               // kernels_lean_*.hip: the regrouping kernels once more, for scenes that keep the promises of MTS_TRAITS
+#define MTS_LAUNCHER_CAT2(a, b) a##b
+#define MTS_LAUNCHER_CAT(a, b) MTS_LAUNCHER_CAT2(a, b)
+#define MTS_LAUNCHER(name) MTS_LAUNCHER_CAT(name, MTS_LEAN)
+#elif MTS_SPEC_N == 3
 #define MTS_LAUNCHER(name) name
 #else
 #define MTS_LAUNCHER(name) name##_spectral
@@ -25,6 +29,7 @@
 namespace mtsamd {
 inline namespace MTS_VARIANT_NS {
 
+#if !defined(MTS_LEAN)
 // librender/integrator.cpp:233-288 + librender/imageblock.cpp:79-172, fused: the sample is splatted
 // straight into the film.  With the default box filter a sample lands in its own pixel and is summed
 // in registers in sample order (bit-identical to the reference's block accumulation); the rare
@@ -268,6 +273,8 @@ __global__ void __launch_bounds__(256, (FLAT && INTEG != NI_PATH) ? 1 : (INTEG =
     }
 }
 
+#endif // !MTS_LEAN
+
 // Asynchronous-regrouping variant of the volpath render kernel (volpath_flat.h, driver 2).  The parameter list must stay in
 // sync with WgArgs: the block functions re-read it from the kernarg segment with scalar loads.  WG paths are served by NT threads;
 // WPE = waves per SIMD the register budget is sized for (512 / WPE VGPRs).
@@ -286,6 +293,7 @@ __global__ void __launch_bounds__(NT, WPE) render_kernel_wga(DScene sc, const DB
 }
 static_assert(sizeof(WgArgs) % 4 == 0, "WgArgs mirrors the kernel parameters");
 
+#if !defined(MTS_LEAN)
 // The same machine on the lane-affine driver (volpath_flat.h, driver 3): conflict-free LDS state, mask claims instead of rings.
 template <bool COUNT, int WG, int NT, int WPE>
 __global__ void __launch_bounds__(NT, WPE) render_kernel_wgl(DScene sc, const DBlock *blocks, uint32_t n_blocks, uint32_t block_size,
@@ -300,6 +308,8 @@ __global__ void __launch_bounds__(NT, WPE) render_kernel_wgl(DScene sc, const DB
         atomicAdd(counters + 2, (unsigned long long) cnt.n_nee_step);
     }
 }
+
+#endif // !MTS_LEAN
 
 // The same driver for volpathmis (volpathmis_flat.h): four weight matrices per path, 512 paths per workgroup, two waves per SIMD.
 template <bool COUNT, bool SPEC, int WG, int NT>
@@ -316,7 +326,7 @@ __global__ void __launch_bounds__(NT, NT <= 256 ? 2 : 1) render_kernel_wga_mis(D
     }
 }
 
-#if MTS_SPEC_N == 3
+#if MTS_SPEC_N == 3 && !defined(MTS_LEAN)
 // SamplingIntegrator::sample for caller-supplied rays (librender/python/integrator_v.cpp:62-78)
 __global__ void __launch_bounds__(256) sample_kernel(DScene sc, int32_t n, uint64_t seed_offset, const float *__restrict__ rays /* 6 SoA rows */,
                                                      float *__restrict__ out_rgb, uint8_t *__restrict__ out_valid) {
@@ -374,7 +384,7 @@ __global__ void __launch_bounds__(256) wavefront_sampler_kernel(int32_t lanes, u
 } // inline namespace
 
 // ---------------------------------------------------------------- launchers
-#if MTS_SPEC_N == 3
+#if MTS_SPEC_N == 3 && !defined(MTS_LEAN)
 hipError_t launch_tea(int32_t n, const uint32_t *v0, const uint32_t *v1, int rounds, uint32_t *out32, uint64_t *out64, float *outf, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(tea_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, v0, v1, rounds, out32, out64, outf);
@@ -411,6 +421,30 @@ size_t render_workspace_floats(uint64_t threads, int variant) {
 
 #endif // MTS_SPEC_N == 3
 
+#if defined(MTS_LEAN)
+// the 1024-path `volpath` machine and the 512-path `volpathmis` machine, nothing else (mts_render sends everything else to launch_render)
+hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,
+                         float *d_film, unsigned long long *d_counters, bool count, int variant, int wg_threads, float *d_workspace,
+                         const uint32_t *d_stop_flag, const uint32_t *d_tiles, uint32_t n_tiles, hipStream_t stream) {
+    if (n_blocks == 0) return hipSuccess;
+    const uint64_t threads = d_tiles != nullptr ? (uint64_t) n_tiles * MTS_TILE_PIXELS : (uint64_t) n_blocks * block_size * block_size;
+    if (threads + 1024 >= ((uint64_t) 1 << 32)) return hipErrorInvalidValue;
+    if (sc.sensor.wavefront || wg_threads != 0) return hipErrorInvalidConfiguration;
+    if (variant == 11024 && sc.integrator.type == MTS_INTEGRATOR_VOLPATH) {
+        const uint32_t grid = (uint32_t) ((threads + 1023) / 1024), stride = grid * 1024;
+        if (count) hipLaunchKernelGGL((render_kernel_wga<true, 1024, 1024, 4>), dim3(grid), dim3(1024), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles);
+        else hipLaunchKernelGGL((render_kernel_wga<false, 1024, 1024, 4>), dim3(grid), dim3(1024), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles);
+        return hipGetLastError();
+    }
+    if (variant == 10512 && sc.integrator.type == MTS_INTEGRATOR_VOLPATHMIS && sc.integrator.use_spectral_mis) {
+        const uint32_t grid = (uint32_t) ((threads + 511) / 512), stride = grid * 512;
+        if (count) hipLaunchKernelGGL((render_kernel_wga_mis<true, true, 512, 512>), dim3(grid), dim3(512), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles);
+        else hipLaunchKernelGGL((render_kernel_wga_mis<false, true, 512, 512>), dim3(grid), dim3(512), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles);
+        return hipGetLastError();
+    }
+    return hipErrorInvalidConfiguration;
+}
+#else
 hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,
                          float *d_film, unsigned long long *d_counters, bool count, int variant, int wg_threads, float *d_workspace,
                          const uint32_t *d_stop_flag, const uint32_t *d_tiles, uint32_t n_tiles, hipStream_t stream) {
@@ -524,8 +558,9 @@ hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks,
     (void) use_flat;
     return hipGetLastError();
 }
+#endif // MTS_LEAN
 
-#if MTS_SPEC_N == 3
+#if MTS_SPEC_N == 3 && !defined(MTS_LEAN)
 
 hipError_t launch_sample(const DScene &sc, int32_t n, uint64_t seed_offset, const float *d_rays, float *d_rgb, uint8_t *d_valid, hipStream_t stream) {
     if (n <= 0) return hipSuccess;

@@ -1,0 +1,11 @@
+// kernels_lean_a.hip -- the regrouping kernels of `volpath` and `volpathmis` (rgb / mono) compiled for scenes that keep EVERY promise of
+// integrator_dev.h's scene traits: heterogeneous grey media on pair grids, a walked primitive list without spheres, no area emitters, no
+// nested blendphase, no rpv, no grid evaluated through volume_eval().  The metric scene (C3) is one: a kernel without a single call
+// (122 VGPRs, no spilled VGPR dword, 28 B of scratch against 384).  Same source as kernels.hip, same arithmetic: the promised-away branches
+// are not compiled.  mts_render (capi.cpp) selects it from HostScene::traits; MTSAMD_LEAN=0 keeps every scene on the general kernels.
+#if !defined(MTSAMD_BLOCKSTATS)
+#define MTS_LEAN _lean_a
+#define MTS_VARIANT_NS v_rgb_lean_a
+#define MTS_TRAITS (MT_MEDIA | MT_NO_BVH | MT_NO_SPHERE | MT_NO_GRID_EVAL | MT_NO_SHAPE_EMITTER | MT_NO_PHASE_TREE | MT_NO_RPV)
+#include "kernels.hip"
+#endif

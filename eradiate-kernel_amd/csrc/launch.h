@@ -19,6 +19,14 @@ hipError_t launch_render_spectral(const DScene &sc, const DBlock *d_blocks, uint
                                   const uint32_t *d_stop_flag, const uint32_t *d_tiles, uint32_t n_tiles, hipStream_t stream);
 // film = sum over k < count of the film-sized slot k of d_slots, added in slot order (the passes of a render: capi.cpp)
 hipError_t launch_film_sum_slots(float *d_film, const float *d_slots, size_t film_floats, uint32_t count, hipStream_t stream);
+// the regrouping kernels of rgb / mono `volpath` (variant 11024) and `volpathmis` (10512) for scenes that keep the promises of
+// kernels_lean_a.hip / kernels_lean_b.hip (integrator_dev.h: MTS_TRAITS); anything else: hipErrorInvalidConfiguration
+hipError_t launch_render_lean_a(const DScene &sc, const DBlock *d_blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,
+                                float *d_film, unsigned long long *d_counters, bool count, int variant, int wg_threads, float *d_workspace,
+                                const uint32_t *d_stop_flag, const uint32_t *d_tiles, uint32_t n_tiles, hipStream_t stream);
+hipError_t launch_render_lean_b(const DScene &sc, const DBlock *d_blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,
+                                float *d_film, unsigned long long *d_counters, bool count, int variant, int wg_threads, float *d_workspace,
+                                const uint32_t *d_stop_flag, const uint32_t *d_tiles, uint32_t n_tiles, hipStream_t stream);
 hipError_t launch_sample(const DScene &sc, int32_t n, uint64_t seed_offset, const float *d_rays, float *d_rgb, uint8_t *d_valid, hipStream_t stream);
 // spectral variant (kernels_spectral.hip): per-ray wavelengths (4 n floats), four-wide result
 hipError_t launch_sample_spectral(const DScene &sc, int32_t n, uint64_t seed_offset, const float *d_rays, const float *d_wavelengths, float *d_spec, uint8_t *d_valid,

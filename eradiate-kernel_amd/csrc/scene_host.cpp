@@ -186,6 +186,35 @@ static DXf xf_perspective(float fov, float near_, float far_) {
     return x;
 }
 
+// Which promises of integrator_dev.h's scene traits (MT_*: what the lean translation units were compiled without) this scene keeps.
+// mts_render launches the leanest kernel whose promises are all kept; a scene that keeps none runs on the general kernels.
+static int scene_traits(const HostScene &hs, bool spectral) {
+    if (spectral) return 0;                                             // the lean units are rgb / mono builds
+    int tr = 0;
+    bool media = !hs.media.empty();
+    for (size_t i = 0; i < hs.media.size(); ++i) {
+        const DMedium &m = hs.media[i];
+        media = media && !m.is_homogeneous && i < hs.pair_data.size() && !hs.pair_data[i].empty() && m.grey && m.has_spectral_extinction;
+    }
+    if (media) tr |= 1;                                                 // MT_MEDIA
+    if (hs.bvh_nodes.empty()) tr |= 2;                                  // MT_NO_BVH
+    bool sphere = false, rpv = false, shape_emitter = false, tree = false, grid_eval = !media && !hs.media.empty();
+    for (const DShape &sh : hs.shapes) sphere = sphere || sh.type == MTS_SHAPE_SPHERE;
+    for (const DBsdf &b : hs.bsdfs) rpv = rpv || b.type == MTS_BSDF_RPV;
+    for (const DEmitter &e : hs.emitters) shape_emitter = shape_emitter || e.shape >= 0;
+    for (const DPhase &ph : hs.phases)
+        if (ph.type == MTS_PHASE_BLEND) {
+            tree = tree || ph.size > 1;
+            grid_eval = grid_eval || (ph.weight_volume >= 0 && hs.volumes[(size_t) ph.weight_volume].type == MTS_VOLUME_GRID);
+        }
+    if (!sphere) tr |= 4;                                               // MT_NO_SPHERE
+    if (!grid_eval) tr |= 8;                                            // MT_NO_GRID_EVAL: no grid reaches volume_eval() (pair-grid media do not)
+    if (!shape_emitter) tr |= 16;                                       // MT_NO_SHAPE_EMITTER
+    if (!tree) tr |= 32;                                                // MT_NO_PHASE_TREE
+    if (!rpv) tr |= 64;                                                 // MT_NO_RPV
+    return tr;
+}
+
 HostScene *build_host_scene(const mts_scene_desc *d) {
     if (!d) throw std::runtime_error("scene description is NULL");
     if (d->abi_version != MTS_ABI_VERSION) throw std::runtime_error("scene description: ABI version mismatch");
@@ -622,6 +651,7 @@ HostScene *build_host_scene(const mts_scene_desc *d) {
     sc.volume_count = (int) hs.volumes.size(); sc.phase_count = (int) hs.phases.size(); sc.medium_count = (int) hs.media.size();
     sc.bsdf_count = (int) hs.bsdfs.size(); sc.shape_count = (int) hs.shapes.size(); sc.prim_count = (int) hs.prims.size();
     sc.emitter_count = (int) hs.emitters.size();
+    hs.traits = scene_traits(hs, spectral);
     return hsp.release();
 }
 

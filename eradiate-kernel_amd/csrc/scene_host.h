@@ -40,6 +40,7 @@ struct HostScene {
     bool srf_lookup_by_wavelength = true;            // the response function's weights can be recovered from the sampled wavelengths (regrouping kernel)
     std::vector<int32_t> bsdf_sp, emitter_sp; std::vector<DVolumeSp> volume_sp;
     std::vector<void *> device_allocs;
+    int traits = 0;                                  // promises of integrator_dev.h's scene traits this scene keeps (MT_* bits; scene_traits())
     int device = 0;
     bool uploaded = false;
     std::atomic<int> stop{0};

@@ -158,30 +158,35 @@ template <bool COUNT>
 DEV MedStep medium_step(const DScene &sc, const DMedium m, const DRay &ray, float sample, uint32_t channel, bool want_albedo, Counters &cnt,
                         const SpecCtx &cx = SpecCtx()) {
     MedStep mi;
+#if MTS_TRAITS & MT_MEDIA                // promised: every medium heterogeneous, grey, on a pair grid, with spectral extinction
+    const bool m_homogeneous = false, m_pair = true, m_grey = true, m_spectral = true;
+#else
+    const bool m_homogeneous = m.is_homogeneous != 0, m_pair = m.pair_grid != nullptr, m_grey = m.grey != 0, m_spectral = m.has_spectral_extinction != 0;
+#endif
     bool active = true; float mint = 0.f, maxt = pm_inf();
-    if (!m.is_homogeneous) {
+    if (!m_homogeneous) {
         active = bbox_ray_intersect(m.aabb, ray, mint, maxt);
         active = active && (pm_isfinite(mint) || pm_isfinite(maxt));
         if (!active) { mint = 0.f; maxt = pm_inf(); }
     }
     mint = pm_max(ray.mint, mint);
     maxt = pm_min(ray.maxt, maxt);
-    Spec combined = m.is_homogeneous ? volume_eval(cload(sc.volumes + m.sigma_t), ray.o MTS_CXI(m.sigma_t)) * m.scale : spec_s(m.max_density);
+    Spec combined = m_homogeneous ? volume_eval(cload(sc.volumes + m.sigma_t), ray.o MTS_CXI(m.sigma_t)) * m.scale : spec_s(m.max_density);
     float mext = pick(combined, channel);
-    const float inv_mext = m.is_homogeneous ? 0.f : m.inv_max_density;
+    const float inv_mext = m_homogeneous ? 0.f : m.inv_max_density;
     float sampled_t = mint + div_by_invariant(-pm_log(1.f - sample), mext, inv_mext);
     bool valid_mi = active && (sampled_t <= maxt);
     mi.t = valid_mi ? sampled_t : pm_inf();
     mi.p = ray_at(ray, sampled_t);
     mi.mint = mint;
     mi.sigma_t = mi.sigma_s = spec_s(0.f);
-    if (m.is_homogeneous) {
+    if (m_homogeneous) {
         Spec st = volume_eval(cload(sc.volumes + m.sigma_t), mi.p MTS_CXI(m.sigma_t)) * m.scale;
         mi.sigma_t = st;
         if (want_albedo) mi.sigma_s = st * volume_eval(cload(sc.volumes + m.albedo), mi.p MTS_CXI(m.albedo));
     } else if (valid_mi) {
         if (COUNT) MTS_SEG(cnt, 1);
-        if (m.pair_grid != nullptr) {                          // everything comes from the medium record and the interleaved grid
+        if (m_pair) {                          // everything comes from the medium record and the interleaved grid
             const int sx = m.pair_nx < 2 ? 2 : m.pair_nx;
             GridCell c = grid_cell_clamp(m.pair_w2l, m.pair_affine & 1, m.pair_nx, m.pair_ny, m.pair_nz, sx, mi.p);
             float st_raw, al_raw;
@@ -224,8 +229,8 @@ DEV MedStep medium_step(const DScene &sc, const DMedium m, const DRay &ray, floa
     }
     mi.combined = combined;
     mi.inv_combined = inv_mext;
-    mi.info = (m.is_homogeneous ? MI_HOMOGENEOUS : 0u) | (m.has_spectral_extinction ? MI_SPECTRAL : 0u) |
-              (m.sample_emitters ? MI_SAMPLE_EMITTERS : 0u) | (m.grey ? MI_GREY : 0u) | ((uint32_t) m.phase << MI_PHASE_SHIFT);
+    mi.info = (m_homogeneous ? MI_HOMOGENEOUS : 0u) | (m_spectral ? MI_SPECTRAL : 0u) |
+              (m.sample_emitters ? MI_SAMPLE_EMITTERS : 0u) | (m_grey ? MI_GREY : 0u) | ((uint32_t) m.phase << MI_PHASE_SHIFT);
     return mi;
 }
 
@@ -539,7 +544,11 @@ struct VolpathMachine {
             mi = medium_step<COUNT>(sc, cload(sc.media + mu), p.ray, u, p.channel, MODEK == 0 ? true : (MODEK == 1 ? false : p.mode == M_MAIN), cnt MTS_CX);
         WATERFALL_END
         if (p.si.t < mi.t) mi.t = pm_inf();                    // volpath.cpp:112 / :300 / :397
+#if MTS_TRAITS & MT_MEDIA
+        const bool spectral = true, homogeneous = false, grey = true;
+#else
         const bool spectral = (mi.info & MI_SPECTRAL) != 0, homogeneous = (mi.info & MI_HOMOGENEOUS) != 0, grey = (mi.info & MI_GREY) != 0;
+#endif
         const Spec sigma_n = homogeneous ? spec_s(0.f) : mi.combined - mi.sigma_t;
         const uint32_t channel = p.channel;
         const bool is_main = MODEK == 0 ? true : (MODEK == 1 ? false : p.mode == M_MAIN), is_nee = MODEK == 0 ? false : p.mode == M_NEE;

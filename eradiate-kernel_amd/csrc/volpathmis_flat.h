@@ -226,7 +226,11 @@ struct VolpathMisMachine {
             mi = medium_step<COUNT>(sc, cload(sc.media + mu), p.ray, u, channel, true, cnt MTS_CX);
         WATERFALL_END
         if (p.si.t < mi.t) mi.t = pm_inf();
+#if MTS_TRAITS & MT_MEDIA
+        const bool spectral = true, homogeneous = false, grey = true;
+#else
         const bool spectral = (mi.info & MI_SPECTRAL) != 0, homogeneous = (mi.info & MI_HOMOGENEOUS) != 0, grey = (mi.info & MI_GREY) != 0;
+#endif
         const Spec sigma_n = homogeneous ? spec_s(0.f) : mi.combined - mi.sigma_t;
         if (spectral) {
             float t = pm_min(mi.t, p.si.t) - mi.mint;                                  // medium.cpp:77-89
@@ -313,7 +317,11 @@ struct VolpathMisMachine {
             mi = medium_step<COUNT>(sc, cload(sc.media + mu), p.ray, u, channel, false, cnt MTS_CX);
         WATERFALL_END
         if (p.si.t < mi.t) mi.t = pm_inf();
+#if MTS_TRAITS & MT_MEDIA
+        const bool spectral = true, homogeneous = false, grey = true;
+#else
         const bool spectral = (mi.info & MI_SPECTRAL) != 0, homogeneous = (mi.info & MI_HOMOGENEOUS) != 0, grey = (mi.info & MI_GREY) != 0;
+#endif
         const Spec sigma_n = homogeneous ? spec_s(0.f) : mi.combined - mi.sigma_t;
         const float remaining_dist = p.ray.maxt;
         if (spectral) {

@@ -67,10 +67,11 @@ def test_default_kernel_resource_budget(tmp_path):
     lib = os.environ.get("MTSAMD_LIB") or os.path.join(ROOT, "eradiate-kernel_amd", "libmtsamd.so")
     fat = str(tmp_path / "fat.bin")
     subprocess.run([tools[0], "-O", "binary", "--only-section=.hip_fatbin", lib, fat], check=True)
-    # the section holds one offload bundle per translation unit (kernels.hip: rgb / mono, kernels_spectral.hip: spectral)
+    # the section holds one offload bundle per translation unit with device code (kernels.hip: rgb / mono, kernels_spectral.hip: spectral,
+    # kernels_lean_a.hip / _b.hip: the regrouping kernels without what a scene of their traits cannot contain)
     blob, magic = open(fat, "rb").read(), b"__CLANG_OFFLOAD_BUNDLE__"
     starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
-    assert len(starts) == 2, starts
+    assert len(starts) == 4, starts
     kernels = {}
     for k, o in enumerate(starts):
         part, co = str(tmp_path / ("b%d.bin" % k)), str(tmp_path / ("b%d.co" % k))
@@ -112,6 +113,14 @@ def test_default_kernel_resource_budget(tmp_path):
     # ... and over four-wide spectra (round 4): three waves per SIMD (168 VGPRs), fewer spills than the nested loop it replaces (51)
     pks = one("10v_spectral13render_kernelILb0ELb1ELi0EE")
     assert pks["vgpr_count"] <= 168 and pks["vgpr_spill_count"] <= 48, pks
+    # the lean units (integrator_dev.h: MTS_TRAITS).  a: every promise kept (the metric scene) -- a kernel without a call: no spilled VGPR,
+    # no scratch frame to speak of; b: rpv and blend-weight grids allowed (the layered atmosphere)
+    la = one("12v_rgb_lean_a17render_kernel_wgaILb0ELi1024ELi1024ELi4ELb0E")
+    assert la["vgpr_count"] <= 128 and la["vgpr_spill_count"] == 0 and la["private_segment_fixed_size"] <= 64 and la["sgpr_spill_count"] <= 160, la
+    lb = one("12v_rgb_lean_b17render_kernel_wgaILb0ELi1024ELi1024ELi4ELb0E")
+    assert lb["vgpr_count"] <= 128 and lb["vgpr_spill_count"] <= 16 and lb["private_segment_fixed_size"] <= 256 and lb["sgpr_spill_count"] <= 160, lb
+    lm = one("12v_rgb_lean_a21render_kernel_wga_misILb0ELb1ELi512ELi512E")
+    assert lm["vgpr_count"] <= 168 and lm["vgpr_spill_count"] == 0, lm
     # the spectral variant's volpath: 256 paths x 42 state dwords, three workgroups per CU
     sp = one("10v_spectral17render_kernel_wgaILb0ELi256ELi256ELi2ELb0E")
     assert sp["vgpr_count"] <= 168 and sp["vgpr_spill_count"] == 0 and 3 * sp["group_segment_fixed_size"] <= 160 * 1024, sp

@@ -393,7 +393,7 @@ def test_metric_job_at_full_size(gpu_rgb):
     spp = 1024
     d = scenes.c3_heterogeneous(512, 512, spp)
     gpu, st = gpu_render(gpu_rgb, d)
-    assert st["samples"] == 512 * 512 * spp and st["kernel_variant"] == 11024       # the regrouping kernel, 1024 paths per workgroup
+    assert st["samples"] == 512 * 512 * spp and st["kernel_variant"] == 111024      # the regrouping kernel, 1024 paths per workgroup, lean unit a
     w = gpu[..., 4]
     assert np.all(np.abs(w - spp) <= 4) and np.sum(w != spp) <= 2e-4 * w.size * spp and w.sum() <= 512 * 512 * spp
     assert np.all(gpu[..., 3] <= w) and np.all(gpu[..., :3] >= 0) and np.isfinite(gpu).all()
@@ -432,6 +432,41 @@ def test_every_kernel_formulation_matches_the_oracle(gpu_rgb, monkeypatch, kerne
         assert np.array_equal(gpu, ref)
         if d["integrator"]["type"] == "volpath":
             assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
+
+
+@pytest.mark.parametrize("case", ["c3", "c4", "c3_volpathmis", "c4_volpathmis", "c3_two_passes"])
+def test_lean_kernels_match_the_oracle_and_the_general_kernels(gpu_rgb, monkeypatch, case):
+    """Scene traits (integrator_dev.h: MTS_TRAITS; kernels_lean_a.hip / _b.hip): a scene that keeps the promises of a lean translation unit
+    -- heterogeneous grey media on pair grids, a walked primitive list without spheres, no area emitters, no nested blendphase (a: no rpv,
+    no blend-weight grid either) -- runs that unit's copy of the regrouping kernel, compiled without the branches and out-of-line calls it
+    cannot need (mts_stats.kernel_variant + 100000 for a, + 200000 for b).  Same source, same arithmetic: the film and the loop counters are
+    the oracle's bit for bit, on the lean unit, on the other lean unit where the scene qualifies for both, and on the general kernel
+    (MTSAMD_LEAN=0).  A scene that breaks a promise stays on the general kernel."""
+    base = scenes.c3_heterogeneous(96, 64, 8, res=16, samples_per_pass=4 if case == "c3_two_passes" else -1) if case.startswith("c3") else scenes.c4_atmosphere(48, 32, 4)
+    d = dict(base)
+    mis = case.endswith("volpathmis")
+    if mis:
+        d["integrator"] = dict(d["integrator"], type="volpathmis")
+    machine = 10512 if mis else 11024
+    unit = 1 if case.startswith("c3") else 2
+    o = ob.OracleScene(d); ref = o.render(); so = o.last_stats
+    assert ref[..., :3].max() > 0
+    for lean_env, expect in ((None, unit), ("0", 0)) + ((("2", 2),) if unit == 1 else ()):
+        if lean_env is None: monkeypatch.delenv("MTSAMD_LEAN", raising=False)
+        else: monkeypatch.setenv("MTSAMD_LEAN", lean_env)
+        gpu, st = gpu_render(gpu_rgb, d, collect_counters=True)
+        assert st["kernel_variant"] == machine + 100000 * expect, (lean_env, st["kernel_variant"])
+        assert np.array_equal(gpu, ref), (lean_env, float(np.abs(gpu - ref).max()))
+        assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
+        plain, st2 = gpu_render(gpu_rgb, d)                      # the instantiation without loop counters is the one a render normally runs
+        assert st2["kernel_variant"] == st["kernel_variant"] and np.array_equal(plain, ref)
+    monkeypatch.delenv("MTSAMD_LEAN", raising=False)
+    if case == "c3":                                            # broken promises: a sphere in the scene; a homogeneous medium
+        with_sphere = dict(d); with_sphere["ball"] = {"type": "sphere", "center": [0.0, 0.0, 30.0], "radius": 0.5, "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.5, 0.5, 0.5]}}}
+        gpu, st = gpu_render(gpu_rgb, with_sphere, collect_counters=True)
+        assert st["kernel_variant"] == 11024 and np.array_equal(gpu, ob.OracleScene(with_sphere).render())
+        gpu, st = gpu_render(gpu_rgb, scenes.c2_homogeneous_slab(64, 48, 8), collect_counters=True)
+        assert st["kernel_variant"] == 11024
 
 
 @pytest.mark.parametrize("spectral", [True, False])
