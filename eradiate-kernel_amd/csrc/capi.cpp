@@ -368,16 +368,17 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
         if (const char *tv = getenv("MTSAMD_WG_THREADS")) wg_threads = atoi(tv);
         // Lean kernels (kernels_lean_a.hip / _b.hip: the regrouping machines of rgb / mono `volpath` and `volpathmis` compiled WITHOUT what
         // this scene cannot contain, integrator_dev.h: MTS_TRAITS): the leanest unit whose promises the scene keeps.  MTSAMD_LEAN=0: never.
-        // mts_stats.kernel_variant reports it as + 100000 (a) / + 200000 (b).
+        // mts_stats.kernel_variant reports it as + 100000 (a) / + 200000 (b) / + 300000 (s: the spectral variant's unit).
         int lean = 0;
 #if !defined(MTSAMD_BLOCKSTATS)
         {
             const char *lv = getenv("MTSAMD_LEAN");
-            const bool machine = (variant == 11024 && hs.integrator.type == MTS_INTEGRATOR_VOLPATH) ||
-                                 (variant == 10512 && hs.integrator.type == MTS_INTEGRATOR_VOLPATHMIS && hs.integrator.use_spectral_mis);
-            if (!(lv && atoi(lv) == 0) && machine && !hs.integrator.spectral && !se.wavefront && wg_threads == 0) {
-                const int promises_a = 127, promises_b = 1 | 2 | 4 | 16 | 32;       // kernels_lean_a.hip: every trait; _b: rpv and grids behind volume_eval() allowed
-                if ((hs.traits & promises_a) == promises_a) lean = 1;
+            const bool mis = hs.integrator.type == MTS_INTEGRATOR_VOLPATHMIS && hs.integrator.use_spectral_mis, vol = hs.integrator.type == MTS_INTEGRATOR_VOLPATH;
+            const bool machine = hs.integrator.spectral ? (variant == 10256 && (vol || mis)) : ((variant == 11024 && vol) || (variant == 10512 && mis));
+            if (!(lv && atoi(lv) == 0) && machine && !se.wavefront && wg_threads == 0) {
+                const int promises_a = 127, promises_b = 1 | 2 | 4 | 16 | 32;       // kernels_lean_a.hip: every trait; _b and _s: rpv and grids behind volume_eval() allowed
+                if (hs.integrator.spectral) { if ((hs.traits & promises_b) == promises_b) lean = 3; }       // kernels_lean_s.hip
+                else if ((hs.traits & promises_a) == promises_a) lean = 1;
                 else if ((hs.traits & promises_b) == promises_b) lean = 2;
                 if (lv && atoi(lv) == 2 && lean == 1) lean = 2;                     // diagnostics: the b unit on a scene that qualifies for a
             }
@@ -403,7 +404,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             float *d_ws = (float *) rc.get(3, render_workspace_floats(paths, variant) * ws_records * sizeof(float));
             auto launcher = hs.integrator.spectral ? launch_render_spectral : launch_render;
 #if !defined(MTSAMD_BLOCKSTATS)
-            if (lean == 1) launcher = launch_render_lean_a; else if (lean == 2) launcher = launch_render_lean_b;
+            if (lean == 1) launcher = launch_render_lean_a; else if (lean == 2) launcher = launch_render_lean_b; else if (lean == 3) launcher = launch_render_lean_s;
 #endif
             HIP_CHECK(launcher(
                           hs.scene, d_blocks, (uint32_t) blocks.size(), block_size, spp, d_target, d_counters,

@@ -18,7 +18,8 @@
 // with MTS_TRAITS != 0 (kernels_lean_*.hip) PROMISES the properties below; the host checks them per scene (scene_host.cpp:
 // scene_traits) and mts_render picks the leanest kernel whose promises the scene keeps.  Same source, same arithmetic: the promised-away
 // branches are simply never compiled (C3 562 -> 629, C4 397 -> 469 Msamples/s on the 256-spp probes, profiles/r04_ab_experiments.log).
-#define MT_MEDIA 1              // every medium: heterogeneous, grey, on a pair grid (DMedium::pair_grid), with spectral extinction
+#define MT_MEDIA 1              // every medium: heterogeneous with spectral extinction and -- rgb / mono: grey, on a pair grid (DMedium::pair_grid);
+                                // spectral variant: two gridvolume_spectral grids sharing geometry and interval (DMedium::shared_grid == 2)
 #define MT_NO_BVH 2             // the primitive list is walked (no BVH)
 #define MT_NO_SPHERE 4          // no sphere shapes
 #define MT_NO_GRID_EVAL 8       // no grid volume is evaluated through volume_eval() (media go through their pair grids; no grid as a blend weight ...)
@@ -32,7 +33,7 @@
 #if !defined(MTS_VARIANT_NS)
 #define MTS_VARIANT_NS v_rgb
 #endif
-#else
+#elif !defined(MTS_VARIANT_NS)
 #define MTS_VARIANT_NS v_spectral
 #endif
 namespace mtsamd {

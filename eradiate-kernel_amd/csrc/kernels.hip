@@ -430,6 +430,21 @@ hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks,
     const uint64_t threads = d_tiles != nullptr ? (uint64_t) n_tiles * MTS_TILE_PIXELS : (uint64_t) n_blocks * block_size * block_size;
     if (threads + 1024 >= ((uint64_t) 1 << 32)) return hipErrorInvalidValue;
     if (sc.sensor.wavefront || wg_threads != 0) return hipErrorInvalidConfiguration;
+#if MTS_SPEC_N != 3          // the spectral variant's machines: 256-path workgroups
+    if (variant == 10256 && sc.integrator.type == MTS_INTEGRATOR_VOLPATH) {
+        const uint32_t grid = (uint32_t) ((threads + 255) / 256), stride = grid * 256;
+        if (count) hipLaunchKernelGGL((render_kernel_wga<true, 256, 256, 2>), dim3(grid), dim3(256), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles);
+        else hipLaunchKernelGGL((render_kernel_wga<false, 256, 256, 2>), dim3(grid), dim3(256), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles);
+        return hipGetLastError();
+    }
+    if (variant == 10256 && sc.integrator.type == MTS_INTEGRATOR_VOLPATHMIS && sc.integrator.use_spectral_mis) {
+        const uint32_t grid = (uint32_t) ((threads + 255) / 256), stride = grid * 256;
+        if (count) hipLaunchKernelGGL((render_kernel_wga_mis<true, true, 256, 256>), dim3(grid), dim3(256), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles);
+        else hipLaunchKernelGGL((render_kernel_wga_mis<false, true, 256, 256>), dim3(grid), dim3(256), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles);
+        return hipGetLastError();
+    }
+    return hipErrorInvalidConfiguration;
+#else
     if (variant == 11024 && sc.integrator.type == MTS_INTEGRATOR_VOLPATH) {
         const uint32_t grid = (uint32_t) ((threads + 1023) / 1024), stride = grid * 1024;
         if (count) hipLaunchKernelGGL((render_kernel_wga<true, 1024, 1024, 4>), dim3(grid), dim3(1024), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles);
@@ -443,6 +458,7 @@ hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks,
         return hipGetLastError();
     }
     return hipErrorInvalidConfiguration;
+#endif
 }
 #else
 hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,
@@ -576,7 +592,7 @@ hipError_t launch_intersect(const DScene &sc, int32_t n, const float *o, const f
 }
 #endif // MTS_SPEC_N == 3
 
-#if MTS_SPEC_N != 3
+#if MTS_SPEC_N != 3 && !defined(MTS_LEAN)
 // SamplingIntegrator::sample in the spectral variant (librender/python/integrator_v.cpp:62-78): the caller's rays carry their wavelengths
 __global__ void __launch_bounds__(256) sample_spectral_kernel(DScene sc, int32_t n, uint64_t seed_offset, const float *__restrict__ rays /* 6 SoA rows */,
                                                               const float *__restrict__ wavelengths /* 4 per ray */,

@@ -189,12 +189,12 @@ static DXf xf_perspective(float fov, float near_, float far_) {
 // Which promises of integrator_dev.h's scene traits (MT_*: what the lean translation units were compiled without) this scene keeps.
 // mts_render launches the leanest kernel whose promises are all kept; a scene that keeps none runs on the general kernels.
 static int scene_traits(const HostScene &hs, bool spectral) {
-    if (spectral) return 0;                                             // the lean units are rgb / mono builds
     int tr = 0;
     bool media = !hs.media.empty();
     for (size_t i = 0; i < hs.media.size(); ++i) {
         const DMedium &m = hs.media[i];
-        media = media && !m.is_homogeneous && i < hs.pair_data.size() && !hs.pair_data[i].empty() && m.grey && m.has_spectral_extinction;
+        if (spectral) media = media && !m.is_homogeneous && m.shared_grid == 2 && m.has_spectral_extinction;      // MT_MEDIA of the spectral variant
+        else media = media && !m.is_homogeneous && i < hs.pair_data.size() && !hs.pair_data[i].empty() && m.grey && m.has_spectral_extinction;
     }
     if (media) tr |= 1;                                                 // MT_MEDIA
     if (hs.bvh_nodes.empty()) tr |= 2;                                  // MT_NO_BVH

@@ -158,8 +158,10 @@ template <bool COUNT>
 DEV MedStep medium_step(const DScene &sc, const DMedium m, const DRay &ray, float sample, uint32_t channel, bool want_albedo, Counters &cnt,
                         const SpecCtx &cx = SpecCtx()) {
     MedStep mi;
-#if MTS_TRAITS & MT_MEDIA                // promised: every medium heterogeneous, grey, on a pair grid, with spectral extinction
+#if (MTS_TRAITS & MT_MEDIA) && MTS_SPEC_N == 3      // promised: every medium heterogeneous, grey, on a pair grid, with spectral extinction
     const bool m_homogeneous = false, m_pair = true, m_grey = true, m_spectral = true;
+#elif MTS_TRAITS & MT_MEDIA                         // spectral variant: heterogeneous, two gridvolume_spectral grids on one geometry and interval
+    const bool m_homogeneous = false, m_pair = false, m_grey = false, m_spectral = true;
 #else
     const bool m_homogeneous = m.is_homogeneous != 0, m_pair = m.pair_grid != nullptr, m_grey = m.grey != 0, m_spectral = m.has_spectral_extinction != 0;
 #endif
@@ -196,14 +198,14 @@ DEV MedStep medium_step(const DScene &sc, const DMedium m, const DRay &ray, floa
             if (want_albedo) mi.sigma_s = spec_s(st * al_raw);
         } else {
             const DVolume vs = cload(sc.volumes + m.sigma_t), va = cload(sc.volumes + m.albedo);
-            if (m.shared_grid && m.grey && vs.filter == MTS_FILTER_TRILINEAR) {
+            if (m.shared_grid && m_grey && vs.filter == MTS_FILTER_TRILINEAR) {
                 // both grids share one cell / one set of weights; single channel: one value serves the three channels
                 GridCell c = grid_cell(vs, mi.p);
                 float st = m.scale * grid_fetch1(as_global(vs.data), c);
                 mi.sigma_t = spec_s(st);
                 if (want_albedo) mi.sigma_s = spec_s(st * grid_fetch1(as_global(va.data), c));    // the tracking walks never read sigma_s
 #if MTS_SPEC_N != 3
-            } else if (m.shared_grid == 2) {
+            } else if ((MTS_TRAITS & MT_MEDIA) != 0 || m.shared_grid == 2) {
                 // gridvolume_spectral for both, same geometry and spectral interval: one cell, one set of weights and spectral nodes
                 GridRef g;
                 for (int k = 0; k < 16; ++k) g.w2l[k] = vs.w2l[k];
@@ -545,7 +547,7 @@ struct VolpathMachine {
         WATERFALL_END
         if (p.si.t < mi.t) mi.t = pm_inf();                    // volpath.cpp:112 / :300 / :397
 #if MTS_TRAITS & MT_MEDIA
-        const bool spectral = true, homogeneous = false, grey = true;
+        const bool spectral = true, homogeneous = false, grey = MTS_SPEC_N == 3;
 #else
         const bool spectral = (mi.info & MI_SPECTRAL) != 0, homogeneous = (mi.info & MI_HOMOGENEOUS) != 0, grey = (mi.info & MI_GREY) != 0;
 #endif

@@ -227,7 +227,7 @@ struct VolpathMisMachine {
         WATERFALL_END
         if (p.si.t < mi.t) mi.t = pm_inf();
 #if MTS_TRAITS & MT_MEDIA
-        const bool spectral = true, homogeneous = false, grey = true;
+        const bool spectral = true, homogeneous = false, grey = MTS_SPEC_N == 3;
 #else
         const bool spectral = (mi.info & MI_SPECTRAL) != 0, homogeneous = (mi.info & MI_HOMOGENEOUS) != 0, grey = (mi.info & MI_GREY) != 0;
 #endif
@@ -318,7 +318,7 @@ struct VolpathMisMachine {
         WATERFALL_END
         if (p.si.t < mi.t) mi.t = pm_inf();
 #if MTS_TRAITS & MT_MEDIA
-        const bool spectral = true, homogeneous = false, grey = true;
+        const bool spectral = true, homogeneous = false, grey = MTS_SPEC_N == 3;
 #else
         const bool spectral = (mi.info & MI_SPECTRAL) != 0, homogeneous = (mi.info & MI_HOMOGENEOUS) != 0, grey = (mi.info & MI_GREY) != 0;
 #endif

@@ -68,10 +68,10 @@ def test_default_kernel_resource_budget(tmp_path):
     fat = str(tmp_path / "fat.bin")
     subprocess.run([tools[0], "-O", "binary", "--only-section=.hip_fatbin", lib, fat], check=True)
     # the section holds one offload bundle per translation unit with device code (kernels.hip: rgb / mono, kernels_spectral.hip: spectral,
-    # kernels_lean_a.hip / _b.hip: the regrouping kernels without what a scene of their traits cannot contain)
+    # kernels_lean_a.hip / _b.hip / _s.hip: the regrouping kernels without what a scene of their traits cannot contain)
     blob, magic = open(fat, "rb").read(), b"__CLANG_OFFLOAD_BUNDLE__"
     starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
-    assert len(starts) == 4, starts
+    assert len(starts) == 5, starts
     kernels = {}
     for k, o in enumerate(starts):
         part, co = str(tmp_path / ("b%d.bin" % k)), str(tmp_path / ("b%d.co" % k))

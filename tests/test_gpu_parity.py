@@ -1277,12 +1277,38 @@ def test_spectral_volpathmis_against_oracle(gpu_spectral, monkeypatch, name, use
     d = _spectral_cases()[name]
     d["integrator"] = dict(d["integrator"], type="volpathmis", use_spectral_mis=use_spectral_mis)
     gpu, st = gpu_render(gpu_spectral, d, collect_counters=True)
-    assert st["kernel_variant"] == (0 if kernel or name == "cornell_path" else 10256)       # no medium: per lane (capi.cpp)
+    assert st["kernel_variant"] % 100000 == (0 if kernel or name == "cornell_path" else 10256)       # no medium: per lane (capi.cpp); + 300000: lean unit s
     o = ob.OracleScene(d, spectral=True)
     ref = o.render()
     assert ref[..., :3].max() > 0
     assert_parity(gpu, ref)
     assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (o.last_stats["n_iter"], o.last_stats["n_lookup"], o.last_stats["n_nee_step"])
+
+
+@pytest.mark.parametrize("integrator", ["volpath", "volpathmis", "nbins"])
+def test_spectral_lean_kernels_match_the_oracle_and_the_general_kernels(gpu_spectral, monkeypatch, integrator):
+    """kernels_lean_s.hip: the spectral variant's regrouping kernels for scenes whose media are heterogeneous pairs of gridvolume_spectral
+    grids (the layered atmosphere as Eradiate renders it) -- mts_stats.kernel_variant 310256 -- against the oracle and the general kernels
+    (MTSAMD_LEAN=0: 10256), films, AOV channels and loop counters bit for bit; a scene with a chromatic homogeneous slab stays general."""
+    d = _spectral_cases()["c5s_atmosphere"]
+    if integrator == "volpathmis":
+        d["integrator"] = dict(d["integrator"], type="volpathmis")
+    elif integrator == "nbins":
+        d["integrator"] = {"type": "nbins", "wavelengths": "400, 480, 560, 640, 720, 800", "tolerance": 30.0, "integrator": dict(d["integrator"])}
+    o = ob.OracleScene(d, spectral=True); ref = o.render(); so = o.last_stats
+    for lean_env, expect in ((None, 310256), ("0", 10256)):
+        if lean_env is None: monkeypatch.delenv("MTSAMD_LEAN", raising=False)
+        else: monkeypatch.setenv("MTSAMD_LEAN", lean_env)
+        scene = gpu_spectral.load_dict(d); sensor = scene.sensors()[0]
+        assert scene.integrator().render(scene, sensor, collect_counters=True)
+        raw = np.array(sensor.film().bitmap(raw=True)); st = scene.integrator().last_stats
+        assert st["kernel_variant"] == expect and np.array_equal(raw, ref)
+        assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
+        assert scene.integrator().render(scene, sensor)                               # the instantiation without loop counters
+        assert np.array_equal(np.array(sensor.film().bitmap(raw=True)), ref)
+    monkeypatch.delenv("MTSAMD_LEAN", raising=False)
+    gpu, st = gpu_render(gpu_spectral, _spectral_cases()["slab_chromatic_medium"])
+    assert st["kernel_variant"] == 10256
 
 
 def test_passes_add_up_in_pass_order_with_aov_channels(gpu_spectral):
@@ -1357,7 +1383,7 @@ def test_bins_on_the_regrouping_machine(gpu_spectral, monkeypatch, wrap, kernel,
     assert scene.integrator().render(scene, sensor, collect_counters=True)
     raw = np.array(sensor.film().bitmap(raw=True))
     st = scene.integrator().last_stats
-    assert st["kernel_variant"] == (0 if kernel else 10256)
+    assert st["kernel_variant"] % 100000 == (0 if kernel else 10256)
     o = ob.OracleScene(d, spectral=True); ref = o.render()
     assert raw.shape[2] == channels and ref[..., 5:].max() > 0
     assert_parity(raw, ref)
@@ -1425,5 +1451,5 @@ def test_bin_integrators_srf_and_irregular_spectra(gpu_spectral):
     assert raw.shape[2] == 11 and ref[..., 5:].max() > 0
     assert_parity(raw, ref)
     st = scene.integrator().last_stats
-    assert st["kernel_variant"] == 10256                        # bins + srf on the regrouping machine (v_spectral::render_kernel_wga), not per lane
+    assert st["kernel_variant"] % 100000 == 10256               # bins + srf on the regrouping machine (v_spectral::render_kernel_wga), not per lane
     assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (o.last_stats["n_iter"], o.last_stats["n_lookup"], o.last_stats["n_nee_step"])
