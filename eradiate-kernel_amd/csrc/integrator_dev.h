@@ -26,6 +26,7 @@
 #define MT_NO_SHAPE_EMITTER 16  // no area emitters (shape_sample_direction)
 #define MT_NO_PHASE_TREE 32     // no nested blendphase
 #define MT_NO_RPV 64            // no rpv BSDF
+#define MT_HOMOG 128            // every medium homogeneous (excludes MT_MEDIA)
 #ifndef MTS_TRAITS
 #define MTS_TRAITS 0
 #endif

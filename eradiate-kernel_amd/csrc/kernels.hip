@@ -29,7 +29,7 @@
 namespace mtsamd {
 inline namespace MTS_VARIANT_NS {
 
-#if !defined(MTS_LEAN)
+#if !defined(MTS_LEAN) || defined(MTS_LEAN_PATH)
 // librender/integrator.cpp:233-288 + librender/imageblock.cpp:79-172, fused: the sample is splatted
 // straight into the film.  With the default box filter a sample lands in its own pixel and is summed
 // in registers in sample order (bit-identical to the reference's block accumulation); the rare
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256, (FLAT && INTEG != NI_PATH) ? 1 : (INTEG =
     }
 }
 
-#endif // !MTS_LEAN
+#endif // !MTS_LEAN || MTS_LEAN_PATH
 
 // Asynchronous-regrouping variant of the volpath render kernel (volpath_flat.h, driver 2).  The parameter list must stay in
 // sync with WgArgs: the block functions re-read it from the kernarg segment with scalar loads.  WG paths are served by NT threads;
@@ -429,6 +429,16 @@ hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks,
     if (n_blocks == 0) return hipSuccess;
     const uint64_t threads = d_tiles != nullptr ? (uint64_t) n_tiles * MTS_TILE_PIXELS : (uint64_t) n_blocks * block_size * block_size;
     if (threads + 1024 >= ((uint64_t) 1 << 32)) return hipErrorInvalidValue;
+#if defined(MTS_LEAN_PATH)    // kernels_lean_p.hip / _ps.hip: `path` as the flat loop with regeneration, nothing else
+    if (variant == 1 && sc.integrator.type == MTS_INTEGRATOR_PATH) {
+        const uint32_t grid = (uint32_t) ((threads + 255) / 256);
+        if (count) hipLaunchKernelGGL((render_kernel<true, true, NI_PATH>), dim3(grid), dim3(256), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_counters, d_stop_flag);
+        else hipLaunchKernelGGL((render_kernel<false, true, NI_PATH>), dim3(grid), dim3(256), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_counters, d_stop_flag);
+        return hipGetLastError();
+    }
+    (void) d_workspace; (void) wg_threads;
+    return hipErrorInvalidConfiguration;
+#else
     if (sc.sensor.wavefront || wg_threads != 0) return hipErrorInvalidConfiguration;
 #if MTS_SPEC_N != 3          // the spectral variant's machines: 256-path workgroups
     if (variant == 10256 && sc.integrator.type == MTS_INTEGRATOR_VOLPATH) {
@@ -459,6 +469,7 @@ hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks,
     }
     return hipErrorInvalidConfiguration;
 #endif
+#endif // MTS_LEAN_PATH
 }
 #else
 hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,

@@ -1,0 +1,9 @@
+// kernels_lean_ps.hip -- kernels_lean_p.hip for the spectral variant (gpu_spectral): `path` as the flat loop, four wavelengths per sample.
+#if !defined(MTSAMD_BLOCKSTATS)
+#define MTS_SPEC_N 4
+#define MTS_LEAN _lean_ps
+#define MTS_LEAN_PATH 1
+#define MTS_VARIANT_NS v_spectral_lean_p
+#define MTS_TRAITS (MT_NO_BVH | MT_NO_SPHERE | MT_NO_GRID_EVAL | MT_NO_PHASE_TREE | MT_NO_RPV)
+#include "kernels.hip"
+#endif

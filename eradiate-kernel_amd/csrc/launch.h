@@ -27,10 +27,20 @@ hipError_t launch_render_lean_a(const DScene &sc, const DBlock *d_blocks, uint32
 hipError_t launch_render_lean_b(const DScene &sc, const DBlock *d_blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,
                                 float *d_film, unsigned long long *d_counters, bool count, int variant, int wg_threads, float *d_workspace,
                                 const uint32_t *d_stop_flag, const uint32_t *d_tiles, uint32_t n_tiles, hipStream_t stream);
+hipError_t launch_render_lean_h(const DScene &sc, const DBlock *d_blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,
+                                float *d_film, unsigned long long *d_counters, bool count, int variant, int wg_threads, float *d_workspace,
+                                const uint32_t *d_stop_flag, const uint32_t *d_tiles, uint32_t n_tiles, hipStream_t stream);      // kernels_lean_h.hip: homogeneous media
 // ... and of the spectral variant's 256-path machines (variant 10256; kernels_lean_s.hip)
 hipError_t launch_render_lean_s(const DScene &sc, const DBlock *d_blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,
                                 float *d_film, unsigned long long *d_counters, bool count, int variant, int wg_threads, float *d_workspace,
                                 const uint32_t *d_stop_flag, const uint32_t *d_tiles, uint32_t n_tiles, hipStream_t stream);
+// ... and `path` as the flat loop (variant 1) for scenes without a BVH, spheres and rpv: kernels_lean_p.hip (rgb / mono), _ps.hip (spectral)
+hipError_t launch_render_lean_p(const DScene &sc, const DBlock *d_blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,
+                                float *d_film, unsigned long long *d_counters, bool count, int variant, int wg_threads, float *d_workspace,
+                                const uint32_t *d_stop_flag, const uint32_t *d_tiles, uint32_t n_tiles, hipStream_t stream);
+hipError_t launch_render_lean_ps(const DScene &sc, const DBlock *d_blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,
+                                 float *d_film, unsigned long long *d_counters, bool count, int variant, int wg_threads, float *d_workspace,
+                                 const uint32_t *d_stop_flag, const uint32_t *d_tiles, uint32_t n_tiles, hipStream_t stream);
 hipError_t launch_sample(const DScene &sc, int32_t n, uint64_t seed_offset, const float *d_rays, float *d_rgb, uint8_t *d_valid, hipStream_t stream);
 // spectral variant (kernels_spectral.hip): per-ray wavelengths (4 n floats), four-wide result
 hipError_t launch_sample_spectral(const DScene &sc, int32_t n, uint64_t seed_offset, const float *d_rays, const float *d_wavelengths, float *d_spec, uint8_t *d_valid,

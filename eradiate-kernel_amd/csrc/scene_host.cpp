@@ -197,11 +197,18 @@ static int scene_traits(const HostScene &hs, bool spectral) {
         else media = media && !m.is_homogeneous && i < hs.pair_data.size() && !hs.pair_data[i].empty() && m.grey && m.has_spectral_extinction;
     }
     if (media) tr |= 1;                                                 // MT_MEDIA
+    bool homog = !hs.media.empty();
+    for (const DMedium &m : hs.media) homog = homog && m.is_homogeneous;
+    if (homog) tr |= 128;                                               // MT_HOMOG
     if (hs.bvh_nodes.empty()) tr |= 2;                                  // MT_NO_BVH
-    bool sphere = false, rpv = false, shape_emitter = false, tree = false, grid_eval = !media && !hs.media.empty();
+    bool sphere = false, rpv = false, shape_emitter = false, tree = false, grid_eval = false;
     for (const DShape &sh : hs.shapes) sphere = sphere || sh.type == MTS_SHAPE_SPHERE;
+    sphere = sphere || hs.scene.sensor.target_shape.type == MTS_SHAPE_SPHERE || hs.scene.sensor.origin_shape.type == MTS_SHAPE_SPHERE;   // the distant sensors' own shapes
     for (const DBsdf &b : hs.bsdfs) rpv = rpv || b.type == MTS_BSDF_RPV;
     for (const DEmitter &e : hs.emitters) shape_emitter = shape_emitter || e.shape >= 0;
+    if (!media)                                                         // a medium that is not on a pair grid reads its grids through volume_eval()
+        for (const DMedium &m : hs.media)
+            grid_eval = grid_eval || hs.volumes[(size_t) m.sigma_t].type == MTS_VOLUME_GRID || hs.volumes[(size_t) m.albedo].type == MTS_VOLUME_GRID;
     for (const DPhase &ph : hs.phases)
         if (ph.type == MTS_PHASE_BLEND) {
             tree = tree || ph.size > 1;

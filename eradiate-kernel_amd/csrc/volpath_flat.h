@@ -162,6 +162,8 @@ DEV MedStep medium_step(const DScene &sc, const DMedium m, const DRay &ray, floa
     const bool m_homogeneous = false, m_pair = true, m_grey = true, m_spectral = true;
 #elif MTS_TRAITS & MT_MEDIA                         // spectral variant: heterogeneous, two gridvolume_spectral grids on one geometry and interval
     const bool m_homogeneous = false, m_pair = false, m_grey = false, m_spectral = true;
+#elif MTS_TRAITS & MT_HOMOG                         // promised: every medium homogeneous
+    const bool m_homogeneous = true, m_pair = false, m_grey = m.grey != 0, m_spectral = m.has_spectral_extinction != 0;
 #else
     const bool m_homogeneous = m.is_homogeneous != 0, m_pair = m.pair_grid != nullptr, m_grey = m.grey != 0, m_spectral = m.has_spectral_extinction != 0;
 #endif
@@ -548,6 +550,8 @@ struct VolpathMachine {
         if (p.si.t < mi.t) mi.t = pm_inf();                    // volpath.cpp:112 / :300 / :397
 #if MTS_TRAITS & MT_MEDIA
         const bool spectral = true, homogeneous = false, grey = MTS_SPEC_N == 3;
+#elif MTS_TRAITS & MT_HOMOG
+        const bool spectral = (mi.info & MI_SPECTRAL) != 0, homogeneous = true, grey = (mi.info & MI_GREY) != 0;
 #else
         const bool spectral = (mi.info & MI_SPECTRAL) != 0, homogeneous = (mi.info & MI_HOMOGENEOUS) != 0, grey = (mi.info & MI_GREY) != 0;
 #endif

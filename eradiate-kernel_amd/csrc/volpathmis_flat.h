@@ -228,6 +228,8 @@ struct VolpathMisMachine {
         if (p.si.t < mi.t) mi.t = pm_inf();
 #if MTS_TRAITS & MT_MEDIA
         const bool spectral = true, homogeneous = false, grey = MTS_SPEC_N == 3;
+#elif MTS_TRAITS & MT_HOMOG
+        const bool spectral = (mi.info & MI_SPECTRAL) != 0, homogeneous = true, grey = (mi.info & MI_GREY) != 0;
 #else
         const bool spectral = (mi.info & MI_SPECTRAL) != 0, homogeneous = (mi.info & MI_HOMOGENEOUS) != 0, grey = (mi.info & MI_GREY) != 0;
 #endif
@@ -319,6 +321,8 @@ struct VolpathMisMachine {
         if (p.si.t < mi.t) mi.t = pm_inf();
 #if MTS_TRAITS & MT_MEDIA
         const bool spectral = true, homogeneous = false, grey = MTS_SPEC_N == 3;
+#elif MTS_TRAITS & MT_HOMOG
+        const bool spectral = (mi.info & MI_SPECTRAL) != 0, homogeneous = true, grey = (mi.info & MI_GREY) != 0;
 #else
         const bool spectral = (mi.info & MI_SPECTRAL) != 0, homogeneous = (mi.info & MI_HOMOGENEOUS) != 0, grey = (mi.info & MI_GREY) != 0;
 #endif

@@ -71,7 +71,7 @@ def test_default_kernel_resource_budget(tmp_path):
     # kernels_lean_a.hip / _b.hip / _s.hip: the regrouping kernels without what a scene of their traits cannot contain)
     blob, magic = open(fat, "rb").read(), b"__CLANG_OFFLOAD_BUNDLE__"
     starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
-    assert len(starts) == 5, starts
+    assert len(starts) == 8, starts
     kernels = {}
     for k, o in enumerate(starts):
         part, co = str(tmp_path / ("b%d.bin" % k)), str(tmp_path / ("b%d.co" % k))
@@ -121,6 +121,11 @@ def test_default_kernel_resource_budget(tmp_path):
     assert lb["vgpr_count"] <= 128 and lb["vgpr_spill_count"] <= 16 and lb["private_segment_fixed_size"] <= 256 and lb["sgpr_spill_count"] <= 160, lb
     lm = one("12v_rgb_lean_a21render_kernel_wga_misILb0ELb1ELi512ELi512E")
     assert lm["vgpr_count"] <= 168 and lm["vgpr_spill_count"] == 0, lm
+    # `path` without the callees a scene without BVH / spheres / rpv cannot reach (kernels_lean_p.hip, _ps.hip)
+    lp = one("12v_rgb_lean_p13render_kernelILb0ELb1ELi0EE")
+    assert lp["vgpr_count"] <= 128 and lp["vgpr_spill_count"] <= 48, lp
+    lps = one("17v_spectral_lean_p13render_kernelILb0ELb1ELi0EE")
+    assert lps["vgpr_count"] <= 168 and lps["vgpr_spill_count"] <= 8, lps
     # the spectral variant's volpath: 256 paths x 42 state dwords, three workgroups per CU
     sp = one("10v_spectral17render_kernel_wgaILb0ELi256ELi256ELi2ELb0E")
     assert sp["vgpr_count"] <= 168 and sp["vgpr_spill_count"] == 0 and 3 * sp["group_segment_fixed_size"] <= 160 * 1024, sp

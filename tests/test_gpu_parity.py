@@ -125,7 +125,7 @@ def test_wavefront_streams_match_the_oracle(gpu_rgb, monkeypatch, case):
     gpu, st = gpu_render(gpu_rgb, d, collect_counters=True)
     assert np.array_equal(gpu, ref)
     # round 4: `volpath` with these streams runs on the regrouping machine (the generator's increment is recomputed on every load)
-    assert st["kernel_variant"] == (11024 if case in ("c3_volpath", "c4_small") else 1 if case == "cornell_path" else 0), st["kernel_variant"]
+    assert st["kernel_variant"] % 100000 == (11024 if case in ("c3_volpath", "c4_small") else 1 if case == "cornell_path" else 0), st["kernel_variant"]
     assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (o.last_stats["n_iter"], o.last_stats["n_lookup"], o.last_stats["n_nee_step"])
     monkeypatch.delenv("MTSAMD_WAVEFRONT_SPLIT")
     spread, st2 = gpu_render(gpu_rgb, d, collect_counters=True)                   # small film: several entries per block
@@ -434,7 +434,7 @@ def test_every_kernel_formulation_matches_the_oracle(gpu_rgb, monkeypatch, kerne
             assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
 
 
-@pytest.mark.parametrize("case", ["c3", "c4", "c3_volpathmis", "c4_volpathmis", "c3_two_passes"])
+@pytest.mark.parametrize("case", ["c3", "c4", "c3_volpathmis", "c4_volpathmis", "c3_two_passes", "c2", "c2_volpathmis", "c2_chromatic"])
 def test_lean_kernels_match_the_oracle_and_the_general_kernels(gpu_rgb, monkeypatch, case):
     """Scene traits (integrator_dev.h: MTS_TRAITS; kernels_lean_a.hip / _b.hip): a scene that keeps the promises of a lean translation unit
     -- heterogeneous grey media on pair grids, a walked primitive list without spheres, no area emitters, no nested blendphase (a: no rpv,
@@ -442,13 +442,18 @@ def test_lean_kernels_match_the_oracle_and_the_general_kernels(gpu_rgb, monkeypa
     cannot need (mts_stats.kernel_variant + 100000 for a, + 200000 for b).  Same source, same arithmetic: the film and the loop counters are
     the oracle's bit for bit, on the lean unit, on the other lean unit where the scene qualifies for both, and on the general kernel
     (MTSAMD_LEAN=0).  A scene that breaks a promise stays on the general kernel."""
-    base = scenes.c3_heterogeneous(96, 64, 8, res=16, samples_per_pass=4 if case == "c3_two_passes" else -1) if case.startswith("c3") else scenes.c4_atmosphere(48, 32, 4)
+    if case.startswith("c3"): base = scenes.c3_heterogeneous(96, 64, 8, res=16, samples_per_pass=4 if case == "c3_two_passes" else -1)
+    elif case.startswith("c2"): base = scenes.c2_homogeneous_slab(64, 48, 8)       # unit h: every medium homogeneous
+    else: base = scenes.c4_atmosphere(48, 32, 4)
     d = dict(base)
+    if case == "c2_chromatic":
+        d["slab"] = dict(d["slab"], interior={"type": "homogeneous", "sigma_t": {"type": "rgb", "value": [0.4, 0.8, 1.6]},
+                                              "albedo": {"type": "rgb", "value": [0.9, 0.7, 0.5]}, "phase": {"type": "hg", "g": 0.5}})
     mis = case.endswith("volpathmis")
     if mis:
         d["integrator"] = dict(d["integrator"], type="volpathmis")
     machine = 10512 if mis else 11024
-    unit = 1 if case.startswith("c3") else 2
+    unit = 1 if case.startswith("c3") else 6 if case.startswith("c2") else 2
     o = ob.OracleScene(d); ref = o.render(); so = o.last_stats
     assert ref[..., :3].max() > 0
     for lean_env, expect in ((None, unit), ("0", 0)) + ((("2", 2),) if unit == 1 else ()):
@@ -465,8 +470,36 @@ def test_lean_kernels_match_the_oracle_and_the_general_kernels(gpu_rgb, monkeypa
         with_sphere = dict(d); with_sphere["ball"] = {"type": "sphere", "center": [0.0, 0.0, 30.0], "radius": 0.5, "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.5, 0.5, 0.5]}}}
         gpu, st = gpu_render(gpu_rgb, with_sphere, collect_counters=True)
         assert st["kernel_variant"] == 11024 and np.array_equal(gpu, ob.OracleScene(with_sphere).render())
-        gpu, st = gpu_render(gpu_rgb, scenes.c2_homogeneous_slab(64, 48, 8), collect_counters=True)
-        assert st["kernel_variant"] == 11024
+        mixed = dict(d); mixed["haze"] = {"type": "cube", "to_world": T.translate([0.0, 0.0, 40.0]), "bsdf": {"type": "null"},
+                                         "interior": {"type": "homogeneous", "sigma_t": 0.05, "albedo": 0.9}}
+        gpu, st = gpu_render(gpu_rgb, mixed, collect_counters=True)                   # a heterogeneous and a homogeneous medium: no unit's promise
+        assert st["kernel_variant"] == 11024 and np.array_equal(gpu, ob.OracleScene(mixed).render())
+
+
+def test_lean_path_kernel_matches_the_oracle_and_the_general_kernel(gpu_rgb, monkeypatch):
+    """kernels_lean_p.hip: `path` as the flat loop for scenes with a walked primitive list, no spheres and no rpv (the cornell box): on the
+    lean unit (mts_stats.kernel_variant 400001) and on the general kernel (MTSAMD_LEAN=0: 1) the oracle's film and counters bit for bit,
+    with the scalar streams and with the wavefront (gpu_*) streams; a sphere in the box keeps it on the general kernel."""
+    for wavefront in (False, True):
+        d = scenes.c1_cornell(48, 40, 8)
+        if wavefront:
+            d["sensor"]["sampler"]["wavefront"] = True
+            monkeypatch.setenv("MTSAMD_WAVEFRONT_SPLIT", "1")
+        o = ob.OracleScene(d); ref = o.render(); so = o.last_stats
+        for lean_env, expect in ((None, 400001), ("0", 1)):
+            if lean_env is None: monkeypatch.delenv("MTSAMD_LEAN", raising=False)
+            else: monkeypatch.setenv("MTSAMD_LEAN", lean_env)
+            gpu, st = gpu_render(gpu_rgb, d, collect_counters=True)
+            assert st["kernel_variant"] == expect and np.array_equal(gpu, ref)
+            assert st["n_iter"] == so["n_iter"]
+            plain, _ = gpu_render(gpu_rgb, d)
+            assert np.array_equal(plain, ref)
+        monkeypatch.delenv("MTSAMD_LEAN", raising=False)
+    monkeypatch.delenv("MTSAMD_WAVEFRONT_SPLIT", raising=False)
+    d = scenes.c1_cornell(48, 40, 8)
+    d["ball"] = {"type": "sphere", "center": [0.0, 0.0, 1.0], "radius": 0.4, "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.5, 0.5, 0.5]}}}
+    gpu, st = gpu_render(gpu_rgb, d)
+    assert st["kernel_variant"] == 1 and np.array_equal(gpu, ob.OracleScene(d).render())
 
 
 @pytest.mark.parametrize("spectral", [True, False])
@@ -1226,7 +1259,7 @@ def test_spectral_variant_against_oracle(gpu_spectral, monkeypatch, name, kernel
     d = _spectral_cases()[name]
     gpu, st = gpu_render(gpu_spectral, d, collect_counters=True)
     if name == "cornell_path":
-        assert st["kernel_variant"] == (0 if kernel else 1)
+        assert st["kernel_variant"] == (0 if kernel else 500001)                     # the flat loop, lean unit ps (no BVH, spheres, rpv in the box)
     o = ob.OracleScene(d, spectral=True)
     ref = o.render()
     assert ref[..., :3].max() > 0
@@ -1353,7 +1386,7 @@ def test_spectral_path_flat_loop_with_bins_and_srf(gpu_spectral, monkeypatch, wr
     assert scene.integrator().render(scene, sensor, collect_counters=True)
     raw = np.array(sensor.film().bitmap(raw=True))
     st = scene.integrator().last_stats
-    assert st["kernel_variant"] == (0 if kernel else 1)
+    assert st["kernel_variant"] == (0 if kernel else 500001)
     o = ob.OracleScene(d, spectral=True); ref = o.render(threads=1)
     assert raw.shape[2] == channels and ref[..., :3].max() > 0 and (channels == 5 or ref[..., 5:].max() > 0)
     assert_parity(raw, ref)
