@@ -7,6 +7,7 @@ from tests.test_gpu_fuzz import _scene, _scene_spectral
 pkg = importlib.import_module("eradiate-kernel_amd")
 first, last = int(sys.argv[1]), int(sys.argv[2])
 bad = 0
+units = {}
 for spectral in (False, True):
     pkg.set_variant("gpu_spectral" if spectral else "gpu_rgb")
     for seed in range(first, last):
@@ -15,6 +16,7 @@ for spectral in (False, True):
             scene = pkg.load_dict(d); sensor = scene.sensors()[0]
             scene.integrator().render(scene, sensor, collect_counters=True)
             gpu = np.array(sensor.film().bitmap(raw=True)); st = scene.integrator().last_stats
+            units[st["kernel_variant"] // 100000] = units.get(st["kernel_variant"] // 100000, 0) + 1
             o = ob.OracleScene(d, spectral=spectral); ref = o.render(); so = o.last_stats
         except Exception as e:
             print("seed", seed, "spectral", spectral, "EXCEPTION", e); bad += 1; continue
@@ -24,5 +26,5 @@ for spectral in (False, True):
         if not ok:
             bad += 1
             print("seed", seed, "spectral", spectral, "MISMATCH", d["integrator"], d["sensor"]["type"], float(np.abs(gpu - ref).max()), flush=True)
-print("soak seeds %d..%d: %d failures" % (first, last, bad))
+print("soak seeds %d..%d: %d failures; renders per lean unit (0 = general kernels, 1 a, 2 b, 3 s, 4 p, 5 ps, 6 h): %s" % (first, last, bad, dict(sorted(units.items()))))
 sys.exit(1 if bad else 0)
