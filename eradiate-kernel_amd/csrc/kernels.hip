@@ -463,6 +463,11 @@ hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks,
     }
     if (variant == 10512 && sc.integrator.type == MTS_INTEGRATOR_VOLPATHMIS && sc.integrator.use_spectral_mis) {
         const uint32_t grid = (uint32_t) ((threads + 511) / 512), stride = grid * 512;
+#if defined(MTS_LEAN_MIS_768)   // the 512 paths served by 768 threads: three waves per SIMD want <= 168 VGPRs, which this unit's kernel meets (C3M 375 -> 393)
+        if (count) hipLaunchKernelGGL((render_kernel_wga_mis<true, true, 512, 768>), dim3(grid), dim3(768), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles);
+        else hipLaunchKernelGGL((render_kernel_wga_mis<false, true, 512, 768>), dim3(grid), dim3(768), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles);
+        return hipGetLastError();
+#endif
         if (count) hipLaunchKernelGGL((render_kernel_wga_mis<true, true, 512, 512>), dim3(grid), dim3(512), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles);
         else hipLaunchKernelGGL((render_kernel_wga_mis<false, true, 512, 512>), dim3(grid), dim3(512), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles);
         return hipGetLastError();
