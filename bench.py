@@ -356,6 +356,8 @@ def main():
     lean = {1: "v_rgb_lean_a::", 2: "v_rgb_lean_b::", 3: "v_spectral_lean::", 4: "v_rgb_lean_p::", 5: "v_spectral_lean_p::", 6: "v_rgb_lean_h::"}.get(getattr(job, "kernel_variant", 0) // 100000, "")
     if lean:
         kernel_name = lean + kernel_name.replace("v_spectral::", "")
+        if lean == "v_spectral_lean::":
+            kernel_name = kernel_name.replace("render_kernel_wga<false, 256, 256, 2, false>", "render_kernel_wga<false, 256, 256, 3, false>")       # budget of three waves per SIMD
         if lean == "v_rgb_lean_a::":
             kernel_name = kernel_name.replace("render_kernel_wga_mis<false, true, 512, 512>", "render_kernel_wga_mis<false, true, 512, 768>")   # three waves per SIMD
     # `achieved` / `frac` follow the contract: ALGORITHMIC bytes (a wavefront formulation's state round trips) over

@@ -42,6 +42,14 @@ inline namespace MTS_VARIANT_NS {
 
 #define DEV __device__ __forceinline__
 #define DEV_NOINLINE __device__ __noinline__
+// functions that are calls in the general kernels so that scenes which never reach them do not carry their registers, and inline in the
+// lean translation units that keep them: a unit has few enough of them left, and a kernel WITHOUT any call does not pay the calling
+// convention at all (EXP_LEAN_CALLS restores the calls: measurement)
+#if defined(MTS_LEAN) && !defined(EXP_LEAN_CALLS)
+#define DEV_CALL_UNLESS_LEAN DEV
+#else
+#define DEV_CALL_UNLESS_LEAN DEV_NOINLINE
+#endif
 
 // ---- scalar-load helpers -------------------------------------------------------------------------------
 // Scene records live in global memory and are addressed with wave-uniform indices, but the compiler only
@@ -474,7 +482,7 @@ DEV float trilerp(float d000, float d100, float d010, float d110, float d001, fl
 // It receives the 23 dwords of the volume record it reads, which travel in argument registers; the whole record (by value) would
 // be copied through scratch memory at every call.
 struct GridRef { float w2l[16]; const float *data; int32_t nx, ny, nz; uint32_t channels_affine_filter_wrap; };
-DEV_NOINLINE F3 volume_eval_grid(const GridRef g, F3 p_world);
+DEV_CALL_UNLESS_LEAN F3 volume_eval_grid(const GridRef g, F3 p_world);
 #if MTS_SPEC_N != 3
 DEV Spec volume_eval_grid_spectral(const GridRef g, F3 p_world, Spec wl, float lambda_min, float lambda_max);
 #endif
@@ -556,7 +564,7 @@ DEV void volume_eval_grid_spectral_n(const GridRef &g, const float *data_b, F3 p
 // Four real functions (eight corners / z profile, one grid / two): their register need counts towards the kernel's, and with both
 // instantiations in one function the allocator took 180 VGPRs where the regrouping kernel has 168 (three 256-path workgroups per CU).
 template <int NG, bool COLUMNS_EQUAL>
-DEV_NOINLINE SpecPair volume_eval_grid_spectral_f(const GridRef g, const float *data_b, F3 p_world, Spec wl, float lambda_min, float lambda_max) {
+DEV_CALL_UNLESS_LEAN SpecPair volume_eval_grid_spectral_f(const GridRef g, const float *data_b, F3 p_world, Spec wl, float lambda_min, float lambda_max) {
     Spec o[2]; o[1] = spec_s(0.f);
     volume_eval_grid_spectral_n<NG, COLUMNS_EQUAL>(g, data_b, p_world, wl, lambda_min, lambda_max, o);
     SpecPair r; r.a = o[0]; r.b = o[1];
@@ -571,7 +579,7 @@ DEV SpecPair volume_eval_grid_spectral_pair(const GridRef g, const float *data_b
     return volume_eval_grid_spectral_f<2, false>(g, data_b, p_world, wl, lambda_min, lambda_max);
 }
 #endif
-DEV_NOINLINE F3 volume_eval_grid(const GridRef g, F3 p_world) {
+DEV_CALL_UNLESS_LEAN F3 volume_eval_grid(const GridRef g, F3 p_world) {
     struct { const float *w2l; const float *data; int nx, ny, nz, channels, affine, filter, wrap; } v;
     v.w2l = g.w2l; v.data = g.data; v.nx = g.nx; v.ny = g.ny; v.nz = g.nz;
     v.channels = (int) (g.channels_affine_filter_wrap & 0xffu); v.affine = (int) ((g.channels_affine_filter_wrap >> 8) & 1u);
@@ -837,7 +845,7 @@ DEV void frame_sincos_phi(F3 v, float &s, float &c) {                           
 }
 // bsdfs/rpv.cpp:85-131
 struct RpvParams { float rho_0[MTS_SPEC_N], k[MTS_SPEC_N], g[MTS_SPEC_N], rho_c[MTS_SPEC_N]; };     // passed by value: a reference would pin the caller's whole DBsdf copy in scratch
-DEV_NOINLINE Spec eval_rpv_p(const RpvParams b, F3 wi, F3 wo) {
+DEV_CALL_UNLESS_LEAN Spec eval_rpv_p(const RpvParams b, F3 wi, F3 wo) {
     float sin_phi1, cos_phi1, sin_phi2, cos_phi2;
     frame_sincos_phi(wi, sin_phi1, cos_phi1); frame_sincos_phi(wo, sin_phi2, cos_phi2);
     float cos_phi1_minus_phi2 = cos_phi1 * cos_phi2 + sin_phi1 * sin_phi2;

@@ -443,8 +443,9 @@ hipError_t MTS_LAUNCHER(launch_render)(const DScene &sc, const DBlock *d_blocks,
 #if MTS_SPEC_N != 3          // the spectral variant's machines: 256-path workgroups
     if (variant == 10256 && sc.integrator.type == MTS_INTEGRATOR_VOLPATH) {
         const uint32_t grid = (uint32_t) ((threads + 255) / 256), stride = grid * 256;
-        if (count) hipLaunchKernelGGL((render_kernel_wga<true, 256, 256, 2>), dim3(grid), dim3(256), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles);
-        else hipLaunchKernelGGL((render_kernel_wga<false, 256, 256, 2>), dim3(grid), dim3(256), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles);
+        // register budget of three waves per SIMD (three 256-path workgroups per CU): with the spectral grid lookups inline the allocator needs the bound
+        if (count) hipLaunchKernelGGL((render_kernel_wga<true, 256, 256, 3>), dim3(grid), dim3(256), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles);
+        else hipLaunchKernelGGL((render_kernel_wga<false, 256, 256, 3>), dim3(grid), dim3(256), 0, stream, sc, d_blocks, n_blocks, block_size, sample_count, d_film, d_workspace, stride, d_counters, d_stop_flag, d_tiles, n_tiles);
         return hipGetLastError();
     }
     if (variant == 10256 && sc.integrator.type == MTS_INTEGRATOR_VOLPATHMIS && sc.integrator.use_spectral_mis) {
