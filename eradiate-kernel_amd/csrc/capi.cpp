@@ -156,6 +156,18 @@ int mts_scene_create(const mts_scene_desc *desc, int device, mts_scene **out) {
     API_CATCH
 }
 
+// Not part of the ABI (include/mtsamd.h does not declare it): which promises of integrator_dev.h's scene traits a description keeps
+// (scene_host.cpp: scene_traits) -- what decides which lean translation unit mts_render launches.  Host only: no device is touched, so the
+// CPU test-suite pins the decision (tests/test_abi.py::test_scene_traits).
+int mts_debug_scene_traits(const mts_scene_desc *desc, int32_t *traits) {
+    API_TRY
+    if (!traits) throw std::runtime_error("mts_debug_scene_traits: traits is NULL");
+    HostScene *hs = build_host_scene(desc);
+    *traits = hs->traits;
+    free_host_scene(hs);
+    API_CATCH
+}
+
 int mts_scene_destroy(mts_scene *scene) {
     if (scene) {
 #if defined(MTSAMD_HOST_ONLY)

@@ -131,6 +131,52 @@ def test_default_kernel_resource_budget(tmp_path):
     assert sp["vgpr_count"] <= 168 and sp["vgpr_spill_count"] == 0 and 3 * sp["group_segment_fixed_size"] <= 160 * 1024, sp
 
 
+def test_scene_traits(L):
+    """Which lean translation unit mts_render may launch is decided per scene on the host (scene_host.cpp: scene_traits; the promises are
+    integrator_dev.h's MT_* bits).  A wrong promise would be a wrong image, so the decision is pinned here, without a GPU, through a
+    host-only debug export: the BASELINE scenes qualify for the units they are benchmarked on, and every feature a unit was compiled
+    without -- a BVH, a sphere (also as a distant sensor's origin shape), an area emitter, a nested blendphase, rpv, a grid behind
+    volume_eval(), a medium of the other kind -- clears its bit."""
+    SD = importlib.import_module("eradiate-kernel_amd.scene_dict")
+    scenes = importlib.import_module("eradiate-kernel_amd.scenes")
+    T = importlib.import_module("eradiate-kernel_amd.transform").ScalarTransform4f
+    L.mts_debug_scene_traits.argtypes = [C.POINTER(A.SceneDesc), C.POINTER(C.c_int32)]
+    MEDIA, NO_BVH, NO_SPHERE, NO_GRID_EVAL, NO_SHAPE_EMITTER, NO_PHASE_TREE, NO_RPV, HOMOG = 1, 2, 4, 8, 16, 32, 64, 128
+    A_UNIT, B_UNIT, H_UNIT, P_UNIT = 127, 1 | 2 | 4 | 16 | 32, 190, 70
+
+    def traits(d, spectral=False):
+        desc, keep = SD.build_scene_desc(d, spectral=spectral)
+        t = C.c_int32(-1)
+        assert L.mts_debug_scene_traits(C.byref(desc), C.byref(t)) == 0, L.mts_last_error()
+        return t.value
+
+    grey = {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.5, 0.5, 0.5]}}
+    c3 = scenes.c3_heterogeneous(64, 64, 4, res=8)
+    assert traits(c3) & A_UNIT == A_UNIT and not traits(c3) & HOMOG                               # the metric scene: unit a
+    c4 = scenes.c4_atmosphere(32, 32, 4, layers=8)
+    t4 = traits(c4)
+    assert t4 & B_UNIT == B_UNIT and not t4 & NO_RPV and t4 & A_UNIT != A_UNIT                     # rpv ground: unit b, not a
+    c2 = scenes.c2_homogeneous_slab(32, 32, 4)
+    assert traits(c2) & H_UNIT == H_UNIT and not traits(c2) & MEDIA                                # homogeneous slab: unit h
+    c1 = scenes.c1_cornell(32, 32, 4)
+    assert traits(c1) & P_UNIT == P_UNIT and not traits(c1) & NO_SHAPE_EMITTER                     # cornell box: unit p (its light is an area emitter)
+    with_sphere = dict(c3, ball={"type": "sphere", "center": [0.0, 0.0, 30.0], "radius": 0.5, "bsdf": grey})
+    assert not traits(with_sphere) & NO_SPHERE and traits(with_sphere) & MEDIA
+    many = dict(c3)
+    for k in range(45):
+        many["leaf%02d" % k] = {"type": "rectangle", "to_world": T.translate([0.1 * k, 0.0, 20.0]) @ T.scale(0.2), "bsdf": grey}
+    assert not traits(many) & NO_BVH                                                               # 47 primitives: a BVH is built
+    mixed = dict(c3, haze={"type": "cube", "to_world": T.translate([0.0, 0.0, 40.0]), "bsdf": {"type": "null"},
+                           "interior": {"type": "homogeneous", "sigma_t": 0.05, "albedo": 0.9}})
+    assert not traits(mixed) & MEDIA and not traits(mixed) & HOMOG and not traits(mixed) & NO_GRID_EVAL   # its grids are then read through volume_eval()
+    distant_sphere = scenes.c2_homogeneous_slab(8, 6, 4)
+    distant_sphere["sensor"] = {"type": "distant", "film": dict(distant_sphere["sensor"]["film"]), "sampler": distant_sphere["sensor"]["sampler"],
+                                "ray_origin": {"type": "sphere", "center": [0, 0, 1], "radius": 30.0},
+                                "ray_target": {"type": "rectangle", "to_world": T.translate([0, 0, 2.0]) @ T.scale(2.0)}}
+    assert not traits(distant_sphere) & NO_SPHERE                                                  # the sensor's own origin shape counts
+    assert traits(scenes.c5_atmosphere_spectral(16, 16, 4, layers=8), spectral=True) & B_UNIT == B_UNIT   # spectral variant: unit s
+
+
 def test_binary_identifies_its_sources(L, tmp_path, monkeypatch):
     """mts_build_id(): the library carries a hash of the sources, headers and flags it was built from; the build script rebuilds when
     the tree's hash differs (no mtimes), and the binding refuses a library that is not the tree's -- a header touched without a
