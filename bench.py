@@ -353,7 +353,7 @@ def main():
         paths = int(kv[3:]); nt = int(os.environ.get("MTSAMD_WG_THREADS", str(paths)))
         kernel_name = "render_kernel_%s<false, %d, %d, %d%s>" % (kv[:3], paths, nt, {1: 4, 0.75: 3, 0.5: 2}[nt / paths], ", false" if kv[:3] == "wga" else "")
     # a scene that keeps the promises of a lean translation unit runs that unit's copy of the kernel (mts_stats.kernel_variant + 100000 / 200000)
-    lean = {1: "v_rgb_lean_a::", 2: "v_rgb_lean_b::", 3: "v_spectral_lean::", 4: "v_rgb_lean_p::", 5: "v_spectral_lean_p::", 6: "v_rgb_lean_h::"}.get(getattr(job, "kernel_variant", 0) // 100000, "")
+    lean = {1: "v_rgb_lean_a::", 2: "v_rgb_lean_b::", 3: "v_spectral_lean::", 4: "v_rgb_lean_p::", 5: "v_spectral_lean_p::", 6: "v_rgb_lean_h::", 7: "v_rgb_lean_c::"}.get(getattr(job, "kernel_variant", 0) // 100000, "")
     if lean:
         kernel_name = lean + kernel_name.replace("v_spectral::", "")
         if lean == "v_spectral_lean::":

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["kernels.hip", "kernels_spectral.hip", "kernels_lean_a.hip", "kernels_lean_b.hip", "kernels_lean_s.hip", "kernels_lean_h.hip", "kernels_lean_p.hip", "kernels_lean_ps.hip", "scene_host.cpp", "capi.cpp"]
+SOURCES = ["kernels.hip", "kernels_spectral.hip", "kernels_lean_a.hip", "kernels_lean_b.hip", "kernels_lean_c.hip", "kernels_lean_s.hip", "kernels_lean_h.hip", "kernels_lean_p.hip", "kernels_lean_ps.hip", "scene_host.cpp", "capi.cpp"]
 HEADERS = ["pmath.h", "dmath.h", "dscene.h", "integrator_dev.h", "volpath_flat.h", "volpathmis_flat.h", "launch.h", "scene_host.h", "cie_tables.h"]
 MARKER = b"MTSAMD_BUILD_ID="
 # hipcc flags of the product build (build.py).  Flags that matter for parity with the CPU restatement: see build.py's docstring.

@@ -380,7 +380,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
         if (const char *tv = getenv("MTSAMD_WG_THREADS")) wg_threads = atoi(tv);
         // Lean kernels (kernels_lean_a.hip / _b.hip: the regrouping machines of rgb / mono `volpath` and `volpathmis` compiled WITHOUT what
         // this scene cannot contain, integrator_dev.h: MTS_TRAITS): the leanest unit whose promises the scene keeps.  MTSAMD_LEAN=0: never.
-        // mts_stats.kernel_variant reports it as + 100000 (a) / + 200000 (b) / + 300000 (s: the spectral variant's unit) / + 400000, + 500000 (`path`: p, ps) / + 600000 (h: homogeneous media).
+        // mts_stats.kernel_variant reports it as + 100000 (a) / + 200000 (b) / + 300000 (s: the spectral variant's unit) / + 400000, + 500000 (`path`: p, ps) / + 600000 (h: homogeneous media) / + 700000 (c: as b, with a BVH).
         int lean = 0;
 #if !defined(MTSAMD_BLOCKSTATS)
         {
@@ -392,6 +392,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
                 if (hs.integrator.spectral) { if ((hs.traits & promises_b) == promises_b) lean = 3; }       // kernels_lean_s.hip
                 else if ((hs.traits & promises_a) == promises_a) lean = 1;
                 else if ((hs.traits & promises_b) == promises_b) lean = 2;
+                else if ((hs.traits & 53) == 53) lean = 7;                           // kernels_lean_c.hip: as b, BVH allowed (MT_MEDIA | no spheres, area emitters, blend trees)
                 else if ((hs.traits & 190) == 190) lean = 6;                         // kernels_lean_h.hip: MT_HOMOG | no BVH, spheres, grids behind volume_eval(), area emitters, blend trees
                 if (lv && atoi(lv) == 2 && lean == 1) lean = 2;                     // diagnostics: the b unit on a scene that qualifies for a
             }
@@ -420,7 +421,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             auto launcher = hs.integrator.spectral ? launch_render_spectral : launch_render;
 #if !defined(MTSAMD_BLOCKSTATS)
             if (lean == 1) launcher = launch_render_lean_a; else if (lean == 2) launcher = launch_render_lean_b; else if (lean == 3) launcher = launch_render_lean_s;
-            else if (lean == 4) launcher = launch_render_lean_p; else if (lean == 5) launcher = launch_render_lean_ps; else if (lean == 6) launcher = launch_render_lean_h;
+            else if (lean == 4) launcher = launch_render_lean_p; else if (lean == 5) launcher = launch_render_lean_ps; else if (lean == 6) launcher = launch_render_lean_h; else if (lean == 7) launcher = launch_render_lean_c;
 #endif
             HIP_CHECK(launcher(
                           hs.scene, d_blocks, (uint32_t) blocks.size(), block_size, spp, d_target, d_counters,

@@ -30,6 +30,9 @@ hipError_t launch_render_lean_b(const DScene &sc, const DBlock *d_blocks, uint32
 hipError_t launch_render_lean_h(const DScene &sc, const DBlock *d_blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,
                                 float *d_film, unsigned long long *d_counters, bool count, int variant, int wg_threads, float *d_workspace,
                                 const uint32_t *d_stop_flag, const uint32_t *d_tiles, uint32_t n_tiles, hipStream_t stream);      // kernels_lean_h.hip: homogeneous media
+hipError_t launch_render_lean_c(const DScene &sc, const DBlock *d_blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,
+                                float *d_film, unsigned long long *d_counters, bool count, int variant, int wg_threads, float *d_workspace,
+                                const uint32_t *d_stop_flag, const uint32_t *d_tiles, uint32_t n_tiles, hipStream_t stream);      // kernels_lean_c.hip: as b, with a BVH
 // ... and of the spectral variant's 256-path machines (variant 10256; kernels_lean_s.hip)
 hipError_t launch_render_lean_s(const DScene &sc, const DBlock *d_blocks, uint32_t n_blocks, uint32_t block_size, uint32_t sample_count,
                                 float *d_film, unsigned long long *d_counters, bool count, int variant, int wg_threads, float *d_workspace,

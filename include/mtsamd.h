@@ -265,7 +265,7 @@ typedef struct mts_stats {
                                  like the reference, render() still returns true then)            */
     int32_t kernel_variant;   /* kernel formulation of the last launch: 0 = nested per-lane loops, 1 = per-lane state machine,
                                  10000 + P = regrouping machine on LDS rings with P paths per workgroup, 20000 + P = lane-affine driver;
-                                 + 100000 U when the kernel came from lean translation unit U (1 a, 2 b, 3 s, 4 p, 5 ps, 6 h: the same kernel
+                                 + 100000 U when the kernel came from lean translation unit U (1 a, 2 b, 3 s, 4 p, 5 ps, 6 h, 7 c: the same kernel
                                  compiled without what this scene cannot contain -- same film; MTSAMD_LEAN=0 turns them off) */
     int32_t calibration_launches; /* 0 or 1: the short launch that measures the blocks' costs before a render with more blocks than CUs
                                      (expensive blocks first; its samples are discarded)          */

@@ -71,7 +71,7 @@ def test_default_kernel_resource_budget(tmp_path):
     # kernels_lean_a.hip / _b.hip / _s.hip: the regrouping kernels without what a scene of their traits cannot contain)
     blob, magic = open(fat, "rb").read(), b"__CLANG_OFFLOAD_BUNDLE__"
     starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
-    assert len(starts) == 8, starts
+    assert len(starts) == 9, starts
     kernels = {}
     for k, o in enumerate(starts):
         part, co = str(tmp_path / ("b%d.bin" % k)), str(tmp_path / ("b%d.co" % k))
@@ -165,7 +165,7 @@ def test_scene_traits(L):
     many = dict(c3)
     for k in range(45):
         many["leaf%02d" % k] = {"type": "rectangle", "to_world": T.translate([0.1 * k, 0.0, 20.0]) @ T.scale(0.2), "bsdf": grey}
-    assert not traits(many) & NO_BVH                                                               # 47 primitives: a BVH is built
+    assert not traits(many) & NO_BVH and traits(many) & 53 == 53                                   # 47 primitives: a BVH is built -- unit c
     mixed = dict(c3, haze={"type": "cube", "to_world": T.translate([0.0, 0.0, 40.0]), "bsdf": {"type": "null"},
                            "interior": {"type": "homogeneous", "sigma_t": 0.05, "albedo": 0.9}})
     assert not traits(mixed) & MEDIA and not traits(mixed) & HOMOG and not traits(mixed) & NO_GRID_EVAL   # its grids are then read through volume_eval()

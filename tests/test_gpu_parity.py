@@ -434,7 +434,7 @@ def test_every_kernel_formulation_matches_the_oracle(gpu_rgb, monkeypatch, kerne
             assert (st["n_iter"], st["n_lookup"], st["n_nee_step"]) == (so["n_iter"], so["n_lookup"], so["n_nee_step"])
 
 
-@pytest.mark.parametrize("case", ["c3", "c4", "c3_volpathmis", "c4_volpathmis", "c3_two_passes", "c2", "c2_volpathmis", "c2_chromatic"])
+@pytest.mark.parametrize("case", ["c3", "c4", "c3_volpathmis", "c4_volpathmis", "c3_two_passes", "c2", "c2_volpathmis", "c2_chromatic", "c3_canopy", "c4_canopy"])
 def test_lean_kernels_match_the_oracle_and_the_general_kernels(gpu_rgb, monkeypatch, case):
     """Scene traits (integrator_dev.h: MTS_TRAITS; kernels_lean_a.hip / _b.hip): a scene that keeps the promises of a lean translation unit
     -- heterogeneous grey media on pair grids, a walked primitive list without spheres, no area emitters, no nested blendphase (a: no rpv,
@@ -446,6 +446,13 @@ def test_lean_kernels_match_the_oracle_and_the_general_kernels(gpu_rgb, monkeypa
     elif case.startswith("c2"): base = scenes.c2_homogeneous_slab(64, 48, 8)       # unit h: every medium homogeneous
     else: base = scenes.c4_atmosphere(48, 32, 4)
     d = dict(base)
+    if case.endswith("canopy"):                                  # 45 leaves under the atmosphere: more than 40 primitives, a BVH is built -- unit c
+        rng = np.random.default_rng(11)
+        for k in range(45):
+            c = rng.uniform([-3, -3, 0.2], [3, 3, 1.5])
+            d["leaf%02d" % k] = {"type": "rectangle", "to_world": T.translate(c) @ T.rotate(rng.normal(size=3), float(rng.uniform(0, 180))) @ T.scale(0.4),
+                                 "bsdf": {"type": "bilambertian", "reflectance": {"type": "rgb", "value": [0.1, 0.45, 0.08]},
+                                          "transmittance": {"type": "rgb", "value": [0.05, 0.4, 0.04]}}}
     if case == "c2_chromatic":
         d["slab"] = dict(d["slab"], interior={"type": "homogeneous", "sigma_t": {"type": "rgb", "value": [0.4, 0.8, 1.6]},
                                               "albedo": {"type": "rgb", "value": [0.9, 0.7, 0.5]}, "phase": {"type": "hg", "g": 0.5}})
@@ -453,7 +460,7 @@ def test_lean_kernels_match_the_oracle_and_the_general_kernels(gpu_rgb, monkeypa
     if mis:
         d["integrator"] = dict(d["integrator"], type="volpathmis")
     machine = 10512 if mis else 11024
-    unit = 1 if case.startswith("c3") else 6 if case.startswith("c2") else 2
+    unit = 7 if case.endswith("canopy") else 1 if case.startswith("c3") else 6 if case.startswith("c2") else 2
     o = ob.OracleScene(d); ref = o.render(); so = o.last_stats
     assert ref[..., :3].max() > 0
     for lean_env, expect in ((None, unit), ("0", 0)) + ((("2", 2),) if unit == 1 else ()):
