@@ -26,5 +26,5 @@ for spectral in (False, True):
         if not ok:
             bad += 1
             print("seed", seed, "spectral", spectral, "MISMATCH", d["integrator"], d["sensor"]["type"], float(np.abs(gpu - ref).max()), flush=True)
-print("soak seeds %d..%d: %d failures; renders per lean unit (0 = general kernels, 1 a, 2 b, 3 s, 4 p, 5 ps, 6 h): %s" % (first, last, bad, dict(sorted(units.items()))))
+print("soak seeds %d..%d: %d failures; renders per lean unit (0 = general kernels, 1 a, 2 b, 3 s, 4 p, 5 ps, 6 h, 7 c): %s" % (first, last, bad, dict(sorted(units.items()))))
 sys.exit(1 if bad else 0)
