@@ -388,16 +388,16 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
             const bool mis = hs.integrator.type == MTS_INTEGRATOR_VOLPATHMIS && hs.integrator.use_spectral_mis, vol = hs.integrator.type == MTS_INTEGRATOR_VOLPATH;
             const bool machine = hs.integrator.spectral ? (variant == 10256 && (vol || mis)) : ((variant == 11024 && vol) || (variant == 10512 && mis));
             if (!(lv && atoi(lv) == 0) && machine && !se.wavefront && wg_threads == 0) {
-                const int promises_a = 127, promises_b = 1 | 2 | 4 | 16 | 32;       // kernels_lean_a.hip: every trait; _b and _s: rpv and grids behind volume_eval() allowed
-                if (hs.integrator.spectral) { if ((hs.traits & promises_b) == promises_b) lean = 3; }       // kernels_lean_s.hip
-                else if ((hs.traits & promises_a) == promises_a) lean = 1;
-                else if ((hs.traits & promises_b) == promises_b) lean = 2;
-                else if ((hs.traits & 53) == 53) lean = 7;                           // kernels_lean_c.hip: as b, BVH allowed (MT_MEDIA | no spheres, area emitters, blend trees)
-                else if ((hs.traits & 190) == 190) lean = 6;                         // kernels_lean_h.hip: MT_HOMOG | no BVH, spheres, grids behind volume_eval(), area emitters, blend trees
+                auto keeps = [&](int promises) { return (hs.traits & promises) == promises; };      // dscene.h: MT_UNIT_*
+                if (hs.integrator.spectral) { if (keeps(MT_UNIT_B)) lean = 3; }     // kernels_lean_s.hip
+                else if (keeps(MT_UNIT_A)) lean = 1;                                 // every promise: no call left
+                else if (keeps(MT_UNIT_B)) lean = 2;                                 // rpv and grids behind volume_eval() allowed
+                else if (keeps(MT_UNIT_C)) lean = 7;                                 // ... and a BVH
+                else if (keeps(MT_UNIT_H)) lean = 6;                                 // homogeneous media
                 if (lv && atoi(lv) == 2 && lean == 1) lean = 2;                     // diagnostics: the b unit on a scene that qualifies for a
             }
-            // `path` as the flat loop: kernels_lean_p.hip / _ps.hip want a walked primitive list, no spheres, no rpv (70 = MT_NO_BVH | MT_NO_SPHERE | MT_NO_RPV)
-            if (!(lv && atoi(lv) == 0) && variant == 1 && hs.integrator.type == MTS_INTEGRATOR_PATH && (hs.traits & 70) == 70) lean = hs.integrator.spectral ? 5 : 4;
+            // `path` as the flat loop: kernels_lean_p.hip / _ps.hip want a walked primitive list, no spheres, no rpv
+            if (!(lv && atoi(lv) == 0) && variant == 1 && hs.integrator.type == MTS_INTEGRATOR_PATH && (hs.traits & MT_UNIT_P_NEEDS) == MT_UNIT_P_NEEDS) lean = hs.integrator.spectral ? 5 : 4;
         }
 #endif
         last_variant = variant + 100000 * lean;

@@ -129,6 +129,24 @@ struct DVolumeSp { int32_t value_sp; int32_t spectral_grid; float lambda_min, la
 struct DIntegrator { int32_t type, max_depth, rr_depth, hide_emitters, use_spectral_mis, monochrome; };
 
 // One spiral block (librender/spiral.cpp:27-72) assigned to this launch
+// Scene traits (integrator_dev.h: MTS_TRAITS; scene_host.cpp: scene_traits; capi.cpp: the choice of the lean translation unit).
+#define MT_MEDIA 1              // every medium: heterogeneous with spectral extinction and -- rgb / mono: grey, on a pair grid (DMedium::pair_grid);
+                                // spectral variant: two gridvolume_spectral grids sharing geometry and interval (DMedium::shared_grid == 2)
+#define MT_NO_BVH 2             // the primitive list is walked (no BVH)
+#define MT_NO_SPHERE 4          // no sphere shapes
+#define MT_NO_GRID_EVAL 8       // no grid volume is evaluated through volume_eval() (media go through their pair grids; no grid as a blend weight ...)
+#define MT_NO_SHAPE_EMITTER 16  // no area emitters (shape_sample_direction)
+#define MT_NO_PHASE_TREE 32     // no nested blendphase
+#define MT_NO_RPV 64            // no rpv BSDF
+#define MT_HOMOG 128            // every medium homogeneous (excludes MT_MEDIA)
+// what each lean translation unit promises (kernels_lean_*.hip) -- mts_render launches the first one in this order whose promises a scene keeps
+#define MT_UNIT_A (MT_MEDIA | MT_NO_BVH | MT_NO_SPHERE | MT_NO_GRID_EVAL | MT_NO_SHAPE_EMITTER | MT_NO_PHASE_TREE | MT_NO_RPV)
+#define MT_UNIT_B (MT_MEDIA | MT_NO_BVH | MT_NO_SPHERE | MT_NO_SHAPE_EMITTER | MT_NO_PHASE_TREE)      // also unit s (spectral variant)
+#define MT_UNIT_C (MT_MEDIA | MT_NO_SPHERE | MT_NO_SHAPE_EMITTER | MT_NO_PHASE_TREE)
+#define MT_UNIT_H (MT_HOMOG | MT_NO_BVH | MT_NO_SPHERE | MT_NO_GRID_EVAL | MT_NO_SHAPE_EMITTER | MT_NO_PHASE_TREE)
+#define MT_UNIT_P (MT_NO_BVH | MT_NO_SPHERE | MT_NO_GRID_EVAL | MT_NO_PHASE_TREE | MT_NO_RPV)          // compiled with these ...
+#define MT_UNIT_P_NEEDS (MT_NO_BVH | MT_NO_SPHERE | MT_NO_RPV)                                          // ... of which `path` can reach these
+
 struct DBlock { int32_t ox, oy, sx, sy; uint32_t id; uint32_t sample_base; /* wavefront streams: first sample index this entry renders */
                 uint32_t film_off_lo, film_off_hi; /* floats from the launch's film pointer to the film this entry adds to: the slot of its pass (capi.cpp) */ };
 static_assert(sizeof(DBlock) == 32, "DBlock is read as eight dwords (volpath_flat.h: wg_env)");

@@ -18,15 +18,7 @@
 // with MTS_TRAITS != 0 (kernels_lean_*.hip) PROMISES the properties below; the host checks them per scene (scene_host.cpp:
 // scene_traits) and mts_render picks the leanest kernel whose promises the scene keeps.  Same source, same arithmetic: the promised-away
 // branches are simply never compiled (C3 562 -> 629, C4 397 -> 469 Msamples/s on the 256-spp probes, profiles/r04_ab_experiments.log).
-#define MT_MEDIA 1              // every medium: heterogeneous with spectral extinction and -- rgb / mono: grey, on a pair grid (DMedium::pair_grid);
-                                // spectral variant: two gridvolume_spectral grids sharing geometry and interval (DMedium::shared_grid == 2)
-#define MT_NO_BVH 2             // the primitive list is walked (no BVH)
-#define MT_NO_SPHERE 4          // no sphere shapes
-#define MT_NO_GRID_EVAL 8       // no grid volume is evaluated through volume_eval() (media go through their pair grids; no grid as a blend weight ...)
-#define MT_NO_SHAPE_EMITTER 16  // no area emitters (shape_sample_direction)
-#define MT_NO_PHASE_TREE 32     // no nested blendphase
-#define MT_NO_RPV 64            // no rpv BSDF
-#define MT_HOMOG 128            // every medium homogeneous (excludes MT_MEDIA)
+// (the MT_* bits themselves live in dscene.h: the host computes them per scene)
 #ifndef MTS_TRAITS
 #define MTS_TRAITS 0
 #endif

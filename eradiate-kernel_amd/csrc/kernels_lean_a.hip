@@ -7,6 +7,6 @@
 #define MTS_LEAN _lean_a
 #define MTS_VARIANT_NS v_rgb_lean_a
 #define MTS_LEAN_MIS_768 1     // `volpathmis`: 164 VGPRs here (general kernel: 193) -- room for a third wave per SIMD, 768 threads on the 512 paths
-#define MTS_TRAITS (MT_MEDIA | MT_NO_BVH | MT_NO_SPHERE | MT_NO_GRID_EVAL | MT_NO_SHAPE_EMITTER | MT_NO_PHASE_TREE | MT_NO_RPV)
+#define MTS_TRAITS MT_UNIT_A      // dscene.h
 #include "kernels.hip"
 #endif

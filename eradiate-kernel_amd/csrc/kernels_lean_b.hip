@@ -3,6 +3,6 @@
 #if !defined(MTSAMD_BLOCKSTATS)
 #define MTS_LEAN _lean_b
 #define MTS_VARIANT_NS v_rgb_lean_b
-#define MTS_TRAITS (MT_MEDIA | MT_NO_BVH | MT_NO_SPHERE | MT_NO_SHAPE_EMITTER | MT_NO_PHASE_TREE)
+#define MTS_TRAITS MT_UNIT_B      // dscene.h
 #include "kernels.hip"
 #endif

@@ -4,6 +4,6 @@
 #if !defined(MTSAMD_BLOCKSTATS)
 #define MTS_LEAN _lean_h
 #define MTS_VARIANT_NS v_rgb_lean_h
-#define MTS_TRAITS (MT_HOMOG | MT_NO_BVH | MT_NO_SPHERE | MT_NO_GRID_EVAL | MT_NO_SHAPE_EMITTER | MT_NO_PHASE_TREE)
+#define MTS_TRAITS MT_UNIT_H      // dscene.h
 #include "kernels.hip"
 #endif

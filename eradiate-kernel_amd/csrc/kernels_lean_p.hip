@@ -5,6 +5,6 @@
 #define MTS_LEAN _lean_p
 #define MTS_LEAN_PATH 1
 #define MTS_VARIANT_NS v_rgb_lean_p
-#define MTS_TRAITS (MT_NO_BVH | MT_NO_SPHERE | MT_NO_GRID_EVAL | MT_NO_PHASE_TREE | MT_NO_RPV)      // (`path` evaluates neither volumes nor phase functions)
+#define MTS_TRAITS MT_UNIT_P      // dscene.h
 #include "kernels.hip"
 #endif

@@ -4,6 +4,6 @@
 #define MTS_LEAN _lean_ps
 #define MTS_LEAN_PATH 1
 #define MTS_VARIANT_NS v_spectral_lean_p
-#define MTS_TRAITS (MT_NO_BVH | MT_NO_SPHERE | MT_NO_GRID_EVAL | MT_NO_PHASE_TREE | MT_NO_RPV)
+#define MTS_TRAITS MT_UNIT_P      // dscene.h
 #include "kernels.hip"
 #endif

@@ -6,6 +6,6 @@
 #define MTS_SPEC_N 4
 #define MTS_LEAN _lean_s
 #define MTS_VARIANT_NS v_spectral_lean
-#define MTS_TRAITS (MT_MEDIA | MT_NO_BVH | MT_NO_SPHERE | MT_NO_SHAPE_EMITTER | MT_NO_PHASE_TREE)
+#define MTS_TRAITS MT_UNIT_B      // dscene.h
 #include "kernels.hip"
 #endif

@@ -196,11 +196,11 @@ static int scene_traits(const HostScene &hs, bool spectral) {
         if (spectral) media = media && !m.is_homogeneous && m.shared_grid == 2 && m.has_spectral_extinction;      // MT_MEDIA of the spectral variant
         else media = media && !m.is_homogeneous && i < hs.pair_data.size() && !hs.pair_data[i].empty() && m.grey && m.has_spectral_extinction;
     }
-    if (media) tr |= 1;                                                 // MT_MEDIA
+    if (media) tr |= MT_MEDIA;
     bool homog = !hs.media.empty();
     for (const DMedium &m : hs.media) homog = homog && m.is_homogeneous;
-    if (homog) tr |= 128;                                               // MT_HOMOG
-    if (hs.bvh_nodes.empty()) tr |= 2;                                  // MT_NO_BVH
+    if (homog) tr |= MT_HOMOG;
+    if (hs.bvh_nodes.empty()) tr |= MT_NO_BVH;
     bool sphere = false, rpv = false, shape_emitter = false, tree = false, grid_eval = false;
     for (const DShape &sh : hs.shapes) sphere = sphere || sh.type == MTS_SHAPE_SPHERE;
     sphere = sphere || hs.scene.sensor.target_shape.type == MTS_SHAPE_SPHERE || hs.scene.sensor.origin_shape.type == MTS_SHAPE_SPHERE;   // the distant sensors' own shapes
@@ -214,11 +214,11 @@ static int scene_traits(const HostScene &hs, bool spectral) {
             tree = tree || ph.size > 1;
             grid_eval = grid_eval || (ph.weight_volume >= 0 && hs.volumes[(size_t) ph.weight_volume].type == MTS_VOLUME_GRID);
         }
-    if (!sphere) tr |= 4;                                               // MT_NO_SPHERE
-    if (!grid_eval) tr |= 8;                                            // MT_NO_GRID_EVAL: no grid reaches volume_eval() (pair-grid media do not)
-    if (!shape_emitter) tr |= 16;                                       // MT_NO_SHAPE_EMITTER
-    if (!tree) tr |= 32;                                                // MT_NO_PHASE_TREE
-    if (!rpv) tr |= 64;                                                 // MT_NO_RPV
+    if (!sphere) tr |= MT_NO_SPHERE;
+    if (!grid_eval) tr |= MT_NO_GRID_EVAL;                               // no grid reaches volume_eval() (pair-grid media do not)
+    if (!shape_emitter) tr |= MT_NO_SHAPE_EMITTER;
+    if (!tree) tr |= MT_NO_PHASE_TREE;
+    if (!rpv) tr |= MT_NO_RPV;
     return tr;
 }
 
