@@ -253,7 +253,7 @@ int mts_render(mts_scene *scene, const mts_render_opts *opts_, float *film, mts_
     const size_t MAX_BLOCKS_PER_LAUNCH = std::max<size_t>(1, ((size_t) 8 << 20) / ((size_t) block_size * block_size));
     // Wavefront (gpu_*) streams make the samples of a pixel independent of each other (one stream per (pixel, sample)), so a film with
     // fewer pixels than the GPU has lanes to fill is spread over more workgroups: `split` entries per spiral block, each rendering
-    // sample_count / split samples of every pixel of the block (DBlock::sample_base); their sums meet in the film by atomics.
+    // sample_count / split samples of every pixel of the block (DBlock::sample_base); their sums go to film slots of their own, added in sample order at the end (below).
     size_t split = 1;
     if (se.wavefront) {
         int cus = 256;
